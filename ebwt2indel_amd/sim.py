@@ -1,0 +1,179 @@
+"""Synthetic-input tooling: read simulator + eBWT/DA builder (no reference counterpart).
+
+The reference ships no data and relies on external eBWT builders
+(/root/reference/README.md:38, datasets/simulate.pdf); offline we make our own
+inputs.  Recipe follows SURVEY.md section 8(d): uniform random genome, second
+haplotype with a SNP every ``snp_every`` bases and a 1-3 base indel every
+``indel_every`` bases, error-free fixed-length reads sampled uniformly and
+alternating between the two haplotypes.
+
+This module is data tooling only; it never touches the hot path.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_BUILD = os.path.join(_HERE, "_build")
+_TOOL_SRC = os.path.join(_HERE, "tools", "ebwt_build.cpp")
+_TOOL_SO = os.path.join(_BUILD, "libebwt_build.so")
+
+BASES = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def build_tool(force: bool = False) -> str:
+    """Compile the suffix-sorting eBWT builder (g++ -O3 -fopenmp)."""
+    os.makedirs(_BUILD, exist_ok=True)
+    if force or not os.path.exists(_TOOL_SO) or os.path.getmtime(_TOOL_SO) < os.path.getmtime(_TOOL_SRC):
+        subprocess.check_call(
+            ["g++", "-O3", "-fopenmp", "-shared", "-fPIC", "-o", _TOOL_SO, _TOOL_SRC]
+        )
+    return _TOOL_SO
+
+
+_lib = None
+
+
+def _tool():
+    global _lib
+    if _lib is None:
+        so = build_tool()
+        _lib = ctypes.CDLL(so)
+        _lib.ebwt_build.restype = ctypes.c_int
+        _lib.ebwt_build.argtypes = [
+            ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint8, ctypes.c_uint64,
+            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+        ]
+    return _lib
+
+
+# --------------------------------------------------------------------------- genomes / reads
+
+def random_genome(length: int, seed: int) -> np.ndarray:
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return BASES[rng.integers(0, 4, size=length, dtype=np.uint8)]
+
+
+def mutate_haplotype(genome: np.ndarray, seed: int, snp_every: int = 500, indel_every: int = 2000,
+                     max_indel: int = 3) -> np.ndarray:
+    """Second haplotype: a substitution every ``snp_every`` bases and an insertion or
+    deletion of 1..max_indel bases every ``indel_every`` bases (offset so they never coincide)."""
+    rng = np.random.Generator(np.random.PCG64(seed ^ 0x5EED))
+    g = genome
+    pieces: List[np.ndarray] = []
+    events: List[Tuple[int, str, int]] = []
+    if snp_every:
+        for p in range(snp_every // 2, len(g), snp_every):
+            events.append((p, "S", 0))
+    if indel_every:
+        for p in range(indel_every // 2 + snp_every // 4 + 7, len(g), indel_every):
+            kind = "I" if rng.integers(0, 2) else "D"
+            events.append((p, kind, int(rng.integers(1, max_indel + 1))))
+    events.sort()
+    cur = 0
+    for p, kind, ln in events:
+        if p < cur:
+            continue
+        pieces.append(g[cur:p])
+        if kind == "S":
+            old = g[p]
+            new = BASES[(int(np.where(BASES == old)[0][0]) + int(rng.integers(1, 4))) % 4]
+            pieces.append(np.array([new], dtype=np.uint8))
+            cur = p + 1
+        elif kind == "I":
+            pieces.append(BASES[rng.integers(0, 4, size=ln, dtype=np.uint8)])
+            cur = p
+        else:
+            cur = min(len(g), p + ln)
+    pieces.append(g[cur:])
+    return np.concatenate(pieces)
+
+
+def sample_reads(haps: Sequence[np.ndarray], n_reads: int, read_len: int, seed: int) -> np.ndarray:
+    """n_reads x read_len uint8 matrix; read j comes from haplotype j % len(haps)."""
+    rng = np.random.Generator(np.random.PCG64(seed ^ 0xBEAD))
+    out = np.empty((n_reads, read_len), dtype=np.uint8)
+    idx = np.arange(read_len, dtype=np.int64)
+    for h, hap in enumerate(haps):
+        rows = np.arange(h, n_reads, len(haps))
+        starts = rng.integers(0, len(hap) - read_len + 1, size=len(rows), dtype=np.int64)
+        out[rows] = hap[starts[:, None] + idx[None, :]]
+    return out
+
+
+def reads_to_text(reads: Iterable, term: int = 35) -> np.ndarray:
+    """Concatenate reads, each followed by the terminator byte."""
+    if isinstance(reads, np.ndarray) and reads.ndim == 2:
+        n, ln = reads.shape
+        t = np.empty((n, ln + 1), dtype=np.uint8)
+        t[:, :ln] = reads
+        t[:, ln] = term
+        return t.reshape(-1)
+    parts = []
+    tb = bytes([term])
+    for r in reads:
+        b = bytes(r) if not isinstance(r, (bytes, bytearray)) else bytes(r)
+        parts.append(b + tb)
+    return np.frombuffer(b"".join(parts), dtype=np.uint8).copy()
+
+
+# --------------------------------------------------------------------------- eBWT construction
+
+def build_ebwt(reads, term: int = 35, threads: int = 0) -> np.ndarray:
+    """eBWT (ASCII uint8 array) of one read collection."""
+    text = np.ascontiguousarray(reads_to_text(reads, term))
+    out = np.empty(len(text), dtype=np.uint8)
+    rc = _tool().ebwt_build(text.ctypes.data, len(text), term, len(text), out.ctypes.data, None, threads)
+    if rc != 0:
+        raise RuntimeError("ebwt_build failed")
+    return out
+
+
+def build_merged_ebwt(reads0, reads1, term: int = 35, threads: int = 0) -> Tuple[np.ndarray, np.ndarray]:
+    """Merged eBWT of two collections plus the ASCII '0'/'1' document array."""
+    t0 = reads_to_text(reads0, term)
+    t1 = reads_to_text(reads1, term)
+    text = np.ascontiguousarray(np.concatenate([t0, t1]))
+    out = np.empty(len(text), dtype=np.uint8)
+    da = np.empty(len(text), dtype=np.uint8)
+    rc = _tool().ebwt_build(text.ctypes.data, len(text), term, len(t0), out.ctypes.data, da.ctypes.data, threads)
+    if rc != 0:
+        raise RuntimeError("ebwt_build failed")
+    return out, da
+
+
+def build_ebwt_naive(reads, term: int = 35) -> bytes:
+    """Pure-Python definition (tiny inputs only); cross-checks the C++ builder in tests."""
+    t = chr(term)
+    assert term < ord("A")
+    rows = []
+    for j, r in enumerate(reads):
+        s = bytes(r).decode() if not isinstance(r, str) else r
+        for i in range(len(s) + 1):
+            rows.append((s[i:] + t, j, s[i - 1] if i > 0 else t))
+    rows.sort(key=lambda x: (x[0], x[1]))
+    return "".join(x[2] for x in rows).encode()
+
+
+# --------------------------------------------------------------------------- canned workloads
+
+def diploid_sample(genome_len: int, n_reads: int, read_len: int, seed: int, **kw):
+    """One individual, two haplotypes (mode 1 input).  Returns (reads, hap1, hap2)."""
+    g = random_genome(genome_len, seed)
+    h2 = mutate_haplotype(g, seed, **kw)
+    return sample_reads([g, h2], n_reads, read_len, seed), g, h2
+
+
+def two_samples(genome_len: int, n_reads_each: int, read_len: int, seed: int, het_second: bool = False, **kw):
+    """Two individuals (mode 2/3 input): sample 0 homozygous for the genome, sample 1
+    homozygous for the mutated haplotype (or heterozygous when ``het_second``)."""
+    g = random_genome(genome_len, seed)
+    h2 = mutate_haplotype(g, seed, **kw)
+    r0 = sample_reads([g], n_reads_each, read_len, seed)
+    r1 = sample_reads([g, h2] if het_second else [h2], n_reads_each, read_len, seed + 1)
+    return r0, r1

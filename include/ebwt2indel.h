@@ -1,0 +1,204 @@
+/*
+ * ebwt2indel.h -- C ABI of the MI355X-native ebwt2InDel hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, opaque handles, no C++
+ * or torch types.  Every entry point names the reference interface it replaces
+ * (file:line relative to the upstream ebwt2InDel tree).  The reference has no
+ * FFI of its own -- its host program calls the C++ classes dna_string / dna_bwt
+ * and the free functions of ebwt2InDel.cpp directly -- so these are the calls a
+ * maintainer would make from ebwt2InDel.cpp instead.
+ *
+ * All work behind this ABI runs on the GPU (hand-written HIP for gfx950).  There
+ * is no CPU fallback: without a usable HIP device every call that needs one
+ * returns EB_ERR_DEVICE and eb_last_error() says why.
+ *
+ * Ownership: the caller owns every buffer it passes in; the library owns the
+ * device memory behind handles and the host memory behind eb_calls.
+ * Threading: a handle is bound to one device and is thread-compatible (one
+ * caller at a time); distinct handles may be driven from distinct threads.
+ * Errors: int return (0 = ok, <0 = error), text via eb_last_error(); the
+ * library never calls exit().
+ */
+#ifndef EBWT2INDEL_H_
+#define EBWT2INDEL_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EB_OK            0
+#define EB_ERR_ARG      -1
+#define EB_ERR_IO       -2
+#define EB_ERR_ALPHABET -3 /* byte outside {A,C,G,T,TERM}: dna_string.hpp:90-96 */
+#define EB_ERR_DEVICE   -4 /* no HIP device, or a HIP call failed */
+#define EB_ERR_NOMEM    -5
+#define EB_ERR_STATE    -6
+
+#define EB_MAX_SLOTS 8 /* <=4 frequent symbols per side, 2 sides */
+
+typedef struct eb_index eb_index; /* packed BWT + rank counters, resident on one GPU  (dna_bwt_t) */
+typedef struct eb_flags eb_flags; /* LCP_threshold / LCP_minima / DA bitvectors on the GPU          */
+typedef struct eb_calls eb_calls; /* phase-4 output: one record per surviving cluster (host memory) */
+
+/* Options of the reference CLI (ebwt2InDel.cpp:20-74, getopt at :1684). */
+typedef struct {
+    int32_t k_left;                    /* -L, default 31 */
+    int32_t k_right;                   /* -R, default 30 */
+    int32_t K;                         /* -k, default 16 */
+    int32_t max_gap;                   /* -g, default 10 */
+    int32_t max_snvs;                  /* -v, default 2  */
+    int32_t mcov_out;                  /* -m, default 3  */
+    int32_t complexity;                /* -c, default 20 (frozen: ebwt2InDel.cpp:64) */
+    int32_t max_variants_per_position; /* -q, default 0 = unlimited */
+    int32_t term;                      /* -t, ASCII code, default 35 ('#') */
+} eb_params;
+
+/* All-zero params, then the reference's "0 means default" rule (ebwt2InDel.cpp:1740-1746). */
+void eb_params_init(eb_params* p);
+void eb_params_resolve(eb_params* p);
+
+/* Message of the last failing call on this thread. */
+const char* eb_last_error(void);
+/* Number of visible HIP devices (0 when there is none). */
+int eb_device_count(void);
+
+/* ------------------------------------------------------------------ index (phase 1)
+ * Replaces dna_bwt_t(path, TERM): dna_bwt.hpp:36-62 (F array) and
+ * dna_string(path, TERM): dna_string.hpp:55-110 (packing), :275-315 (counters).
+ * `ascii` is the raw eBWT over {A,C,G,T,TERM}, n bytes, host memory.
+ * On EB_ERR_ALPHABET, eb_index_bad_symbol() reports the first offending byte. */
+int eb_index_create(const uint8_t* ascii, uint64_t n, uint8_t term, int device, eb_index** out);
+int eb_index_create_from_file(const char* path, uint8_t term, int device, eb_index** out);
+/* Same, with the ASCII text already in device memory on `device` (synthetic benchmarks). */
+int eb_index_create_from_device(const void* d_ascii, uint64_t n, uint8_t term, int device, eb_index** out);
+void eb_index_destroy(eb_index* h);
+void eb_index_bad_symbol(uint8_t* symbol, uint64_t* position);
+
+typedef struct {
+    uint64_t n;            /* dna_bwt::size() (dna_bwt.hpp:231) */
+    uint64_t F[4];         /* F_A, F_C, F_G, F_T (dna_bwt.hpp:51-60) */
+    uint64_t n_blocks;     /* 128-symbol blocks, ceil((n+1)/128) (dna_string.hpp:62) */
+    uint64_t device_bytes; /* HBM held by the handle */
+    int32_t device;
+    int32_t term;
+} eb_index_info_t;
+int eb_index_info(const eb_index* h, eb_index_info_t* info);
+
+/* ------------------------------------------------------------------ rank / LF primitives
+ * Host-buffer batches.  m queries in, results out; positions are 0 <= i <= n. */
+/* dna_string::parallel_rank (dna_string.hpp:140-152): out4[4q..4q+3] = #A,#C,#G,#T in [0,pos[q]). */
+int eb_rank4_batch(eb_index* h, const uint64_t* pos, uint64_t m, uint64_t* out4);
+/* dna_string::operator[] (dna_string.hpp:113-135): ASCII symbol at pos[q] (< n). */
+int eb_access_batch(eb_index* h, const uint64_t* pos, uint64_t m, uint8_t* out);
+/* dna_bwt::LF(range_t) (dna_bwt.hpp:138-166): lr[2q..2q+1] = [l,r) -> out8[8q..] = A.first,A.second,C..,G..,T.. */
+int eb_lf_range_batch(eb_index* h, const uint64_t* lr, uint64_t m, uint64_t* out8);
+/* dna_bwt::LF(range_t, char) (dna_bwt.hpp:168-192): sym[q] in {A,C,G,T}. */
+int eb_lf_range_sym_batch(eb_index* h, const uint64_t* lr, const uint8_t* sym, uint64_t m, uint64_t* out2);
+/* dna_bwt::FL (dna_bwt.hpp:115-133) = dna_string::select (dna_string.hpp:182-188, 254-272);
+ * pos[q] must not be a TERM row (pos >= F_A). */
+int eb_fl_batch(eb_index* h, const uint64_t* pos, uint64_t m, uint64_t* out);
+/* dna_bwt::LF(sa_node) (dna_bwt.hpp:323-356): nodes[7q..] = first_TERM,first_A,first_C,first_G,first_T,last,depth
+ * -> out28[28q..] = the four sa_nodes for A,C,G,T. */
+int eb_lf_node_batch(eb_index* h, const uint64_t* nodes7, uint64_t m, uint64_t* out28);
+
+/* Device-buffer form of eb_rank4_batch for benchmarks: d_pos / d_out4 are device
+ * pointers on the handle's device; the launch goes on the handle's stream and, when
+ * kernel_ms != NULL, is bracketed by HIP events on that stream. */
+int eb_rank4_batch_device(eb_index* h, const void* d_pos, uint64_t m, void* d_out4, float* kernel_ms);
+
+/* ------------------------------------------------------------------ phases 2-3
+ * Replaces navigate_one_bwt (ebwt2InDel.cpp:555-676) when b2 == NULL and
+ * navigate_two_bwts (:679-831) when b2 != NULL: builds, on the GPU,
+ *   thrK[i]  = LCP[i] >= K        (LCP_threshold[2i],   :344-355, include.hpp:826-860)
+ *   thrR[i]  = LCP[i] >= k_right  (LCP_threshold[2i+1])
+ *   minima[i]                     (LCP_minima, :357-391)
+ *   da[i]    (two-BWT mode only: update_DA :394-449, find_leaves :474-527)
+ * over the n (or n1+n2) merged positions. */
+typedef struct {
+    uint64_t n;          /* merged length */
+    uint64_t leaves;     /* "Processed ... suffix-tree leaves"  */
+    uint64_t nodes;      /* "Processed ... suffix-tree nodes"   */
+    uint64_t lcp_values; /* positions whose LCP slot was written (reaches n) */
+    uint64_t da_values;  /* two-BWT mode: DA slots written (reaches n) */
+    uint64_t minima;     /* "Found ... LCP minima" */
+    uint64_t rank_queries; /* parallel_rank evaluations issued */
+    uint64_t batches;    /* frontier kernel launches */
+    double   seconds_leaves, seconds_nodes;
+} eb_nav_stats;
+int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_right, eb_flags** out, eb_nav_stats* stats);
+/* Mode 3: ASCII '0'/'1' document array, '1' -> 1, anything else -> 0 (ebwt2InDel.cpp:1503-1508). */
+int eb_flags_set_da(eb_flags* f, const uint8_t* ascii01, uint64_t n);
+/* Bit i of each vector is bit (i & 63) of word (i >> 6).  Any pointer may be NULL.
+ * export: device -> host (tests, broadcast to other ranks); import: host -> device. */
+uint64_t eb_flags_words(const eb_flags* f);
+int eb_flags_has_da(const eb_flags* f);
+int eb_flags_export(eb_flags* f, uint64_t* thrK, uint64_t* thrR, uint64_t* minima, uint64_t* da);
+int eb_flags_import(uint64_t n, int device, const uint64_t* thrK, const uint64_t* thrR, const uint64_t* minima,
+                    const uint64_t* da, eb_flags** out);
+void eb_flags_destroy(eb_flags* f);
+
+/* ------------------------------------------------------------------ phase 4
+ * One record per cluster that passed the length and frequent-symbol filters
+ * (find_variants, ebwt2InDel.cpp:840-934, 941-1005, 1013-1096), in BWT order. */
+typedef struct {
+    uint64_t begin, end;           /* cluster [begin,end) in merged coordinates (:1618,1632) */
+    uint32_t n_slots;              /* left-context chains started, side 0 first, A<C<G<T within a side */
+    uint32_t right_len;            /* chars of right context extracted (0: no position with thrR) */
+    uint8_t  slot_side[EB_MAX_SLOTS];    /* 0/1 (always 0 in one-sample mode) */
+    uint8_t  slot_sym[EB_MAX_SLOTS];     /* 'A','C','G','T' */
+    uint32_t slot_len[EB_MAX_SLOTS];     /* chars obtained; a context is valid iff == k_left (:317) */
+    uint32_t slot_support[EB_MAX_SLOTS]; /* |LF(range,c)| (:308-310) */
+} eb_cluster;
+
+typedef struct {
+    uint64_t begin, end;       /* scanned range */
+    uint64_t runs_closed;      /* clusters closed inside the range (any length) */
+    uint64_t clusters;         /* "Analyzed ... clusters" (len >= 2*mcov_out) */
+    uint64_t bases_in_runs;    /* sum of closed-run lengths ("Average cluster length") */
+    uint64_t survivors;        /* records emitted */
+    uint64_t chains;           /* left-context chains extended */
+    uint64_t hist[201];        /* CLUST_SIZES (:1604,1627) */
+    float    ms_scan, ms_extend, ms_right, ms_total; /* HIP-event times on the handle's stream */
+} eb_scan_stats;
+
+/* Replaces the phase-4 loops run_one_dataset (:1609-1655), run_two_datasets (:1395-1445)
+ * and run_two_datasets_da (:1510-1560) restricted to clusters whose first position lies
+ * in [begin,end) (the whole BWT: begin=0, end=n).  Mode: b2 != NULL -> two BWTs;
+ * else flags carrying a DA -> merged BWT + DA; else one sample. */
+int eb_scan_clusters(eb_index* b1, eb_index* b2, eb_flags* f, uint64_t begin, uint64_t end, const eb_params* p,
+                     eb_calls** out, eb_scan_stats* stats);
+
+typedef struct {
+    uint64_t count;
+    int32_t k_left, k_right;
+    const eb_cluster* clusters;    /* count records */
+    const uint8_t* left;           /* count * EB_MAX_SLOTS * k_left ASCII bytes, slot-major per cluster */
+    const uint8_t* right;          /* count * k_right ASCII bytes */
+} eb_calls_view;
+int eb_calls_get(const eb_calls* c, eb_calls_view* view);
+void eb_calls_free(eb_calls* c);
+/* Flat byte image of a call set, for the RCCL gather between ranks. */
+uint64_t eb_calls_packed_size(const eb_calls* c);
+int eb_calls_pack(const eb_calls* c, uint8_t* buf, uint64_t cap);
+int eb_calls_unpack(const uint8_t* buf, uint64_t len, eb_calls** out);
+
+/* ------------------------------------------------------------------ event logic + KisSNP2 writer (host)
+ * Replaces to_file (ebwt2InDel.cpp:1254-1330 one sample, :1149-1252 pairs) with distance (:192-240),
+ * event_type (:1102-1144), has_run (:144-152).  `two_samples` selects the pair writer.
+ * cluster_nr is the running counter (:52), threaded through so shards can be written in order;
+ * *events counts records written by the one-sample writer (:1320).  Appends to `path`
+ * when `append` != 0, otherwise truncates it. */
+int eb_write_snp(const eb_calls* c, const eb_params* p, int two_samples, const char* path, int append,
+                 uint64_t* cluster_nr, uint64_t* events);
+/* Same, into a malloc'd buffer the caller frees with eb_free(). */
+int eb_format_snp(const eb_calls* c, const eb_params* p, int two_samples, uint64_t* cluster_nr, uint64_t* events,
+                  char** text, uint64_t* len);
+void eb_free(void* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EBWT2INDEL_H_ */

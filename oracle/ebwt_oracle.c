@@ -1,0 +1,989 @@
+/*
+ * ebwt_oracle.c -- CPU restatement of ebwt2InDel's algorithm.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may build,
+ * load or call this file.  Nothing under ebwt2indel_amd/ links it: the product path
+ * is the HIP library and fails loudly without a GPU.
+ *
+ * Parity status: PINNED.  tests/test_oracle_golden.py checks this restatement
+ * byte-for-byte against .snp files written by the reference binary itself
+ * (oracle/_ref/ebwt2InDel_ref, compiled from /root/reference by oracle/Makefile) on
+ * the committed fixtures under tests/golden/ (all three modes, option variants),
+ * and tests/test_oracle_vs_ref.py re-runs the reference binary on fresh seeded inputs
+ * whenever oracle/_ref exists (build container only).
+ *
+ * Every function cites the reference code it follows (paths relative to the
+ * upstream tree).  The algorithm is the reference's -- same rank structure idea
+ * (one 64-byte block per 128 symbols), same DFS order, same select-by-bisection --
+ * so that timing this code is a fair single-thread CPU baseline ("port").
+ * The code itself is new: plain C, explicit stacks, own data layout.
+ */
+#define _GNU_SOURCE
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "../include/ebwt2indel.h" /* eb_cluster record layout, eb_params (shared with the product ABI) */
+
+/* ------------------------------------------------------------------ small utilities */
+
+typedef struct { uint64_t v[4]; } rank4_t; /* A,C,G,T  (p_rank, internal/include.hpp:590-628) */
+typedef struct { uint64_t l, r; } range_t; /* [l,r)    (range_t, internal/include.hpp:25) */
+
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+typedef struct { char* p; size_t len, cap; } sbuf;
+static void sb_put(sbuf* s, const char* d, size_t n) {
+    if (s->len + n + 1 > s->cap) {
+        size_t c = s->cap ? s->cap * 2 : 4096;
+        while (c < s->len + n + 1) c *= 2;
+        s->p = (char*)realloc(s->p, c);
+        s->cap = c;
+    }
+    memcpy(s->p + s->len, d, n);
+    s->len += n;
+    s->p[s->len] = 0;
+}
+static void sb_puts(sbuf* s, const char* d) { sb_put(s, d, strlen(d)); }
+static void sb_putu(sbuf* s, uint64_t v) {
+    char t[32];
+    int n = snprintf(t, sizeof t, "%llu", (unsigned long long)v);
+    sb_put(s, t, (size_t)n);
+}
+static void sb_puti(sbuf* s, long long v) {
+    char t[32];
+    int n = snprintf(t, sizeof t, "%lld", v);
+    sb_put(s, t, (size_t)n);
+}
+
+static inline int bit_get(const uint64_t* b, uint64_t i) { return (int)((b[i >> 6] >> (i & 63)) & 1); }
+static inline void bit_set(uint64_t* b, uint64_t i) { b[i >> 6] |= 1ull << (i & 63); }
+
+/* ------------------------------------------------------------------ rank string
+ * dna_string (internal/dna_string.hpp:46-602): 128 symbols per 64-byte block =
+ * three bit-planes + four 32-bit counters relative to a 2^32-symbol superblock. */
+
+typedef struct {
+    uint32_t cnt[4];  /* #A,#C,#G,#T before this block inside its superblock (dna_string.hpp:554-585) */
+    uint64_t b0[2];   /* code bit 0 of symbols 0..127, symbol j at bit j&63 of word j>>6 */
+    uint64_t b1[2];   /* code bit 1 */
+    uint64_t b2[2];   /* code bit 2 (terminator only) */
+} oblock;
+
+typedef struct {
+    uint64_t n;
+    uint8_t term;
+    uint64_t nblocks;   /* ceil((n+1)/128), dna_string.hpp:62 */
+    uint64_t nsuper;    /* ceil((n+1)/2^32), dna_string.hpp:61 */
+    oblock* blk;
+    rank4_t* super;     /* absolute counts at superblock starts (dna_string.hpp:65,285-289) */
+    uint64_t F[4];      /* F_A,F_C,F_G,F_T (dna_bwt.hpp:51-60) */
+    uint8_t bad_sym;
+    uint64_t bad_pos;
+} oindex;
+
+static inline int sym_code(uint8_t c, uint8_t term) {
+    if (c == term) return 4;
+    switch (c) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; }
+    return -1;
+}
+
+void orc_index_free(oindex* x) {
+    if (!x) return;
+    free(x->blk);
+    free(x->super);
+    free(x);
+}
+
+/* Constructor: dna_string(path,TERM) dna_string.hpp:55-110 (validation :90-96, packing :320-369),
+ * build_rank_support :275-315, F array dna_bwt.hpp:36-62. */
+oindex* orc_index_from_buffer(const uint8_t* ascii, uint64_t n, uint8_t term) {
+    oindex* x = (oindex*)calloc(1, sizeof *x);
+    x->n = n;
+    x->term = term;
+    x->nblocks = (n + 1 + 127) / 128;
+    x->nsuper = (n + 1 + 0xFFFFFFFFull) >> 32;
+    x->blk = (oblock*)aligned_alloc(64, x->nblocks * sizeof(oblock));
+    memset(x->blk, 0, x->nblocks * sizeof(oblock));
+    x->super = (rank4_t*)calloc(x->nsuper, sizeof(rank4_t));
+    uint64_t tot[4] = {0, 0, 0, 0}, nterm = 0;
+    uint32_t rel[4] = {0, 0, 0, 0};
+    for (uint64_t b = 0; b < x->nblocks; ++b) {
+        if ((b & ((1ull << 25) - 1)) == 0) { /* 2^25 blocks per superblock, dna_string.hpp:37 */
+            for (int c = 0; c < 4; ++c) x->super[b >> 25].v[c] = tot[c];
+            rel[0] = rel[1] = rel[2] = rel[3] = 0;
+        }
+        oblock* k = &x->blk[b];
+        for (int c = 0; c < 4; ++c) k->cnt[c] = rel[c];
+        uint64_t base = b * 128;
+        for (uint64_t j = 0; j < 128 && base + j < n; ++j) {
+            int code = sym_code(ascii[base + j], term);
+            if (code < 0) {
+                x->bad_sym = ascii[base + j];
+                x->bad_pos = base + j;
+                x->n = UINT64_MAX; /* marks failure */
+                return x;
+            }
+            uint64_t m = 1ull << (j & 63);
+            if (code & 1) k->b0[j >> 6] |= m;
+            if (code & 2) k->b1[j >> 6] |= m;
+            if (code & 4) k->b2[j >> 6] |= m;
+            if (code < 4) { tot[code]++; rel[code]++; } else nterm++;
+        }
+    }
+    /* F column: cumulative counts of TERM, A, C, G (dna_bwt.hpp:47-60) */
+    x->F[0] = nterm;
+    x->F[1] = x->F[0] + tot[0];
+    x->F[2] = x->F[1] + tot[1];
+    x->F[3] = x->F[2] + tot[2];
+    return x;
+}
+
+oindex* orc_index_from_file(const char* path, uint8_t term) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return NULL;
+    fseek(f, 0, SEEK_END);
+    long long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    uint8_t* buf = (uint8_t*)malloc(sz > 0 ? (size_t)sz : 1);
+    if (sz > 0 && fread(buf, 1, (size_t)sz, f) != (size_t)sz) { fclose(f); free(buf); return NULL; }
+    fclose(f);
+    oindex* x = orc_index_from_buffer(buf, (uint64_t)sz, term);
+    free(buf);
+    return x;
+}
+
+int orc_index_ok(const oindex* x) { return x && x->n != UINT64_MAX; }
+uint64_t orc_index_size(const oindex* x) { return x->n; }
+void orc_index_F(const oindex* x, uint64_t* F4) { memcpy(F4, x->F, sizeof x->F); }
+void orc_index_bad(const oindex* x, uint8_t* sym, uint64_t* pos) { *sym = x->bad_sym; *pos = x->bad_pos; }
+
+/* parallel_rank: dna_string.hpp:140-152 = superblock counts + block counters (get_counters :572)
+ * + in-block popcounts over the first `o` symbols (block_rank :375-403, block_rank64 :408-434). */
+static inline rank4_t rank4(const oindex* x, uint64_t i) {
+    const oblock* k = &x->blk[i >> 7];
+    const rank4_t* s = &x->super[i >> 32];
+    unsigned o = (unsigned)(i & 127);
+    uint64_t m0 = o >= 64 ? ~0ull : ((1ull << o) - 1);
+    uint64_t m1 = o > 64 ? ((1ull << (o - 64)) - 1) : 0; /* o-64 <= 63 */
+    uint64_t d0 = ~k->b2[0] & m0, d1 = ~k->b2[1] & m1;    /* non-terminator symbols before o */
+    rank4_t r;
+    r.v[0] = s->v[0] + k->cnt[0] + __builtin_popcountll(d0 & ~k->b1[0] & ~k->b0[0]) + __builtin_popcountll(d1 & ~k->b1[1] & ~k->b0[1]);
+    r.v[1] = s->v[1] + k->cnt[1] + __builtin_popcountll(d0 & ~k->b1[0] & k->b0[0]) + __builtin_popcountll(d1 & ~k->b1[1] & k->b0[1]);
+    r.v[2] = s->v[2] + k->cnt[2] + __builtin_popcountll(d0 & k->b1[0] & ~k->b0[0]) + __builtin_popcountll(d1 & k->b1[1] & ~k->b0[1]);
+    r.v[3] = s->v[3] + k->cnt[3] + __builtin_popcountll(d0 & k->b1[0] & k->b0[0]) + __builtin_popcountll(d1 & k->b1[1] & k->b0[1]);
+    return r;
+}
+
+/* operator[]: dna_string.hpp:113-135 */
+static inline uint8_t access_sym(const oindex* x, uint64_t i) {
+    const oblock* k = &x->blk[i >> 7];
+    unsigned j = (unsigned)(i & 127), w = j >> 6, s = j & 63;
+    unsigned code = (unsigned)((k->b0[w] >> s) & 1) | (unsigned)(((k->b1[w] >> s) & 1) << 1) | (unsigned)(((k->b2[w] >> s) & 1) << 2);
+    static const char tab[4] = {'A', 'C', 'G', 'T'};
+    return code < 4 ? (uint8_t)tab[code] : x->term;
+}
+
+/* rank(i,c): dna_string.hpp:157-174 (always a full parallel_rank first), rank_non_dna :194-203 */
+static inline uint64_t rank1(const oindex* x, uint64_t i, uint8_t c) {
+    rank4_t r = rank4(x, i);
+    if (c == x->term) return i - (r.v[0] + r.v[1] + r.v[2] + r.v[3]);
+    switch (c) { case 'A': return r.v[0]; case 'C': return r.v[1]; case 'G': return r.v[2]; case 'T': return r.v[3]; }
+    return 0;
+}
+
+/* select(i,c): bisection over [0,n) with rank, dna_string.hpp:182-188, 254-272 */
+static uint64_t select1(const oindex* x, uint64_t i, uint8_t c) {
+    uint64_t lo = 0, hi = x->n;
+    while (hi > lo + 1) {
+        uint64_t mid = (lo + hi) / 2;
+        if (rank1(x, mid, c) > i) hi = mid; else lo = mid;
+    }
+    return lo;
+}
+
+/* F(i): dna_bwt.hpp:100-110 */
+static inline uint8_t F_sym(const oindex* x, uint64_t i) {
+    return i < x->F[0] ? x->term : i < x->F[1] ? 'A' : i < x->F[2] ? 'C' : i < x->F[3] ? 'G' : 'T';
+}
+/* FL(i): dna_bwt.hpp:115-133 */
+static inline uint64_t FL(const oindex* x, uint64_t i) {
+    uint8_t c = F_sym(x, i);
+    uint64_t r = i < x->F[0] ? i : i < x->F[1] ? i - x->F[0] : i < x->F[2] ? i - x->F[1] : i < x->F[3] ? i - x->F[2] : i - x->F[3];
+    return select1(x, r, c);
+}
+
+typedef struct { range_t c[4]; } prange_t; /* p_range, include.hpp:540-547 */
+
+/* LF(range): dna_bwt.hpp:138-166 (second rank skipped for an empty range :148-151) */
+static inline prange_t LF_range(const oindex* x, range_t rn) {
+    rank4_t a = rank4(x, rn.l);
+    rank4_t b = rn.r > rn.l ? rank4(x, rn.r) : a;
+    prange_t p;
+    for (int c = 0; c < 4; ++c) { p.c[c].l = x->F[c] + a.v[c]; p.c[c].r = x->F[c] + b.v[c]; }
+    return p;
+}
+/* LF(range,c): dna_bwt.hpp:168-192 */
+static inline range_t LF_range_sym(const oindex* x, range_t rn, uint8_t c) {
+    uint64_t a = rank1(x, rn.l, c);
+    uint64_t b = rn.r > rn.l ? rank1(x, rn.r, c) : a;
+    range_t z = {0, 0};
+    int k = sym_code(c, 0);
+    if (k < 0 || k > 3) return z;
+    z.l = x->F[k] + a;
+    z.r = x->F[k] + b;
+    return z;
+}
+
+/* batch entry points used by tests (parity of the HIP primitives) */
+void orc_rank4_batch(const oindex* x, const uint64_t* pos, uint64_t m, uint64_t* out4) {
+    for (uint64_t q = 0; q < m; ++q) { rank4_t r = rank4(x, pos[q]); memcpy(out4 + 4 * q, r.v, 32); }
+}
+void orc_access_batch(const oindex* x, const uint64_t* pos, uint64_t m, uint8_t* out) {
+    for (uint64_t q = 0; q < m; ++q) out[q] = access_sym(x, pos[q]);
+}
+void orc_lf_range_batch(const oindex* x, const uint64_t* lr, uint64_t m, uint64_t* out8) {
+    for (uint64_t q = 0; q < m; ++q) {
+        range_t rn = {lr[2 * q], lr[2 * q + 1]};
+        prange_t p = LF_range(x, rn);
+        for (int c = 0; c < 4; ++c) { out8[8 * q + 2 * c] = p.c[c].l; out8[8 * q + 2 * c + 1] = p.c[c].r; }
+    }
+}
+void orc_lf_range_sym_batch(const oindex* x, const uint64_t* lr, const uint8_t* sym, uint64_t m, uint64_t* out2) {
+    for (uint64_t q = 0; q < m; ++q) {
+        range_t rn = {lr[2 * q], lr[2 * q + 1]};
+        range_t z = LF_range_sym(x, rn, sym[q]);
+        out2[2 * q] = z.l;
+        out2[2 * q + 1] = z.r;
+    }
+}
+void orc_fl_batch(const oindex* x, const uint64_t* pos, uint64_t m, uint64_t* out) {
+    for (uint64_t q = 0; q < m; ++q) out[q] = FL(x, pos[q]);
+}
+
+/* ------------------------------------------------------------------ suffix-tree records */
+
+typedef struct { uint64_t b[6]; uint64_t depth; } onode; /* first_TERM,first_A,first_C,first_G,first_T,last  (sa_node, include.hpp:394-413) */
+typedef struct { range_t rn; uint64_t depth; } oleaf;    /* sa_leaf, include.hpp:513-527 */
+
+static inline int node_children(const onode* x) { /* number_of_children, include.hpp:760-768 */
+    int k = 0;
+    for (int j = 0; j < 5; ++j) k += x->b[j + 1] > x->b[j];
+    return k;
+}
+
+/* LF(sa_node): dna_bwt.hpp:323-356 -- one parallel_rank per distinct boundary */
+static void LF_node(const oindex* x, const onode* N, onode out[4]) {
+    rank4_t r[6];
+    r[0] = rank4(x, N->b[0]);
+    for (int j = 1; j < 6; ++j) r[j] = N->b[j] == N->b[j - 1] ? r[j - 1] : rank4(x, N->b[j]);
+    for (int c = 0; c < 4; ++c) {
+        for (int j = 0; j < 6; ++j) out[c].b[j] = x->F[c] + r[j].v[c];
+        out[c].depth = N->depth + 1;
+    }
+}
+
+void orc_lf_node_batch(const oindex* x, const uint64_t* nodes7, uint64_t m, uint64_t* out28) {
+    for (uint64_t q = 0; q < m; ++q) {
+        onode N, o[4];
+        memcpy(N.b, nodes7 + 7 * q, 48);
+        N.depth = nodes7[7 * q + 6];
+        LF_node(x, &N, o);
+        for (int c = 0; c < 4; ++c) {
+            memcpy(out28 + 28 * q + 7 * c, o[c].b, 48);
+            out28[28 * q + 7 * c + 6] = o[c].depth;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ run state */
+
+typedef struct {
+    uint64_t n;             /* merged length */
+    uint64_t words;
+    uint64_t *thrK, *thrR;  /* LCP_threshold[2i], LCP_threshold[2i+1] (ebwt2InDel.cpp:57,571) */
+    uint64_t *minima;       /* LCP_minima (:56,624) */
+    uint64_t *da;           /* DA (:58,694,1495) or NULL */
+    uint64_t leaves, nodes, lcp_values, da_values, n_min, max_stack;
+} oflags;
+
+void orc_flags_free(oflags* f) {
+    if (!f) return;
+    free(f->thrK); free(f->thrR); free(f->minima); free(f->da); free(f);
+}
+static oflags* flags_new(uint64_t n, int with_da) {
+    oflags* f = (oflags*)calloc(1, sizeof *f);
+    f->n = n;
+    f->words = (n + 63) / 64 + 1;
+    f->thrK = (uint64_t*)calloc(f->words, 8);
+    f->thrR = (uint64_t*)calloc(f->words, 8);
+    f->minima = (uint64_t*)calloc(f->words, 8);
+    if (with_da) f->da = (uint64_t*)calloc(f->words, 8);
+    f->lcp_values = 1; /* ebwt2InDel.cpp:575 */
+    return f;
+}
+uint64_t orc_flags_words(const oflags* f) { return (f->n + 63) / 64; }
+void orc_flags_export(const oflags* f, uint64_t* thrK, uint64_t* thrR, uint64_t* minima, uint64_t* da) {
+    uint64_t w = orc_flags_words(f) * 8;
+    if (thrK) memcpy(thrK, f->thrK, w);
+    if (thrR) memcpy(thrR, f->thrR, w);
+    if (minima) memcpy(minima, f->minima, w);
+    if (da && f->da) memcpy(da, f->da, w);
+}
+void orc_flags_counters(const oflags* f, uint64_t* out6) {
+    out6[0] = f->leaves; out6[1] = f->nodes; out6[2] = f->lcp_values; out6[3] = f->da_values; out6[4] = f->n_min; out6[5] = f->max_stack;
+}
+
+/* growable stacks (std::stack in the reference, ebwt2InDel.cpp:581,631,712,773) */
+#define DEFINE_STACK(T, NAME)                                                         \
+    typedef struct { T* a; size_t n, cap; } NAME;                                     \
+    static void NAME##_push(NAME* s, T v) {                                           \
+        if (s->n == s->cap) { s->cap = s->cap ? s->cap * 2 : 256; s->a = (T*)realloc(s->a, s->cap * sizeof(T)); } \
+        s->a[s->n++] = v;                                                             \
+    }
+typedef struct { oleaf a, b; } oleaf2;
+typedef struct { onode a, b; } onode2;
+DEFINE_STACK(oleaf, leaf_stack)
+DEFINE_STACK(onode, node_stack)
+DEFINE_STACK(oleaf2, leaf2_stack)
+DEFINE_STACK(onode2, node2_stack)
+
+/* stable insertion sort by ascending key (std::sort on <=4 items; libstdc++ uses insertion sort below 16) */
+#define SORT_ASC(T, arr, cnt, KEY)                                      \
+    for (int i_ = 1; i_ < (cnt); ++i_) {                                \
+        T t_ = (arr)[i_];                                               \
+        int j_ = i_ - 1;                                                \
+        while (j_ >= 0 && KEY((arr)[j_]) > KEY(t_)) { (arr)[j_ + 1] = (arr)[j_]; --j_; } \
+        (arr)[j_ + 1] = t_;                                             \
+    }
+
+/* update_lcp_threshold: include.hpp:826-860 -- LCP at each child border of a right-maximal node */
+static void node_borders(oflags* f, const onode* x, int K, int k_right) {
+    for (int j = 0; j < 4; ++j) {
+        /* child j (TERM,A,C,G) non-empty and its right border is not the node's end */
+        if (x->b[j + 1] > x->b[j] && x->b[j + 1] != x->b[5]) {
+            if ((int64_t)x->depth >= K) bit_set(f->thrK, x->b[j + 1]);
+            if ((int64_t)x->depth >= k_right) bit_set(f->thrR, x->b[j + 1]);
+            f->lcp_values++;
+        }
+    }
+}
+/* update_lcp_minima: ebwt2InDel.cpp:357-391 -- a minimum follows every A/C/G child of size >= 2 */
+static void node_minima(oflags* f, const onode* x) {
+    for (int j = 1; j <= 3; ++j) {
+        if (x->b[j + 1] - x->b[j] >= 2 && x->b[j + 1] < x->b[5] - 1) {
+            bit_set(f->minima, x->b[j + 1]);
+            f->n_min++;
+        }
+    }
+}
+
+/* navigate_one_bwt: ebwt2InDel.cpp:555-676 */
+oflags* orc_navigate_one(const oindex* x, int K, int k_right) {
+    oflags* f = flags_new(x->n, 0);
+    { /* phase 2: leaves (W TERM intervals), :577-615 */
+        leaf_stack S = {0};
+        oleaf first = {{0, x->F[0]}, 0}; /* first_leaf, dna_bwt.hpp:313-317 */
+        leaf_stack_push(&S, first);
+        while (S.n) {
+            oleaf L = S.a[--S.n];
+            f->leaves++;
+            if (S.n > f->max_stack) f->max_stack = S.n;
+            /* update_LCP_leaf :344-355 */
+            for (uint64_t i = L.rn.l + 1; i < L.rn.r; ++i) {
+                if ((int64_t)L.depth >= K) bit_set(f->thrK, i);
+                if ((int64_t)L.depth >= k_right) bit_set(f->thrR, i);
+                f->lcp_values++;
+            }
+            /* next_leaves dna_bwt.hpp:358-379: children of size >= 2, ascending by size */
+            prange_t e = LF_range(x, L.rn);
+            oleaf tmp[4];
+            int t = 0;
+            for (int c = 0; c < 4; ++c)
+                if (e.c[c].r - e.c[c].l >= 2) { tmp[t].rn = e.c[c]; tmp[t].depth = L.depth + 1; ++t; }
+#define LEAF_KEY(v) ((v).rn.r - (v).rn.l)
+            SORT_ASC(oleaf, tmp, t, LEAF_KEY)
+            for (int i = t - 1; i >= 0; --i) leaf_stack_push(&S, tmp[i]);
+        }
+        free(S.a);
+    }
+    { /* phase 3: right-maximal nodes via Weiner links, :622-673 */
+        node_stack S = {0};
+        onode root = {{0, x->F[0], x->F[1], x->F[2], x->F[3], x->n}, 0}; /* root(), dna_bwt.hpp:296-308 */
+        node_stack_push(&S, root);
+        uint64_t mx = 0;
+        while (S.n) {
+            if (S.n > mx) mx = S.n;
+            onode N = S.a[--S.n];
+            f->nodes++;
+            node_borders(f, &N, K, k_right);
+            node_minima(f, &N);
+            /* next_nodes dna_bwt.hpp:381-404 */
+            onode ch[4], tmp[4];
+            LF_node(x, &N, ch);
+            int t = 0;
+            for (int c = 0; c < 4; ++c)
+                if (node_children(&ch[c]) >= 2) tmp[t++] = ch[c];
+#define NODE_KEY(v) ((v).b[5] - (v).b[0])
+            SORT_ASC(onode, tmp, t, NODE_KEY)
+            for (int i = t - 1; i >= 0; --i) node_stack_push(&S, tmp[i]);
+        }
+        f->max_stack = mx;
+        free(S.a);
+    }
+    return f;
+}
+
+/* update_DA: ebwt2InDel.cpp:394-425 (with LCP) and :429-449 (DA only) */
+static void leaf_pair_da(oflags* f, const oleaf* L1, const oleaf* L2, int with_lcp, int K, int k_right) {
+    uint64_t s1 = L1->rn.l + L2->rn.l, s2 = L2->rn.l + L1->rn.r, e = L1->rn.r + L2->rn.r;
+    for (uint64_t i = s1; i < s2; ++i) f->da_values++;            /* DA[i] = 0 */
+    for (uint64_t i = s2; i < e; ++i) { bit_set(f->da, i); f->da_values++; }
+    if (with_lcp) {
+        for (uint64_t i = s1 + 1; i < e; ++i) {
+            if ((int64_t)L1->depth >= K) bit_set(f->thrK, i);
+            if ((int64_t)L1->depth >= k_right) bit_set(f->thrR, i);
+            f->lcp_values++;
+        }
+    }
+}
+
+/* navigate_two_bwts: ebwt2InDel.cpp:679-831 */
+oflags* orc_navigate_two(const oindex* x1, const oindex* x2, int K, int k_right) {
+    uint64_t n = x1->n + x2->n;
+    oflags* f = flags_new(n, 1);
+    { /* phase 2 :708-756 */
+        leaf2_stack S = {0};
+        oleaf2 first = {{{0, x1->F[0]}, 0}, {{0, x2->F[0]}, 0}};
+        leaf2_stack_push(&S, first);
+        while (S.n) {
+            oleaf2 L = S.a[--S.n];
+            f->leaves++;
+            if (S.n > f->max_stack) f->max_stack = S.n;
+            leaf_pair_da(f, &L.a, &L.b, 1, K, k_right);
+            /* next_leaves :452-472: keep children whose merged size >= 2 */
+            prange_t e1 = LF_range(x1, L.a.rn), e2 = LF_range(x2, L.b.rn);
+            oleaf2 tmp[4];
+            int t = 0;
+            for (int c = 0; c < 4; ++c)
+                if ((e1.c[c].r - e1.c[c].l) + (e2.c[c].r - e2.c[c].l) >= 2) {
+                    tmp[t].a.rn = e1.c[c]; tmp[t].a.depth = L.a.depth + 1;
+                    tmp[t].b.rn = e2.c[c]; tmp[t].b.depth = L.b.depth + 1;
+                    ++t;
+                }
+#define LEAF2_KEY(v) (((v).a.rn.r - (v).a.rn.l) + ((v).b.rn.r - (v).b.rn.l))
+            SORT_ASC(oleaf2, tmp, t, LEAF2_KEY)
+            for (int i = t - 1; i >= 0; --i) leaf2_stack_push(&S, tmp[i]);
+        }
+        free(S.a);
+    }
+    { /* phase 3 :764-823 */
+        node2_stack S = {0};
+        onode2 root = {{{0, x1->F[0], x1->F[1], x1->F[2], x1->F[3], x1->n}, 0}, {{0, x2->F[0], x2->F[1], x2->F[2], x2->F[3], x2->n}, 0}};
+        node2_stack_push(&S, root);
+        uint64_t mx = 0;
+        while (S.n) {
+            if (S.n > mx) mx = S.n;
+            onode2 N = S.a[--S.n];
+            f->nodes++;
+            onode M; /* merge_nodes include.hpp:476-490 */
+            for (int j = 0; j < 6; ++j) M.b[j] = N.a.b[j] + N.b.b[j];
+            M.depth = N.a.depth;
+            /* find_leaves :474-527: children of merged size exactly 1 were skipped in phase 2 */
+            for (int j = 0; j < 5; ++j) {
+                uint64_t s1 = N.a.b[j + 1] - N.a.b[j], s2 = N.b.b[j + 1] - N.b.b[j];
+                if (s1 + s2 == 1) {
+                    oleaf A = {{N.a.b[j], N.a.b[j + 1]}, 0}, B = {{N.b.b[j], N.b.b[j + 1]}, 0};
+                    leaf_pair_da(f, &A, &B, 0, K, k_right);
+                }
+            }
+            node_borders(f, &M, K, k_right);
+            node_minima(f, &M);
+            /* next_nodes :529-553: children of the union >= 2 (include.hpp:784-792) */
+            onode c1[4], c2[4];
+            LF_node(x1, &N.a, c1);
+            LF_node(x2, &N.b, c2);
+            onode2 tmp[4];
+            int t = 0;
+            for (int c = 0; c < 4; ++c) {
+                int k = 0;
+                for (int j = 0; j < 5; ++j) k += (c1[c].b[j + 1] > c1[c].b[j]) || (c2[c].b[j + 1] > c2[c].b[j]);
+                if (k >= 2) { tmp[t].a = c1[c]; tmp[t].b = c2[c]; ++t; }
+            }
+#define NODE2_KEY(v) (((v).a.b[5] - (v).a.b[0]) + ((v).b.b[5] - (v).b.b[0]))
+            SORT_ASC(onode2, tmp, t, NODE2_KEY)
+            for (int i = t - 1; i >= 0; --i) node2_stack_push(&S, tmp[i]);
+        }
+        f->max_stack = mx;
+        free(S.a);
+    }
+    return f;
+}
+
+/* mode 3 DA reader: ebwt2InDel.cpp:1503-1508 ('1' -> 1, anything else -> 0) */
+void orc_flags_set_da(oflags* f, const uint8_t* ascii01, uint64_t n) {
+    if (!f->da) f->da = (uint64_t*)calloc(f->words, 8);
+    else memset(f->da, 0, f->words * 8);
+    for (uint64_t i = 0; i < n && i < f->n; ++i)
+        if (ascii01[i] == '1') bit_set(f->da, i);
+}
+
+/* ------------------------------------------------------------------ per-cluster analysis */
+
+typedef struct { char* s; int len; int support; } octx; /* pair<string,int> of left_contexts */
+
+typedef struct {
+    const eb_params* p;
+    oflags* f;
+    const oindex *x1, *x2;
+    sbuf out;
+    uint64_t cluster_nr, id_nr, events;
+    /* optional record capture (same layout the HIP path emits) */
+    eb_cluster* recs; uint8_t* rec_left; uint8_t* rec_right; uint64_t nrecs, rec_cap;
+    int capture;
+    uint64_t n_clusters, clust_size, runs_closed, chains;
+    uint64_t hist[201];
+} orun;
+
+/* consensus_letter ebwt2InDel.cpp:243-261 + extract_consensus recursion :265-282:
+ * repeatedly extend by the symbol with the largest interval; ties keep A<C<G<T
+ * (stable descending sort); stop when every interval is empty. */
+static int extend_left(const oindex* x, range_t R, char* rev, int have, int want) {
+    while (have < want) {
+        prange_t pr = LF_range(x, R);
+        int best = 0;
+        uint64_t bl = pr.c[0].r - pr.c[0].l;
+        for (int c = 1; c < 4; ++c) {
+            uint64_t l = pr.c[c].r - pr.c[c].l;
+            if (l > bl) { bl = l; best = c; }
+        }
+        if (bl == 0) break;
+        rev[have++] = "ACGT"[best];
+        R = pr.c[best];
+    }
+    return have;
+}
+
+/* extract_consensus(bwt, range, c, left_contexts, len): ebwt2InDel.cpp:303-319.
+ * Returns chars obtained (context valid iff == k_left); *support = |LF(range,c)|. */
+static int left_context(const oindex* x, range_t range, uint8_t c, int k_left, char* out, int* support) {
+    char* rev = (char*)malloc((size_t)k_left + 1);
+    rev[0] = (char)c;
+    range_t R = LF_range_sym(x, range, c);
+    *support = (int)(R.r - R.l);
+    int have = extend_left(x, R, rev, 1, k_left);
+    for (int i = 0; i < have; ++i) out[i] = rev[have - 1 - i]; /* reverse :315 */
+    free(rev);
+    return have;
+}
+
+/* extract_dna: ebwt2InDel.cpp:325-342 */
+static int right_context(const oindex* x, uint64_t i, int len, char* out) {
+    int k = 0;
+    uint8_t c = F_sym(x, i);
+    while (c != x->term && len > 0) {
+        out[k++] = (char)c;
+        i = FL(x, i);
+        c = F_sym(x, i);
+        --len;
+    }
+    return k;
+}
+
+/* has_run: ebwt2InDel.cpp:144-152 */
+static int has_run(const char* s, int slen, int k) {
+    if (k > slen) return 0;
+    for (int i = 1; i < k; ++i) if (s[i] != s[i - 1]) return 0;
+    return 1;
+}
+/* dH: ebwt2InDel.cpp:157-171 -- right-aligned Hamming distance over the shorter length */
+static int dH(const char* a, int la, const char* b, int lb) {
+    int len = la < lb ? la : lb, d = 0;
+    for (int i = 0; i < len; ++i) d += a[la - i - 1] != b[lb - i - 1];
+    return d;
+}
+/* distance: ebwt2InDel.cpp:192-240 -> (mismatches outside the gap, signed gap length) */
+static void distance(const char* a, const char* b, int len, int max_gap, int* D, int* L) {
+    int none = dH(a, len, b, len);
+    if (max_gap == 0) { *D = none; *L = 0; return; }
+    int best_ab = 0, best_ba = 0, iab = 0, iba = 0;
+    for (int i = 1; i <= max_gap; ++i) {
+        int cut = len - i >= 0 ? len - i : len; /* substr(0, len-i) clamps to the whole string when i > len */
+        int dab = dH(a, cut, b, len) + i; /* drop i chars from the right of a */
+        int dba = dH(a, len, b, cut) + i;
+        if (i == 1 || dab < best_ab) { best_ab = dab; iab = i; } /* first minimum = shortest gap */
+        if (i == 1 || dba < best_ba) { best_ba = dba; iba = i; }
+    }
+    if (none < best_ab && none < best_ba) { *D = none; *L = 0; }
+    else if (best_ab < best_ba) { *D = best_ab - iab; *L = iab; }
+    else { *D = best_ba - iba; *L = -iba; }
+}
+/* event_type: ebwt2InDel.cpp:1102-1144 */
+static void event_type(sbuf* s, const char* a, const char* b, int len, int L) {
+    sb_puts(s, "type:");
+    if (L != 0) sb_puts(s, "_INDEL_event:"); else sb_puts(s, "_SNP_event:");
+    if (L == 0) { sb_put(s, a + len - 1, 1); sb_puts(s, "/"); sb_put(s, b + len - 1, 1); }
+    else if (L > 0) { sb_put(s, a + len - L, (size_t)L); sb_puts(s, "/"); }
+    else { sb_puts(s, "/"); sb_put(s, b + len + L, (size_t)(-L)); }
+}
+static void header(orun* r, int right_len, int cov) {
+    sb_puts(&r->out, ">cluster:"); sb_putu(&r->out, r->cluster_nr);
+    sb_puts(&r->out, "_id:"); sb_putu(&r->out, r->id_nr);
+    sb_puts(&r->out, "_right:"); sb_puti(&r->out, right_len);
+    sb_puts(&r->out, "_cov:"); sb_puti(&r->out, cov);
+    sb_puts(&r->out, "_");
+}
+
+/* to_file(vector<variant_single_t>): ebwt2InDel.cpp:1254-1330 */
+static void write_single(orun* r, octx* v, int nv, const char* right, int rlen) {
+    const eb_params* p = r->p;
+    if (nv < 2) return;
+    int max_dist = 0, ng = 0;
+    octx* good[EB_MAX_SLOTS];
+    for (int i = 0; i + 1 < nv; ++i) {
+        int D, L;
+        distance(v[i].s, v[i + 1].s, v[i].len, p->max_gap, &D, &L);
+        if (D > max_dist) max_dist = D;
+        if (v[i].support >= p->mcov_out) good[ng++] = &v[i];
+    }
+    if (v[nv - 1].support >= p->mcov_out) good[ng++] = &v[nv - 1];
+    if (max_dist <= p->max_snvs && ng >= 2) {
+        r->id_nr = 1;
+        for (int i = 0; i < ng; ++i) {
+            if (has_run(right, rlen, p->complexity)) continue;
+            header(r, rlen, good[i]->support);
+            r->id_nr++;
+            const char* a = i == 0 ? good[0]->s : good[i - 1]->s; /* :1299-1307 */
+            int D, L;
+            distance(a, good[1]->s, good[1]->len, p->max_gap, &D, &L);
+            event_type(&r->out, a, good[1]->s, good[1]->len, L);
+            sb_puts(&r->out, "\n");
+            sb_put(&r->out, good[i]->s, (size_t)good[i]->len);
+            sb_put(&r->out, right, (size_t)rlen);
+            sb_puts(&r->out, "\n");
+            r->events++;
+        }
+    }
+    r->cluster_nr++; /* unconditional, :1328 */
+}
+
+/* to_file(vector<variant_t>): ebwt2InDel.cpp:1149-1252 -- pairs (side-0 ctx, side-1 ctx) */
+static void write_pairs(orun* r, octx* c0, int n0, octx* c1, int n1, const char* right, int rlen) {
+    const eb_params* p = r->p;
+    int found = 0;
+    r->id_nr = 1;
+    for (int i = 0; i < n0; ++i)
+        for (int j = 0; j < n1; ++j) {
+            const octx *a = &c0[i], *b = &c1[j];
+            if (a->s[a->len - 1] == b->s[b->len - 1]) continue; /* find_variants :921,:1083 */
+            int D, L;
+            distance(a->s, b->s, a->len, p->max_gap, &D, &L);
+            if (has_run(right, rlen, p->complexity) || D > p->max_snvs || a->support < p->mcov_out || b->support < p->mcov_out) continue;
+            found = 1;
+            size_t mark;
+            header(r, rlen, a->support);
+            mark = r->out.len;
+            event_type(&r->out, a->s, b->s, a->len, L);
+            size_t tlen = r->out.len - mark;
+            char* type = (char*)malloc(tlen + 1);
+            memcpy(type, r->out.p + mark, tlen);
+            sb_puts(&r->out, "\n");
+            if (L < 0) sb_put(&r->out, a->s + (-L), (size_t)(a->len + L)); else sb_put(&r->out, a->s, (size_t)a->len); /* :1189-1201 */
+            sb_put(&r->out, right, (size_t)rlen);
+            sb_puts(&r->out, "\n");
+            header(r, rlen, b->support);
+            sb_put(&r->out, type, tlen);
+            free(type);
+            sb_puts(&r->out, "\n");
+            if (L > 0) sb_put(&r->out, b->s + L, (size_t)(b->len - L)); else sb_put(&r->out, b->s, (size_t)b->len); /* :1227-1239 */
+            sb_put(&r->out, right, (size_t)rlen);
+            sb_puts(&r->out, "\n");
+            r->id_nr++;
+        }
+    r->cluster_nr += (uint64_t)found; /* :1250 */
+}
+
+static eb_cluster* capture_new(orun* r, uint64_t begin, uint64_t end) {
+    if (!r->capture) return NULL;
+    if (r->nrecs == r->rec_cap) {
+        r->rec_cap = r->rec_cap ? r->rec_cap * 2 : 1024;
+        r->recs = (eb_cluster*)realloc(r->recs, r->rec_cap * sizeof(eb_cluster));
+        r->rec_left = (uint8_t*)realloc(r->rec_left, r->rec_cap * EB_MAX_SLOTS * (size_t)r->p->k_left);
+        r->rec_right = (uint8_t*)realloc(r->rec_right, r->rec_cap * (size_t)r->p->k_right);
+    }
+    eb_cluster* c = &r->recs[r->nrecs];
+    memset(c, 0, sizeof *c);
+    memset(r->rec_left + r->nrecs * EB_MAX_SLOTS * (size_t)r->p->k_left, 0, EB_MAX_SLOTS * (size_t)r->p->k_left);
+    memset(r->rec_right + r->nrecs * (size_t)r->p->k_right, 0, (size_t)r->p->k_right);
+    c->begin = begin;
+    c->end = end;
+    r->nrecs++;
+    return c;
+}
+
+/* One cluster.  mode 1: find_variants(bwt,range) ebwt2InDel.cpp:941-1005;
+ * mode 2: find_variants(bwt1,bwt2,range1,range2) :840-934; mode 3: find_variants(bwt,DA,range) :1013-1096.
+ * (b,e) merged range; (b0,e0),(b1,e1) per-BWT ranges in mode 2. */
+static void analyse_cluster(orun* r, int mode, uint64_t b, uint64_t e, uint64_t b0, uint64_t e0, uint64_t b1, uint64_t e1) {
+    const eb_params* p = r->p;
+    unsigned cnt[2][4] = {{0}};
+    /* histograms: base_to_int maps TERM to 0 = 'A' (include.hpp:275-289) */
+    if (mode == 1) {
+        for (uint64_t i = b; i < e; ++i) { int k = sym_code(access_sym(r->x1, i), r->x1->term); cnt[0][k > 3 ? 0 : k]++; }
+    } else if (mode == 2) {
+        for (uint64_t i = b0; i < e0; ++i) { int k = sym_code(access_sym(r->x1, i), r->x1->term); cnt[0][k > 3 ? 0 : k]++; }
+        for (uint64_t i = b1; i < e1; ++i) { int k = sym_code(access_sym(r->x2, i), r->x2->term); cnt[1][k > 3 ? 0 : k]++; }
+    } else {
+        for (uint64_t i = b; i < e; ++i) { int k = sym_code(access_sym(r->x1, i), r->x1->term); cnt[bit_get(r->f->da, i)][k > 3 ? 0 : k]++; }
+    }
+    uint8_t fr[2][4];
+    int nf[2] = {0, 0};
+    for (int c = 0; c < 4; ++c) {
+        if ((int64_t)cnt[0][c] >= p->mcov_out) fr[0][nf[0]++] = (uint8_t)"ACGT"[c];
+        if ((int64_t)cnt[1][c] >= p->mcov_out) fr[1][nf[1]++] = (uint8_t)"ACGT"[c];
+    }
+    int q = p->max_variants_per_position;
+    if (mode == 1) {
+        if (nf[0] < 2 || (q > 0 && nf[0] > q)) return; /* :961-966 */
+    } else {
+        if (nf[0] == 0 || nf[1] == 0 || (q > 0 && nf[0] > q) || (q > 0 && nf[1] > q)) return; /* :870-880, :1042-1052 */
+    }
+    eb_cluster* rec = capture_new(r, b, e);
+    uint8_t* rleft = rec ? r->rec_left + (r->nrecs - 1) * EB_MAX_SLOTS * (size_t)p->k_left : NULL;
+    uint8_t* rright = rec ? r->rec_right + (r->nrecs - 1) * (size_t)p->k_right : NULL;
+
+    octx ctx[2][4];
+    int nctx[2] = {0, 0};
+    char* store = (char*)malloc(8 * ((size_t)p->k_left + 1));
+    int slot = 0;
+    for (int side = 0; side < (mode == 1 ? 1 : 2); ++side) {
+        const oindex* x = (mode == 2 && side == 1) ? r->x2 : r->x1;
+        range_t rng;
+        if (mode == 2) { rng.l = side ? b1 : b0; rng.r = side ? e1 : e0; } else { rng.l = b; rng.r = e; }
+        for (int k = 0; k < nf[side]; ++k, ++slot) {
+            char* dst = store + (size_t)slot * ((size_t)p->k_left + 1);
+            int support = 0;
+            int len = left_context(x, rng, fr[side][k], p->k_left, dst, &support);
+            r->chains++;
+            if (rec) {
+                rec->slot_side[slot] = (uint8_t)side; rec->slot_sym[slot] = fr[side][k];
+                rec->slot_len[slot] = (uint32_t)len; rec->slot_support[slot] = (uint32_t)support;
+                memcpy(rleft + (size_t)slot * (size_t)p->k_left, dst, (size_t)len);
+            }
+            if (len == p->k_left) { /* :317 */
+                octx* c = &ctx[side][nctx[side]++];
+                c->s = dst; c->len = len; c->support = support;
+            }
+        }
+    }
+    if (rec) rec->n_slots = (uint32_t)slot;
+
+    /* right context at the first cluster position with LCP >= k_right (:979-988, :896-912, :1065-1074) */
+    char* right = (char*)malloc((size_t)p->k_right + 1);
+    int rlen = -1;
+    if (mode == 2) {
+        uint64_t i0 = b0, i1 = b1, i = b0 + b1;
+        while (i < e0 + e1 && !bit_get(r->f->thrR, i)) { int d = bit_get(r->f->da, i); i0 += !d; i1 += d; ++i; }
+        if (i < e0 + e1) { int d = bit_get(r->f->da, i); rlen = right_context(d ? r->x2 : r->x1, d ? i1 : i0, p->k_right, right); }
+    } else {
+        uint64_t i = b;
+        while (i < e && !bit_get(r->f->thrR, i)) ++i;
+        if (i < e) rlen = right_context(r->x1, i, p->k_right, right);
+    }
+    if (rec && rlen > 0) { rec->right_len = (uint32_t)rlen; memcpy(rright, right, (size_t)rlen); }
+    if (rlen >= 0) {
+        if (mode == 1) write_single(r, ctx[0], nctx[0], right, rlen);
+        else write_pairs(r, ctx[0], nctx[0], ctx[1], nctx[1], right, rlen);
+    } else if (mode != 1) {
+        r->id_nr = 1; /* to_file(pairs) still runs on an empty list (:1153) */
+    }
+    free(right);
+    free(store);
+}
+
+/* Phase-4 loops: run_one_dataset ebwt2InDel.cpp:1609-1655, run_two_datasets :1395-1445,
+ * run_two_datasets_da :1510-1560.  Clusters whose first position is in [sb,se) are analysed. */
+static void scan(orun* r, int mode, uint64_t sb, uint64_t se) {
+    const oflags* f = r->f;
+    uint64_t n = f->n, begin = 0, begin0 = 0, begin1 = 0, i0 = 0, i1 = 0, len = 0;
+    int open = 0;
+    uint64_t start = 0;
+    if (sb > 0) { /* shard entry: DA prefix counts and "is a run already open" */
+        start = sb;
+        if (mode == 2) for (uint64_t i = 0; i < sb; ++i) { int d = bit_get(f->da, i); i0 += !d; i1 += d; }
+        /* skip a run that began before the shard */
+        while (start < n && bit_get(f->thrK, start - 1) && !bit_get(f->minima, start - 1) && bit_get(f->thrK, start) && !bit_get(f->minima, start)) {
+            if (mode == 2) { int d = bit_get(f->da, start); i0 += !d; i1 += d; }
+            ++start;
+        }
+    }
+    for (uint64_t i = start; i < n; ++i) {
+        if (bit_get(f->thrK, i) && !bit_get(f->minima, i)) {
+            if (open) ++len;
+            else {
+                if (i >= se) break; /* next cluster belongs to the following shard */
+                open = 1; len = 1; begin = i; begin0 = i0; begin1 = i1;
+            }
+        } else {
+            if (open) {
+                r->clust_size += len;
+                r->runs_closed++;
+                if (len <= 200) r->hist[len] += len;
+                if ((int64_t)len >= 2 * (int64_t)r->p->mcov_out) {
+                    r->n_clusters++;
+                    analyse_cluster(r, mode, begin, i, begin0, i0, begin1, i1);
+                }
+            } else if (i >= se) break;
+            open = 0;
+            len = 0;
+        }
+        if (mode == 2) { int d = bit_get(f->da, i); i0 += !d; i1 += d; }
+    }
+}
+
+/* ------------------------------------------------------------------ public driver */
+
+typedef struct {
+    uint64_t n, leaves, nodes, lcp_values, da_values, minima;
+    uint64_t clusters, bases_in_runs, runs_closed, survivors, chains, events, cluster_nr;
+    double t_load, t_nav, t_scan;
+} orc_stats;
+
+/* Full pipeline on in-memory inputs; returns malloc'd .snp text (caller frees with orc_free). */
+char* orc_run_mem(const uint8_t* bwt1, uint64_t n1, const uint8_t* bwt2, uint64_t n2, const uint8_t* da, uint64_t nda,
+                  const eb_params* p, uint64_t* out_len, orc_stats* st) {
+    orc_stats s;
+    memset(&s, 0, sizeof s);
+    double t0 = now_s();
+    oindex* x1 = orc_index_from_buffer(bwt1, n1, (uint8_t)p->term);
+    oindex* x2 = bwt2 ? orc_index_from_buffer(bwt2, n2, (uint8_t)p->term) : NULL;
+    if (!orc_index_ok(x1) || (x2 && !orc_index_ok(x2))) { orc_index_free(x1); orc_index_free(x2); return NULL; }
+    double t1 = now_s();
+    int mode = x2 ? 2 : (da ? 3 : 1);
+    oflags* f = x2 ? orc_navigate_two(x1, x2, p->K, p->k_right) : orc_navigate_one(x1, p->K, p->k_right);
+    if (mode == 3) orc_flags_set_da(f, da, nda);
+    double t2 = now_s();
+    orun r;
+    memset(&r, 0, sizeof r);
+    r.p = p; r.f = f; r.x1 = x1; r.x2 = x2; r.cluster_nr = 1; r.id_nr = 1;
+    sb_put(&r.out, "", 0);
+    scan(&r, mode, 0, f->n);
+    double t3 = now_s();
+    s.n = f->n; s.leaves = f->leaves; s.nodes = f->nodes; s.lcp_values = f->lcp_values; s.da_values = f->da_values; s.minima = f->n_min;
+    s.clusters = r.n_clusters; s.bases_in_runs = r.clust_size; s.runs_closed = r.runs_closed; s.chains = r.chains;
+    s.events = r.events; s.cluster_nr = r.cluster_nr;
+    s.t_load = t1 - t0; s.t_nav = t2 - t1; s.t_scan = t3 - t2;
+    if (st) *st = s;
+    if (out_len) *out_len = r.out.len;
+    orc_flags_free(f);
+    orc_index_free(x1);
+    orc_index_free(x2);
+    return r.out.p;
+}
+
+void orc_free(void* p) { free(p); }
+
+/* Phase 4 only, on prebuilt index/flags, over clusters starting in [sb,se).
+ * Writes .snp text (continuing *cluster_nr) and, when recs_out != NULL, the cluster records
+ * in the product ABI's layout (used to test shard/gather/writer logic without a GPU). */
+char* orc_scan(const oindex* x1, const oindex* x2, oflags* f, const eb_params* p, uint64_t sb, uint64_t se,
+               uint64_t* cluster_nr, uint64_t* events, uint64_t* out_len,
+               eb_cluster** recs_out, uint8_t** left_out, uint8_t** right_out, uint64_t* nrecs, uint64_t* stats5) {
+    orun r;
+    memset(&r, 0, sizeof r);
+    r.p = p; r.f = f; r.x1 = x1; r.x2 = x2; r.cluster_nr = cluster_nr ? *cluster_nr : 1; r.id_nr = 1;
+    r.capture = recs_out != NULL;
+    sb_put(&r.out, "", 0);
+    int mode = x2 ? 2 : (f->da ? 3 : 1);
+    scan(&r, mode, sb, se);
+    if (cluster_nr) *cluster_nr = r.cluster_nr;
+    if (events) *events = r.events;
+    if (out_len) *out_len = r.out.len;
+    if (recs_out) { *recs_out = r.recs; *left_out = r.rec_left; *right_out = r.rec_right; *nrecs = r.nrecs; }
+    if (stats5) { stats5[0] = r.runs_closed; stats5[1] = r.n_clusters; stats5[2] = r.clust_size; stats5[3] = r.nrecs; stats5[4] = r.chains; }
+    return r.out.p;
+}
+
+/* bounded rank micro-benchmark for bench.py's cpu_baseline leg: m pseudo-random queries, returns seconds */
+double orc_rank_bench(const oindex* x, uint64_t m, uint64_t seed, uint64_t* checksum) {
+    uint64_t s = seed * 0x9E3779B97F4A7C15ull + 1, acc = 0;
+    double t0 = now_s();
+    for (uint64_t q = 0; q < m; ++q) {
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        rank4_t r = rank4(x, s % (x->n + 1));
+        acc += r.v[0] ^ r.v[3];
+    }
+    double t = now_s() - t0;
+    if (checksum) *checksum = acc;
+    return t;
+}
+
+#ifdef ORC_MAIN
+/* Stand-alone CLI (same flags as the reference, ebwt2InDel.cpp:1677-1823); used for differential runs. */
+#include <unistd.h>
+static uint8_t* slurp(const char* path, uint64_t* n) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return NULL;
+    fseek(f, 0, SEEK_END);
+    long long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    uint8_t* b = (uint8_t*)malloc(sz > 0 ? (size_t)sz : 1);
+    if (sz > 0 && fread(b, 1, (size_t)sz, f) != (size_t)sz) { fclose(f); free(b); return NULL; }
+    fclose(f);
+    *n = (uint64_t)sz;
+    return b;
+}
+int main(int argc, char** argv) {
+    eb_params p;
+    memset(&p, 0, sizeof p);
+    p.term = '#';
+    const char *in1 = NULL, *in2 = NULL, *inda = NULL, *out = NULL;
+    int opt;
+    while ((opt = getopt(argc, argv, "h1:2:v:L:R:m:g:k:t:o:d:c:q:")) != -1) {
+        switch (opt) {
+            case '1': in1 = optarg; break;
+            case '2': in2 = optarg; break;
+            case 'd': inda = optarg; break;
+            case 'o': out = optarg; break;
+            case 'm': p.mcov_out = atoi(optarg); break;
+            case 'k': p.K = atoi(optarg); break;
+            case 'g': p.max_gap = atoi(optarg); break;
+            case 'L': p.k_left = atoi(optarg); break;
+            case 'R': p.k_right = atoi(optarg); break;
+            case 'v': p.max_snvs = atoi(optarg); break;
+            case 't': p.term = atoi(optarg); break;
+            case 'c': p.complexity = atoi(optarg); break;
+            case 'q': p.max_variants_per_position = atoi(optarg); break;
+            default: fprintf(stderr, "usage: -1 in.ebwt [-2 in2.ebwt | -d da] -o out.snp [options]\n"); return 2;
+        }
+    }
+    /* 0 -> default, ebwt2InDel.cpp:1740-1746 */
+    if (!p.complexity) p.complexity = 20;
+    if (!p.K) p.K = 16;
+    if (!p.max_gap) p.max_gap = 10;
+    if (!p.k_left) p.k_left = 31;
+    if (!p.k_right) p.k_right = 30;
+    if (!p.max_snvs) p.max_snvs = 2;
+    if (!p.mcov_out) p.mcov_out = 3;
+    if (!in1 || !out) { fprintf(stderr, "need -1 and -o\n"); return 2; }
+    uint64_t n1 = 0, n2 = 0, nd = 0, olen = 0;
+    uint8_t *b1 = slurp(in1, &n1), *b2 = in2 ? slurp(in2, &n2) : NULL, *d = inda ? slurp(inda, &nd) : NULL;
+    if (!b1 || (in2 && !b2) || (inda && !d)) { fprintf(stderr, "cannot read input\n"); return 1; }
+    orc_stats st;
+    char* txt = orc_run_mem(b1, n1, b2, n2, d, nd, &p, &olen, &st);
+    if (!txt) { fprintf(stderr, "forbidden character in input\n"); return 1; }
+    FILE* f = fopen(out, "wb");
+    fwrite(txt, 1, olen, f);
+    fclose(f);
+    printf("n=%llu leaves=%llu nodes=%llu minima=%llu clusters=%llu events=%llu load=%.3fs nav=%.3fs scan=%.3fs\n",
+           (unsigned long long)st.n, (unsigned long long)st.leaves, (unsigned long long)st.nodes, (unsigned long long)st.minima,
+           (unsigned long long)st.clusters, (unsigned long long)st.events, st.t_load, st.t_nav, st.t_scan);
+    return 0;
+}
+#endif

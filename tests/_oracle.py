@@ -1,0 +1,245 @@
+"""ctypes binding of oracle/_build/liboracle.so -- the CPU restatement used as the checker.
+
+TEST INFRASTRUCTURE: imported only from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Builds the library with gcc on first use (no GPU needed).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORC_DIR = os.path.join(ROOT, "oracle")
+ORC_SO = os.path.join(ORC_DIR, "_build", "liboracle.so")
+REF_BIN = os.path.join(ORC_DIR, "_ref", "ebwt2InDel_ref")
+
+
+class Params(C.Structure):
+    """Mirror of eb_params (include/ebwt2indel.h)."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "k_left", "k_right", "K", "max_gap", "max_snvs", "mcov_out", "complexity",
+        "max_variants_per_position", "term")]
+
+    DEFAULTS = dict(k_left=31, k_right=30, K=16, max_gap=10, max_snvs=2, mcov_out=3, complexity=20,
+                    max_variants_per_position=0, term=35)
+
+    @classmethod
+    def from_args(cls, args=(), **kw):
+        """Parse reference-style CLI options (-L -R -k -g -v -m -c -q -t); 0 means default."""
+        opt = {"-L": "k_left", "-R": "k_right", "-k": "K", "-g": "max_gap", "-v": "max_snvs", "-m": "mcov_out",
+               "-c": "complexity", "-q": "max_variants_per_position", "-t": "term"}
+        vals = dict(cls.DEFAULTS)
+        it = iter(args)
+        for a in it:
+            v = int(next(it))
+            name = opt[a]
+            if name in ("max_variants_per_position", "term"):
+                vals[name] = v
+            elif v != 0:
+                vals[name] = v
+        vals.update(kw)
+        return cls(**vals)
+
+
+class Cluster(C.Structure):
+    """Mirror of eb_cluster (include/ebwt2indel.h)."""
+    _fields_ = [("begin", C.c_uint64), ("end", C.c_uint64), ("n_slots", C.c_uint32), ("right_len", C.c_uint32),
+                ("slot_side", C.c_uint8 * 8), ("slot_sym", C.c_uint8 * 8), ("slot_len", C.c_uint32 * 8),
+                ("slot_support", C.c_uint32 * 8)]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("n", "leaves", "nodes", "lcp_values", "da_values", "minima", "clusters",
+                                          "bases_in_runs", "runs_closed", "survivors", "chains", "events", "cluster_nr")] + \
+               [(n, C.c_double) for n in ("t_load", "t_nav", "t_scan")]
+
+
+def build_oracle(force=False):
+    src = os.path.join(ORC_DIR, "ebwt_oracle.c")
+    if force or not os.path.exists(ORC_SO) or os.path.getmtime(ORC_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", ORC_DIR, "_build/liboracle.so"], stdout=subprocess.DEVNULL)
+    return ORC_SO
+
+
+def _u8(a):
+    return np.ascontiguousarray(np.frombuffer(a, dtype=np.uint8) if isinstance(a, (bytes, bytearray)) else a, dtype=np.uint8)
+
+
+class Oracle:
+    def __init__(self):
+        self.lib = L = C.CDLL(build_oracle())
+        vp, u64, u8 = C.c_void_p, C.c_uint64, C.c_uint8
+        L.orc_index_from_buffer.restype = vp
+        L.orc_index_from_buffer.argtypes = [vp, u64, u8]
+        L.orc_index_free.argtypes = [vp]
+        L.orc_index_ok.argtypes = [vp]
+        L.orc_index_size.restype = u64
+        L.orc_index_size.argtypes = [vp]
+        L.orc_index_F.argtypes = [vp, vp]
+        L.orc_index_bad.argtypes = [vp, vp, vp]
+        for f in ("orc_rank4_batch", "orc_access_batch", "orc_lf_range_batch", "orc_fl_batch", "orc_lf_node_batch"):
+            getattr(L, f).argtypes = [vp, vp, u64, vp]
+        L.orc_lf_range_sym_batch.argtypes = [vp, vp, vp, u64, vp]
+        L.orc_navigate_one.restype = vp
+        L.orc_navigate_one.argtypes = [vp, C.c_int, C.c_int]
+        L.orc_navigate_two.restype = vp
+        L.orc_navigate_two.argtypes = [vp, vp, C.c_int, C.c_int]
+        L.orc_flags_set_da.argtypes = [vp, vp, u64]
+        L.orc_flags_words.restype = u64
+        L.orc_flags_words.argtypes = [vp]
+        L.orc_flags_export.argtypes = [vp, vp, vp, vp, vp]
+        L.orc_flags_counters.argtypes = [vp, vp]
+        L.orc_flags_free.argtypes = [vp]
+        L.orc_run_mem.restype = vp
+        L.orc_run_mem.argtypes = [vp, u64, vp, u64, vp, u64, C.POINTER(Params), C.POINTER(u64), C.POINTER(Stats)]
+        L.orc_scan.restype = vp
+        L.orc_scan.argtypes = [vp, vp, vp, C.POINTER(Params), u64, u64, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64),
+                               C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(u64), vp]
+        L.orc_free.argtypes = [vp]
+        L.orc_rank_bench.restype = C.c_double
+        L.orc_rank_bench.argtypes = [vp, u64, u64, C.POINTER(u64)]
+
+    # ---- whole pipeline
+    def run(self, bwt1, bwt2=None, da=None, params=None):
+        """Returns (.snp bytes, Stats).  Raises ValueError on a forbidden input symbol."""
+        p = params or Params.from_args()
+        b1 = _u8(bwt1)
+        b2 = _u8(bwt2) if bwt2 is not None else None
+        d = _u8(da) if da is not None else None
+        n = C.c_uint64(0)
+        st = Stats()
+        ptr = self.lib.orc_run_mem(b1.ctypes.data, len(b1), b2.ctypes.data if b2 is not None else None,
+                                   len(b2) if b2 is not None else 0, d.ctypes.data if d is not None else None,
+                                   len(d) if d is not None else 0, C.byref(p), C.byref(n), C.byref(st))
+        if not ptr:
+            raise ValueError("forbidden character in input")
+        out = C.string_at(ptr, n.value)
+        self.lib.orc_free(ptr)
+        return out, st
+
+    # ---- index + primitives
+    def index(self, ascii_bwt, term=35):
+        return OracleIndex(self, ascii_bwt, term)
+
+
+class OracleIndex:
+    def __init__(self, orc, ascii_bwt, term=35):
+        self.o = orc
+        self.buf = _u8(ascii_bwt)
+        self.h = orc.lib.orc_index_from_buffer(self.buf.ctypes.data, len(self.buf), term)
+        self.ok = bool(orc.lib.orc_index_ok(self.h))
+        self.n = len(self.buf)
+        self.term = term
+
+    def __del__(self):
+        try:
+            self.o.lib.orc_index_free(self.h)
+        except Exception:
+            pass
+
+    def bad(self):
+        s, p = C.c_uint8(0), C.c_uint64(0)
+        self.o.lib.orc_index_bad(self.h, C.byref(s), C.byref(p))
+        return s.value, p.value
+
+    def F(self):
+        f = np.zeros(4, dtype=np.uint64)
+        self.o.lib.orc_index_F(self.h, f.ctypes.data)
+        return f
+
+    def rank4(self, pos):
+        pos = np.ascontiguousarray(pos, dtype=np.uint64)
+        out = np.zeros((len(pos), 4), dtype=np.uint64)
+        self.o.lib.orc_rank4_batch(self.h, pos.ctypes.data, len(pos), out.ctypes.data)
+        return out
+
+    def access(self, pos):
+        pos = np.ascontiguousarray(pos, dtype=np.uint64)
+        out = np.zeros(len(pos), dtype=np.uint8)
+        self.o.lib.orc_access_batch(self.h, pos.ctypes.data, len(pos), out.ctypes.data)
+        return out
+
+    def lf_range(self, lr):
+        lr = np.ascontiguousarray(lr, dtype=np.uint64).reshape(-1, 2)
+        out = np.zeros((len(lr), 8), dtype=np.uint64)
+        self.o.lib.orc_lf_range_batch(self.h, lr.ctypes.data, len(lr), out.ctypes.data)
+        return out
+
+    def lf_range_sym(self, lr, sym):
+        lr = np.ascontiguousarray(lr, dtype=np.uint64).reshape(-1, 2)
+        sym = np.ascontiguousarray(sym, dtype=np.uint8)
+        out = np.zeros((len(lr), 2), dtype=np.uint64)
+        self.o.lib.orc_lf_range_sym_batch(self.h, lr.ctypes.data, sym.ctypes.data, len(lr), out.ctypes.data)
+        return out
+
+    def fl(self, pos):
+        pos = np.ascontiguousarray(pos, dtype=np.uint64)
+        out = np.zeros(len(pos), dtype=np.uint64)
+        self.o.lib.orc_fl_batch(self.h, pos.ctypes.data, len(pos), out.ctypes.data)
+        return out
+
+    def lf_node(self, nodes7):
+        nodes7 = np.ascontiguousarray(nodes7, dtype=np.uint64).reshape(-1, 7)
+        out = np.zeros((len(nodes7), 28), dtype=np.uint64)
+        self.o.lib.orc_lf_node_batch(self.h, nodes7.ctypes.data, len(nodes7), out.ctypes.data)
+        return out
+
+
+class OracleFlags:
+    """Phases 2-3 on the CPU oracle: bitvectors as uint64 word arrays."""
+
+    def __init__(self, orc, idx1, idx2=None, K=16, k_right=30, da=None):
+        self.o = orc
+        self.idx1, self.idx2 = idx1, idx2
+        L = orc.lib
+        self.h = L.orc_navigate_two(idx1.h, idx2.h, K, k_right) if idx2 is not None else L.orc_navigate_one(idx1.h, K, k_right)
+        if da is not None:
+            d = _u8(da)
+            L.orc_flags_set_da(self.h, d.ctypes.data, len(d))
+        self.words = L.orc_flags_words(self.h)
+        self.has_da = idx2 is not None or da is not None
+
+    def __del__(self):
+        try:
+            self.o.lib.orc_flags_free(self.h)
+        except Exception:
+            pass
+
+    def export(self):
+        w = self.words
+        thrK, thrR, mn = (np.zeros(w, dtype=np.uint64) for _ in range(3))
+        da = np.zeros(w, dtype=np.uint64) if self.has_da else None
+        self.o.lib.orc_flags_export(self.h, thrK.ctypes.data, thrR.ctypes.data, mn.ctypes.data,
+                                    da.ctypes.data if da is not None else None)
+        return thrK, thrR, mn, da
+
+    def counters(self):
+        c = np.zeros(6, dtype=np.uint64)
+        self.o.lib.orc_flags_counters(self.h, c.ctypes.data)
+        return dict(zip(("leaves", "nodes", "lcp_values", "da_values", "minima", "max_stack"), (int(x) for x in c)))
+
+    def scan(self, params, begin, end, cluster_nr=1, capture=False):
+        """Phase 4 over clusters starting in [begin,end).  Returns dict(text, cluster_nr, events, stats[, clusters, left, right])."""
+        L = self.o.lib
+        cn, ev, ln = C.c_uint64(cluster_nr), C.c_uint64(0), C.c_uint64(0)
+        recs, left, right, nrec = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64(0)
+        st = np.zeros(5, dtype=np.uint64)
+        ptr = L.orc_scan(self.idx1.h, self.idx2.h if self.idx2 is not None else None, self.h, C.byref(params), begin, end,
+                         C.byref(cn), C.byref(ev), C.byref(ln),
+                         C.byref(recs) if capture else None, C.byref(left) if capture else None,
+                         C.byref(right) if capture else None, C.byref(nrec) if capture else None, st.ctypes.data)
+        text = C.string_at(ptr, ln.value)
+        L.orc_free(ptr)
+        out = dict(text=text, cluster_nr=cn.value, events=ev.value,
+                   stats=dict(zip(("runs_closed", "clusters", "bases_in_runs", "survivors", "chains"), (int(x) for x in st))))
+        if capture:
+            k = nrec.value
+            out["clusters"] = np.frombuffer(C.string_at(recs, k * C.sizeof(Cluster)), dtype=np.uint8).copy() if k else np.zeros(0, np.uint8)
+            out["left"] = np.frombuffer(C.string_at(left, k * 8 * params.k_left), dtype=np.uint8).copy() if k else np.zeros(0, np.uint8)
+            out["right"] = np.frombuffer(C.string_at(right, k * params.k_right), dtype=np.uint8).copy() if k else np.zeros(0, np.uint8)
+            out["count"] = k
+            for p_ in (recs, left, right):
+                if p_.value:
+                    L.orc_free(p_)
+        return out

@@ -1,0 +1,57 @@
+"""Differential runs: CPU oracle vs the reference binary itself on fresh seeded inputs.
+Runs only where oracle/_ref/ebwt2InDel_ref exists (the build container); the GPU box has
+no reference, there the committed golden fixtures pin the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from ebwt2indel_amd import sim
+from tests import _oracle
+
+pytestmark = pytest.mark.skipif(not os.path.exists(_oracle.REF_BIN), reason="reference binary not built here")
+
+
+def _ref(tmp_path, args):
+    out = tmp_path / "ref.snp"
+    rc = subprocess.run([_oracle.REF_BIN] + args + ["-o", str(out)], stdout=subprocess.DEVNULL).returncode
+    return out.read_bytes(), rc
+
+
+@pytest.mark.parametrize("seed,extra", [(101, []), (102, ["-m", "4", "-k", "18"]), (103, ["-L", "36", "-R", "28", "-g", "4", "-q", "2"])])
+def test_mode1_fresh(oracle, tmp_path, seed, extra):
+    reads, _, _ = sim.diploid_sample(20000, 5000, 90, seed=seed, snp_every=350, indel_every=900)
+    e = sim.build_ebwt(reads)
+    (tmp_path / "x.ebwt").write_bytes(e.tobytes())
+    want, rc = _ref(tmp_path, ["-1", str(tmp_path / "x.ebwt")] + extra)
+    got, _ = oracle.run(e, params=_oracle.Params.from_args(extra))
+    assert rc == 0 and want.count(b">") > 20
+    assert got == want
+
+
+@pytest.mark.parametrize("seed,het,extra", [(201, False, []), (202, True, []), (203, True, ["-m", "2", "-v", "3", "-c", "3"])])
+def test_modes23_fresh(oracle, tmp_path, seed, het, extra):
+    r0, r1 = sim.two_samples(15000, 3500, 80, seed=seed, het_second=het, snp_every=250, indel_every=700)
+    a, b = sim.build_ebwt(r0), sim.build_ebwt(r1)
+    m, da = sim.build_merged_ebwt(r0, r1)
+    for name, x in (("a", a), ("b", b), ("m", m), ("da", da)):
+        (tmp_path / name).write_bytes(x.tobytes())
+    p = _oracle.Params.from_args(extra)
+    want2, rc2 = _ref(tmp_path, ["-1", str(tmp_path / "a"), "-2", str(tmp_path / "b")] + extra)
+    got2, _ = oracle.run(a, bwt2=b, params=p)
+    assert rc2 == 0 and got2 == want2 and want2.count(b">") > 10
+    want3, rc3 = _ref(tmp_path, ["-1", str(tmp_path / "m"), "-d", str(tmp_path / "da")] + extra)
+    got3, _ = oracle.run(m, da=da, params=p)
+    assert rc3 == 0 and got3 == want3
+    if not het:
+        assert want2 == want3      # restricted equivalence of modes 2 and 3
+
+
+def test_merged_bwt_consistency():
+    """The merged eBWT restricted to DA==0 / DA==1 equals the two single-collection eBWTs."""
+    r0, r1 = sim.two_samples(3000, 400, 60, seed=5)
+    a, b = sim.build_ebwt(r0), sim.build_ebwt(r1)
+    m, da = sim.build_merged_ebwt(r0, r1)
+    assert np.array_equal(m[da == ord("0")], a)
+    assert np.array_equal(m[da == ord("1")], b)
