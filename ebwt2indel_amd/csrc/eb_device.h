@@ -1,0 +1,149 @@
+// eb_device.h -- device-side data layout and the rank primitive (gfx950 / wave64).
+//
+// HBM layout of the packed BWT (replaces dna_string's block, dna_string.hpp:19-41,554-585):
+//   one 64-byte block per 128 symbols, made of four 16-byte chunks; chunk j holds
+//     .x/.y/.z = code bit 0 / 1 / 2 of symbols 32j..32j+31 (symbol 32j+k at bit k),
+//     .w      = number of symbol j (A,C,G,T for j=0..3) before this block inside its
+//               2^32-symbol superblock.
+//   Codes: A=0 C=1 G=2 T=3 TERM=4 (3 bits/char).  A query needs exactly one block:
+//   four adjacent lanes each load one chunk (one 64-byte coalesced segment per query),
+//   popcount their 32 symbols for all four letters, and combine with two lane swaps.
+//   Absolute counts at superblock starts (<= 36 entries for 151 G symbols) sit in a
+//   small table that stays cache resident.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define EB_BLOCK_SYMS 128u
+#define EB_SUPER_SHIFT 32 /* 2^32 symbols per superblock (dna_string.hpp:36) */
+
+struct eb_dev_index {
+    const uint4* chunks;    // 4 * n_blocks chunks
+    const uint64_t* super;  // 4 * n_super absolute counts (A,C,G,T)
+    uint64_t n;             // symbols
+    uint64_t n_blocks;      // ceil((n+1)/128)
+    uint64_t F[4];          // F_A,F_C,F_G,F_T
+    uint32_t term;          // ASCII terminator
+};
+
+struct eb_dev_flags {
+    uint64_t* thrK;   // LCP[i] >= K
+    uint64_t* thrR;   // LCP[i] >= k_right
+    uint64_t* minima; // local LCP minimum
+    uint64_t* da;     // document array (may be null)
+    const uint64_t* da_rank; // ones before each group of 8 words (two-BWT mode), may be null
+    uint64_t n;
+    uint64_t words;   // ceil(n/64)
+};
+
+struct rank4_t {
+    uint64_t v[4];
+};
+
+__device__ __forceinline__ uint32_t eb_prefix_mask32(uint32_t o, uint32_t j) {
+    // mask of the symbols of chunk j that lie before in-block offset o (0..127)
+    uint32_t w = o >> 5;
+    return j < w ? 0xFFFFFFFFu : (j == w ? ((1u << (o & 31u)) - 1u) : 0u);
+}
+
+// Packed per-letter popcounts (A | C<<8 | G<<16 | T<<24) of the symbols selected by `mask`.
+__device__ __forceinline__ uint32_t eb_chunk_counts(uint4 c, uint32_t mask) {
+    uint32_t d = ~c.z & mask;
+    uint32_t lo = d & ~c.y, hi = d & c.y;
+    return (uint32_t)__popc(lo & ~c.x) | ((uint32_t)__popc(lo & c.x) << 8) | ((uint32_t)__popc(hi & ~c.x) << 16) |
+           ((uint32_t)__popc(hi & c.x) << 24);
+}
+
+// parallel_rank (dna_string.hpp:140-152) by ONE lane: loads the whole 64-byte block.
+__device__ __forceinline__ rank4_t eb_rank4(const eb_dev_index& x, uint64_t i) {
+    const uint4* b = x.chunks + ((i >> 7) << 2);
+    const uint64_t* s = x.super + ((i >> EB_SUPER_SHIFT) << 2);
+    uint32_t o = (uint32_t)(i & 127u);
+    uint4 c0 = b[0], c1 = b[1], c2 = b[2], c3 = b[3];
+    uint32_t p = eb_chunk_counts(c0, eb_prefix_mask32(o, 0)) + eb_chunk_counts(c1, eb_prefix_mask32(o, 1)) +
+                 eb_chunk_counts(c2, eb_prefix_mask32(o, 2)) + eb_chunk_counts(c3, eb_prefix_mask32(o, 3));
+    rank4_t r;
+    r.v[0] = s[0] + c0.w + (p & 0xFFu);
+    r.v[1] = s[1] + c1.w + ((p >> 8) & 0xFFu);
+    r.v[2] = s[2] + c2.w + ((p >> 16) & 0xFFu);
+    r.v[3] = s[3] + c3.w + (p >> 24);
+    return r;
+}
+
+// parallel_rank by FOUR adjacent lanes (lane&3 = j): each loads chunk j; returns the rank of letter j.
+// All four lanes of the quad must be active and pass the same i.
+__device__ __forceinline__ uint64_t eb_rank4_quad(const eb_dev_index& x, uint64_t i, uint32_t j) {
+    uint4 c = x.chunks[((i >> 7) << 2) + j];
+    uint32_t p = eb_chunk_counts(c, eb_prefix_mask32((uint32_t)(i & 127u), j));
+    p += (uint32_t)__shfl_xor((int)p, 1);
+    p += (uint32_t)__shfl_xor((int)p, 2);
+    return x.super[((i >> EB_SUPER_SHIFT) << 2) + j] + c.w + ((p >> (8u * j)) & 0xFFu);
+}
+
+// operator[] (dna_string.hpp:113-135): 3-bit code of symbol i.
+__device__ __forceinline__ uint32_t eb_code(const eb_dev_index& x, uint64_t i) {
+    uint4 c = x.chunks[i >> 5];
+    uint32_t k = (uint32_t)(i & 31u);
+    return ((c.x >> k) & 1u) | (((c.y >> k) & 1u) << 1) | (((c.z >> k) & 1u) << 2);
+}
+
+__device__ __forceinline__ uint32_t eb_code_to_ascii(uint32_t code, uint32_t term) {
+    return code == 0 ? 'A' : code == 1 ? 'C' : code == 2 ? 'G' : code == 3 ? 'T' : term;
+}
+
+// F(i) (dna_bwt.hpp:100-110) as a letter index: -1 for a TERM row.
+__device__ __forceinline__ int eb_F_letter(const eb_dev_index& x, uint64_t i) {
+    return i < x.F[0] ? -1 : i < x.F[1] ? 0 : i < x.F[2] ? 1 : i < x.F[3] ? 2 : 3;
+}
+
+// Absolute count of letter c before block b.
+__device__ __forceinline__ uint64_t eb_block_count(const eb_dev_index& x, uint64_t b, int c) {
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(x.chunks + (b << 2) + c);
+    return x.super[((b >> 25) << 2) + c] + w[3];
+}
+
+// select (dna_string.hpp:182-188,254-272): position of the r-th (0-based) letter c.  The reference
+// bisects [0,n) with full rank queries; here the bisection runs on the per-block counters and the
+// last step is an in-block select -- same unique answer, one 4-byte probe per step.
+__device__ __forceinline__ uint64_t eb_select(const eb_dev_index& x, uint64_t r, int c) {
+    uint64_t lo = 0, hi = x.n_blocks; // invariant: count(lo) <= r, and (hi == n_blocks or count(hi) > r)
+    while (hi - lo > 1) {
+        uint64_t mid = (lo + hi) >> 1;
+        if (eb_block_count(x, mid, c) > r) hi = mid; else lo = mid;
+    }
+    uint32_t need = (uint32_t)(r - eb_block_count(x, lo, c)); // occurrences to skip inside block lo
+    const uint4* b = x.chunks + (lo << 2);
+    uint32_t off = 0;
+    for (uint32_t j = 0; j < 4; ++j) {
+        uint4 ch = b[j];
+        uint32_t m = ~ch.z & ((c & 2) ? ch.y : ~ch.y) & ((c & 1) ? ch.x : ~ch.x);
+        uint32_t k = (uint32_t)__popc(m);
+        if (need < k) {
+            for (uint32_t t = 0; t < need; ++t) m &= m - 1; // drop the `need` lowest set bits
+            off = j * 32u + (uint32_t)__ffs((int)m) - 1u;
+            break;
+        }
+        need -= k;
+    }
+    return (lo << 7) + off;
+}
+
+// FL(i) (dna_bwt.hpp:115-133); i must not be a TERM row.
+__device__ __forceinline__ uint64_t eb_FL(const eb_dev_index& x, uint64_t i, int letter) {
+    return eb_select(x, i - x.F[letter], letter);
+}
+
+__device__ __forceinline__ bool eb_bit(const uint64_t* b, uint64_t i) { return (b[i >> 6] >> (i & 63u)) & 1ull; }
+__device__ __forceinline__ void eb_bit_set_atomic(uint64_t* b, uint64_t i) {
+    atomicOr(reinterpret_cast<unsigned long long*>(b + (i >> 6)), 1ull << (i & 63u));
+}
+// set bits [lo,hi) (hi > lo) with one atomic per touched word
+__device__ __forceinline__ void eb_bits_fill_atomic(uint64_t* b, uint64_t lo, uint64_t hi) {
+    uint64_t w0 = lo >> 6, w1 = (hi - 1) >> 6;
+    for (uint64_t w = w0; w <= w1; ++w) {
+        uint64_t m = ~0ull;
+        if (w == w0) m &= ~0ull << (lo & 63u);
+        if (w == w1) m &= ~0ull >> (63u - ((hi - 1) & 63u));
+        atomicOr(reinterpret_cast<unsigned long long*>(b + w), m);
+    }
+}

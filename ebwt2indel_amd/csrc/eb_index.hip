@@ -1,0 +1,338 @@
+// eb_index.hip -- phase 1 on the GPU: ASCII eBWT -> packed 3-bit planes + rank counters + F array.
+// Replaces dna_string(path,TERM) (dna_string.hpp:55-110: read/validate/pack; :275-315: counters)
+// and the F-array loop of dna_bwt(path,TERM) (dna_bwt.hpp:36-62).
+#include <fcntl.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include "eb_internal.h"
+
+// ------------------------------------------------------------------ errors / params
+
+static thread_local char g_err[512] = "";
+static thread_local uint8_t g_bad_sym = 0;
+static thread_local uint64_t g_bad_pos = 0;
+
+void eb_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* eb_last_error(void) { return g_err; }
+
+extern "C" int eb_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" void eb_params_init(eb_params* p) {
+    memset(p, 0, sizeof *p);
+    p->term = '#';
+    eb_params_resolve(p);
+}
+
+// 0 means "use the default" (ebwt2InDel.cpp:1740-1746); -q and -t are taken as given.
+extern "C" void eb_params_resolve(eb_params* p) {
+    if (p->complexity == 0) p->complexity = 20; // complexity_def is frozen at 30-10 (ebwt2InDel.cpp:64)
+    if (p->K == 0) p->K = 16;
+    if (p->max_gap == 0) p->max_gap = 10;
+    if (p->k_left == 0) p->k_left = 31;
+    if (p->k_right == 0) p->k_right = 30;
+    if (p->max_snvs == 0) p->max_snvs = 2;
+    if (p->mcov_out == 0) p->mcov_out = 3;
+}
+
+extern "C" void eb_index_bad_symbol(uint8_t* symbol, uint64_t* position) {
+    if (symbol) *symbol = g_bad_sym;
+    if (position) *position = g_bad_pos;
+}
+
+// ------------------------------------------------------------------ kernels
+
+// One thread packs 32 symbols into one chunk (planes only; counter filled later).
+// Positions >= n_total are padding: code bit 2 set, so they never count as A,C,G,T.
+__global__ void __launch_bounds__(256) k_pack(const uint8_t* __restrict__ ascii, uint64_t piece_pos, uint64_t piece_len,
+                                              uint64_t first_chunk, uint64_t n_chunks, uint32_t term, int aligned16,
+                                              uint4* __restrict__ chunks, unsigned long long* __restrict__ bad_pos) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_chunks) return;
+    uint64_t off = t * 32; // offset inside the piece
+    uint8_t s[32];
+    if (off + 32 <= piece_len && aligned16) {
+        const uint4* p = reinterpret_cast<const uint4*>(ascii + off);
+        *reinterpret_cast<uint4*>(s) = p[0];
+        *reinterpret_cast<uint4*>(s + 16) = p[1];
+    } else {
+        for (int k = 0; k < 32; ++k) s[k] = off + k < piece_len ? ascii[off + k] : 0;
+    }
+    uint32_t p0 = 0, p1 = 0, p2 = 0;
+    for (int k = 0; k < 32; ++k) {
+        uint32_t code;
+        if (off + k >= piece_len) {
+            code = 4; // padding behind the last symbol
+        } else {
+            uint32_t c = s[k];
+            code = c == term ? 4u : c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 8u;
+            if (code == 8u) {
+                atomicMin(bad_pos, (unsigned long long)(piece_pos + off + k));
+                code = 4;
+            }
+        }
+        p0 |= (code & 1u) << k;
+        p1 |= ((code >> 1) & 1u) << k;
+        p2 |= ((code >> 2) & 1u) << k;
+    }
+    chunks[first_chunk + t] = make_uint4(p0, p1, p2, 0u);
+}
+
+__device__ __forceinline__ uint32_t block_letter_counts(const uint4* b) {
+    return eb_chunk_counts(b[0], ~0u) + eb_chunk_counts(b[1], ~0u) + eb_chunk_counts(b[2], ~0u) + eb_chunk_counts(b[3], ~0u);
+}
+
+#define TILE_BLOCKS 256 /* BWT blocks per workgroup tile; divides 2^25 so superblocks start on tile borders */
+
+// Per tile: sum of the four letter counts (packed bytes can reach 128 per block -> widen before summing).
+__global__ void __launch_bounds__(TILE_BLOCKS) k_tile_sums(const uint4* __restrict__ chunks, uint64_t n_blocks,
+                                                           uint64_t* __restrict__ tile_sums /* 4 per tile */) {
+    __shared__ uint32_t sh[4][TILE_BLOCKS / 64];
+    uint64_t b = (uint64_t)blockIdx.x * TILE_BLOCKS + threadIdx.x;
+    uint32_t p = b < n_blocks ? block_letter_counts(chunks + (b << 2)) : 0u;
+    uint32_t v[4] = {p & 0xFFu, (p >> 8) & 0xFFu, (p >> 16) & 0xFFu, p >> 24};
+    for (int c = 0; c < 4; ++c) {
+        uint32_t x = v[c];
+        for (int o = 32; o > 0; o >>= 1) x += (uint32_t)__shfl_down((int)x, o);
+        if ((threadIdx.x & 63) == 0) sh[c][threadIdx.x >> 6] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        uint64_t s = 0;
+        for (int w = 0; w < TILE_BLOCKS / 64; ++w) s += sh[threadIdx.x][w];
+        tile_sums[(uint64_t)blockIdx.x * 4 + threadIdx.x] = s;
+    }
+}
+
+// Per tile: exclusive scan of block counts + tile prefix -> counters relative to the superblock start
+// (set_counters, dna_string.hpp:554-567); records superblock_ranks (dna_string.hpp:285-289).
+__global__ void __launch_bounds__(TILE_BLOCKS) k_write_counters(uint4* __restrict__ chunks, uint64_t n_blocks,
+                                                                const uint64_t* __restrict__ tile_prefix,
+                                                                uint64_t* __restrict__ super) {
+    __shared__ uint32_t sh[4][TILE_BLOCKS];
+    uint64_t b = (uint64_t)blockIdx.x * TILE_BLOCKS + threadIdx.x;
+    uint32_t p = b < n_blocks ? block_letter_counts(chunks + (b << 2)) : 0u;
+    sh[0][threadIdx.x] = p & 0xFFu;
+    sh[1][threadIdx.x] = (p >> 8) & 0xFFu;
+    sh[2][threadIdx.x] = (p >> 16) & 0xFFu;
+    sh[3][threadIdx.x] = p >> 24;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over 256 entries, 4 letters
+    for (int o = 1; o < TILE_BLOCKS; o <<= 1) {
+        uint32_t a[4];
+        for (int c = 0; c < 4; ++c) a[c] = threadIdx.x >= (unsigned)o ? sh[c][threadIdx.x - o] : 0u;
+        __syncthreads();
+        for (int c = 0; c < 4; ++c) sh[c][threadIdx.x] += a[c];
+        __syncthreads();
+    }
+    if (b >= n_blocks) return;
+    uint64_t tile = blockIdx.x;
+    uint64_t sb_tile = ((b >> 25) << 25) / TILE_BLOCKS; // tile at which this block's superblock starts
+    uint32_t own[4] = {p & 0xFFu, (p >> 8) & 0xFFu, (p >> 16) & 0xFFu, p >> 24};
+    for (int c = 0; c < 4; ++c) {
+        uint64_t abs_before = tile_prefix[tile * 4 + c] + (sh[c][threadIdx.x] - own[c]);
+        uint64_t sb_base = tile_prefix[sb_tile * 4 + c];
+        reinterpret_cast<uint32_t*>(chunks + (b << 2) + c)[3] = (uint32_t)(abs_before - sb_base);
+        if ((b & ((1ull << 25) - 1)) == 0) super[(b >> 25) * 4 + c] = abs_before;
+    }
+}
+
+// ------------------------------------------------------------------ host side
+
+static int index_alloc(uint64_t n, uint8_t term, int device, eb_index** out) {
+    int ndev = eb_device_count();
+    if (ndev <= 0) {
+        eb_set_error("no HIP device available: the ebwt2InDel hot path runs on the GPU only (no CPU fallback)");
+        return EB_ERR_DEVICE;
+    }
+    if (device < 0 || device >= ndev) {
+        eb_set_error("device %d out of range (have %d)", device, ndev);
+        return EB_ERR_ARG;
+    }
+    EB_HIP(hipSetDevice(device));
+    eb_index* h = new eb_index();
+    h->device = device;
+    h->n = n;
+    h->term = term;
+    h->n_blocks = (n + 1 + 127) / 128;                 // dna_string.hpp:62
+    h->n_super = (n + 1 + 0xFFFFFFFFull) >> 32;        // dna_string.hpp:61
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc(&h->d_chunks, h->n_blocks * 64);
+    if (e == hipSuccess) e = hipMalloc(&h->d_super, h->n_super * 4 * sizeof(uint64_t));
+    if (e != hipSuccess) {
+        eb_set_error("index allocation failed (%llu bytes): %s", (unsigned long long)(h->n_blocks * 64), hipGetErrorString(e));
+        eb_index_destroy(h);
+        return e == hipErrorOutOfMemory ? EB_ERR_NOMEM : EB_ERR_DEVICE;
+    }
+    h->device_bytes = h->n_blocks * 64 + h->n_super * 32;
+    *out = h;
+    return EB_OK;
+}
+
+// Packs one piece of text that is already on the device.
+static int pack_piece(eb_index* h, const uint8_t* d_ascii, uint64_t piece_pos, uint64_t piece_len, bool last,
+                      unsigned long long* d_bad) {
+    uint64_t first_chunk = piece_pos / 32;
+    uint64_t n_chunks = last ? h->n_blocks * 4 - first_chunk : piece_len / 32;
+    if (n_chunks == 0) return EB_OK;
+    int aligned = (reinterpret_cast<uintptr_t>(d_ascii) & 15u) == 0;
+    uint64_t grid = (n_chunks + 255) / 256;
+    hipLaunchKernelGGL(k_pack, dim3((unsigned)grid), dim3(256), 0, h->stream, d_ascii, piece_pos, piece_len, first_chunk,
+                       n_chunks, (uint32_t)h->term, aligned, h->d_chunks, d_bad);
+    EB_HIP(hipGetLastError());
+    return EB_OK;
+}
+
+// Counters, superblock table and F array from the packed planes.
+static int finish_index(eb_index* h, unsigned long long* d_bad, const uint8_t* d_text_or_null, const uint8_t* h_text_or_null) {
+    unsigned long long bad = ~0ull;
+    EB_HIP(hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, h->stream));
+    EB_HIP(hipStreamSynchronize(h->stream));
+    if (bad != ~0ull) {
+        uint8_t sym = 0;
+        if (h_text_or_null) sym = h_text_or_null[bad];
+        else if (d_text_or_null) (void)hipMemcpy(&sym, d_text_or_null + bad, 1, hipMemcpyDeviceToHost);
+        g_bad_sym = sym;
+        g_bad_pos = bad;
+        // same wording as dna_string.hpp:91-93
+        eb_set_error("Error while reading file: read forbidden character '%c' (ASCII code %d) at position %llu. "
+                     "Only A,C,G,T, and %c are admitted in the input BWT!", sym, (int)sym, bad, h->term);
+        return EB_ERR_ALPHABET;
+    }
+    uint64_t n_tiles = (h->n_blocks + TILE_BLOCKS - 1) / TILE_BLOCKS;
+    uint64_t* d_tiles = nullptr;
+    uint64_t* d_tmp = nullptr;
+    EB_HIP(hipMalloc(&d_tiles, (n_tiles + 1) * 4 * sizeof(uint64_t)));
+    EB_HIP(hipMalloc(&d_tmp, eb_scan4_tmp_elems(n_tiles + 1) * 4 * sizeof(uint64_t)));
+    EB_HIP(hipMemsetAsync(d_tiles, 0, (n_tiles + 1) * 4 * sizeof(uint64_t), h->stream));
+    hipLaunchKernelGGL(k_tile_sums, dim3((unsigned)n_tiles), dim3(TILE_BLOCKS), 0, h->stream, h->d_chunks, h->n_blocks, d_tiles);
+    int rc = eb_scan4_exclusive(d_tiles, n_tiles + 1, d_tmp, h->stream); // element n_tiles becomes the grand total
+    if (rc != EB_OK) return rc;
+    hipLaunchKernelGGL(k_write_counters, dim3((unsigned)n_tiles), dim3(TILE_BLOCKS), 0, h->stream, h->d_chunks, h->n_blocks,
+                       d_tiles, h->d_super);
+    uint64_t tot[4];
+    EB_HIP(hipMemcpyAsync(tot, d_tiles + n_tiles * 4, sizeof tot, hipMemcpyDeviceToHost, h->stream));
+    EB_HIP(hipStreamSynchronize(h->stream));
+    EB_HIP(hipGetLastError());
+    EB_HIP(hipFree(d_tiles));
+    EB_HIP(hipFree(d_tmp));
+    uint64_t n_term = h->n - (tot[0] + tot[1] + tot[2] + tot[3]);
+    h->F[0] = n_term;            // F_A = #TERM            (dna_bwt.hpp:51)
+    h->F[1] = h->F[0] + tot[0];  // F_C = F_A + #A         (dna_bwt.hpp:58)
+    h->F[2] = h->F[1] + tot[1];
+    h->F[3] = h->F[2] + tot[2];
+    return EB_OK;
+}
+
+extern "C" int eb_index_create_from_device(const void* d_ascii, uint64_t n, uint8_t term, int device, eb_index** out) {
+    if (!out || (!d_ascii && n)) { eb_set_error("null argument"); return EB_ERR_ARG; }
+    *out = nullptr;
+    eb_index* h = nullptr;
+    int rc = index_alloc(n, term, device, &h);
+    if (rc != EB_OK) return rc;
+    unsigned long long* d_bad = nullptr;
+    unsigned long long init = ~0ull;
+    EB_HIP(hipMalloc(&d_bad, sizeof init));
+    EB_HIP(hipMemcpy(d_bad, &init, sizeof init, hipMemcpyHostToDevice));
+    EB_HIP(hipDeviceSynchronize()); // the caller's text may have been produced on another stream
+    rc = pack_piece(h, static_cast<const uint8_t*>(d_ascii), 0, n, true, d_bad);
+    if (rc == EB_OK) rc = finish_index(h, d_bad, static_cast<const uint8_t*>(d_ascii), nullptr);
+    (void)hipFree(d_bad);
+    if (rc != EB_OK) { eb_index_destroy(h); return rc; }
+    *out = h;
+    return EB_OK;
+}
+
+extern "C" int eb_index_create(const uint8_t* ascii, uint64_t n, uint8_t term, int device, eb_index** out) {
+    if (!out || (!ascii && n)) { eb_set_error("null argument"); return EB_ERR_ARG; }
+    *out = nullptr;
+    eb_index* h = nullptr;
+    int rc = index_alloc(n, term, device, &h);
+    if (rc != EB_OK) return rc;
+    // Upload in pieces (multiple of 128 symbols) through two staging buffers so copies overlap packing.
+    const uint64_t PIECE = 256ull << 20;
+    uint8_t* d_stage[2] = {nullptr, nullptr};
+    hipEvent_t done[2];
+    unsigned long long* d_bad = nullptr;
+    unsigned long long init = ~0ull;
+    uint64_t stage_bytes = n < PIECE ? (n ? n : 1) : PIECE;
+    hipError_t e = hipMalloc(&d_bad, sizeof init);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        e = hipMalloc(&d_stage[i], stage_bytes);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) { eb_set_error("staging allocation failed: %s", hipGetErrorString(e)); eb_index_destroy(h); return EB_ERR_NOMEM; }
+    EB_HIP(hipMemcpy(d_bad, &init, sizeof init, hipMemcpyHostToDevice));
+    uint64_t pos = 0;
+    int slot = 0;
+    bool first_use[2] = {true, true};
+    do {
+        uint64_t len = n - pos < PIECE ? n - pos : PIECE;
+        bool last = pos + len == n;
+        if (!first_use[slot]) EB_HIP(hipEventSynchronize(done[slot]));
+        first_use[slot] = false;
+        if (len) EB_HIP(hipMemcpyAsync(d_stage[slot], ascii + pos, len, hipMemcpyHostToDevice, h->stream));
+        rc = pack_piece(h, d_stage[slot], pos, len, last, d_bad);
+        if (rc != EB_OK) break;
+        EB_HIP(hipEventRecord(done[slot], h->stream));
+        pos += len;
+        slot ^= 1;
+    } while (pos < n);
+    if (rc == EB_OK) rc = finish_index(h, d_bad, nullptr, ascii);
+    for (int i = 0; i < 2; ++i) { (void)hipFree(d_stage[i]); (void)hipEventDestroy(done[i]); }
+    (void)hipFree(d_bad);
+    if (rc != EB_OK) { eb_index_destroy(h); return rc; }
+    *out = h;
+    return EB_OK;
+}
+
+extern "C" int eb_index_create_from_file(const char* path, uint8_t term, int device, eb_index** out) {
+    if (!path || !out) { eb_set_error("null argument"); return EB_ERR_ARG; }
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) { eb_set_error("Error: could not find file %s", path); return EB_ERR_IO; }
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); eb_set_error("cannot stat %s", path); return EB_ERR_IO; }
+    uint64_t n = (uint64_t)st.st_size; // n = file size (dna_string.hpp:59)
+    void* map = n ? mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
+    if (n && map == MAP_FAILED) { close(fd); eb_set_error("cannot map %s", path); return EB_ERR_IO; }
+    if (n) madvise(map, n, MADV_SEQUENTIAL);
+    static const uint8_t empty = 0;
+    int rc = eb_index_create(n ? static_cast<const uint8_t*>(map) : &empty, n, term, device, out);
+    if (n) munmap(map, n);
+    close(fd);
+    return rc;
+}
+
+extern "C" void eb_index_destroy(eb_index* h) {
+    if (!h) return;
+    if (h->device >= 0) (void)hipSetDevice(h->device);
+    if (h->d_chunks) (void)hipFree(h->d_chunks);
+    if (h->d_super) (void)hipFree(h->d_super);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" int eb_index_info(const eb_index* h, eb_index_info_t* info) {
+    if (!h || !info) { eb_set_error("null argument"); return EB_ERR_ARG; }
+    info->n = h->n;
+    for (int i = 0; i < 4; ++i) info->F[i] = h->F[i];
+    info->n_blocks = h->n_blocks;
+    info->device_bytes = h->device_bytes;
+    info->device = h->device;
+    info->term = h->term;
+    return EB_OK;
+}

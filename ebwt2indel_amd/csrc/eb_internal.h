@@ -1,0 +1,80 @@
+// eb_internal.h -- host-side definitions shared by the translation units of libebwt2indel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/ebwt2indel.h"
+#include "eb_device.h"
+
+void eb_set_error(const char* fmt, ...);
+
+#define EB_HIP(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            eb_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return EB_ERR_DEVICE;                                                                 \
+        }                                                                                         \
+    } while (0)
+
+struct eb_index {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    uint4* d_chunks = nullptr;
+    uint64_t* d_super = nullptr;
+    uint64_t n = 0, n_blocks = 0, n_super = 0;
+    uint64_t F[4] = {0, 0, 0, 0};
+    uint8_t term = '#';
+    uint64_t device_bytes = 0;
+    eb_dev_index dev() const {
+        eb_dev_index d;
+        d.chunks = d_chunks;
+        d.super = d_super;
+        d.n = n;
+        d.n_blocks = n_blocks;
+        for (int i = 0; i < 4; ++i) d.F[i] = F[i];
+        d.term = term;
+        return d;
+    }
+};
+
+struct eb_flags {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    uint64_t n = 0, words = 0;
+    uint64_t *d_thrK = nullptr, *d_thrR = nullptr, *d_min = nullptr, *d_da = nullptr, *d_da_rank = nullptr;
+    eb_dev_flags dev() const {
+        eb_dev_flags f;
+        f.thrK = d_thrK;
+        f.thrR = d_thrR;
+        f.minima = d_min;
+        f.da = d_da;
+        f.da_rank = d_da_rank;
+        f.n = n;
+        f.words = words;
+        return f;
+    }
+};
+
+struct eb_calls {
+    int32_t k_left = 0, k_right = 0;
+    std::vector<eb_cluster> clusters;
+    std::vector<uint8_t> left;  // count * EB_MAX_SLOTS * k_left
+    std::vector<uint8_t> right; // count * k_right
+};
+
+// words allocated for a bitvector of n bits (one spare word so neighbours can be read unguarded)
+static inline uint64_t eb_bit_words(uint64_t n) { return (n + 63) / 64; }
+static inline uint64_t eb_bit_alloc_words(uint64_t n) { return (n + 63) / 64 + 2; }
+
+// eb_scanutil.hip: exclusive prefix sum of `count` vectors of 4 x u64 (in place), on `stream`.
+// tmp must hold eb_scan4_tmp_elems(count) vectors.
+uint64_t eb_scan4_tmp_elems(uint64_t count);
+int eb_scan4_exclusive(uint64_t* d_vec4, uint64_t count, uint64_t* d_tmp, hipStream_t stream);
+
+// (re)builds d_da_rank from d_da
+int eb_flags_build_da_rank(eb_flags* f);
+int eb_flags_alloc(uint64_t n, int device, bool with_da, eb_flags** out);

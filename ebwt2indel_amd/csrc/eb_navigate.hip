@@ -1,0 +1,500 @@
+// eb_navigate.hip -- phases 2-3 on the GPU: LCP-threshold / LCP-minima / DA bitvectors.
+//
+// Replaces navigate_one_bwt (ebwt2InDel.cpp:555-676) and navigate_two_bwts (:679-831).
+// The reference walks suffix-tree leaves and right-maximal nodes depth-first with an explicit
+// stack, one record at a time.  Every LCP / DA slot has exactly one writer, so the visiting order
+// is free; here the stack lives in HBM and is drained in batches: a launch pops up to `batch`
+// records from the top, one lane expands one record (<= 6 parallel_rank queries per BWT), and the
+// surviving children are pushed back with one wave-aggregated atomic reservation.  Popping from
+// the top keeps the footprint of a depth-first walk; a batch of millions keeps HBM busy with
+// independent 64-byte block reads.  Bit writes are atomicOr on 64-bit words and are skipped when
+// the value is 0 (vectors start zeroed), i.e. for records shallower than K / k_right.
+#include <stdlib.h>
+#include <string.h>
+
+#include <chrono>
+#include <type_traits>
+
+#include "eb_internal.h"
+
+namespace {
+
+struct Leaf1 { uint64_t l, r, depth; };                         // sa_leaf (include.hpp:513-527)
+struct Node1 { uint64_t b[6]; uint64_t depth; };                // sa_node (include.hpp:394-413)
+struct Leaf2 { uint64_t l1, r1, l2, r2, depth; };               // pair<sa_leaf,sa_leaf>
+struct Node2 { uint64_t a[6]; uint64_t b[6]; uint64_t depth; }; // pair<sa_node,sa_node>
+
+struct NavCounters {
+    unsigned long long pushed;     // children appended by the current launch
+    unsigned long long leaves, nodes, lcp_values, da_values, minima, ranks;
+};
+
+struct NavParams {
+    int K, k_right;
+};
+
+__device__ __forceinline__ uint64_t wave_sum(uint64_t v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor((unsigned long long)v, o);
+    return v;
+}
+
+// Reserve room for `t` records per lane with one atomic per wave; returns this lane's first slot.
+__device__ __forceinline__ uint64_t wave_reserve(unsigned long long* counter, uint32_t t) {
+    uint32_t lane = threadIdx.x & 63u;
+    uint32_t inc = t;
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t v = (uint32_t)__shfl_up((int)inc, o);
+        if (lane >= (uint32_t)o) inc += v;
+    }
+    uint32_t total = (uint32_t)__shfl((int)inc, 63);
+    unsigned long long base = 0;
+    if (lane == 63 && total) base = atomicAdd(counter, (unsigned long long)total);
+    base = __shfl((unsigned long long)base, 63);
+    return base + inc - t;
+}
+
+__device__ __forceinline__ void flush_stat(unsigned long long* dst, uint64_t v) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63u) == 0 && v) atomicAdd(dst, (unsigned long long)v);
+}
+
+__device__ __forceinline__ void set_lcp_bits(const eb_dev_flags& f, const NavParams& p, uint64_t depth, uint64_t lo, uint64_t hi) {
+    // LCP_threshold[2i] = depth >= K, LCP_threshold[2i+1] = depth >= k_right for i in [lo,hi)
+    if (hi <= lo) return;
+    if ((int64_t)depth >= p.K) eb_bits_fill_atomic(f.thrK, lo, hi);
+    if ((int64_t)depth >= p.k_right) eb_bits_fill_atomic(f.thrR, lo, hi);
+}
+
+// ---- phase 2: leaves.  update_LCP_leaf (ebwt2InDel.cpp:344-355) / update_DA (:394-425) and
+// next_leaves (dna_bwt.hpp:358-379; two BWTs: ebwt2InDel.cpp:452-472).
+template <int NB>
+__global__ void __launch_bounds__(256) k_leaves(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, NavParams p, const void* in_,
+                                               uint64_t count, void* out_, uint64_t out_cap, NavCounters* cnt) {
+    using Leaf = typename std::conditional<NB == 1, Leaf1, Leaf2>::type;
+    const Leaf* in = static_cast<const Leaf*>(in_);
+    Leaf* out = static_cast<Leaf*>(out_);
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool active = i < count;
+    Leaf child[4];
+    uint32_t t = 0;
+    uint64_t n_lcp = 0, n_da = 0, n_rank = 0;
+    if (active) {
+        Leaf L = in[i];
+        if constexpr (NB == 1) {
+            if (L.r > L.l + 1) { set_lcp_bits(f, p, L.depth, L.l + 1, L.r); n_lcp = L.r - L.l - 1; }
+            rank4_t a = eb_rank4(x1, L.l);
+            rank4_t b = L.r > L.l ? eb_rank4(x1, L.r) : a;
+            n_rank = L.r > L.l ? 2 : 1;
+            for (int c = 0; c < 4; ++c) {
+                uint64_t cl = x1.F[c] + a.v[c], cr = x1.F[c] + b.v[c];
+                if (cr - cl >= 2) { child[t].l = cl; child[t].r = cr; child[t].depth = L.depth + 1; ++t; }
+            }
+        } else {
+            uint64_t s1 = L.l1 + L.l2, s2 = L.l2 + L.r1, e = L.r1 + L.r2;
+            if (e > s2) eb_bits_fill_atomic(f.da, s2, e); // DA = 1 for the second collection's rows
+            n_da = e - s1;
+            if (e > s1 + 1) { set_lcp_bits(f, p, L.depth, s1 + 1, e); n_lcp = e - s1 - 1; }
+            rank4_t a1 = eb_rank4(x1, L.l1), b1 = L.r1 > L.l1 ? eb_rank4(x1, L.r1) : a1;
+            rank4_t a2 = eb_rank4(x2, L.l2), b2 = L.r2 > L.l2 ? eb_rank4(x2, L.r2) : a2;
+            n_rank = (L.r1 > L.l1 ? 2 : 1) + (L.r2 > L.l2 ? 2 : 1);
+            for (int c = 0; c < 4; ++c) {
+                uint64_t l1 = x1.F[c] + a1.v[c], r1 = x1.F[c] + b1.v[c];
+                uint64_t l2 = x2.F[c] + a2.v[c], r2 = x2.F[c] + b2.v[c];
+                if ((r1 - l1) + (r2 - l2) >= 2) { child[t].l1 = l1; child[t].r1 = r1; child[t].l2 = l2; child[t].r2 = r2; child[t].depth = L.depth + 1; ++t; }
+            }
+        }
+    }
+    uint64_t slot = wave_reserve(&cnt->pushed, t);
+    for (uint32_t k = 0; k < t; ++k)
+        if (slot + k < out_cap) out[slot + k] = child[k];
+    flush_stat(&cnt->leaves, active ? 1 : 0);
+    flush_stat(&cnt->lcp_values, n_lcp);
+    flush_stat(&cnt->ranks, n_rank);
+    if constexpr (NB == 2) flush_stat(&cnt->da_values, n_da);
+}
+
+// LF(sa_node) (dna_bwt.hpp:323-356): ranks at the six boundaries, equal neighbours share one query.
+__device__ __forceinline__ uint32_t node_ranks(const eb_dev_index& x, const uint64_t* b, rank4_t* r) {
+    uint32_t q = 1;
+    r[0] = eb_rank4(x, b[0]);
+    for (int k = 1; k < 6; ++k) {
+        if (b[k] == b[k - 1]) r[k] = r[k - 1];
+        else { r[k] = eb_rank4(x, b[k]); ++q; }
+    }
+    return q;
+}
+
+// ---- phase 3: right-maximal nodes.  update_lcp_threshold (include.hpp:826-860), update_lcp_minima
+// (ebwt2InDel.cpp:357-391), find_leaves (:474-527), next_nodes (dna_bwt.hpp:381-404 / ebwt2InDel.cpp:529-553).
+template <int NB>
+__global__ void __launch_bounds__(256) k_nodes(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, NavParams p, const void* in_,
+                                              uint64_t count, void* out_, uint64_t out_cap, NavCounters* cnt) {
+    using Node = typename std::conditional<NB == 1, Node1, Node2>::type;
+    const Node* in = static_cast<const Node*>(in_);
+    Node* out = static_cast<Node*>(out_);
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool active = i < count;
+    Node child[4];
+    uint32_t t = 0;
+    uint64_t n_lcp = 0, n_da = 0, n_rank = 0, n_min = 0;
+    if (active) {
+        Node N = in[i];
+        uint64_t m[6]; // merged boundaries (merge_nodes, include.hpp:476-490)
+        if constexpr (NB == 1) {
+            for (int k = 0; k < 6; ++k) m[k] = N.b[k];
+        } else {
+            for (int k = 0; k < 6; ++k) m[k] = N.a[k] + N.b[k];
+            // leaves of merged size 1 were not visited in phase 2: write their DA slot now
+            for (int k = 0; k < 5; ++k) {
+                uint64_t s1 = N.a[k + 1] - N.a[k], s2 = N.b[k + 1] - N.b[k];
+                if (s1 + s2 == 1) {
+                    if (s2) eb_bit_set_atomic(f.da, N.b[k] + N.a[k + 1]);
+                    ++n_da;
+                }
+            }
+        }
+        // LCP at the right border of each non-empty child TERM,A,C,G unless it is the node's end
+        for (int k = 0; k < 4; ++k)
+            if (m[k + 1] > m[k] && m[k + 1] != m[5]) {
+                if ((int64_t)N.depth >= p.K) eb_bit_set_atomic(f.thrK, m[k + 1]);
+                if ((int64_t)N.depth >= p.k_right) eb_bit_set_atomic(f.thrR, m[k + 1]);
+                ++n_lcp;
+            }
+        // a local LCP minimum follows each child A,C,G of size >= 2 that ends before last-1
+        for (int k = 1; k <= 3; ++k)
+            if (m[k + 1] - m[k] >= 2 && m[k + 1] < m[5] - 1) {
+                eb_bit_set_atomic(f.minima, m[k + 1]);
+                ++n_min;
+            }
+        // Weiner links
+        if constexpr (NB == 1) {
+            rank4_t r[6];
+            n_rank = node_ranks(x1, N.b, r);
+            for (int c = 0; c < 4; ++c) {
+                uint64_t cb[6];
+                int kids = 0;
+                for (int k = 0; k < 6; ++k) cb[k] = x1.F[c] + r[k].v[c];
+                for (int k = 0; k < 5; ++k) kids += cb[k + 1] > cb[k];
+                if (kids >= 2) { // number_of_children (include.hpp:760-768)
+                    for (int k = 0; k < 6; ++k) child[t].b[k] = cb[k];
+                    child[t].depth = N.depth + 1;
+                    ++t;
+                }
+            }
+        } else {
+            rank4_t r1[6], r2[6];
+            n_rank = node_ranks(x1, N.a, r1) + node_ranks(x2, N.b, r2);
+            for (int c = 0; c < 4; ++c) {
+                uint64_t ca[6], cb[6];
+                int kids = 0;
+                for (int k = 0; k < 6; ++k) { ca[k] = x1.F[c] + r1[k].v[c]; cb[k] = x2.F[c] + r2[k].v[c]; }
+                for (int k = 0; k < 5; ++k) kids += (ca[k + 1] > ca[k]) || (cb[k + 1] > cb[k]); // include.hpp:784-792
+                if (kids >= 2) {
+                    for (int k = 0; k < 6; ++k) { child[t].a[k] = ca[k]; child[t].b[k] = cb[k]; }
+                    child[t].depth = N.depth + 1;
+                    ++t;
+                }
+            }
+        }
+    }
+    uint64_t slot = wave_reserve(&cnt->pushed, t);
+    for (uint32_t k = 0; k < t; ++k)
+        if (slot + k < out_cap) out[slot + k] = child[k];
+    flush_stat(&cnt->nodes, active ? 1 : 0);
+    flush_stat(&cnt->lcp_values, n_lcp);
+    flush_stat(&cnt->minima, n_min);
+    flush_stat(&cnt->ranks, n_rank);
+    if constexpr (NB == 2) flush_stat(&cnt->da_values, n_da);
+}
+
+// ones in each group of 8 DA words -> exclusive prefix = ones before the group
+__global__ void __launch_bounds__(256) k_da_group_counts(const uint64_t* __restrict__ da, uint64_t words, uint64_t groups,
+                                                         uint64_t* __restrict__ vec4) {
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= groups) return;
+    uint64_t s = 0;
+    for (int k = 0; k < 8; ++k) {
+        uint64_t w = g * 8 + k;
+        if (w < words) s += (uint64_t)__popcll(da[w]);
+    }
+    vec4[g * 4] = s;
+    vec4[g * 4 + 1] = vec4[g * 4 + 2] = vec4[g * 4 + 3] = 0;
+}
+__global__ void __launch_bounds__(256) k_take_first(const uint64_t* __restrict__ vec4, uint64_t groups, uint64_t* __restrict__ out) {
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < groups) out[g] = vec4[g * 4];
+}
+
+template <typename Item>
+struct Drain {
+    // Drains a LIFO work stack in HBM with batched launches.  `launch(in, count, out, out_cap)` must append
+    // children through NavCounters::pushed.
+    int device;
+    hipStream_t stream;
+    Item* d_stack = nullptr;
+    Item* d_in = nullptr;
+    uint64_t cap = 0, batch = 0, top = 0;
+    uint64_t launches = 0, max_top = 0;
+
+    int init(uint64_t n_bound, uint64_t batch_max) {
+        size_t free_b = 0, total_b = 0;
+        EB_HIP(hipMemGetInfo(&free_b, &total_b));
+        uint64_t budget = (uint64_t)(free_b * 0.6) / sizeof(Item);
+        batch = batch_max;
+        if (batch > n_bound / 2 + 64) batch = n_bound / 2 + 64;
+        cap = n_bound + 4 * batch + 64;             // every pending record is a distinct suffix-tree node/leaf
+        if (cap + batch > budget) {
+            if (budget < 8 * 1024) { eb_set_error("not enough device memory for the traversal stack"); return EB_ERR_NOMEM; }
+            if (batch > budget / 8) batch = budget / 8;
+            cap = budget - batch;
+        }
+        hipError_t e = hipMalloc(&d_stack, cap * sizeof(Item));
+        if (e == hipSuccess) e = hipMalloc(&d_in, batch * sizeof(Item));
+        if (e != hipSuccess) { eb_set_error("traversal stack allocation failed: %s", hipGetErrorString(e)); return EB_ERR_NOMEM; }
+        return EB_OK;
+    }
+    ~Drain() {
+        if (d_stack) (void)hipFree(d_stack);
+        if (d_in) (void)hipFree(d_in);
+    }
+    int push_host(const Item& it) {
+        EB_HIP(hipMemcpyAsync(d_stack + top, &it, sizeof(Item), hipMemcpyHostToDevice, stream));
+        EB_HIP(hipStreamSynchronize(stream));
+        ++top;
+        return EB_OK;
+    }
+    template <typename Launch>
+    int run(NavCounters* d_cnt, unsigned long long* h_pushed /* pinned */, Launch launch) {
+        while (top > 0) {
+            uint64_t room = cap - top;
+            uint64_t B = top < batch ? top : batch;
+            if (B > 1 && 3 * B > room + 0) { // children (<= 4B) go where the popped B were, plus `room`
+                uint64_t fit = room / 3;
+                B = fit < 1 ? 1 : (fit < B ? fit : B);
+            }
+            if (top - B + 4 * B > cap) { eb_set_error("traversal stack capacity exceeded (cap %llu records)", (unsigned long long)cap); return EB_ERR_NOMEM; }
+            uint64_t base = top - B;
+            EB_HIP(hipMemcpyAsync(d_in, d_stack + base, B * sizeof(Item), hipMemcpyDeviceToDevice, stream));
+            EB_HIP(hipMemsetAsync(&d_cnt->pushed, 0, sizeof(unsigned long long), stream));
+            launch(d_in, B, d_stack + base, cap - base);
+            EB_HIP(hipGetLastError());
+            EB_HIP(hipMemcpyAsync(h_pushed, &d_cnt->pushed, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+            EB_HIP(hipStreamSynchronize(stream));
+            if (*h_pushed > cap - base) { eb_set_error("traversal stack overflow"); return EB_ERR_STATE; }
+            top = base + *h_pushed;
+            if (top > max_top) max_top = top;
+            ++launches;
+        }
+        return EB_OK;
+    }
+};
+
+uint64_t env_u64(const char* name, uint64_t dflt) {
+    const char* s = getenv(name);
+    if (!s || !*s) return dflt;
+    return strtoull(s, nullptr, 10);
+}
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+}  // namespace
+
+int eb_flags_alloc(uint64_t n, int device, bool with_da, eb_flags** out) {
+    int ndev = eb_device_count();
+    if (ndev <= 0) { eb_set_error("no HIP device available: the ebwt2InDel hot path runs on the GPU only (no CPU fallback)"); return EB_ERR_DEVICE; }
+    if (device < 0 || device >= ndev) { eb_set_error("device %d out of range (have %d)", device, ndev); return EB_ERR_ARG; }
+    EB_HIP(hipSetDevice(device));
+    eb_flags* f = new eb_flags();
+    f->device = device;
+    f->n = n;
+    f->words = eb_bit_words(n);
+    size_t bytes = eb_bit_alloc_words(n) * 8;
+    hipError_t e = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking);
+    uint64_t** vecs[4] = {&f->d_thrK, &f->d_thrR, &f->d_min, with_da ? &f->d_da : nullptr};
+    for (int i = 0; i < 4 && e == hipSuccess; ++i) {
+        if (!vecs[i]) continue;
+        e = hipMalloc(vecs[i], bytes);
+        if (e == hipSuccess) e = hipMemsetAsync(*vecs[i], 0, bytes, f->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(f->stream);
+    if (e != hipSuccess) { eb_set_error("flag vector allocation failed: %s", hipGetErrorString(e)); eb_flags_destroy(f); return EB_ERR_NOMEM; }
+    *out = f;
+    return EB_OK;
+}
+
+int eb_flags_build_da_rank(eb_flags* f) {
+    if (!f->d_da) return EB_OK;
+    EB_HIP(hipSetDevice(f->device));
+    uint64_t groups = (f->words + 7) / 8 + 1;
+    uint64_t* d_vec = nullptr;
+    EB_HIP(hipMalloc(&d_vec, groups * 4 * sizeof(uint64_t)));
+    if (f->d_da_rank) { (void)hipFree(f->d_da_rank); f->d_da_rank = nullptr; }
+    EB_HIP(hipMalloc(&f->d_da_rank, groups * sizeof(uint64_t)));
+    unsigned grid = (unsigned)((groups + 255) / 256);
+    hipLaunchKernelGGL(k_da_group_counts, dim3(grid), dim3(256), 0, f->stream, f->d_da, f->words, groups, d_vec);
+    int rc = eb_scan4_exclusive(d_vec, groups, nullptr, f->stream);
+    if (rc != EB_OK) return rc;
+    hipLaunchKernelGGL(k_take_first, dim3(grid), dim3(256), 0, f->stream, d_vec, groups, f->d_da_rank);
+    EB_HIP(hipStreamSynchronize(f->stream));
+    EB_HIP(hipGetLastError());
+    EB_HIP(hipFree(d_vec));
+    return EB_OK;
+}
+
+extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_right, eb_flags** out, eb_nav_stats* stats) {
+    if (!b1 || !out) { eb_set_error("null argument"); return EB_ERR_ARG; }
+    if (b2 && b2->device != b1->device) { eb_set_error("both indexes must live on the same device"); return EB_ERR_ARG; }
+    *out = nullptr;
+    EB_HIP(hipSetDevice(b1->device));
+    const uint64_t n = b1->n + (b2 ? b2->n : 0);
+    eb_flags* f = nullptr;
+    int rc = eb_flags_alloc(n, b1->device, b2 != nullptr, &f);
+    if (rc != EB_OK) return rc;
+    struct Guard { eb_flags* f; ~Guard() { if (f) eb_flags_destroy(f); } } guard{f};
+
+    NavCounters* d_cnt = nullptr;
+    unsigned long long* h_pushed = nullptr;
+    EB_HIP(hipMalloc(&d_cnt, sizeof(NavCounters)));
+    EB_HIP(hipMemset(d_cnt, 0, sizeof(NavCounters)));
+    EB_HIP(hipHostMalloc(&h_pushed, sizeof(unsigned long long)));
+    struct Guard2 { NavCounters* c; unsigned long long* h; ~Guard2() { (void)hipFree(c); (void)hipHostFree(h); } } guard2{d_cnt, h_pushed};
+
+    eb_dev_index x1 = b1->dev(), x2 = b2 ? b2->dev() : b1->dev();
+    eb_dev_flags df = f->dev();
+    NavParams p{K, k_right};
+    hipStream_t st = f->stream;
+    const uint64_t batch_max = env_u64("EB_NAV_BATCH", 4ull << 20);
+    eb_nav_stats s;
+    memset(&s, 0, sizeof s);
+    s.n = n;
+    double t0 = now_s();
+    uint64_t launches = 0;
+
+    if (!b2) {
+        { // phase 2 (ebwt2InDel.cpp:577-615); first_leaf = {[0,F_A), 0} (dna_bwt.hpp:313-317)
+            Drain<Leaf1> d;
+            d.device = b1->device; d.stream = st;
+            if ((rc = d.init(n, batch_max)) != EB_OK) return rc;
+            if ((rc = d.push_host(Leaf1{0, b1->F[0], 0})) != EB_OK) return rc;
+            rc = d.run(d_cnt, h_pushed, [&](Leaf1* in, uint64_t cnt, Leaf1* o, uint64_t ocap) {
+                hipLaunchKernelGGL(k_leaves<1>, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, x1, x2, df, p, in, cnt, o, ocap, d_cnt);
+            });
+            if (rc != EB_OK) return rc;
+            launches += d.launches;
+        }
+        double t1 = now_s();
+        s.seconds_leaves = t1 - t0;
+        { // phase 3 (ebwt2InDel.cpp:622-673); root (dna_bwt.hpp:296-308)
+            Drain<Node1> d;
+            d.device = b1->device; d.stream = st;
+            if ((rc = d.init(n, batch_max)) != EB_OK) return rc;
+            Node1 root{{0, b1->F[0], b1->F[1], b1->F[2], b1->F[3], b1->n}, 0};
+            if ((rc = d.push_host(root)) != EB_OK) return rc;
+            rc = d.run(d_cnt, h_pushed, [&](Node1* in, uint64_t cnt, Node1* o, uint64_t ocap) {
+                hipLaunchKernelGGL(k_nodes<1>, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, x1, x2, df, p, in, cnt, o, ocap, d_cnt);
+            });
+            if (rc != EB_OK) return rc;
+            launches += d.launches;
+        }
+        s.seconds_nodes = now_s() - t1;
+    } else {
+        { // phase 2 (ebwt2InDel.cpp:708-756)
+            Drain<Leaf2> d;
+            d.device = b1->device; d.stream = st;
+            if ((rc = d.init(n, batch_max)) != EB_OK) return rc;
+            if ((rc = d.push_host(Leaf2{0, b1->F[0], 0, b2->F[0], 0})) != EB_OK) return rc;
+            rc = d.run(d_cnt, h_pushed, [&](Leaf2* in, uint64_t cnt, Leaf2* o, uint64_t ocap) {
+                hipLaunchKernelGGL(k_leaves<2>, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, x1, x2, df, p, in, cnt, o, ocap, d_cnt);
+            });
+            if (rc != EB_OK) return rc;
+            launches += d.launches;
+        }
+        double t1 = now_s();
+        s.seconds_leaves = t1 - t0;
+        { // phase 3 (ebwt2InDel.cpp:764-823)
+            Drain<Node2> d;
+            d.device = b1->device; d.stream = st;
+            if ((rc = d.init(n, batch_max)) != EB_OK) return rc;
+            Node2 root{{0, b1->F[0], b1->F[1], b1->F[2], b1->F[3], b1->n}, {0, b2->F[0], b2->F[1], b2->F[2], b2->F[3], b2->n}, 0};
+            if ((rc = d.push_host(root)) != EB_OK) return rc;
+            rc = d.run(d_cnt, h_pushed, [&](Node2* in, uint64_t cnt, Node2* o, uint64_t ocap) {
+                hipLaunchKernelGGL(k_nodes<2>, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, x1, x2, df, p, in, cnt, o, ocap, d_cnt);
+            });
+            if (rc != EB_OK) return rc;
+            launches += d.launches;
+        }
+        s.seconds_nodes = now_s() - t1;
+        if ((rc = eb_flags_build_da_rank(f)) != EB_OK) return rc;
+    }
+    NavCounters c;
+    EB_HIP(hipMemcpy(&c, d_cnt, sizeof c, hipMemcpyDeviceToHost));
+    s.leaves = c.leaves;
+    s.nodes = c.nodes;
+    s.lcp_values = c.lcp_values + 1; // the reference starts its counter at 1 (ebwt2InDel.cpp:575)
+    s.da_values = c.da_values;
+    s.minima = c.minima;
+    s.rank_queries = c.ranks;
+    s.batches = launches;
+    if (stats) *stats = s;
+    guard.f = nullptr;
+    *out = f;
+    return EB_OK;
+}
+
+extern "C" int eb_flags_set_da(eb_flags* f, const uint8_t* ascii01, uint64_t n) {
+    if (!f || (!ascii01 && n)) { eb_set_error("null argument"); return EB_ERR_ARG; }
+    EB_HIP(hipSetDevice(f->device));
+    // '1' -> 1, anything else (and anything past the end of the file) -> 0  (ebwt2InDel.cpp:1503-1508)
+    std::vector<uint64_t> bits(eb_bit_alloc_words(f->n), 0);
+    uint64_t lim = n < f->n ? n : f->n;
+    for (uint64_t i = 0; i < lim; ++i)
+        if (ascii01[i] == '1') bits[i >> 6] |= 1ull << (i & 63);
+    if (!f->d_da) EB_HIP(hipMalloc(&f->d_da, bits.size() * 8));
+    EB_HIP(hipMemcpy(f->d_da, bits.data(), bits.size() * 8, hipMemcpyHostToDevice));
+    return eb_flags_build_da_rank(f);
+}
+
+extern "C" uint64_t eb_flags_words(const eb_flags* f) { return f ? f->words : 0; }
+extern "C" int eb_flags_has_da(const eb_flags* f) { return f && f->d_da ? 1 : 0; }
+
+extern "C" int eb_flags_export(eb_flags* f, uint64_t* thrK, uint64_t* thrR, uint64_t* minima, uint64_t* da) {
+    if (!f) { eb_set_error("null argument"); return EB_ERR_ARG; }
+    EB_HIP(hipSetDevice(f->device));
+    size_t bytes = f->words * 8;
+    if (thrK) EB_HIP(hipMemcpy(thrK, f->d_thrK, bytes, hipMemcpyDeviceToHost));
+    if (thrR) EB_HIP(hipMemcpy(thrR, f->d_thrR, bytes, hipMemcpyDeviceToHost));
+    if (minima) EB_HIP(hipMemcpy(minima, f->d_min, bytes, hipMemcpyDeviceToHost));
+    if (da) {
+        if (!f->d_da) { eb_set_error("flags carry no document array"); return EB_ERR_STATE; }
+        EB_HIP(hipMemcpy(da, f->d_da, bytes, hipMemcpyDeviceToHost));
+    }
+    return EB_OK;
+}
+
+extern "C" int eb_flags_import(uint64_t n, int device, const uint64_t* thrK, const uint64_t* thrR, const uint64_t* minima,
+                               const uint64_t* da, eb_flags** out) {
+    if (!out || !thrK || !thrR || !minima) { eb_set_error("null argument"); return EB_ERR_ARG; }
+    *out = nullptr;
+    eb_flags* f = nullptr;
+    int rc = eb_flags_alloc(n, device, da != nullptr, &f);
+    if (rc != EB_OK) return rc;
+    size_t bytes = f->words * 8;
+    hipError_t e = hipMemcpy(f->d_thrK, thrK, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(f->d_thrR, thrR, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(f->d_min, minima, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess && da) e = hipMemcpy(f->d_da, da, bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { eb_set_error("flag upload failed: %s", hipGetErrorString(e)); eb_flags_destroy(f); return EB_ERR_DEVICE; }
+    if (da && (rc = eb_flags_build_da_rank(f)) != EB_OK) { eb_flags_destroy(f); return rc; }
+    *out = f;
+    return EB_OK;
+}
+
+extern "C" void eb_flags_destroy(eb_flags* f) {
+    if (!f) return;
+    if (f->device >= 0) (void)hipSetDevice(f->device);
+    uint64_t* v[5] = {f->d_thrK, f->d_thrR, f->d_min, f->d_da, f->d_da_rank};
+    for (auto p : v)
+        if (p) (void)hipFree(p);
+    if (f->stream) (void)hipStreamDestroy(f->stream);
+    delete f;
+}

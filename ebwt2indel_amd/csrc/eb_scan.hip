@@ -1,0 +1,429 @@
+// eb_scan.hip -- phase 4 on the GPU: cluster scan, frequent-symbol filter, backward left-context
+// extension and right-context extraction.
+//
+// Replaces the loops of run_one_dataset (ebwt2InDel.cpp:1609-1655), run_two_datasets (:1395-1445),
+// run_two_datasets_da (:1510-1560) and find_variants (:941-1005, :840-934, :1013-1096) with
+// extract_consensus/consensus_letter (:243-319) and extract_dna (:325-342).
+//
+//   k_scan     one lane per 64 positions: flag = thrK & ~minima; every 1->0 transition closes a
+//              cluster [b,e).  Clusters of length >= 2*mcov_out get their symbol histogram
+//              (rank difference over the packed BWT; TERM counts as 'A', include.hpp:275-289) and
+//              the frequent-symbol test; the few survivors are appended to a list.
+//   (sort)     survivors ordered by cluster begin (BWT order) with a device radix sort.
+//   k_extend   four lanes per (cluster, frequent symbol) chain: k_left-1 dependent LF(range)
+//              steps, each two quad-cooperative rank queries; arg-max with ties A<C<G<T.
+//   k_right    one lane per cluster: first position with thrR, then k_right x (F, FL).
+// Host text formatting (distance / event_type / to_file) lives in eb_writer.cpp.
+#include <hipcub/hipcub.hpp>
+
+#include "eb_internal.h"
+
+namespace {
+
+struct ScanParams {
+    int mode;           // 1 one sample, 2 two BWTs, 3 merged BWT + DA
+    uint32_t mcov;      // mcov_out
+    uint32_t min_len;   // 2 * mcov_out
+    int q;              // max_variants_per_position (0 = unlimited)
+    int k_left, k_right;
+    uint64_t begin, end; // closing positions owned by this call
+    uint64_t n;          // merged length
+};
+
+struct Survivor {
+    uint64_t b, e;            // merged coordinates
+    uint64_t b0, e0, b1, e1;  // per-BWT ranges (mode 2)
+    uint32_t fmask0, fmask1;  // frequent letters per side, bit c = "ACGT"[c]
+};
+
+struct ScanCounters {
+    unsigned long long nsurv, runs_closed, clusters, bases, chains;
+    unsigned long long hist[201];
+};
+
+__device__ __forceinline__ uint64_t flag_word(const eb_dev_flags& f, uint64_t w) { return f.thrK[w] & ~f.minima[w]; }
+
+// ones in DA[0,p)
+__device__ __forceinline__ uint64_t da_rank(const eb_dev_flags& f, uint64_t p) {
+    uint64_t g = p >> 9, w = p >> 6;
+    uint64_t s = f.da_rank[g];
+    for (uint64_t k = g << 3; k < w; ++k) s += (uint64_t)__popcll(f.da[k]);
+    uint32_t o = (uint32_t)(p & 63u);
+    if (o) s += (uint64_t)__popcll(f.da[w] & ((1ull << o) - 1ull));
+    return s;
+}
+
+__device__ __forceinline__ uint32_t frequent_mask(const uint32_t* cnt, uint32_t mcov) {
+    uint32_t m = 0;
+    for (int c = 0; c < 4; ++c) m |= (cnt[c] >= mcov ? 1u : 0u) << c;
+    return m;
+}
+
+// histogram of [b,e) by rank difference; TERM rows fall into 'A'
+__device__ __forceinline__ void hist_by_rank(const eb_dev_index& x, uint64_t b, uint64_t e, uint32_t* cnt) {
+    rank4_t rb = eb_rank4(x, b), re = eb_rank4(x, e);
+    uint64_t acgt = 0;
+    for (int c = 0; c < 4; ++c) { cnt[c] = (uint32_t)(re.v[c] - rb.v[c]); acgt += re.v[c] - rb.v[c]; }
+    cnt[0] += (uint32_t)((e - b) - acgt);
+}
+
+// mode 3: histogram split by DA (counts[DA[i]][base_to_int(bwt[i])], ebwt2InDel.cpp:1019)
+__device__ __forceinline__ void hist_by_da(const eb_dev_index& x, const eb_dev_flags& f, uint64_t b, uint64_t e, uint32_t* c0, uint32_t* c1) {
+    for (int c = 0; c < 4; ++c) c0[c] = c1[c] = 0;
+    for (uint64_t ci = b >> 5; ci <= (e - 1) >> 5; ++ci) {
+        uint4 ch = x.chunks[ci];
+        uint64_t lo = ci << 5;
+        uint32_t m = 0xFFFFFFFFu;
+        if (b > lo) m &= 0xFFFFFFFFu << (uint32_t)(b - lo);
+        if (e < lo + 32) m &= 0xFFFFFFFFu >> (uint32_t)(lo + 32 - e);
+        uint32_t d = (uint32_t)(f.da[ci >> 1] >> ((ci & 1u) * 32u));
+        uint32_t L[4] = {~ch.y & ~ch.x, ~ch.y & ch.x, ch.y & ~ch.x, ch.y & ch.x}; // TERM (x=y=0) lands in 'A'
+        for (int c = 0; c < 4; ++c) {
+            c1[c] += (uint32_t)__popc(L[c] & m & d);
+            c0[c] += (uint32_t)__popc(L[c] & m & ~d);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, ScanParams p, uint64_t w_lo,
+                                             uint64_t w_count, Survivor* __restrict__ surv, uint64_t surv_cap,
+                                             ScanCounters* __restrict__ cnt) {
+    __shared__ unsigned int sh_hist[201];
+    for (int k = threadIdx.x; k < 201; k += blockDim.x) sh_hist[k] = 0;
+    __syncthreads();
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t n_runs = 0, n_clusters = 0, n_bases = 0;
+    if (t < w_count) {
+        uint64_t w = w_lo + t;
+        uint64_t fw = flag_word(f, w);
+        uint64_t prev = w > 0 ? flag_word(f, w - 1) >> 63 : 0ull;
+        uint64_t ends = ~fw & ((fw << 1) | prev); // positions e with flag[e]=0 and flag[e-1]=1
+        // keep closing positions inside [begin,end) and below n (a run still open at n-1 is dropped, ebwt2InDel.cpp:1609-1655)
+        uint64_t base = w << 6;
+        uint64_t hi = p.end < p.n ? p.end : p.n;
+        if (base < p.begin) ends &= (p.begin - base >= 64) ? 0ull : (~0ull << (p.begin - base));
+        if (base + 64 > hi) ends &= (hi <= base) ? 0ull : (~0ull >> (base + 64 - hi));
+        while (ends) {
+            uint32_t bit = (uint32_t)__ffsll((long long)ends) - 1u;
+            ends &= ends - 1;
+            uint64_t e = base + bit;
+            // begin = one past the nearest 0 below e
+            uint64_t b;
+            uint64_t zeros = ~fw & ((1ull << bit) - 1ull);
+            if (zeros) {
+                b = base + (64u - (uint32_t)__clzll((long long)zeros));
+            } else {
+                uint64_t ww = w;
+                b = 0;
+                while (ww > 0) {
+                    --ww;
+                    uint64_t g = ~flag_word(f, ww);
+                    if (g) { b = (ww << 6) + (64u - (uint32_t)__clzll((long long)g)); break; }
+                }
+            }
+            uint64_t len = e - b;
+            ++n_runs;
+            n_bases += len;
+            if (len <= 200) atomicAdd(&sh_hist[len], 1u);
+            if (len < p.min_len) continue;
+            ++n_clusters;
+            Survivor s;
+            s.b = b; s.e = e; s.b0 = s.e0 = s.b1 = s.e1 = 0; s.fmask0 = s.fmask1 = 0;
+            uint32_t c0[4], c1[4];
+            bool keep;
+            if (p.mode == 1) {
+                hist_by_rank(x1, b, e, c0);
+                s.fmask0 = frequent_mask(c0, p.mcov);
+                int nf = __popc(s.fmask0);
+                keep = nf >= 2 && !(p.q > 0 && nf > p.q); // ebwt2InDel.cpp:961-966
+            } else {
+                if (p.mode == 2) {
+                    s.b1 = da_rank(f, b); s.e1 = da_rank(f, e);
+                    s.b0 = b - s.b1; s.e0 = e - s.e1;
+                    hist_by_rank(x1, s.b0, s.e0, c0);
+                    hist_by_rank(x2, s.b1, s.e1, c1);
+                } else {
+                    hist_by_da(x1, f, b, e, c0, c1);
+                }
+                s.fmask0 = frequent_mask(c0, p.mcov);
+                s.fmask1 = frequent_mask(c1, p.mcov);
+                int n0 = __popc(s.fmask0), n1 = __popc(s.fmask1);
+                keep = n0 > 0 && n1 > 0 && !(p.q > 0 && (n0 > p.q || n1 > p.q)); // :870-880, :1042-1052
+            }
+            if (keep) {
+                unsigned long long slot = atomicAdd(&cnt->nsurv, 1ull);
+                if (slot < surv_cap) surv[slot] = s;
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        n_runs += __shfl_xor((unsigned long long)n_runs, o);
+        n_clusters += __shfl_xor((unsigned long long)n_clusters, o);
+        n_bases += __shfl_xor((unsigned long long)n_bases, o);
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        if (n_runs) atomicAdd(&cnt->runs_closed, (unsigned long long)n_runs);
+        if (n_clusters) atomicAdd(&cnt->clusters, (unsigned long long)n_clusters);
+        if (n_bases) atomicAdd(&cnt->bases, (unsigned long long)n_bases);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 201; k += blockDim.x)
+        if (sh_hist[k]) atomicAdd(&cnt->hist[k], (unsigned long long)sh_hist[k] * (unsigned long long)k); // CLUST_SIZES[len] += len
+}
+
+__global__ void __launch_bounds__(256) k_surv_keys(const Survivor* __restrict__ s, uint64_t n, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { keys[i] = s[i].b; idx[i] = (uint32_t)i; }
+}
+__global__ void __launch_bounds__(256) k_surv_gather(const Survivor* __restrict__ s, const uint32_t* __restrict__ idx, uint64_t n, Survivor* __restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = s[idx[i]];
+}
+
+__device__ __forceinline__ uint64_t pick4(const uint64_t* F, uint32_t c) { return c == 0 ? F[0] : c == 1 ? F[1] : c == 2 ? F[2] : F[3]; }
+
+// Four lanes per chain.  extract_consensus(bwt,range,c,...) ebwt2InDel.cpp:303-319 -> LF(range,c), then
+// up to k_left-1 x { LF(range) ; consensus_letter } (:243-282).
+__global__ void __launch_bounds__(256) k_extend(eb_dev_index x1, eb_dev_index x2, ScanParams p, const Survivor* __restrict__ surv,
+                                               uint64_t nsurv, eb_cluster* __restrict__ recs, uint8_t* __restrict__ left,
+                                               ScanCounters* __restrict__ cnt) {
+    const uint32_t j = threadIdx.x & 3u;
+    const uint32_t qbase = (threadIdx.x & 63u) & ~3u; // first lane of this quad inside the wave
+    uint64_t chain = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    uint64_t i = chain >> 3;
+    uint32_t sidx = (uint32_t)(chain & 7u);
+    if (i >= nsurv) return; // uniform inside a quad
+    Survivor s = surv[i];
+    uint32_t side = sidx >> 2, c = sidx & 3u;
+    uint32_t fm = side ? s.fmask1 : s.fmask0;
+    if (!((fm >> c) & 1u)) return;
+    uint32_t slot = (side ? (uint32_t)__popc(s.fmask0) : 0u) + (uint32_t)__popc(fm & ((1u << c) - 1u));
+    const bool second = p.mode == 2 && side == 1;
+    const eb_dev_index& x = second ? x2 : x1;
+    uint64_t L, R;
+    if (p.mode == 2) { L = side ? s.b1 : s.b0; R = side ? s.e1 : s.e0; } else { L = s.b; R = s.e; }
+    uint8_t* out = left + ((size_t)i * EB_MAX_SLOTS + slot) * (size_t)p.k_left;
+    // LF(range, c)
+    uint64_t a = eb_rank4_quad(x, L, j);
+    uint64_t bq = R > L ? eb_rank4_quad(x, R, j) : a;
+    uint64_t Fc = pick4(x.F, c);
+    L = Fc + __shfl((unsigned long long)a, qbase + c);
+    R = Fc + __shfl((unsigned long long)bq, qbase + c);
+    uint32_t support = (uint32_t)(R - L);
+    int have = 1;
+    if (j == 0) out[p.k_left - 1] = (uint8_t)"ACGT"[c];
+    while (have < p.k_left) {
+        a = eb_rank4_quad(x, L, j);
+        bq = R > L ? eb_rank4_quad(x, R, j) : a;
+        uint64_t len = bq - a;
+        // arg-max over the quad, ties to the smaller letter (stable descending sort, ebwt2InDel.cpp:252-255)
+        uint64_t bl = len;
+        uint32_t bj = j;
+        for (int o = 1; o <= 2; o <<= 1) {
+            uint64_t ol = __shfl_xor((unsigned long long)bl, o);
+            uint32_t oj = (uint32_t)__shfl_xor((int)bj, o);
+            if (ol > bl || (ol == bl && oj < bj)) { bl = ol; bj = oj; }
+        }
+        if (bl == 0) break; // consensus_letter returns 0 (:257)
+        uint64_t Fb = pick4(x.F, bj);
+        L = Fb + __shfl((unsigned long long)a, qbase + bj);
+        R = Fb + __shfl((unsigned long long)bq, qbase + bj);
+        if (j == 0) out[p.k_left - 1 - have] = (uint8_t)"ACGT"[bj];
+        ++have;
+    }
+    if (j == 0) {
+        eb_cluster* r = recs + i;
+        r->slot_side[slot] = (uint8_t)side;
+        r->slot_sym[slot] = (uint8_t)"ACGT"[c];
+        r->slot_len[slot] = (uint32_t)have;
+        r->slot_support[slot] = support;
+        atomicAdd(&cnt->chains, 1ull);
+    }
+}
+
+// One lane per cluster: record header + right context (extract_dna, ebwt2InDel.cpp:325-342) at the first
+// cluster position whose LCP >= k_right (:979-988; two BWTs :896-912).
+__global__ void __launch_bounds__(256) k_right(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, ScanParams p,
+                                              const Survivor* __restrict__ surv, uint64_t nsurv, eb_cluster* __restrict__ recs,
+                                              uint8_t* __restrict__ right) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nsurv) return;
+    Survivor s = surv[i];
+    eb_cluster* r = recs + i;
+    r->begin = s.b;
+    r->end = s.e;
+    r->n_slots = (uint16_t)(__popc(s.fmask0) + __popc(s.fmask1));
+    // first position in [b,e) with thrR
+    uint64_t pos = ~0ull;
+    for (uint64_t w = s.b >> 6; w <= (s.e - 1) >> 6; ++w) {
+        uint64_t m = f.thrR[w];
+        uint64_t lo = w << 6;
+        if (s.b > lo) m &= ~0ull << (s.b - lo);
+        if (s.e < lo + 64) m &= ~0ull >> (lo + 64 - s.e);
+        if (m) { pos = lo + (uint32_t)__ffsll((long long)m) - 1u; break; }
+    }
+    uint32_t len = 0;
+    if (pos != ~0ull) {
+        bool second = false;
+        uint64_t row = pos;
+        if (p.mode == 2) {
+            second = eb_bit(f.da, pos);
+            uint64_t i1 = da_rank(f, pos);
+            row = second ? i1 : pos - i1;
+        }
+        const eb_dev_index& x = second ? x2 : x1;
+        uint8_t* out = right + (size_t)i * (size_t)p.k_right;
+        int c = eb_F_letter(x, row);
+        while (c >= 0 && len < (uint32_t)p.k_right) {
+            out[len++] = (uint8_t)"ACGT"[c];
+            row = eb_FL(x, row, c);
+            c = eb_F_letter(x, row);
+        }
+    }
+    r->right_found = pos != ~0ull ? 1 : 0;
+    r->right_len = len;
+}
+
+struct DevMem {
+    void* p = nullptr;
+    ~DevMem() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) {
+        if (p) { (void)hipFree(p); p = nullptr; }
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+        if (e != hipSuccess) { eb_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return EB_ERR_NOMEM; }
+        return EB_OK;
+    }
+    template <typename T> T* as() { return static_cast<T*>(p); }
+};
+
+unsigned grid_of(uint64_t threads) { return (unsigned)((threads + 255) / 256); }
+
+}  // namespace
+
+extern "C" int eb_scan_clusters(eb_index* b1, eb_index* b2, eb_flags* f, uint64_t begin, uint64_t end, const eb_params* prm,
+                                eb_calls** out, eb_scan_stats* stats) {
+    if (!b1 || !f || !prm || !out) { eb_set_error("null argument"); return EB_ERR_ARG; }
+    *out = nullptr;
+    const uint64_t n = b1->n + (b2 ? b2->n : 0);
+    if (f->n != n) { eb_set_error("flag vectors cover %llu positions, BWT has %llu", (unsigned long long)f->n, (unsigned long long)n); return EB_ERR_ARG; }
+    if (b1->device != f->device || (b2 && b2->device != b1->device)) { eb_set_error("handles live on different devices"); return EB_ERR_ARG; }
+    if (b2 && !f->d_da) { eb_set_error("two-BWT mode needs flags built from both indexes"); return EB_ERR_STATE; }
+    if (prm->k_left < 1 || prm->k_right < 1 || prm->mcov_out < 1) { eb_set_error("parameters not resolved (call eb_params_resolve)"); return EB_ERR_ARG; }
+    if (end > n) end = n;
+    if (begin > end) begin = end;
+    EB_HIP(hipSetDevice(b1->device));
+    hipStream_t st = b1->stream;
+
+    ScanParams p;
+    p.mode = b2 ? 2 : (f->d_da ? 3 : 1);
+    p.mcov = (uint32_t)prm->mcov_out;
+    p.min_len = 2u * (uint32_t)prm->mcov_out;
+    p.q = prm->max_variants_per_position;
+    p.k_left = prm->k_left;
+    p.k_right = prm->k_right;
+    p.begin = begin;
+    p.end = end;
+    p.n = n;
+    eb_dev_index x1 = b1->dev(), x2 = b2 ? b2->dev() : b1->dev();
+    eb_dev_flags df = f->dev();
+
+    hipEvent_t ev[5];
+    for (auto& e : ev) EB_HIP(hipEventCreate(&e));
+    struct EvGuard { hipEvent_t* e; ~EvGuard() { for (int i = 0; i < 5; ++i) (void)hipEventDestroy(e[i]); } } evg{ev};
+
+    DevMem d_cnt, d_surv, d_sorted, d_keys, d_keys2, d_idx, d_idx2, d_tmp, d_recs, d_left, d_right;
+    int rc;
+    if ((rc = d_cnt.alloc(sizeof(ScanCounters))) != EB_OK) return rc;
+    uint64_t w_lo = begin >> 6, w_hi = (end + 63) >> 6;
+    uint64_t w_count = w_hi > w_lo ? w_hi - w_lo : 0;
+    uint64_t cap = w_count / 16 + 4096; // survivors are ~1e-4 per position; grown on demand
+    ScanCounters c;
+    EB_HIP(hipEventRecord(ev[0], st));
+    for (;;) {
+        if ((rc = d_surv.alloc(cap * sizeof(Survivor))) != EB_OK) return rc;
+        EB_HIP(hipMemsetAsync(d_cnt.p, 0, sizeof(ScanCounters), st));
+        if (w_count)
+            hipLaunchKernelGGL(k_scan, dim3(grid_of(w_count)), dim3(256), 0, st, x1, x2, df, p, w_lo, w_count, d_surv.as<Survivor>(), cap,
+                               d_cnt.as<ScanCounters>());
+        EB_HIP(hipGetLastError());
+        EB_HIP(hipMemcpyAsync(&c, d_cnt.p, sizeof c, hipMemcpyDeviceToHost, st));
+        EB_HIP(hipStreamSynchronize(st));
+        if (c.nsurv <= cap) break;
+        cap = c.nsurv + 1024; // rare: rerun the scan with room for every survivor
+        EB_HIP(hipEventRecord(ev[0], st));
+    }
+    EB_HIP(hipEventRecord(ev[1], st));
+    const uint64_t ns = c.nsurv;
+    eb_calls* calls = new eb_calls();
+    calls->k_left = prm->k_left;
+    calls->k_right = prm->k_right;
+    struct CallGuard { eb_calls* c; ~CallGuard() { delete c; } } cg{calls};
+    float ms_scan = 0, ms_ext = 0, ms_right = 0, ms_total = 0;
+    if (ns) {
+        if (ns > 0xFFFFFFFFull) { eb_set_error("too many surviving clusters in one call; shard the range"); return EB_ERR_STATE; }
+        // BWT order: sort survivors by begin
+        if ((rc = d_keys.alloc(ns * 8)) != EB_OK || (rc = d_keys2.alloc(ns * 8)) != EB_OK || (rc = d_idx.alloc(ns * 4)) != EB_OK ||
+            (rc = d_idx2.alloc(ns * 4)) != EB_OK || (rc = d_sorted.alloc(ns * sizeof(Survivor))) != EB_OK)
+            return rc;
+        hipLaunchKernelGGL(k_surv_keys, dim3(grid_of(ns)), dim3(256), 0, st, d_surv.as<Survivor>(), ns, d_keys.as<uint64_t>(), d_idx.as<uint32_t>());
+        size_t tmp_bytes = 0;
+        EB_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_keys.as<uint64_t>(), d_keys2.as<uint64_t>(), d_idx.as<uint32_t>(),
+                                                  d_idx2.as<uint32_t>(), (int)ns, 0, 64, st));
+        if ((rc = d_tmp.alloc(tmp_bytes)) != EB_OK) return rc;
+        EB_HIP(hipcub::DeviceRadixSort::SortPairs(d_tmp.p, tmp_bytes, d_keys.as<uint64_t>(), d_keys2.as<uint64_t>(), d_idx.as<uint32_t>(),
+                                                  d_idx2.as<uint32_t>(), (int)ns, 0, 64, st));
+        hipLaunchKernelGGL(k_surv_gather, dim3(grid_of(ns)), dim3(256), 0, st, d_surv.as<Survivor>(), d_idx2.as<uint32_t>(), ns, d_sorted.as<Survivor>());
+        size_t left_bytes = (size_t)ns * EB_MAX_SLOTS * (size_t)prm->k_left, right_bytes = (size_t)ns * (size_t)prm->k_right;
+        if ((rc = d_recs.alloc(ns * sizeof(eb_cluster))) != EB_OK || (rc = d_left.alloc(left_bytes)) != EB_OK || (rc = d_right.alloc(right_bytes)) != EB_OK)
+            return rc;
+        EB_HIP(hipMemsetAsync(d_recs.p, 0, ns * sizeof(eb_cluster), st));
+        EB_HIP(hipMemsetAsync(d_left.p, 0, left_bytes, st));
+        EB_HIP(hipMemsetAsync(d_right.p, 0, right_bytes, st));
+        EB_HIP(hipEventRecord(ev[2], st));
+        hipLaunchKernelGGL(k_extend, dim3(grid_of(ns * 32)), dim3(256), 0, st, x1, x2, p, d_sorted.as<Survivor>(), ns, d_recs.as<eb_cluster>(),
+                           d_left.as<uint8_t>(), d_cnt.as<ScanCounters>());
+        EB_HIP(hipEventRecord(ev[3], st));
+        hipLaunchKernelGGL(k_right, dim3(grid_of(ns)), dim3(256), 0, st, x1, x2, df, p, d_sorted.as<Survivor>(), ns, d_recs.as<eb_cluster>(),
+                           d_right.as<uint8_t>());
+        EB_HIP(hipEventRecord(ev[4], st));
+        EB_HIP(hipGetLastError());
+        calls->clusters.resize(ns);
+        calls->left.resize(left_bytes);
+        calls->right.resize(right_bytes);
+        EB_HIP(hipMemcpyAsync(calls->clusters.data(), d_recs.p, ns * sizeof(eb_cluster), hipMemcpyDeviceToHost, st));
+        EB_HIP(hipMemcpyAsync(calls->left.data(), d_left.p, left_bytes, hipMemcpyDeviceToHost, st));
+        EB_HIP(hipMemcpyAsync(calls->right.data(), d_right.p, right_bytes, hipMemcpyDeviceToHost, st));
+        EB_HIP(hipMemcpyAsync(&c, d_cnt.p, sizeof c, hipMemcpyDeviceToHost, st));
+        EB_HIP(hipStreamSynchronize(st));
+        EB_HIP(hipEventElapsedTime(&ms_ext, ev[2], ev[3]));
+        EB_HIP(hipEventElapsedTime(&ms_right, ev[3], ev[4]));
+        EB_HIP(hipEventElapsedTime(&ms_total, ev[0], ev[4]));
+        // contexts shorter than k_left are dropped by the writer (ebwt2InDel.cpp:317): blank them
+        for (uint64_t i = 0; i < ns; ++i)
+            for (uint32_t s = 0; s < EB_MAX_SLOTS; ++s)
+                if (calls->clusters[i].slot_len[s] != (uint32_t)prm->k_left)
+                    memset(calls->left.data() + (i * EB_MAX_SLOTS + s) * (size_t)prm->k_left, 0, (size_t)prm->k_left);
+    } else {
+        EB_HIP(hipEventSynchronize(ev[1]));
+        EB_HIP(hipEventElapsedTime(&ms_total, ev[0], ev[1]));
+    }
+    EB_HIP(hipEventElapsedTime(&ms_scan, ev[0], ev[1]));
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->begin = begin;
+        stats->end = end;
+        stats->runs_closed = c.runs_closed;
+        stats->clusters = c.clusters;
+        stats->bases_in_runs = c.bases;
+        stats->survivors = ns;
+        stats->chains = c.chains;
+        for (int k = 0; k < 201; ++k) stats->hist[k] = c.hist[k];
+        stats->ms_scan = ms_scan;
+        stats->ms_extend = ms_ext;
+        stats->ms_right = ms_right;
+        stats->ms_total = ms_total;
+    }
+    cg.c = nullptr;
+    *out = calls;
+    return EB_OK;
+}

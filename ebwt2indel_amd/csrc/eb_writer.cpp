@@ -1,0 +1,276 @@
+// eb_writer.cpp -- host side of the hot path: call-set container, event logic, KisSNP2 text.
+//
+// Replaces to_file (ebwt2InDel.cpp:1254-1330 one sample; :1149-1252 pairs), distance (:192-240),
+// dH (:157-171), has_run (:144-152) and event_type (:1102-1144).  This part stays on the host in
+// the reference's own language (C++): it is sequential by construction (running cluster_nr / id_nr
+// counters, :52,:72) and touches ~1e-4 of the BWT positions.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "eb_internal.h"
+
+namespace {
+
+struct Ctx {
+    std::string s;
+    int support;
+};
+
+// true iff s starts with a run of >= k equal characters (:144-152)
+bool has_run(const std::string& s, int k) {
+    if ((size_t)k > s.length()) return false; // int -> size_t like the reference: a negative k never matches
+    for (int i = 1; i < k; ++i)
+        if (s[i] != s[i - 1]) return false;
+    return true;
+}
+
+// Hamming distance, strings aligned on the right, extra characters on the left ignored (:157-171)
+int hamming_right(const std::string& a, const std::string& b) {
+    size_t len = std::min(a.size(), b.size());
+    int d = 0;
+    for (size_t i = 0; i < len; ++i) d += a[a.size() - i - 1] != b[b.size() - i - 1];
+    return d;
+}
+
+struct Align {
+    int mism; // mismatches outside the gap
+    int gap;  // > 0: insertion in a, < 0: insertion in b, 0: none
+};
+
+// distance (:192-240): best of {no indel, i = 1..max_gap characters cut from the right end of a, same for b};
+// an indel wins ties against "no indel", "insert in b" wins ties against "insert in a", shortest gap first.
+Align align_pair(const std::string& a, const std::string& b, int max_gap) {
+    int none = hamming_right(a, b);
+    if (max_gap == 0) return {none, 0};
+    std::vector<int> cut_a(max_gap), cut_b(max_gap);
+    for (int i = 1; i <= max_gap; ++i) {
+        // substr(0, len - i): the count wraps for i > len and substr clamps it to the whole string
+        std::string a1 = a.substr(0, a.length() - (size_t)i);
+        std::string b1 = b.substr(0, b.length() - (size_t)i);
+        cut_a[i - 1] = hamming_right(a1, b) + i;
+        cut_b[i - 1] = hamming_right(a, b1) + i;
+    }
+    int ia = (int)(std::min_element(cut_a.begin(), cut_a.end()) - cut_a.begin());
+    int ib = (int)(std::min_element(cut_b.begin(), cut_b.end()) - cut_b.begin());
+    if (none < cut_a[ia] && none < cut_b[ib]) return {none, 0};
+    if (cut_a[ia] < cut_b[ib]) return {cut_a[ia] - (ia + 1), ia + 1};
+    return {cut_b[ib] - (ib + 1), -(ib + 1)};
+}
+
+// event_type (:1102-1144)
+std::string event_label(const std::string& a, const std::string& b, int gap) {
+    std::string out = "type:";
+    out += gap != 0 ? "_INDEL_event:" : "_SNP_event:";
+    if (gap == 0) {
+        out += a[a.size() - 1];
+        out += '/';
+        out += b[b.size() - 1];
+    } else if (gap > 0) {
+        out += a.substr(a.size() - (size_t)gap);
+        out += '/';
+    } else {
+        out += '/';
+        out += b.substr(b.size() - (size_t)(-gap));
+    }
+    return out;
+}
+
+void header(std::string& o, uint64_t cluster_nr, uint64_t id_nr, size_t right_len, int cov, const std::string& type) {
+    o += ">cluster:";
+    o += std::to_string(cluster_nr);
+    o += "_id:";
+    o += std::to_string(id_nr);
+    o += "_right:";
+    o += std::to_string(right_len);
+    o += "_cov:";
+    o += std::to_string(cov);
+    o += '_';
+    o += type;
+    o += '\n';
+}
+
+// one-sample writer (:1254-1330)
+void write_single(std::string& o, const std::vector<Ctx>& v, const std::string& right, const eb_params& p, uint64_t& cluster_nr,
+                  uint64_t& events) {
+    if (v.size() < 2) return; // :1256 -- cluster_nr untouched
+    int max_dist = 0;
+    std::vector<const Ctx*> good;
+    for (size_t i = 0; i + 1 < v.size(); ++i) { // consecutive contexts in A,C,G,T order, low-support ones included (:1262-1270)
+        Align d = align_pair(v[i].s, v[i + 1].s, p.max_gap);
+        max_dist = std::max(max_dist, d.mism);
+        if (v[i].support >= p.mcov_out) good.push_back(&v[i]);
+    }
+    if (v.back().support >= p.mcov_out) good.push_back(&v.back());
+    if (max_dist <= p.max_snvs && good.size() >= 2) {
+        uint64_t id_nr = 1;
+        for (size_t i = 0; i < good.size(); ++i) {
+            if (has_run(right, p.complexity)) continue;
+            // allele 0 is labelled against allele 1; allele i >= 1 carries distance(good[i-1], good[1]) (:1299-1307)
+            const std::string& a = i == 0 ? good[0]->s : good[i - 1]->s;
+            Align d = align_pair(a, good[1]->s, p.max_gap);
+            header(o, cluster_nr, id_nr++, right.size(), good[i]->support, event_label(a, good[1]->s, d.gap));
+            o += good[i]->s;
+            o += right;
+            o += '\n';
+            ++events;
+        }
+    }
+    ++cluster_nr; // even when nothing was printed (:1328)
+}
+
+// pair writer (:1149-1252)
+void write_pairs(std::string& o, const std::vector<Ctx>& c0, const std::vector<Ctx>& c1, const std::string& right, const eb_params& p,
+                 uint64_t& cluster_nr) {
+    bool found = false;
+    uint64_t id_nr = 1;
+    for (const Ctx& a : c0)
+        for (const Ctx& b : c1) {
+            if (a.s.empty() || b.s.empty()) continue;
+            if (a.s.back() == b.s.back()) continue; // only pairs whose last characters differ are variants (:921,:1083)
+            Align d = align_pair(a.s, b.s, p.max_gap);
+            if (has_run(right, p.complexity) || d.mism > p.max_snvs || a.support < p.mcov_out || b.support < p.mcov_out) continue;
+            found = true;
+            std::string type = event_label(a.s, b.s, d.gap);
+            header(o, cluster_nr, id_nr, right.size(), a.support, type);
+            o += d.gap < 0 ? a.s.substr((size_t)(-d.gap)) : a.s; // insertion in sample 1: sample 0 loses its first |gap| chars (:1197-1201)
+            o += right;
+            o += '\n';
+            header(o, cluster_nr, id_nr, right.size(), b.support, type);
+            o += d.gap > 0 ? b.s.substr((size_t)d.gap) : b.s; // (:1231-1233)
+            o += right;
+            o += '\n';
+            ++id_nr;
+        }
+    cluster_nr += found ? 1 : 0; // :1250
+}
+
+int format_calls(const eb_calls* c, const eb_params* p, int two_samples, uint64_t* cluster_nr, uint64_t* events, std::string& o) {
+    if (!c || !p || !cluster_nr) { eb_set_error("null argument"); return EB_ERR_ARG; }
+    if (c->k_left != p->k_left || c->k_right != p->k_right) { eb_set_error("call set was produced with other -L/-R values"); return EB_ERR_ARG; }
+    uint64_t ev = events ? *events : 0;
+    const size_t kl = (size_t)c->k_left, kr = (size_t)c->k_right;
+    for (size_t i = 0; i < c->clusters.size(); ++i) {
+        const eb_cluster& r = c->clusters[i];
+        if (!r.right_found) continue; // no variants are collected without a right context (:985, :909, :1071)
+        std::string right(reinterpret_cast<const char*>(c->right.data() + i * kr), r.right_len);
+        std::vector<Ctx> side[2];
+        for (uint32_t s = 0; s < r.n_slots && s < EB_MAX_SLOTS; ++s) {
+            if (r.slot_len[s] != (uint32_t)c->k_left) continue; // shorter contexts are dropped (:317)
+            Ctx x;
+            x.s.assign(reinterpret_cast<const char*>(c->left.data() + (i * EB_MAX_SLOTS + s) * kl), kl);
+            x.support = (int)r.slot_support[s];
+            side[r.slot_side[s] ? 1 : 0].push_back(std::move(x));
+        }
+        if (two_samples) write_pairs(o, side[0], side[1], right, *p, *cluster_nr);
+        else write_single(o, side[0], right, *p, *cluster_nr, ev);
+    }
+    if (events) *events = ev;
+    return EB_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ call-set container
+
+extern "C" int eb_calls_get(const eb_calls* c, eb_calls_view* v) {
+    if (!c || !v) { eb_set_error("null argument"); return EB_ERR_ARG; }
+    v->count = c->clusters.size();
+    v->k_left = c->k_left;
+    v->k_right = c->k_right;
+    v->clusters = c->clusters.data();
+    v->left = c->left.data();
+    v->right = c->right.data();
+    return EB_OK;
+}
+
+extern "C" void eb_calls_free(eb_calls* c) { delete c; }
+
+static const uint64_t kMagic = 0x31534C4C41434245ull; // "EBCALLS1"
+
+extern "C" uint64_t eb_calls_packed_size(const eb_calls* c) {
+    if (!c) return 0;
+    return 32 + c->clusters.size() * sizeof(eb_cluster) + c->left.size() + c->right.size();
+}
+
+extern "C" int eb_calls_pack(const eb_calls* c, uint8_t* buf, uint64_t cap) {
+    if (!c || !buf) { eb_set_error("null argument"); return EB_ERR_ARG; }
+    uint64_t need = eb_calls_packed_size(c);
+    if (cap < need) { eb_set_error("buffer too small: need %llu bytes", (unsigned long long)need); return EB_ERR_ARG; }
+    uint64_t hdr[4] = {kMagic, c->clusters.size(), (uint64_t)(uint32_t)c->k_left, (uint64_t)(uint32_t)c->k_right};
+    memcpy(buf, hdr, 32);
+    uint8_t* q = buf + 32;
+    if (!c->clusters.empty()) {
+        memcpy(q, c->clusters.data(), c->clusters.size() * sizeof(eb_cluster));
+        q += c->clusters.size() * sizeof(eb_cluster);
+        memcpy(q, c->left.data(), c->left.size());
+        q += c->left.size();
+        memcpy(q, c->right.data(), c->right.size());
+    }
+    return EB_OK;
+}
+
+extern "C" int eb_calls_unpack(const uint8_t* buf, uint64_t len, eb_calls** out) {
+    if (!buf || !out) { eb_set_error("null argument"); return EB_ERR_ARG; }
+    *out = nullptr;
+    uint64_t hdr[4];
+    if (len < 32) { eb_set_error("truncated call set"); return EB_ERR_ARG; }
+    memcpy(hdr, buf, 32);
+    if (hdr[0] != kMagic) { eb_set_error("not a packed call set"); return EB_ERR_ARG; }
+    uint64_t cnt = hdr[1], kl = hdr[2], kr = hdr[3];
+    uint64_t need = 32 + cnt * sizeof(eb_cluster) + cnt * EB_MAX_SLOTS * kl + cnt * kr;
+    if (len < need) { eb_set_error("truncated call set"); return EB_ERR_ARG; }
+    eb_calls* c = new eb_calls();
+    c->k_left = (int32_t)kl;
+    c->k_right = (int32_t)kr;
+    c->clusters.resize(cnt);
+    c->left.resize(cnt * EB_MAX_SLOTS * kl);
+    c->right.resize(cnt * kr);
+    const uint8_t* q = buf + 32;
+    if (cnt) {
+        memcpy(c->clusters.data(), q, cnt * sizeof(eb_cluster));
+        q += cnt * sizeof(eb_cluster);
+        memcpy(c->left.data(), q, c->left.size());
+        q += c->left.size();
+        memcpy(c->right.data(), q, c->right.size());
+    }
+    *out = c;
+    return EB_OK;
+}
+
+// ------------------------------------------------------------------ writer entry points
+
+extern "C" int eb_format_snp(const eb_calls* c, const eb_params* p, int two_samples, uint64_t* cluster_nr, uint64_t* events,
+                             char** text, uint64_t* len) {
+    if (!text || !len) { eb_set_error("null argument"); return EB_ERR_ARG; }
+    std::string o;
+    int rc = format_calls(c, p, two_samples, cluster_nr, events, o);
+    if (rc != EB_OK) return rc;
+    char* b = static_cast<char*>(malloc(o.size() + 1));
+    if (!b) { eb_set_error("out of memory"); return EB_ERR_NOMEM; }
+    memcpy(b, o.data(), o.size());
+    b[o.size()] = 0;
+    *text = b;
+    *len = o.size();
+    return EB_OK;
+}
+
+extern "C" int eb_write_snp(const eb_calls* c, const eb_params* p, int two_samples, const char* path, int append,
+                            uint64_t* cluster_nr, uint64_t* events) {
+    if (!path) { eb_set_error("null argument"); return EB_ERR_ARG; }
+    std::string o;
+    int rc = format_calls(c, p, two_samples, cluster_nr, events, o);
+    if (rc != EB_OK) return rc;
+    FILE* f = fopen(path, append ? "ab" : "wb");
+    if (!f) { eb_set_error("cannot open %s for writing", path); return EB_ERR_IO; }
+    size_t w = o.empty() ? 0 : fwrite(o.data(), 1, o.size(), f);
+    int bad = fclose(f);
+    if (w != o.size() || bad) { eb_set_error("short write to %s", path); return EB_ERR_IO; }
+    return EB_OK;
+}
+
+extern "C" void eb_free(void* p) { free(p); }

@@ -145,8 +145,9 @@ void eb_flags_destroy(eb_flags* f);
  * (find_variants, ebwt2InDel.cpp:840-934, 941-1005, 1013-1096), in BWT order. */
 typedef struct {
     uint64_t begin, end;           /* cluster [begin,end) in merged coordinates (:1618,1632) */
-    uint32_t n_slots;              /* left-context chains started, side 0 first, A<C<G<T within a side */
-    uint32_t right_len;            /* chars of right context extracted (0: no position with thrR) */
+    uint16_t n_slots;              /* left-context chains started, side 0 first, A<C<G<T within a side */
+    uint16_t right_found;          /* 1 iff some cluster position has LCP >= k_right (:982-985) */
+    uint32_t right_len;            /* chars of right context extracted there (k_right unless TERM was met) */
     uint8_t  slot_side[EB_MAX_SLOTS];    /* 0/1 (always 0 in one-sample mode) */
     uint8_t  slot_sym[EB_MAX_SLOTS];     /* 'A','C','G','T' */
     uint32_t slot_len[EB_MAX_SLOTS];     /* chars obtained; a context is valid iff == k_left (:317) */
@@ -165,8 +166,9 @@ typedef struct {
 } eb_scan_stats;
 
 /* Replaces the phase-4 loops run_one_dataset (:1609-1655), run_two_datasets (:1395-1445)
- * and run_two_datasets_da (:1510-1560) restricted to clusters whose first position lies
- * in [begin,end) (the whole BWT: begin=0, end=n).  Mode: b2 != NULL -> two BWTs;
+ * and run_two_datasets_da (:1510-1560) restricted to clusters whose closing position (the
+ * first unflagged position after the run, :1623) lies in [begin,end); the whole BWT is
+ * begin=0, end=n.  Shards that tile [0,n) therefore partition the clusters.  Mode: b2 != NULL -> two BWTs;
  * else flags carrying a DA -> merged BWT + DA; else one sample. */
 int eb_scan_clusters(eb_index* b1, eb_index* b2, eb_flags* f, uint64_t begin, uint64_t end, const eb_params* p,
                      eb_calls** out, eb_scan_stats* stats);

@@ -774,7 +774,7 @@ static void analyse_cluster(orun* r, int mode, uint64_t b, uint64_t e, uint64_t 
             if (rec) {
                 rec->slot_side[slot] = (uint8_t)side; rec->slot_sym[slot] = fr[side][k];
                 rec->slot_len[slot] = (uint32_t)len; rec->slot_support[slot] = (uint32_t)support;
-                memcpy(rleft + (size_t)slot * (size_t)p->k_left, dst, (size_t)len);
+                if (len == p->k_left) memcpy(rleft + (size_t)slot * (size_t)p->k_left, dst, (size_t)len);
             }
             if (len == p->k_left) { /* :317 */
                 octx* c = &ctx[side][nctx[side]++];
@@ -782,7 +782,7 @@ static void analyse_cluster(orun* r, int mode, uint64_t b, uint64_t e, uint64_t 
             }
         }
     }
-    if (rec) rec->n_slots = (uint32_t)slot;
+    if (rec) rec->n_slots = (uint16_t)slot;
 
     /* right context at the first cluster position with LCP >= k_right (:979-988, :896-912, :1065-1074) */
     char* right = (char*)malloc((size_t)p->k_right + 1);
@@ -796,7 +796,7 @@ static void analyse_cluster(orun* r, int mode, uint64_t b, uint64_t e, uint64_t 
         while (i < e && !bit_get(r->f->thrR, i)) ++i;
         if (i < e) rlen = right_context(r->x1, i, p->k_right, right);
     }
-    if (rec && rlen > 0) { rec->right_len = (uint32_t)rlen; memcpy(rright, right, (size_t)rlen); }
+    if (rec && rlen >= 0) { rec->right_found = 1; rec->right_len = (uint32_t)rlen; memcpy(rright, right, (size_t)rlen); }
     if (rlen >= 0) {
         if (mode == 1) write_single(r, ctx[0], nctx[0], right, rlen);
         else write_pairs(r, ctx[0], nctx[0], ctx[1], nctx[1], right, rlen);
@@ -808,30 +808,23 @@ static void analyse_cluster(orun* r, int mode, uint64_t b, uint64_t e, uint64_t 
 }
 
 /* Phase-4 loops: run_one_dataset ebwt2InDel.cpp:1609-1655, run_two_datasets :1395-1445,
- * run_two_datasets_da :1510-1560.  Clusters whose first position is in [sb,se) are analysed. */
+ * run_two_datasets_da :1510-1560.  Clusters whose closing position is in [sb,se) are analysed
+ * (the whole BWT: sb=0, se=n; a run still open at n-1 never closes and is dropped). */
 static void scan(orun* r, int mode, uint64_t sb, uint64_t se) {
     const oflags* f = r->f;
     uint64_t n = f->n, begin = 0, begin0 = 0, begin1 = 0, i0 = 0, i1 = 0, len = 0;
     int open = 0;
-    uint64_t start = 0;
-    if (sb > 0) { /* shard entry: DA prefix counts and "is a run already open" */
-        start = sb;
-        if (mode == 2) for (uint64_t i = 0; i < sb; ++i) { int d = bit_get(f->da, i); i0 += !d; i1 += d; }
-        /* skip a run that began before the shard */
-        while (start < n && bit_get(f->thrK, start - 1) && !bit_get(f->minima, start - 1) && bit_get(f->thrK, start) && !bit_get(f->minima, start)) {
-            if (mode == 2) { int d = bit_get(f->da, start); i0 += !d; i1 += d; }
-            ++start;
-        }
-    }
-    for (uint64_t i = start; i < n; ++i) {
+    if (se > n) se = n;
+    /* shard entry: a run that is open at sb closes inside this shard, so rewind to its first position */
+    uint64_t start = sb;
+    while (start > 0 && bit_get(f->thrK, start - 1) && !bit_get(f->minima, start - 1)) --start;
+    if (mode == 2) for (uint64_t i = 0; i < start; ++i) { int d = bit_get(f->da, i); i0 += !d; i1 += d; }
+    for (uint64_t i = start; i < se; ++i) {
         if (bit_get(f->thrK, i) && !bit_get(f->minima, i)) {
             if (open) ++len;
-            else {
-                if (i >= se) break; /* next cluster belongs to the following shard */
-                open = 1; len = 1; begin = i; begin0 = i0; begin1 = i1;
-            }
+            else { open = 1; len = 1; begin = i; begin0 = i0; begin1 = i1; }
         } else {
-            if (open) {
+            if (open) { /* close at i (sb <= i < se) */
                 r->clust_size += len;
                 r->runs_closed++;
                 if (len <= 200) r->hist[len] += len;
@@ -839,7 +832,7 @@ static void scan(orun* r, int mode, uint64_t sb, uint64_t se) {
                     r->n_clusters++;
                     analyse_cluster(r, mode, begin, i, begin0, i0, begin1, i1);
                 }
-            } else if (i >= se) break;
+            }
             open = 0;
             len = 0;
         }

@@ -44,7 +44,7 @@ class Params(C.Structure):
 
 class Cluster(C.Structure):
     """Mirror of eb_cluster (include/ebwt2indel.h)."""
-    _fields_ = [("begin", C.c_uint64), ("end", C.c_uint64), ("n_slots", C.c_uint32), ("right_len", C.c_uint32),
+    _fields_ = [("begin", C.c_uint64), ("end", C.c_uint64), ("n_slots", C.c_uint16), ("right_found", C.c_uint16), ("right_len", C.c_uint32),
                 ("slot_side", C.c_uint8 * 8), ("slot_sym", C.c_uint8 * 8), ("slot_len", C.c_uint32 * 8),
                 ("slot_support", C.c_uint32 * 8)]
 
@@ -243,3 +243,9 @@ class OracleFlags:
                 if p_.value:
                     L.orc_free(p_)
         return out
+
+
+def pack_calls(rec: dict, k_left: int, k_right: int) -> bytes:
+    """Byte image understood by eb_calls_unpack (csrc/eb_writer.cpp) from an oracle record capture."""
+    hdr = np.array([0x31534C4C41434245, rec["count"], k_left, k_right], dtype=np.uint64).tobytes()
+    return hdr + rec["clusters"].tobytes() + rec["left"].tobytes() + rec["right"].tobytes()

@@ -1,0 +1,333 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every call goes through the C ABI of
+libebwt2indel.so; the CPU oracle (pinned to the reference by tests/test_oracle_golden.py) is the checker.
+Bit-exact everywhere: this path is integer / byte work."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from ebwt2indel_amd import _lib, api, sim
+from tests import _oracle
+from tests.conftest import CASES, CASE_IDS, golden_bytes
+
+pytestmark = pytest.mark.gpu
+
+
+def _rng(seed):
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+def _positions(n, m, seed, upto_n=True):
+    r = _rng(seed)
+    hi = n + 1 if upto_n else n
+    pos = r.integers(0, hi, size=m, dtype=np.uint64)
+    edge = np.array([0, 1, 31, 32, 63, 64, 127, 128, 129, n - 1 if n else 0, n if upto_n else max(n - 1, 0)], dtype=np.uint64)
+    return np.concatenate([edge[edge < hi], pos])
+
+
+@pytest.fixture(scope="module")
+def dip(oracle):
+    e = golden_bytes("dip.ebwt")
+    return e, api.DnaBwt(e), oracle.index(e)
+
+
+# ------------------------------------------------------------------ phase 1 + primitives
+
+@pytest.mark.parametrize("name,term", [("dip.ebwt", 35), ("edge.ebwt", 35), ("n128_t36.ebwt", 36), ("tiny.ebwt", 35)])
+def test_index_F_and_size(oracle, name, term):
+    e = golden_bytes(name)
+    g, o = api.DnaBwt(e, term=term), oracle.index(e, term)
+    assert g.size() == len(e) == o.n
+    assert g.F_arr == [int(x) for x in o.F()]
+    assert g.n_blocks == (len(e) + 128) // 128
+
+
+def test_index_from_file_and_device_buffer(tmp_path, dip):
+    e, g, o = dip
+    path = tmp_path / "x.ebwt"
+    path.write_bytes(e)
+    gf = api.DnaBwt(str(path))
+    pos = _positions(len(e), 5000, 1)
+    assert np.array_equal(gf.parallel_rank(pos), o.rank4(pos))
+    torch = pytest.importorskip("torch")
+    t = torch.frombuffer(bytearray(e), dtype=torch.uint8).cuda()
+    gd = api.DnaBwt(None, device_ptr=t.data_ptr(), n=t.numel())
+    assert gd.F_arr == g.F_arr
+    assert np.array_equal(gd.parallel_rank(pos), o.rank4(pos))
+
+
+def test_forbidden_character_is_reported():
+    e = bytearray(golden_bytes("dip.ebwt"))
+    e[70001] = ord("N")
+    e[90000] = ord("x")
+    with pytest.raises(_lib.EbError) as err:
+        api.DnaBwt(bytes(e))
+    assert err.value.code == _lib.EB_ERR_ALPHABET
+    assert api.DnaBwt.bad_symbol() == (ord("N"), 70001)
+    assert "forbidden character 'N' (ASCII code 78)" in str(err.value)
+
+
+def test_parallel_rank_exhaustive_small(oracle):
+    e = golden_bytes("tiny.ebwt") + golden_bytes("edge.ebwt")[:1000]
+    g, o = api.DnaBwt(e), oracle.index(e)
+    pos = np.arange(len(e) + 1, dtype=np.uint64)
+    got = g.parallel_rank(pos)
+    assert np.array_equal(got, o.rank4(pos))
+    naive = np.zeros((len(e) + 1, 4), dtype=np.uint64)        # definition: prefix counts
+    arr = np.frombuffer(e, dtype=np.uint8)
+    for c, ch in enumerate(b"ACGT"):
+        naive[1:, c] = np.cumsum(arr == ch)
+    assert np.array_equal(got, naive)
+
+
+def test_parallel_rank_random(dip):
+    e, g, o = dip
+    pos = _positions(len(e), 200_000, 2)
+    assert np.array_equal(g.parallel_rank(pos), o.rank4(pos))
+
+
+def test_access(dip):
+    e, g, o = dip
+    pos = _positions(len(e), 50_000, 3, upto_n=False)
+    got = g[pos]
+    assert np.array_equal(got, np.frombuffer(e, dtype=np.uint8)[pos.astype(np.int64)])
+    assert np.array_equal(got, o.access(pos))
+
+
+def test_lf_range_and_sym(dip):
+    e, g, o = dip
+    r = _rng(4)
+    l = r.integers(0, len(e) + 1, size=60_000, dtype=np.uint64)
+    w = r.integers(0, 300, size=60_000, dtype=np.uint64)
+    w[:2000] = 0                                               # empty ranges take the one-rank path
+    rr = np.minimum(l + w, np.uint64(len(e)))
+    lr = np.stack([l, rr], axis=1)
+    assert np.array_equal(g.LF(lr), o.lf_range(lr))
+    sym = np.frombuffer(b"ACGT", dtype=np.uint8)[r.integers(0, 4, size=len(lr))]
+    assert np.array_equal(g.LF(lr, sym), o.lf_range_sym(lr, sym))
+
+
+def test_fl_is_inverse_of_lf(dip):
+    e, g, o = dip
+    r = _rng(5)
+    pos = r.integers(g.F_arr[0], len(e), size=40_000, dtype=np.uint64)
+    fl = g.FL(pos)
+    assert np.array_equal(fl, o.fl(pos))
+    # LF(FL(i)) == i : row fl holds the letter F(i); its LF image is i
+    arr = np.frombuffer(e, dtype=np.uint8)
+    letters = arr[fl.astype(np.int64)]
+    back = g.LF(np.stack([fl, fl + np.uint64(1)], axis=1), letters)[:, 0]
+    assert np.array_equal(back, pos)
+
+
+def test_lf_node(dip):
+    e, g, o = dip
+    r = _rng(6)
+    m = 20_000
+    b = np.sort(r.integers(0, len(e) + 1, size=(m, 6), dtype=np.uint64), axis=1)
+    b[: m // 4, 1] = b[: m // 4, 0]                            # repeated boundaries share a rank query
+    b[: m // 8, 5] = b[: m // 8, 4]
+    nodes = np.concatenate([b, r.integers(0, 100, size=(m, 1), dtype=np.uint64)], axis=1)
+    nodes[0] = g.root()
+    assert np.array_equal(g.LF_node(nodes), o.lf_node(nodes))
+
+
+# ------------------------------------------------------------------ phases 2-3
+
+def _flag_case(oracle, case):
+    p = _oracle.Params.from_args(case["args"])
+    inp = case["inputs"]
+    e1 = golden_bytes(inp["bwt1"])
+    e2 = golden_bytes(inp["bwt2"]) if case["mode"] == 2 else None
+    da = golden_bytes(inp["da"]) if case["mode"] == 3 else None
+    return p, e1, e2, da
+
+
+FLAG_CASES = [c for c in CASES if c["name"] in ("m1_default", "m1_k20", "m1_L40_R35", "m1_edge_default", "m1_n128_term36",
+                                                "m2_hom_default", "m2_het_default", "m2_edge_default", "m2_hom_L25_R20_k14",
+                                                "m3_het_default", "m1_tiny_nocluster")]
+
+
+@pytest.mark.parametrize("case", FLAG_CASES, ids=lambda c: c["name"])
+def test_flag_vectors_bit_exact(oracle, case):
+    p, e1, e2, da = _flag_case(oracle, case)
+    o1 = oracle.index(e1, p.term)
+    o2 = oracle.index(e2, p.term) if e2 is not None else None
+    of = _oracle.OracleFlags(oracle, o1, o2, p.K, p.k_right, da)
+    g1 = api.DnaBwt(e1, term=p.term)
+    g2 = api.DnaBwt(e2, term=p.term) if e2 is not None else None
+    gf = api.Flags.build(g1, g2, p.K, p.k_right)
+    if da is not None:
+        gf.set_da(da)
+    want = of.export()
+    got = gf.export()
+    for name, a, b in zip(("thrK", "thrR", "minima", "da"), got, want):
+        assert (a is None) == (b is None), name
+        if a is not None:
+            assert np.array_equal(a, b), name
+    oc, st = of.counters(), gf.stats
+    n = len(e1) + (len(e2) if e2 is not None else 0)
+    assert (st.leaves, st.nodes, st.minima) == (oc["leaves"], oc["nodes"], oc["minima"])
+    assert st.lcp_values == oc["lcp_values"] == n              # every LCP slot written exactly once
+    if e2 is not None:
+        assert st.da_values == oc["da_values"] == n
+
+
+def test_flags_batch_size_does_not_change_result(oracle, monkeypatch):
+    e = golden_bytes("dip.ebwt")
+    g = api.DnaBwt(e)
+    ref = api.Flags.build(g, None, 16, 30).export()
+    for batch in ("64", "1000"):                               # tiny batches: many launches, depth-first order
+        monkeypatch.setenv("EB_NAV_BATCH", batch)
+        got = api.Flags.build(g, None, 16, 30).export()
+        for a, b in zip(got[:3], ref[:3]):
+            assert np.array_equal(a, b)
+
+
+def test_flags_import_export_round_trip(oracle):
+    e = golden_bytes("het_m.ebwt")
+    da = golden_bytes("het_m.da")
+    of = _oracle.OracleFlags(oracle, oracle.index(e), None, 16, 30, da)
+    want = of.export()
+    f = api.Flags.from_host(len(e), *want)
+    for a, b in zip(f.export(), want):
+        assert np.array_equal(a, b)
+
+
+# ------------------------------------------------------------------ phase 4 and the whole path
+
+@pytest.mark.parametrize("case", CASES, ids=CASE_IDS)
+def test_snp_byte_identical_to_reference(case):
+    """End to end on the GPU (index -> flags -> scan -> writer) against the reference-written golden .snp."""
+    p = api.make_params(case["args"])
+    inp = case["inputs"]
+    if case["mode"] == 1:
+        got = api.run_one_dataset(golden_bytes(inp["bwt1"]), p)
+    elif case["mode"] == 2:
+        got = api.run_two_datasets(golden_bytes(inp["bwt1"]), golden_bytes(inp["bwt2"]), p)
+    else:
+        got = api.run_two_datasets_da(golden_bytes(inp["bwt1"]), golden_bytes(inp["da"]), p)
+    assert got == golden_bytes(case["snp"])
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c["name"] in ("m1_default", "m1_edge_m2", "m2_het_default", "m2_edge_default",
+                                                                      "m3_het_default", "m3_edge_default")], ids=lambda c: c["name"])
+def test_cluster_records_match_oracle(oracle, case):
+    """Record-level parity of phase 4 (clusters, supports, contexts, counters), whole range and sharded."""
+    p, e1, e2, da = _flag_case(oracle, case)
+    pp = api.make_params(case["args"])
+    o1 = oracle.index(e1, p.term)
+    o2 = oracle.index(e2, p.term) if e2 is not None else None
+    of = _oracle.OracleFlags(oracle, o1, o2, p.K, p.k_right, da)
+    g1 = api.DnaBwt(e1, term=p.term)
+    g2 = api.DnaBwt(e2, term=p.term) if e2 is not None else None
+    gf = api.Flags.from_host(of.words * 0 + len(e1) + (len(e2) if e2 is not None else 0), *of.export())   # oracle flags: isolates phase 4
+    n = g1.n + (g2.n if g2 is not None else 0)
+    for cuts in ([0, n], [0, n // 3, n // 2 + 17, n]):
+        text, cluster_nr, events = b"", 1, 0
+        for b, e in zip(cuts[:-1], cuts[1:]):
+            want = of.scan(p, b, e, capture=True)
+            calls = api.scan_clusters(g1, gf, pp, bwt2=g2, begin=b, end=e)
+            cl, left, right = calls.arrays()
+            assert len(calls) == want["count"]
+            assert np.array_equal(cl, want["clusters"])
+            assert np.array_equal(left, want["left"])
+            assert np.array_equal(right, want["right"])
+            st = calls.stats
+            assert dict(runs_closed=st.runs_closed, clusters=st.clusters, bases_in_runs=st.bases_in_runs,
+                        survivors=st.survivors, chains=st.chains) == want["stats"]
+            t, cluster_nr, events = calls.format_snp(pp, case["mode"] != 1, cluster_nr, events)
+            text += t
+        assert text == golden_bytes(case["snp"])
+
+
+def test_cluster_histogram_matches_oracle_counts(oracle):
+    e = golden_bytes("dip.ebwt")
+    g = api.DnaBwt(e)
+    p = api.make_params()
+    calls = api.scan_clusters(g, api.Flags.build(g, None, p.K, p.k_right), p)
+    st = calls.stats
+    hist = np.array(list(st.hist), dtype=np.uint64)
+    assert hist[0] == 0 and all(hist[k] % k == 0 for k in range(1, 201))   # CLUST_SIZES[len] += len
+    assert hist.sum() <= st.bases_in_runs
+
+
+def test_cli_binary_byte_identical(tmp_path):
+    """The ebwt2InDel executable (same flags as the reference) on the three modes."""
+    def run(args, out):
+        r = subprocess.run([_lib.CLI_PATH] + args + ["-o", str(out)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        return out.read_bytes(), r.stdout
+    for name in ("dip.ebwt", "hom_a.ebwt", "hom_b.ebwt", "hom_m.ebwt", "hom_m.da", "tiny.ebwt"):
+        (tmp_path / name).write_bytes(golden_bytes(name))
+    got, log = run(["-1", str(tmp_path / "dip.ebwt"), "-m", "5"], tmp_path / "o1.snp")
+    assert got == golden_bytes("m1_m5.snp") and "Phase 4/4" in log and "Stored to file 54 events" in log
+    got, _ = run(["-1", str(tmp_path / "hom_a.ebwt"), "-2", str(tmp_path / "hom_b.ebwt"), "-m", "4", "-v", "1"], tmp_path / "o2.snp")
+    assert got == golden_bytes("m2_hom_m4_v1.snp")
+    got, _ = run(["-1", str(tmp_path / "hom_m.ebwt"), "-d", str(tmp_path / "hom_m.da"), "-g", "2"], tmp_path / "o3.snp")
+    assert got == golden_bytes("m3_hom_g2.snp")
+    got, _ = run(["-1", str(tmp_path / "tiny.ebwt")], tmp_path / "o4.snp")     # the reference dies with SIGFPE here; we exit 0
+    assert got == b""
+    bad = bytearray(golden_bytes("tiny.ebwt"))
+    bad[3] = ord("N")
+    (tmp_path / "bad.ebwt").write_bytes(bytes(bad))
+    r = subprocess.run([_lib.CLI_PATH, "-1", str(tmp_path / "bad.ebwt"), "-o", str(tmp_path / "o5.snp")], capture_output=True, text=True)
+    assert r.returncode == 1 and "read forbidden character 'N' (ASCII code 78)" in r.stdout and '"-t 78"' in r.stdout
+
+
+# ------------------------------------------------------------------ larger seeded inputs (oracle finishes in seconds)
+
+@pytest.mark.parametrize("seed,extra", [(7, []), (8, ["-m", "4", "-k", "14", "-q", "3"])])
+def test_config1_size_mode1(oracle, seed, extra):
+    """BASELINE.json configs[0]: 10k x 100 bp reads (n = 1.01 M)."""
+    reads, _, _ = sim.diploid_sample(50_000, 10_000, 100, seed=seed)
+    e = sim.build_ebwt(reads)
+    want, st = oracle.run(e, params=_oracle.Params.from_args(extra))
+    got = api.run_one_dataset(e, api.make_params(extra))
+    assert want.count(b">") > 100
+    assert got == want
+
+
+def test_medium_modes23(oracle):
+    r0, r1 = sim.two_samples(40_000, 8_000, 100, seed=31, het_second=True)
+    a, b = sim.build_ebwt(r0), sim.build_ebwt(r1)
+    m, da = sim.build_merged_ebwt(r0, r1)
+    p = _oracle.Params.from_args([])
+    want2, _ = oracle.run(a, bwt2=b, params=p)
+    want3, _ = oracle.run(m, da=da, params=p)
+    assert api.run_two_datasets(a, b) == want2
+    assert api.run_two_datasets_da(m, da) == want3
+    # the DA rebuilt on the GPU from the two BWTs equals the merged builder's document array
+    g1, g2 = api.DnaBwt(a), api.DnaBwt(b)
+    fl = api.Flags.build(g1, g2, 16, 30)
+    da_bits = np.unpackbits(fl.export()[3].view(np.uint8), bitorder="little")[: len(da)]
+    assert np.array_equal(da_bits, (da == ord("1")).astype(np.uint8))
+
+
+def test_properties_at_larger_size():
+    """Size-independent properties on an input too large for per-query oracle checks in the default run:
+    rank is monotone, rank(n) sums to n - #TERM, LF intervals tile the F column, every LCP slot is written."""
+    reads, _, _ = sim.diploid_sample(400_000, 80_000, 100, seed=99)       # n = 8.08 M
+    e = sim.build_ebwt(reads)
+    g = api.DnaBwt(e)
+    n = len(e)
+    counts = [int((e == c).sum()) for c in b"ACGT"]
+    assert g.F_arr == [n - sum(counts), n - sum(counts) + counts[0], n - sum(counts) + counts[0] + counts[1], n - counts[3]]
+    pos = np.sort(_positions(n, 300_000, 11))
+    r = g.parallel_rank(pos)
+    assert (np.diff(r.astype(np.int64), axis=0) >= 0).all()
+    d = np.diff(pos.astype(np.int64))
+    assert (np.diff(r.astype(np.int64), axis=0).sum(axis=1) <= d).all()
+    assert [int(x) for x in g.parallel_rank(np.array([n], dtype=np.uint64))[0]] == counts
+    full = g.LF(np.array([[0, n]], dtype=np.uint64))[0]
+    assert [int(x) for x in full] == [g.F_arr[0], g.F_arr[1], g.F_arr[1], g.F_arr[2], g.F_arr[2], g.F_arr[3], g.F_arr[3], n]
+    fl = api.Flags.build(g, None, 16, 30)
+    assert fl.stats.lcp_values == n
+    thrK, thrR, mn, _ = fl.export()
+    assert not (thrR & ~thrK).any()                           # LCP >= 30 implies LCP >= 16
+    calls = api.scan_clusters(g, fl, api.make_params())
+    assert calls.stats.survivors == len(calls) > 500
+    text, cluster_nr, events = calls.format_snp(api.make_params(), False)
+    assert events == text.count(b">") and events > 500

@@ -1,0 +1,55 @@
+"""Host logic of the product (C++ event logic + KisSNP2 writer + call-set container, csrc/eb_writer.cpp)
+checked on the CPU: cluster records captured from the oracle's phase 4 are fed through the product's
+eb_calls_unpack / eb_format_snp and must reproduce the reference-written golden .snp byte for byte --
+whole range and sharded (records gathered shard by shard with a running cluster_nr)."""
+import pytest
+
+from ebwt2indel_amd import api
+from tests import _oracle
+from tests.conftest import CASES, CASE_IDS, golden_bytes
+
+
+def _setup(oracle, case):
+    p = _oracle.Params.from_args(case["args"])
+    inp = case["inputs"]
+    x1 = oracle.index(golden_bytes(inp["bwt1"]), p.term)
+    x2 = oracle.index(golden_bytes(inp["bwt2"]), p.term) if case["mode"] == 2 else None
+    da = golden_bytes(inp["da"]) if case["mode"] == 3 else None
+    fl = _oracle.OracleFlags(oracle, x1, x2, p.K, p.k_right, da)
+    n = x1.n + (x2.n if x2 is not None else 0)
+    return p, fl, n
+
+
+@pytest.mark.parametrize("case", CASES, ids=CASE_IDS)
+def test_writer_reproduces_golden(oracle, case):
+    p, fl, n = _setup(oracle, case)
+    rec = fl.scan(p, 0, n, capture=True)
+    assert rec["text"] == golden_bytes(case["snp"])          # the oracle's own phase-4 entry point
+    pp = api.make_params(case["args"])
+    calls = api.Calls.unpack(_oracle.pack_calls(rec, p.k_left, p.k_right))
+    assert len(calls) == rec["count"]
+    text, cluster_nr, events = calls.format_snp(pp, case["mode"] != 1)
+    assert text == golden_bytes(case["snp"])
+    assert cluster_nr == rec["cluster_nr"]
+    if case["mode"] == 1:
+        assert events == rec["events"] == case["records"]
+    assert api.Calls.unpack(calls.pack()).format_snp(pp, case["mode"] != 1)[0] == text   # pack/unpack round trip
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c["name"] in ("m1_default", "m1_edge_default", "m2_het_default", "m3_hom_default")],
+                         ids=lambda c: c["name"])
+@pytest.mark.parametrize("shards", [2, 5])
+def test_sharded_scan_concatenates(oracle, case, shards):
+    p, fl, n = _setup(oracle, case)
+    pp = api.make_params(case["args"])
+    cuts = [n * i // shards for i in range(shards + 1)]
+    text, cluster_nr, events, stats = b"", 1, 0, None
+    for i in range(shards):
+        rec = fl.scan(p, cuts[i], cuts[i + 1], capture=True)
+        calls = api.Calls.unpack(_oracle.pack_calls(rec, p.k_left, p.k_right))
+        t, cluster_nr, events = calls.format_snp(pp, case["mode"] != 1, cluster_nr, events)
+        text += t
+        stats = rec["stats"] if stats is None else {k: stats[k] + v for k, v in rec["stats"].items()}
+    assert text == golden_bytes(case["snp"])
+    whole = fl.scan(p, 0, n, capture=True)
+    assert stats == whole["stats"]                            # shards partition the clusters exactly
