@@ -73,6 +73,15 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `make -C {CSRC}` (hipcc, gfx950). "
                           "There is no CPU fallback for the ebwt2InDel hot path.")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (same SONAME as /opt/rocm's).
+    # If torch is imported AFTER this library has pulled in the system runtime, the process ends up with two
+    # runtimes and the second finds no GPU.  So when torch is present, let it load its runtime first; the
+    # library then binds to that one.  EB_NO_TORCH=1 skips this (pure C / CLI use binds to /opt/rocm).
+    if os.environ.get("EB_NO_TORCH", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     L = C.CDLL(LIB_PATH)
     vp, u64, u8, i32 = C.c_void_p, C.c_uint64, C.c_uint8, C.c_int32
     P = C.POINTER
