@@ -173,7 +173,8 @@ def main():
         want, st = orc.run(se)                      # single thread, the reference's algorithm
         got = api.run_one_dataset(se, p, device=local)
         assert got == want, "GPU .snp differs from the CPU oracle on the baseline sample"
-        rt = orc.lib.orc_rank_bench(orc.index(se).h, 20_000_000, 7, None)
+        sidx = orc.index(se)                        # keep the handle alive across the call
+        rt = orc.lib.orc_rank_bench(sidx.h, 20_000_000, 7, None)
         cpu = {"value": round(len(se) / st.t_scan, 1), "unit": "positions/s", "cores": 1, "kind": "port",
                "sample": f"{s_reads} x {args.read_len} bp reads (n={len(se)}), same generator; phase-4 scan only ({st.t_scan:.3f}s); "
                          f"phases 2-3 took {st.t_nav:.2f}s",
