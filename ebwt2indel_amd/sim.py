@@ -177,3 +177,115 @@ def two_samples(genome_len: int, n_reads_each: int, read_len: int, seed: int, he
     r0 = sample_reads([g], n_reads_each, read_len, seed)
     r1 = sample_reads([g, h2] if het_second else [h2], n_reads_each, read_len, seed + 1)
     return r0, r1
+
+
+# --------------------------------------------------------------------------- GPU generator (benchmark scale)
+
+_GEN_SRC = os.path.join(_HERE, "tools", "ebwt_gen.hip")
+_GEN_SO = os.path.join(_BUILD, "libebwt_gen.so")
+_gen = None
+
+
+def build_gpu_tool(force: bool = False) -> str:
+    """Compile the GPU eBWT generator (hipcc, gfx950)."""
+    os.makedirs(_BUILD, exist_ok=True)
+    if force or not os.path.exists(_GEN_SO) or os.path.getmtime(_GEN_SO) < os.path.getmtime(_GEN_SRC):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC",
+                               "-Wl,-rpath,/opt/rocm/lib", "-o", _GEN_SO, _GEN_SRC])
+    return _GEN_SO
+
+
+def _gpu_tool():
+    global _gen
+    if _gen is None:
+        if not os.path.exists(_GEN_SO):
+            raise ImportError(f"{_GEN_SO} missing: run __graft_entry__.build()")
+        try:
+            import torch  # noqa: F401  (one HIP runtime per process, see _lib.load)
+        except Exception:
+            pass
+        _gen = ctypes.CDLL(_GEN_SO)
+        _gen.ebgen_last_error.restype = ctypes.c_char_p
+        _gen.ebgen_free.argtypes = [ctypes.c_void_p]
+        _gen.ebgen_free.restype = None
+        _gen.ebgen_to_host.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
+        _gen.ebgen_build.restype = ctypes.c_int
+        _gen.ebgen_build.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint8,
+                                     ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
+                                     ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double)]
+    return _gen
+
+
+def haplotype_text(haps: Sequence[np.ndarray]) -> Tuple[np.ndarray, np.ndarray]:
+    """Concatenate haplotypes, each followed by its own separator byte (1, 2, ...).  Returns (text, offsets)."""
+    assert len(haps) <= 2
+    parts, offs, pos = [], [], 0
+    for k, hp in enumerate(haps):
+        offs.append(pos)
+        parts.append(hp)
+        parts.append(np.array([k + 1], dtype=np.uint8))
+        pos += len(hp) + 1
+    return np.ascontiguousarray(np.concatenate(parts)), np.array(offs, dtype=np.int64)
+
+
+def sample_read_starts(haps: Sequence[np.ndarray], offsets: np.ndarray, n_reads: int, read_len: int, seed: int) -> np.ndarray:
+    """Start offsets (into haplotype_text) of n_reads reads; read j comes from haplotype j % len(haps)."""
+    rng = np.random.Generator(np.random.PCG64(seed ^ 0xBEAD))
+    starts = np.empty(n_reads, dtype=np.uint64)
+    for h, hap in enumerate(haps):
+        rows = np.arange(h, n_reads, len(haps))
+        s = rng.integers(0, len(hap) - read_len + 1, size=len(rows), dtype=np.int64)
+        starts[rows] = (s + offsets[h]).astype(np.uint64)
+    return starts
+
+
+def reads_from_starts(text: np.ndarray, starts: np.ndarray, read_len: int) -> np.ndarray:
+    idx = np.arange(read_len, dtype=np.int64)
+    return text[starts.astype(np.int64)[:, None] + idx[None, :]]
+
+
+class DeviceEbwt:
+    """eBWT (and optional DA) left in GPU memory by the generator; free() releases it."""
+
+    def __init__(self, ptr, da_ptr, n, timings):
+        self.ptr, self.da_ptr, self.n, self.timings = ptr, da_ptr, n, timings
+
+    def to_host(self):
+        out = np.empty(self.n, dtype=np.uint8)
+        _hip_copy_to_host(out, self.ptr, self.n)
+        da = None
+        if self.da_ptr:
+            da = np.empty(self.n, dtype=np.uint8)
+            _hip_copy_to_host(da, self.da_ptr, self.n)
+        return out, da
+
+    def free(self):
+        g = _gpu_tool()
+        if self.ptr:
+            g.ebgen_free(self.ptr)
+            self.ptr = None
+        if self.da_ptr:
+            g.ebgen_free(self.da_ptr)
+            self.da_ptr = None
+
+
+def _hip_copy_to_host(dst: np.ndarray, src_ptr: int, nbytes: int):
+    rc = _gpu_tool().ebgen_to_host(dst.ctypes.data, ctypes.c_void_p(src_ptr), nbytes)
+    if rc != 0:
+        raise RuntimeError(f"device-to-host copy failed: {_gpu_tool().ebgen_last_error().decode()}")
+
+
+def build_ebwt_gpu(text: np.ndarray, starts: np.ndarray, read_len: int, term: int = 35, n_first: Optional[int] = None,
+                   want_da: bool = False, device: int = 0) -> DeviceEbwt:
+    """eBWT of fixed-length reads text[starts[r] : starts[r]+read_len], built on the GPU; result stays on the device."""
+    g = _gpu_tool()
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    starts = np.ascontiguousarray(starts, dtype=np.uint64)
+    d_bwt, d_da, n = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_uint64(0)
+    tm = (ctypes.c_double * 4)()
+    rc = g.ebgen_build(text.ctypes.data, len(text), starts.ctypes.data, len(starts), read_len, term,
+                       len(starts) if n_first is None else n_first, device, ctypes.byref(d_bwt),
+                       ctypes.byref(d_da) if want_da else None, ctypes.byref(n), tm)
+    if rc != 0:
+        raise RuntimeError(f"ebgen_build failed ({rc}): {g.ebgen_last_error().decode()}")
+    return DeviceEbwt(d_bwt.value, d_da.value if want_da else None, n.value, list(tm))
