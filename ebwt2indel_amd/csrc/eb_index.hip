@@ -190,10 +190,16 @@ static int pack_piece(eb_index* h, const uint8_t* d_ascii, uint64_t piece_pos, u
     uint64_t n_chunks = last ? h->n_blocks * 4 - first_chunk : piece_len / 32;
     if (n_chunks == 0) return EB_OK;
     int aligned = (reinterpret_cast<uintptr_t>(d_ascii) & 15u) == 0;
-    uint64_t grid = (n_chunks + 255) / 256;
-    hipLaunchKernelGGL(k_pack, dim3((unsigned)grid), dim3(256), 0, h->stream, d_ascii, piece_pos, piece_len, first_chunk,
-                       n_chunks, (uint32_t)h->term, aligned, h->d_chunks, d_bad);
-    EB_HIP(hipGetLastError());
+    // a dispatch holds fewer than 2^32 work-items: pack at most 2^30 chunks (2^35 symbols) per launch
+    const uint64_t MAX_CHUNKS = 1ull << 30;
+    for (uint64_t done = 0; done < n_chunks; done += MAX_CHUNKS) {
+        uint64_t cnt = n_chunks - done < MAX_CHUNKS ? n_chunks - done : MAX_CHUNKS;
+        uint64_t byte_off = done * 32;
+        uint64_t sub_len = piece_len > byte_off ? piece_len - byte_off : 0;
+        hipLaunchKernelGGL(k_pack, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, d_ascii + byte_off, piece_pos + byte_off,
+                           sub_len, first_chunk + done, cnt, (uint32_t)h->term, aligned, h->d_chunks, d_bad);
+        EB_HIP(hipGetLastError());
+    }
     return EB_OK;
 }
 

@@ -19,13 +19,15 @@
 
 namespace {
 
-struct Leaf1 { uint64_t l, r, depth; };                         // sa_leaf (include.hpp:513-527)
-struct Node1 { uint64_t b[6]; uint64_t depth; };                // sa_node (include.hpp:394-413)
-struct Leaf2 { uint64_t l1, r1, l2, r2, depth; };               // pair<sa_leaf,sa_leaf>
-struct Node2 { uint64_t a[6]; uint64_t b[6]; uint64_t depth; }; // pair<sa_node,sa_node>
+// Records are padded to a multiple of 16 bytes so that lanes move them as uint4.
+struct alignas(16) Leaf1 { uint64_t l, r, depth, pad; };                              // sa_leaf (include.hpp:513-527)
+struct alignas(16) Node1 { uint64_t b[6]; uint64_t depth, pad; };                     // sa_node (include.hpp:394-413)
+struct alignas(16) Leaf2 { uint64_t l1, r1, l2, r2, depth, pad[3]; };                 // pair<sa_leaf,sa_leaf>
+struct alignas(16) Node2 { uint64_t a[6]; uint64_t b[6]; uint64_t depth, pad[3]; };   // pair<sa_node,sa_node>
 
 struct NavCounters {
     unsigned long long pushed;     // children appended by the current launch
+    unsigned long long pad0[7];    // keep the hot word on its own 64-byte line
     unsigned long long leaves, nodes, lcp_values, da_values, minima, ranks;
 };
 
@@ -38,169 +40,248 @@ __device__ __forceinline__ uint64_t wave_sum(uint64_t v) {
     return v;
 }
 
-// Reserve room for `t` records per lane with one atomic per wave; returns this lane's first slot.
-__device__ __forceinline__ uint64_t wave_reserve(unsigned long long* counter, uint32_t t) {
-    uint32_t lane = threadIdx.x & 63u;
-    uint32_t inc = t;
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t v = (uint32_t)__shfl_up((int)inc, o);
-        if (lane >= (uint32_t)o) inc += v;
-    }
-    uint32_t total = (uint32_t)__shfl((int)inc, 63);
-    unsigned long long base = 0;
-    if (lane == 63 && total) base = atomicAdd(counter, (unsigned long long)total);
-    base = __shfl((unsigned long long)base, 63);
-    return base + inc - t;
-}
-
 __device__ __forceinline__ void flush_stat(unsigned long long* dst, uint64_t v) {
     v = wave_sum(v);
     if ((threadIdx.x & 63u) == 0 && v) atomicAdd(dst, (unsigned long long)v);
 }
 
-__device__ __forceinline__ void set_lcp_bits(const eb_dev_flags& f, const NavParams& p, uint64_t depth, uint64_t lo, uint64_t hi) {
-    // LCP_threshold[2i] = depth >= K, LCP_threshold[2i+1] = depth >= k_right for i in [lo,hi)
-    if (hi <= lo) return;
-    if ((int64_t)depth >= p.K) eb_bits_fill_atomic(f.thrK, lo, hi);
-    if ((int64_t)depth >= p.k_right) eb_bits_fill_atomic(f.thrR, lo, hi);
-}
+__device__ __forceinline__ uint64_t pick4(const uint64_t* F, uint32_t c) { return c == 0 ? F[0] : c == 1 ? F[1] : c == 2 ? F[2] : F[3]; }
 
-// ---- phase 2: leaves.  update_LCP_leaf (ebwt2InDel.cpp:344-355) / update_DA (:394-425) and
-// next_leaves (dna_bwt.hpp:358-379; two BWTs: ebwt2InDel.cpp:452-472).
+// Children are staged in LDS and appended to the stack in HBM with ONE global atomic per few hundred
+// records (a per-wave atomic on a single word would serialise at ~11 ns each, tens of millions of times).
+template <typename Item, int STAGE>
+struct Stager {
+    static constexpr int W = sizeof(Item) / 16; // uint4 per record
+    uint4* buf;                                 // STAGE * W uint4 in LDS
+    uint32_t* s_count;
+    unsigned long long* s_base;
+
+    // every thread of the block calls this once per tile; `keep` lanes hand over one record
+    __device__ __forceinline__ void push(bool keep, const Item& rec) {
+        unsigned long long mask = __ballot(keep);
+        uint32_t lane = threadIdx.x & 63u;
+        uint32_t wcount = (uint32_t)__popcll(mask);
+        uint32_t wbase = 0;
+        if (lane == 0 && wcount) wbase = atomicAdd(s_count, wcount);
+        wbase = (uint32_t)__shfl((int)wbase, 0);
+        if (keep) {
+            uint32_t slot = wbase + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            const uint4* src = reinterpret_cast<const uint4*>(&rec);
+            for (int k = 0; k < W; ++k) buf[slot * W + k] = src[k];
+        }
+    }
+    // block-uniform: append the staged records to out[] and reset
+    __device__ __forceinline__ void flush(Item* out, uint64_t out_cap, unsigned long long* pushed) {
+        __syncthreads();
+        uint32_t n = *s_count;
+        if (n == 0) return; // uniform
+        if (threadIdx.x == 0) *s_base = atomicAdd(pushed, (unsigned long long)n);
+        __syncthreads();
+        unsigned long long base = *s_base;
+        uint4* dst = reinterpret_cast<uint4*>(out);
+        if (base + n <= out_cap)
+            for (uint32_t k = threadIdx.x; k < n * W; k += blockDim.x) dst[base * W + k] = buf[k];
+        __syncthreads();
+        if (threadIdx.x == 0) *s_count = 0;
+        __syncthreads();
+    }
+};
+
+// ---- phase 2: leaves.  update_LCP_leaf (ebwt2InDel.cpp:344-355) / update_DA (:394-425) and next_leaves
+// (dna_bwt.hpp:358-379; two BWTs: ebwt2InDel.cpp:452-472).  Four lanes per leaf: lane j owns letter j --
+// it loads the j-th chunk of each rank query and builds the child leaf obtained by prepending "ACGT"[j].
 template <int NB>
 __global__ void __launch_bounds__(256) k_leaves(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, NavParams p, const void* in_,
                                                uint64_t count, void* out_, uint64_t out_cap, NavCounters* cnt) {
     using Leaf = typename std::conditional<NB == 1, Leaf1, Leaf2>::type;
+    constexpr int STAGE = 1024;
+    __shared__ uint4 s_buf[STAGE * (sizeof(Leaf) / 16)];
+    __shared__ uint32_t s_count;
+    __shared__ unsigned long long s_base;
+    Stager<Leaf, STAGE> stage{s_buf, &s_count, &s_base};
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
     const Leaf* in = static_cast<const Leaf*>(in_);
     Leaf* out = static_cast<Leaf*>(out_);
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool active = i < count;
-    Leaf child[4];
-    uint32_t t = 0;
-    uint64_t n_lcp = 0, n_da = 0, n_rank = 0;
-    if (active) {
-        Leaf L = in[i];
+    const uint32_t j = threadIdx.x & 3u, q = threadIdx.x >> 2;
+    uint64_t n_leaf = 0, n_lcp = 0, n_da = 0, n_rank = 0;
+    const uint64_t tiles = (count + 63) / 64;
+    uint32_t trips = 0;
+    for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        uint64_t i = tile * 64 + q;
+        bool active = i < count;
+        Leaf L;
+        memset(&L, 0, sizeof L);
+        if (active) L = in[i];
+        Leaf child;
+        memset(&child, 0, sizeof child);
+        bool keep = false;
         if constexpr (NB == 1) {
-            if (L.r > L.l + 1) { set_lcp_bits(f, p, L.depth, L.l + 1, L.r); n_lcp = L.r - L.l - 1; }
-            rank4_t a = eb_rank4(x1, L.l);
-            rank4_t b = L.r > L.l ? eb_rank4(x1, L.r) : a;
-            n_rank = L.r > L.l ? 2 : 1;
-            for (int c = 0; c < 4; ++c) {
-                uint64_t cl = x1.F[c] + a.v[c], cr = x1.F[c] + b.v[c];
-                if (cr - cl >= 2) { child[t].l = cl; child[t].r = cr; child[t].depth = L.depth + 1; ++t; }
+            uint64_t a = eb_rank4_quad(x1, L.l, j);
+            uint64_t b = eb_rank4_quad(x1, L.r > L.l ? L.r : L.l, j);
+            uint64_t Fj = pick4(x1.F, j);
+            child.l = Fj + a; child.r = Fj + b; child.depth = L.depth + 1;
+            keep = active && (b - a >= 2);
+            if (active && L.r > L.l + 1) {
+                // LCP slots l+1 .. r-1 of the leaf: the quad splits the touched words
+                uint64_t lo = L.l + 1, hi = L.r;
+                bool setK = (int64_t)L.depth >= p.K, setR = (int64_t)L.depth >= p.k_right;
+                if (setK || setR) {
+                    uint64_t w0 = lo >> 6, w1 = (hi - 1) >> 6;
+                    for (uint64_t w = w0 + j; w <= w1; w += 4) {
+                        uint64_t m = ~0ull;
+                        if (w == w0) m &= ~0ull << (lo & 63u);
+                        if (w == w1) m &= ~0ull >> (63u - ((hi - 1) & 63u));
+                        if (setK) atomicOr(reinterpret_cast<unsigned long long*>(f.thrK + w), m);
+                        if (setR) atomicOr(reinterpret_cast<unsigned long long*>(f.thrR + w), m);
+                    }
+                }
+                if (j == 0) n_lcp += hi - lo;
             }
+            if (active && j == 0) { ++n_leaf; n_rank += L.r > L.l ? 2 : 1; }
         } else {
-            uint64_t s1 = L.l1 + L.l2, s2 = L.l2 + L.r1, e = L.r1 + L.r2;
-            if (e > s2) eb_bits_fill_atomic(f.da, s2, e); // DA = 1 for the second collection's rows
-            n_da = e - s1;
-            if (e > s1 + 1) { set_lcp_bits(f, p, L.depth, s1 + 1, e); n_lcp = e - s1 - 1; }
-            rank4_t a1 = eb_rank4(x1, L.l1), b1 = L.r1 > L.l1 ? eb_rank4(x1, L.r1) : a1;
-            rank4_t a2 = eb_rank4(x2, L.l2), b2 = L.r2 > L.l2 ? eb_rank4(x2, L.r2) : a2;
-            n_rank = (L.r1 > L.l1 ? 2 : 1) + (L.r2 > L.l2 ? 2 : 1);
-            for (int c = 0; c < 4; ++c) {
-                uint64_t l1 = x1.F[c] + a1.v[c], r1 = x1.F[c] + b1.v[c];
-                uint64_t l2 = x2.F[c] + a2.v[c], r2 = x2.F[c] + b2.v[c];
-                if ((r1 - l1) + (r2 - l2) >= 2) { child[t].l1 = l1; child[t].r1 = r1; child[t].l2 = l2; child[t].r2 = r2; child[t].depth = L.depth + 1; ++t; }
+            uint64_t a1 = eb_rank4_quad(x1, L.l1, j), b1 = eb_rank4_quad(x1, L.r1 > L.l1 ? L.r1 : L.l1, j);
+            uint64_t a2 = eb_rank4_quad(x2, L.l2, j), b2 = eb_rank4_quad(x2, L.r2 > L.l2 ? L.r2 : L.l2, j);
+            uint64_t F1 = pick4(x1.F, j), F2 = pick4(x2.F, j);
+            child.l1 = F1 + a1; child.r1 = F1 + b1; child.l2 = F2 + a2; child.r2 = F2 + b2; child.depth = L.depth + 1;
+            keep = active && ((b1 - a1) + (b2 - a2) >= 2);
+            if (active) {
+                uint64_t s1 = L.l1 + L.l2, s2 = L.l2 + L.r1, e = L.r1 + L.r2;
+                bool setK = (int64_t)L.depth >= p.K, setR = (int64_t)L.depth >= p.k_right;
+                // words of [s1, e): DA = 1 on [s2,e) (second collection), LCP bits on [s1+1, e)
+                uint64_t w0 = s1 >> 6, w1 = e > s1 ? (e - 1) >> 6 : w0;
+                for (uint64_t w = w0 + j; w <= w1 && e > s1; w += 4) {
+                    uint64_t base = w << 6;
+                    auto span = [&](uint64_t lo, uint64_t hi) -> uint64_t { // bits of word w inside [lo,hi)
+                        if (hi <= lo || hi <= base || lo >= base + 64) return 0ull;
+                        uint64_t m = ~0ull;
+                        if (lo > base) m &= ~0ull << (lo - base);
+                        if (hi < base + 64) m &= ~0ull >> (base + 64 - hi);
+                        return m;
+                    };
+                    uint64_t md = span(s2, e), ml = span(s1 + 1, e);
+                    if (md) atomicOr(reinterpret_cast<unsigned long long*>(f.da + w), md);
+                    if (ml && setK) atomicOr(reinterpret_cast<unsigned long long*>(f.thrK + w), ml);
+                    if (ml && setR) atomicOr(reinterpret_cast<unsigned long long*>(f.thrR + w), ml);
+                }
+                if (j == 0) {
+                    ++n_leaf;
+                    n_da += e - s1;
+                    if (e > s1 + 1) n_lcp += e - s1 - 1;
+                    n_rank += (L.r1 > L.l1 ? 2 : 1) + (L.r2 > L.l2 ? 2 : 1);
+                }
             }
         }
+        stage.push(keep, child);
+        // every tile adds at most 256 records: flushing every STAGE/256 tiles never overflows the buffer, and the
+        // decision is the same in every thread without looking at shared state
+        if (++trips % (STAGE / 256) == 0) stage.flush(out, out_cap, &cnt->pushed);
     }
-    uint64_t slot = wave_reserve(&cnt->pushed, t);
-    for (uint32_t k = 0; k < t; ++k)
-        if (slot + k < out_cap) out[slot + k] = child[k];
-    flush_stat(&cnt->leaves, active ? 1 : 0);
+    stage.flush(out, out_cap, &cnt->pushed);
+    flush_stat(&cnt->leaves, n_leaf);
     flush_stat(&cnt->lcp_values, n_lcp);
     flush_stat(&cnt->ranks, n_rank);
     if constexpr (NB == 2) flush_stat(&cnt->da_values, n_da);
 }
 
-// LF(sa_node) (dna_bwt.hpp:323-356): ranks at the six boundaries, equal neighbours share one query.
-__device__ __forceinline__ uint32_t node_ranks(const eb_dev_index& x, const uint64_t* b, rank4_t* r) {
-    uint32_t q = 1;
-    r[0] = eb_rank4(x, b[0]);
-    for (int k = 1; k < 6; ++k) {
-        if (b[k] == b[k - 1]) r[k] = r[k - 1];
-        else { r[k] = eb_rank4(x, b[k]); ++q; }
-    }
-    return q;
-}
-
 // ---- phase 3: right-maximal nodes.  update_lcp_threshold (include.hpp:826-860), update_lcp_minima
-// (ebwt2InDel.cpp:357-391), find_leaves (:474-527), next_nodes (dna_bwt.hpp:381-404 / ebwt2InDel.cpp:529-553).
+// (ebwt2InDel.cpp:357-391), find_leaves (:474-527), LF(sa_node) (dna_bwt.hpp:323-356), next_nodes
+// (dna_bwt.hpp:381-404 / ebwt2InDel.cpp:529-553).  Four lanes per node: lane j loads the j-th chunk of the
+// six boundary blocks (one coalesced 64-byte segment per rank query), owns letter j, i.e. the Weiner-link
+// child "ACGT"[j] + W, and writes border j's LCP / minimum bits.
 template <int NB>
 __global__ void __launch_bounds__(256) k_nodes(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, NavParams p, const void* in_,
                                               uint64_t count, void* out_, uint64_t out_cap, NavCounters* cnt) {
     using Node = typename std::conditional<NB == 1, Node1, Node2>::type;
+    constexpr int STAGE = NB == 1 ? 768 : 512;
+    __shared__ uint4 s_buf[STAGE * (sizeof(Node) / 16)];
+    __shared__ uint32_t s_count;
+    __shared__ unsigned long long s_base;
+    Stager<Node, STAGE> stage{s_buf, &s_count, &s_base};
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
     const Node* in = static_cast<const Node*>(in_);
     Node* out = static_cast<Node*>(out_);
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool active = i < count;
-    Node child[4];
-    uint32_t t = 0;
-    uint64_t n_lcp = 0, n_da = 0, n_rank = 0, n_min = 0;
-    if (active) {
-        Node N = in[i];
+    const uint32_t j = threadIdx.x & 3u, q = threadIdx.x >> 2;
+    uint64_t n_node = 0, n_lcp = 0, n_da = 0, n_rank = 0, n_min = 0;
+    const uint64_t tiles = (count + 63) / 64;
+    uint32_t trips = 0;
+    for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        uint64_t i = tile * 64 + q;
+        bool active = i < count;
+        Node N;
+        memset(&N, 0, sizeof N);
+        if (active) N = in[i];
         uint64_t m[6]; // merged boundaries (merge_nodes, include.hpp:476-490)
         if constexpr (NB == 1) {
             for (int k = 0; k < 6; ++k) m[k] = N.b[k];
         } else {
             for (int k = 0; k < 6; ++k) m[k] = N.a[k] + N.b[k];
-            // leaves of merged size 1 were not visited in phase 2: write their DA slot now
-            for (int k = 0; k < 5; ++k) {
-                uint64_t s1 = N.a[k + 1] - N.a[k], s2 = N.b[k + 1] - N.b[k];
-                if (s1 + s2 == 1) {
-                    if (s2) eb_bit_set_atomic(f.da, N.b[k] + N.a[k + 1]);
-                    ++n_da;
-                }
-            }
         }
-        // LCP at the right border of each non-empty child TERM,A,C,G unless it is the node's end
-        for (int k = 0; k < 4; ++k)
-            if (m[k + 1] > m[k] && m[k + 1] != m[5]) {
-                if ((int64_t)N.depth >= p.K) eb_bit_set_atomic(f.thrK, m[k + 1]);
-                if ((int64_t)N.depth >= p.k_right) eb_bit_set_atomic(f.thrR, m[k + 1]);
+        if (active) {
+            // lane j looks after border j (right end of child TERM,A,C,G)
+            uint64_t lo = 0, hi = 0;
+            for (int k = 0; k < 4; ++k) if (j == (uint32_t)k) { lo = m[k]; hi = m[k + 1]; }
+            if (hi > lo && hi != m[5]) {
+                if ((int64_t)N.depth >= p.K) eb_bit_set_atomic(f.thrK, hi);
+                if ((int64_t)N.depth >= p.k_right) eb_bit_set_atomic(f.thrR, hi);
                 ++n_lcp;
             }
-        // a local LCP minimum follows each child A,C,G of size >= 2 that ends before last-1
-        for (int k = 1; k <= 3; ++k)
-            if (m[k + 1] - m[k] >= 2 && m[k + 1] < m[5] - 1) {
-                eb_bit_set_atomic(f.minima, m[k + 1]);
+            // a local LCP minimum follows each child A,C,G of size >= 2 that ends before last-1
+            if (j >= 1 && hi - lo >= 2 && hi < m[5] - 1) {
+                eb_bit_set_atomic(f.minima, hi);
                 ++n_min;
             }
-        // Weiner links
-        if constexpr (NB == 1) {
-            rank4_t r[6];
-            n_rank = node_ranks(x1, N.b, r);
-            for (int c = 0; c < 4; ++c) {
-                uint64_t cb[6];
-                int kids = 0;
-                for (int k = 0; k < 6; ++k) cb[k] = x1.F[c] + r[k].v[c];
-                for (int k = 0; k < 5; ++k) kids += cb[k + 1] > cb[k];
-                if (kids >= 2) { // number_of_children (include.hpp:760-768)
-                    for (int k = 0; k < 6; ++k) child[t].b[k] = cb[k];
-                    child[t].depth = N.depth + 1;
-                    ++t;
-                }
-            }
-        } else {
-            rank4_t r1[6], r2[6];
-            n_rank = node_ranks(x1, N.a, r1) + node_ranks(x2, N.b, r2);
-            for (int c = 0; c < 4; ++c) {
-                uint64_t ca[6], cb[6];
-                int kids = 0;
-                for (int k = 0; k < 6; ++k) { ca[k] = x1.F[c] + r1[k].v[c]; cb[k] = x2.F[c] + r2[k].v[c]; }
-                for (int k = 0; k < 5; ++k) kids += (ca[k + 1] > ca[k]) || (cb[k + 1] > cb[k]); // include.hpp:784-792
-                if (kids >= 2) {
-                    for (int k = 0; k < 6; ++k) { child[t].a[k] = ca[k]; child[t].b[k] = cb[k]; }
-                    child[t].depth = N.depth + 1;
-                    ++t;
+            if constexpr (NB == 2) {
+                // leaves of merged size 1 were not visited in phase 2: write their DA slot now (find_leaves)
+                for (int k = 0; k < 5; ++k) {
+                    if ((uint32_t)(k & 3) != j || (k == 4 && j != 0)) continue;
+                    uint64_t s1 = N.a[k + 1] - N.a[k], s2 = N.b[k + 1] - N.b[k];
+                    if (s1 + s2 == 1) {
+                        if (s2) eb_bit_set_atomic(f.da, N.b[k] + N.a[k + 1]);
+                        ++n_da;
+                    }
                 }
             }
         }
+        Node child;
+        memset(&child, 0, sizeof child);
+        bool keep = false;
+        if constexpr (NB == 1) {
+            uint64_t Fj = pick4(x1.F, j);
+            int kids = 0;
+            for (int k = 0; k < 6; ++k) child.b[k] = Fj + eb_rank4_quad(x1, N.b[k], j);
+            for (int k = 0; k < 5; ++k) kids += child.b[k + 1] > child.b[k];
+            child.depth = N.depth + 1;
+            keep = active && kids >= 2; // number_of_children (include.hpp:760-768)
+            if (active && j == 0) {
+                ++n_node;
+                n_rank += 1;
+                for (int k = 1; k < 6; ++k) n_rank += N.b[k] != N.b[k - 1]; // the reference shares the query of equal neighbours
+            }
+        } else {
+            uint64_t F1 = pick4(x1.F, j), F2 = pick4(x2.F, j);
+            int kids = 0;
+            for (int k = 0; k < 6; ++k) {
+                child.a[k] = F1 + eb_rank4_quad(x1, N.a[k], j);
+                child.b[k] = F2 + eb_rank4_quad(x2, N.b[k], j);
+            }
+            for (int k = 0; k < 5; ++k) kids += (child.a[k + 1] > child.a[k]) || (child.b[k + 1] > child.b[k]); // include.hpp:784-792
+            child.depth = N.depth + 1;
+            keep = active && kids >= 2;
+            if (active && j == 0) {
+                ++n_node;
+                n_rank += 2;
+                for (int k = 1; k < 6; ++k) n_rank += (N.a[k] != N.a[k - 1]) + (N.b[k] != N.b[k - 1]);
+            }
+        }
+        stage.push(keep, child);
+        // every tile adds at most 256 records: flushing every STAGE/256 tiles never overflows the buffer, and the
+        // decision is the same in every thread without looking at shared state
+        if (++trips % (STAGE / 256) == 0) stage.flush(out, out_cap, &cnt->pushed);
     }
-    uint64_t slot = wave_reserve(&cnt->pushed, t);
-    for (uint32_t k = 0; k < t; ++k)
-        if (slot + k < out_cap) out[slot + k] = child[k];
-    flush_stat(&cnt->nodes, active ? 1 : 0);
+    stage.flush(out, out_cap, &cnt->pushed);
+    flush_stat(&cnt->nodes, n_node);
     flush_stat(&cnt->lcp_values, n_lcp);
     flush_stat(&cnt->minima, n_min);
     flush_stat(&cnt->ranks, n_rank);
@@ -289,6 +370,13 @@ struct Drain {
     }
 };
 
+// 64 records per 256-thread workgroup and trip; the grid is capped and strides over the batch
+unsigned nav_grid(uint64_t count) {
+    uint64_t tiles = (count + 63) / 64;
+    const uint64_t cap = 256ull * 8;
+    return (unsigned)(tiles < 1 ? 1 : (tiles > cap ? cap : tiles));
+}
+
 uint64_t env_u64(const char* name, uint64_t dflt) {
     const char* s = getenv(name);
     if (!s || !*s) return dflt;
@@ -375,9 +463,9 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
             Drain<Leaf1> d;
             d.device = b1->device; d.stream = st;
             if ((rc = d.init(n, batch_max)) != EB_OK) return rc;
-            if ((rc = d.push_host(Leaf1{0, b1->F[0], 0})) != EB_OK) return rc;
+            if ((rc = d.push_host(Leaf1{0, b1->F[0], 0, 0})) != EB_OK) return rc;
             rc = d.run(d_cnt, h_pushed, [&](Leaf1* in, uint64_t cnt, Leaf1* o, uint64_t ocap) {
-                hipLaunchKernelGGL(k_leaves<1>, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, x1, x2, df, p, in, cnt, o, ocap, d_cnt);
+                hipLaunchKernelGGL(k_leaves<1>, dim3(nav_grid(cnt)), dim3(256), 0, st, x1, x2, df, p, in, cnt, o, ocap, d_cnt);
             });
             if (rc != EB_OK) return rc;
             launches += d.launches;
@@ -388,10 +476,10 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
             Drain<Node1> d;
             d.device = b1->device; d.stream = st;
             if ((rc = d.init(n, batch_max)) != EB_OK) return rc;
-            Node1 root{{0, b1->F[0], b1->F[1], b1->F[2], b1->F[3], b1->n}, 0};
+            Node1 root{{0, b1->F[0], b1->F[1], b1->F[2], b1->F[3], b1->n}, 0, 0};
             if ((rc = d.push_host(root)) != EB_OK) return rc;
             rc = d.run(d_cnt, h_pushed, [&](Node1* in, uint64_t cnt, Node1* o, uint64_t ocap) {
-                hipLaunchKernelGGL(k_nodes<1>, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, x1, x2, df, p, in, cnt, o, ocap, d_cnt);
+                hipLaunchKernelGGL(k_nodes<1>, dim3(nav_grid(cnt)), dim3(256), 0, st, x1, x2, df, p, in, cnt, o, ocap, d_cnt);
             });
             if (rc != EB_OK) return rc;
             launches += d.launches;
@@ -402,9 +490,9 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
             Drain<Leaf2> d;
             d.device = b1->device; d.stream = st;
             if ((rc = d.init(n, batch_max)) != EB_OK) return rc;
-            if ((rc = d.push_host(Leaf2{0, b1->F[0], 0, b2->F[0], 0})) != EB_OK) return rc;
+            if ((rc = d.push_host(Leaf2{0, b1->F[0], 0, b2->F[0], 0, {0, 0, 0}})) != EB_OK) return rc;
             rc = d.run(d_cnt, h_pushed, [&](Leaf2* in, uint64_t cnt, Leaf2* o, uint64_t ocap) {
-                hipLaunchKernelGGL(k_leaves<2>, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, x1, x2, df, p, in, cnt, o, ocap, d_cnt);
+                hipLaunchKernelGGL(k_leaves<2>, dim3(nav_grid(cnt)), dim3(256), 0, st, x1, x2, df, p, in, cnt, o, ocap, d_cnt);
             });
             if (rc != EB_OK) return rc;
             launches += d.launches;
@@ -415,10 +503,10 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
             Drain<Node2> d;
             d.device = b1->device; d.stream = st;
             if ((rc = d.init(n, batch_max)) != EB_OK) return rc;
-            Node2 root{{0, b1->F[0], b1->F[1], b1->F[2], b1->F[3], b1->n}, {0, b2->F[0], b2->F[1], b2->F[2], b2->F[3], b2->n}, 0};
+            Node2 root{{0, b1->F[0], b1->F[1], b1->F[2], b1->F[3], b1->n}, {0, b2->F[0], b2->F[1], b2->F[2], b2->F[3], b2->n}, 0, {0, 0, 0}};
             if ((rc = d.push_host(root)) != EB_OK) return rc;
             rc = d.run(d_cnt, h_pushed, [&](Node2* in, uint64_t cnt, Node2* o, uint64_t ocap) {
-                hipLaunchKernelGGL(k_nodes<2>, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, x1, x2, df, p, in, cnt, o, ocap, d_cnt);
+                hipLaunchKernelGGL(k_nodes<2>, dim3(nav_grid(cnt)), dim3(256), 0, st, x1, x2, df, p, in, cnt, o, ocap, d_cnt);
             });
             if (rc != EB_OK) return rc;
             launches += d.launches;

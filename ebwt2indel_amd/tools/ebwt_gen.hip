@@ -129,28 +129,30 @@ __global__ void __launch_bounds__(256) k_make_keys(const uint64_t* __restrict__ 
 
 __global__ void __launch_bounds__(256) k_scatter_slabs(const uint64_t* __restrict__ keys, uint64_t n, KeyLayout kl, unsigned long long* __restrict__ cursor,
                                                        uint64_t* __restrict__ out) {
-    uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    uint64_t key = keys[k];
-    uint32_t lo = (uint32_t)(key >> (8 + kl.rbits));
-    unsigned long long pos = atomicAdd(&cursor[lo >> kl.slab_shift], 1ull);
-    out[pos] = key;
+    // grid-stride: a dispatch holds fewer than 2^32 work-items, n can be larger
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t key = keys[k];
+        uint32_t lo = (uint32_t)(key >> (8 + kl.rbits));
+        unsigned long long pos = atomicAdd(&cursor[lo >> kl.slab_shift], 1ull);
+        out[pos] = key;
+    }
 }
 
 __global__ void __launch_bounds__(256) k_emit(const uint64_t* __restrict__ keys, uint64_t n, KeyLayout kl, const uint8_t* __restrict__ t,
                                               const uint64_t* __restrict__ starts, uint32_t L, uint8_t term, uint64_t n_first,
                                               uint8_t* __restrict__ bwt, uint8_t* __restrict__ da) {
-    uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    uint64_t key = keys[k];
-    uint64_t r = key & ((1ull << kl.rbits) - 1ull);
-    uint32_t len = (uint32_t)(key >> kl.rbits) & 0xFFu;
-    uint32_t i = L - len;
-    bwt[k] = i == 0 ? term : t[starts[r] + i - 1];
-    if (da) da[k] = r < n_first ? '0' : '1';
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t key = keys[k];
+        uint64_t r = key & ((1ull << kl.rbits) - 1ull);
+        uint32_t len = (uint32_t)(key >> kl.rbits) & 0xFFu;
+        uint32_t i = L - len;
+        bwt[k] = i == 0 ? term : t[starts[r] + i - 1];
+        if (da) da[k] = r < n_first ? '0' : '1';
+    }
 }
 
 unsigned grid_of(uint64_t n) { return (unsigned)((n + 255) / 256); }
+unsigned grid_capped(uint64_t n) { uint64_t b = (n + 255) / 256; return (unsigned)(b > (1ull << 22) ? (1ull << 22) : b); }
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 }  // namespace
@@ -291,7 +293,7 @@ int ebgen_build(const uint8_t* text, uint64_t text_len, const uint64_t* starts, 
     } else {
         GEN_HIP(d_slabbed.alloc(n * 8));
         GEN_HIP(hipMemcpy(d_slab_count.p, off.data(), (size_t)n_slabs * 8, hipMemcpyHostToDevice)); // cursors
-        hipLaunchKernelGGL(k_scatter_slabs, dim3(grid_of(n)), dim3(256), 0, st, d_all.as<uint64_t>(), n, kl, d_slab_count.as<unsigned long long>(),
+        hipLaunchKernelGGL(k_scatter_slabs, dim3(grid_capped(n)), dim3(256), 0, st, d_all.as<uint64_t>(), n, kl, d_slab_count.as<unsigned long long>(),
                            d_slabbed.as<uint64_t>());
         GEN_HIP(hipDeviceSynchronize());
         d_all.release();
@@ -315,7 +317,7 @@ int ebgen_build(const uint8_t* text, uint64_t text_len, const uint64_t* starts, 
     void* out_da = nullptr;
     GEN_HIP(hipMalloc(&out_bwt, n));
     if (d_da) GEN_HIP(hipMalloc(&out_da, n));
-    hipLaunchKernelGGL(k_emit, dim3(grid_of(n)), dim3(256), 0, st, sorted, n, kl, d_text.as<uint8_t>(), d_starts.as<uint64_t>(), L, term, n_first,
+    hipLaunchKernelGGL(k_emit, dim3(grid_capped(n)), dim3(256), 0, st, sorted, n, kl, d_text.as<uint8_t>(), d_starts.as<uint64_t>(), L, term, n_first,
                        static_cast<uint8_t*>(out_bwt), static_cast<uint8_t*>(out_da));
     GEN_HIP(hipDeviceSynchronize());
     GEN_HIP(hipGetLastError());
