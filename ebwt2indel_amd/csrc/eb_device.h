@@ -147,3 +147,45 @@ __device__ __forceinline__ void eb_bits_fill_atomic(uint64_t* b, uint64_t lo, ui
         atomicOr(reinterpret_cast<unsigned long long*>(b + w), m);
     }
 }
+
+// Output records (suffix-tree children, surviving clusters) are staged in LDS and appended to their list in
+// HBM with ONE global atomic per few hundred records: a returning atomic on a single word serialises at
+// ~11 ns (MI355X_MICROARCH.md, 'dequeue'), which per wave or per record would dominate these kernels.
+template <typename Item, int STAGE>
+struct Stager {
+    static constexpr int W = sizeof(Item) / 16; // uint4 per record
+    uint4* buf;                                 // STAGE * W uint4 in LDS
+    uint32_t* s_count;
+    unsigned long long* s_base;
+
+    // every thread of the block calls this once per tile; `keep` lanes hand over one record
+    __device__ __forceinline__ void push(bool keep, const Item& rec) {
+        unsigned long long mask = __ballot(keep);
+        uint32_t lane = threadIdx.x & 63u;
+        uint32_t wcount = (uint32_t)__popcll(mask);
+        uint32_t wbase = 0;
+        if (lane == 0 && wcount) wbase = atomicAdd(s_count, wcount);
+        wbase = (uint32_t)__shfl((int)wbase, 0);
+        if (keep) {
+            uint32_t slot = wbase + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            const uint4* src = reinterpret_cast<const uint4*>(&rec);
+            for (int k = 0; k < W; ++k) buf[slot * W + k] = src[k];
+        }
+    }
+    // block-uniform: append the staged records to out[] and reset
+    __device__ __forceinline__ void flush(Item* out, uint64_t out_cap, unsigned long long* pushed) {
+        __syncthreads();
+        uint32_t n = *s_count;
+        if (n == 0) return; // uniform
+        if (threadIdx.x == 0) *s_base = atomicAdd(pushed, (unsigned long long)n);
+        __syncthreads();
+        unsigned long long base = *s_base;
+        uint4* dst = reinterpret_cast<uint4*>(out);
+        if (base + n <= out_cap)
+            for (uint32_t k = threadIdx.x; k < n * W; k += blockDim.x) dst[base * W + k] = buf[k];
+        __syncthreads();
+        if (threadIdx.x == 0) *s_count = 0;
+        __syncthreads();
+    }
+};
+

@@ -47,46 +47,6 @@ __device__ __forceinline__ void flush_stat(unsigned long long* dst, uint64_t v) 
 
 __device__ __forceinline__ uint64_t pick4(const uint64_t* F, uint32_t c) { return c == 0 ? F[0] : c == 1 ? F[1] : c == 2 ? F[2] : F[3]; }
 
-// Children are staged in LDS and appended to the stack in HBM with ONE global atomic per few hundred
-// records (a per-wave atomic on a single word would serialise at ~11 ns each, tens of millions of times).
-template <typename Item, int STAGE>
-struct Stager {
-    static constexpr int W = sizeof(Item) / 16; // uint4 per record
-    uint4* buf;                                 // STAGE * W uint4 in LDS
-    uint32_t* s_count;
-    unsigned long long* s_base;
-
-    // every thread of the block calls this once per tile; `keep` lanes hand over one record
-    __device__ __forceinline__ void push(bool keep, const Item& rec) {
-        unsigned long long mask = __ballot(keep);
-        uint32_t lane = threadIdx.x & 63u;
-        uint32_t wcount = (uint32_t)__popcll(mask);
-        uint32_t wbase = 0;
-        if (lane == 0 && wcount) wbase = atomicAdd(s_count, wcount);
-        wbase = (uint32_t)__shfl((int)wbase, 0);
-        if (keep) {
-            uint32_t slot = wbase + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-            const uint4* src = reinterpret_cast<const uint4*>(&rec);
-            for (int k = 0; k < W; ++k) buf[slot * W + k] = src[k];
-        }
-    }
-    // block-uniform: append the staged records to out[] and reset
-    __device__ __forceinline__ void flush(Item* out, uint64_t out_cap, unsigned long long* pushed) {
-        __syncthreads();
-        uint32_t n = *s_count;
-        if (n == 0) return; // uniform
-        if (threadIdx.x == 0) *s_base = atomicAdd(pushed, (unsigned long long)n);
-        __syncthreads();
-        unsigned long long base = *s_base;
-        uint4* dst = reinterpret_cast<uint4*>(out);
-        if (base + n <= out_cap)
-            for (uint32_t k = threadIdx.x; k < n * W; k += blockDim.x) dst[base * W + k] = buf[k];
-        __syncthreads();
-        if (threadIdx.x == 0) *s_count = 0;
-        __syncthreads();
-    }
-};
-
 // ---- phase 2: leaves.  update_LCP_leaf (ebwt2InDel.cpp:344-355) / update_DA (:394-425) and next_leaves
 // (dna_bwt.hpp:358-379; two BWTs: ebwt2InDel.cpp:452-472).  Four lanes per leaf: lane j owns letter j --
 // it loads the j-th chunk of each rank query and builds the child leaf obtained by prepending "ACGT"[j].

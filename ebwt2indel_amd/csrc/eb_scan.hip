@@ -16,6 +16,8 @@
 // Host text formatting (distance / event_type / to_file) lives in eb_writer.cpp.
 #include <hipcub/hipcub.hpp>
 
+#include <stdlib.h>
+
 #include "eb_internal.h"
 
 namespace {
@@ -28,12 +30,14 @@ struct ScanParams {
     int k_left, k_right;
     uint64_t begin, end; // closing positions owned by this call
     uint64_t n;          // merged length
+    uint32_t dbg;        // EB_SCAN_DEBUG bits (profiling experiments only): 1 no length histogram, 2 no cluster analysis, 4 no run loop
 };
 
-struct Survivor {
+struct alignas(16) Survivor {
     uint64_t b, e;            // merged coordinates
     uint64_t b0, e0, b1, e1;  // per-BWT ranges (mode 2)
     uint32_t fmask0, fmask1;  // frequent letters per side, bit c = "ACGT"[c]
+    uint64_t pad;
 };
 
 struct ScanCounters {
@@ -85,54 +89,153 @@ __device__ __forceinline__ void hist_by_da(const eb_dev_index& x, const eb_dev_f
     }
 }
 
+// Letter masks of 64 symbols from their two low code planes; TERM (x=y=0) and padding land in 'A',
+// which is exactly base_to_int's mapping (include.hpp:275-289).
+struct Planes {
+    uint64_t x, y;
+    __device__ __forceinline__ uint64_t letter(int c) const {
+        return c == 0 ? ~y & ~x : c == 1 ? ~y & x : c == 2 ? y & ~x : y & x;
+    }
+};
+
+__device__ __forceinline__ Planes load_planes(const eb_dev_index& x, uint64_t w) {
+    uint4 c0 = x.chunks[2 * w], c1 = x.chunks[2 * w + 1];
+    Planes p;
+    p.x = (uint64_t)c0.x | ((uint64_t)c1.x << 32);
+    p.y = (uint64_t)c0.y | ((uint64_t)c1.y << 32);
+    return p;
+}
+
+// K3+K4 fused.  One lane per 64 positions, all loads issued up front and independent of each other:
+// the two flag words (16 B), the two BWT chunks of the same 64 positions (32 B) and, with a document
+// array, its word (8 B) -- 0.75 B (0.875 B) per position, streamed once.  A cluster that begins in the
+// lane's own word or in the previous one (the neighbour lane's registers) gets its symbol histogram from
+// popcounts on registers; only runs longer than that (and the two-BWT mode, whose symbols live in other
+// coordinates) take the memory path.  Persistent grid: counters are flushed once per wave.
 __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, ScanParams p, uint64_t w_lo,
                                              uint64_t w_count, Survivor* __restrict__ surv, uint64_t surv_cap,
                                              ScanCounters* __restrict__ cnt) {
     __shared__ unsigned int sh_hist[201];
+    constexpr int STAGE = 256; // survivors are ~1 per 10^4 positions: a workgroup rarely fills this before its last tile
+    __shared__ uint4 s_buf[STAGE * (sizeof(Survivor) / 16)];
+    __shared__ uint32_t s_count;
+    __shared__ unsigned long long s_base;
+    Stager<Survivor, STAGE> stage{s_buf, &s_count, &s_base};
     for (int k = threadIdx.x; k < 201; k += blockDim.x) sh_hist[k] = 0;
+    if (threadIdx.x == 0) s_count = 0;
     __syncthreads();
-    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t hi_pos = p.end < p.n ? p.end : p.n;
+    const uint64_t n_bwt_words = (x1.n_blocks << 1); // 64-symbol words backed by the packed BWT
     uint64_t n_runs = 0, n_clusters = 0, n_bases = 0;
-    if (t < w_count) {
-        uint64_t w = w_lo + t;
+    const uint64_t tiles = (w_count + 255) / 256;
+    for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        uint64_t t = tile * 256 + threadIdx.x;
+        bool active = t < w_count;
+        uint64_t w = w_lo + (active ? t : 0);
+        // ---- independent loads
         uint64_t fw = flag_word(f, w);
-        uint64_t prev = w > 0 ? flag_word(f, w - 1) >> 63 : 0ull;
-        uint64_t ends = ~fw & ((fw << 1) | prev); // positions e with flag[e]=0 and flag[e-1]=1
+        Planes cur = {0, 0}, prv = {0, 0};
+        uint64_t da_cur = 0, da_prv = 0;
+        const bool local_syms = p.mode != 2;
+        if (local_syms) {
+            if (w < n_bwt_words) cur = load_planes(x1, w);
+            if (p.mode == 3) da_cur = f.da[w];
+        }
+        // previous word: neighbour lane's registers, lane 0 reads memory
+        uint64_t pfw = __shfl_up((unsigned long long)fw, 1);
+        prv.x = __shfl_up((unsigned long long)cur.x, 1);
+        prv.y = __shfl_up((unsigned long long)cur.y, 1);
+        da_prv = __shfl_up((unsigned long long)da_cur, 1);
+        if (lane == 0) {
+            if (w > 0) {
+                pfw = flag_word(f, w - 1);
+                if (local_syms) {
+                    prv = load_planes(x1, w - 1);
+                    if (p.mode == 3) da_prv = f.da[w - 1];
+                }
+            } else {
+                pfw = 0;
+            }
+        }
+        uint64_t ends = active ? ~fw & ((fw << 1) | (pfw >> 63)) : 0ull; // positions e with flag[e]=0 and flag[e-1]=1
         // keep closing positions inside [begin,end) and below n (a run still open at n-1 is dropped, ebwt2InDel.cpp:1609-1655)
         uint64_t base = w << 6;
-        uint64_t hi = p.end < p.n ? p.end : p.n;
         if (base < p.begin) ends &= (p.begin - base >= 64) ? 0ull : (~0ull << (p.begin - base));
-        if (base + 64 > hi) ends &= (hi <= base) ? 0ull : (~0ull >> (base + 64 - hi));
+        if (base + 64 > hi_pos) ends &= (hi_pos <= base) ? 0ull : (~0ull >> (base + 64 - hi_pos));
+        if (p.dbg & 4u) { n_runs += (uint64_t)__popcll(ends); ends = 0; }
+        // Geometry of the run that closes at bit `bit`: begin, and which bits of the lane's own word (mcur)
+        // and of the previous word (mprv) it covers; in_regs = false when it starts further back.
+        auto run_at = [&](uint32_t bit, uint64_t& b, uint64_t& mcur, uint64_t& mprv) -> bool {
+            uint64_t below = (1ull << bit) - 1ull;
+            uint64_t zeros = ~fw & below;
+            mprv = 0;
+            if (zeros) {
+                uint32_t zb = 64u - (uint32_t)__clzll((long long)zeros); // first flagged bit after the nearest 0
+                b = base + zb;
+                mcur = below & (~0ull << zb);
+                return true;
+            }
+            if (~pfw) {
+                uint32_t zb = 64u - (uint32_t)__clzll((long long)~pfw);   // 1..64
+                b = base - 64 + zb;
+                mcur = below;
+                mprv = zb < 64 ? ~0ull << zb : 0ull;
+                return true;
+            }
+            // run longer than the two words at hand: walk back through memory
+            mcur = 0;
+            uint64_t ww = w - 1;
+            b = 0;
+            while (ww > 0) {
+                --ww;
+                uint64_t g = ~flag_word(f, ww);
+                if (g) { b = (ww << 6) + (64u - (uint32_t)__clzll((long long)g)); break; }
+            }
+            return false;
+        };
+        // ---- pass 1 over the closing positions: run statistics, and which clusters need their histogram.
+        // Most clusters hold one letter only (no variant, no read start): both code planes are constant over
+        // the cluster, at most one letter can be frequent and the one-sample filter drops it (:961).  Keeping
+        // the rare others for a second loop means the wave does not drag every lane through the analysis.
+        uint64_t todo = 0;
         while (ends) {
             uint32_t bit = (uint32_t)__ffsll((long long)ends) - 1u;
             ends &= ends - 1;
-            uint64_t e = base + bit;
-            // begin = one past the nearest 0 below e
-            uint64_t b;
-            uint64_t zeros = ~fw & ((1ull << bit) - 1ull);
-            if (zeros) {
-                b = base + (64u - (uint32_t)__clzll((long long)zeros));
-            } else {
-                uint64_t ww = w;
-                b = 0;
-                while (ww > 0) {
-                    --ww;
-                    uint64_t g = ~flag_word(f, ww);
-                    if (g) { b = (ww << 6) + (64u - (uint32_t)__clzll((long long)g)); break; }
-                }
-            }
-            uint64_t len = e - b;
+            uint64_t b, mcur, mprv;
+            bool in_regs = run_at(bit, b, mcur, mprv);
+            uint64_t len = base + bit - b;
             ++n_runs;
             n_bases += len;
-            if (len <= 200) atomicAdd(&sh_hist[len], 1u);
+            if (len <= 200 && !(p.dbg & 1u)) atomicAdd(&sh_hist[len], 1u);
             if (len < p.min_len) continue;
             ++n_clusters;
+            if (p.mode == 1 && in_regs) {
+                uint64_t xc = cur.x & mcur, xp = prv.x & mprv, yc = cur.y & mcur, yp = prv.y & mprv;
+                bool px = (xc == mcur && xp == mprv) || ((xc | xp) == 0);
+                bool py = (yc == mcur && yp == mprv) || ((yc | yp) == 0);
+                if (px && py) continue;
+            }
+            todo |= 1ull << bit;
+        }
+        if (p.dbg & 2u) todo = 0;
+        // ---- pass 2: histogram + frequent-symbol filter of the remaining clusters
+        while (todo) {
+            uint32_t bit = (uint32_t)__ffsll((long long)todo) - 1u;
+            todo &= todo - 1;
+            uint64_t b, mcur, mprv;
+            bool in_regs = run_at(bit, b, mcur, mprv);
+            uint64_t e = base + bit;
             Survivor s;
             s.b = b; s.e = e; s.b0 = s.e0 = s.b1 = s.e1 = 0; s.fmask0 = s.fmask1 = 0;
             uint32_t c0[4], c1[4];
             bool keep;
             if (p.mode == 1) {
-                hist_by_rank(x1, b, e, c0);
+                if (in_regs) {
+                    for (int c = 0; c < 4; ++c) c0[c] = (uint32_t)__popcll(cur.letter(c) & mcur) + (uint32_t)__popcll(prv.letter(c) & mprv);
+                } else {
+                    hist_by_rank(x1, b, e, c0);
+                }
                 s.fmask0 = frequent_mask(c0, p.mcov);
                 int nf = __popc(s.fmask0);
                 keep = nf >= 2 && !(p.q > 0 && nf > p.q); // ebwt2InDel.cpp:961-966
@@ -142,6 +245,12 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
                     s.b0 = b - s.b1; s.e0 = e - s.e1;
                     hist_by_rank(x1, s.b0, s.e0, c0);
                     hist_by_rank(x2, s.b1, s.e1, c1);
+                } else if (in_regs) {
+                    for (int c = 0; c < 4; ++c) {
+                        uint64_t lc = cur.letter(c) & mcur, lp = prv.letter(c) & mprv;
+                        c1[c] = (uint32_t)__popcll(lc & da_cur) + (uint32_t)__popcll(lp & da_prv);
+                        c0[c] = (uint32_t)__popcll(lc & ~da_cur) + (uint32_t)__popcll(lp & ~da_prv);
+                    }
                 } else {
                     hist_by_da(x1, f, b, e, c0, c1);
                 }
@@ -151,17 +260,35 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
                 keep = n0 > 0 && n1 > 0 && !(p.q > 0 && (n0 > p.q || n1 > p.q)); // :870-880, :1042-1052
             }
             if (keep) {
-                unsigned long long slot = atomicAdd(&cnt->nsurv, 1ull);
-                if (slot < surv_cap) surv[slot] = s;
+                // LDS staging (no per-survivor global atomic); a full buffer spills straight to the list
+                uint32_t slot = atomicAdd(&s_count, 1u);
+                if (slot < (uint32_t)STAGE) {
+                    const uint4* src = reinterpret_cast<const uint4*>(&s);
+                    for (int k = 0; k < (int)(sizeof(Survivor) / 16); ++k) s_buf[slot * (sizeof(Survivor) / 16) + k] = src[k];
+                } else {
+                    unsigned long long g = atomicAdd(&cnt->nsurv, 1ull);
+                    if (g < surv_cap) surv[g] = s;
+                }
             }
         }
+        // block-uniform flush decision: look at the fill level between two barriers
+        __syncthreads();
+        uint32_t filled = s_count;
+        __syncthreads();
+        if (filled >= (uint32_t)STAGE / 2) {
+            if (threadIdx.x == 0 && filled > (uint32_t)STAGE) s_count = STAGE; // overflowing records went to the list directly
+            stage.flush(surv, surv_cap, &cnt->nsurv);
+        }
     }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_count > (uint32_t)STAGE) s_count = STAGE;
+    stage.flush(surv, surv_cap, &cnt->nsurv);
     for (int o = 32; o > 0; o >>= 1) {
         n_runs += __shfl_xor((unsigned long long)n_runs, o);
         n_clusters += __shfl_xor((unsigned long long)n_clusters, o);
         n_bases += __shfl_xor((unsigned long long)n_bases, o);
     }
-    if ((threadIdx.x & 63u) == 0) {
+    if (lane == 0) {
         if (n_runs) atomicAdd(&cnt->runs_closed, (unsigned long long)n_runs);
         if (n_clusters) atomicAdd(&cnt->clusters, (unsigned long long)n_clusters);
         if (n_bases) atomicAdd(&cnt->bases, (unsigned long long)n_bases);
@@ -237,7 +364,6 @@ __global__ void __launch_bounds__(256) k_extend(eb_dev_index x1, eb_dev_index x2
         r->slot_sym[slot] = (uint8_t)"ACGT"[c];
         r->slot_len[slot] = (uint32_t)have;
         r->slot_support[slot] = support;
-        atomicAdd(&cnt->chains, 1ull);
     }
 }
 
@@ -297,6 +423,12 @@ struct DevMem {
 };
 
 unsigned grid_of(uint64_t threads) { return (unsigned)((threads + 255) / 256); }
+// persistent scan grid: 8 workgroups per CU, each striding over 256-word tiles
+unsigned scan_grid(uint64_t words) {
+    uint64_t tiles = (words + 255) / 256;
+    const uint64_t cap = 256ull * 8;
+    return (unsigned)(tiles < 1 ? 1 : (tiles > cap ? cap : tiles));
+}
 
 }  // namespace
 
@@ -324,6 +456,7 @@ extern "C" int eb_scan_clusters(eb_index* b1, eb_index* b2, eb_flags* f, uint64_
     p.begin = begin;
     p.end = end;
     p.n = n;
+    p.dbg = getenv("EB_SCAN_DEBUG") ? (uint32_t)atoi(getenv("EB_SCAN_DEBUG")) : 0u;
     eb_dev_index x1 = b1->dev(), x2 = b2 ? b2->dev() : b1->dev();
     eb_dev_flags df = f->dev();
 
@@ -343,7 +476,7 @@ extern "C" int eb_scan_clusters(eb_index* b1, eb_index* b2, eb_flags* f, uint64_
         if ((rc = d_surv.alloc(cap * sizeof(Survivor))) != EB_OK) return rc;
         EB_HIP(hipMemsetAsync(d_cnt.p, 0, sizeof(ScanCounters), st));
         if (w_count)
-            hipLaunchKernelGGL(k_scan, dim3(grid_of(w_count)), dim3(256), 0, st, x1, x2, df, p, w_lo, w_count, d_surv.as<Survivor>(), cap,
+            hipLaunchKernelGGL(k_scan, dim3(scan_grid(w_count)), dim3(256), 0, st, x1, x2, df, p, w_lo, w_count, d_surv.as<Survivor>(), cap,
                                d_cnt.as<ScanCounters>());
         EB_HIP(hipGetLastError());
         EB_HIP(hipMemcpyAsync(&c, d_cnt.p, sizeof c, hipMemcpyDeviceToHost, st));
@@ -416,7 +549,9 @@ extern "C" int eb_scan_clusters(eb_index* b1, eb_index* b2, eb_flags* f, uint64_
         stats->clusters = c.clusters;
         stats->bases_in_runs = c.bases;
         stats->survivors = ns;
-        stats->chains = c.chains;
+        uint64_t chains = 0;
+        for (const eb_cluster& r : calls->clusters) chains += r.n_slots; // one left-context chain per frequent symbol
+        stats->chains = chains;
         for (int k = 0; k < 201; ++k) stats->hist[k] = c.hist[k];
         stats->ms_scan = ms_scan;
         stats->ms_extend = ms_ext;
