@@ -16,6 +16,7 @@
 
 #define EB_BLOCK_SYMS 128u
 #define EB_SUPER_SHIFT 32 /* 2^32 symbols per superblock (dna_string.hpp:36) */
+#define EB_SEL_SHIFT 10   /* select directory samples every 1024th occurrence of a letter */
 
 struct eb_dev_index {
     const uint4* chunks;    // 4 * n_blocks chunks
@@ -23,6 +24,8 @@ struct eb_dev_index {
     uint64_t n;             // symbols
     uint64_t n_blocks;      // ceil((n+1)/128)
     uint64_t F[4];          // F_A,F_C,F_G,F_T
+    const uint32_t* sel_dir; // select directory: block of every EB_SEL_SAMPLE-th occurrence of each letter
+    uint64_t sel_stride;     // entries per letter
     uint32_t term;          // ASCII terminator
 };
 
@@ -103,10 +106,15 @@ __device__ __forceinline__ uint64_t eb_block_count(const eb_dev_index& x, uint64
 }
 
 // select (dna_string.hpp:182-188,254-272): position of the r-th (0-based) letter c.  The reference
-// bisects [0,n) with full rank queries; here the bisection runs on the per-block counters and the
-// last step is an in-block select -- same unique answer, one 4-byte probe per step.
+// bisects [0,n) with ~log2(n) full rank queries.  Here a small directory (block of every 1024th occurrence,
+// n/1024 bytes) brackets the answer to ~32 blocks, ~5 bisection steps on the per-block counters finish the
+// search and the last step is an in-block select -- the same unique answer, ~6 dependent 64-byte reads
+// instead of ~33.
 __device__ __forceinline__ uint64_t eb_select(const eb_dev_index& x, uint64_t r, int c) {
-    uint64_t lo = 0, hi = x.n_blocks; // invariant: count(lo) <= r, and (hi == n_blocks or count(hi) > r)
+    const uint32_t* dir = x.sel_dir + (uint64_t)c * x.sel_stride;
+    uint64_t m = r >> EB_SEL_SHIFT;
+    uint64_t lo = dir[m], hi = (uint64_t)dir[m + 1] + 1; // count(lo) <= m*1024 <= r; occurrence (m+1)*1024 > r lies in block hi-1
+    // invariant: count(lo) <= r, and (hi == n_blocks or count(hi) > r)
     while (hi - lo > 1) {
         uint64_t mid = (lo + hi) >> 1;
         if (eb_block_count(x, mid, c) > r) hi = mid; else lo = mid;
@@ -116,11 +124,11 @@ __device__ __forceinline__ uint64_t eb_select(const eb_dev_index& x, uint64_t r,
     uint32_t off = 0;
     for (uint32_t j = 0; j < 4; ++j) {
         uint4 ch = b[j];
-        uint32_t m = ~ch.z & ((c & 2) ? ch.y : ~ch.y) & ((c & 1) ? ch.x : ~ch.x);
-        uint32_t k = (uint32_t)__popc(m);
+        uint32_t mk = ~ch.z & ((c & 2) ? ch.y : ~ch.y) & ((c & 1) ? ch.x : ~ch.x);
+        uint32_t k = (uint32_t)__popc(mk);
         if (need < k) {
-            for (uint32_t t = 0; t < need; ++t) m &= m - 1; // drop the `need` lowest set bits
-            off = j * 32u + (uint32_t)__ffs((int)m) - 1u;
+            for (uint32_t t = 0; t < need; ++t) mk &= mk - 1; // drop the `need` lowest set bits
+            off = j * 32u + (uint32_t)__ffs((int)mk) - 1u;
             break;
         }
         need -= k;

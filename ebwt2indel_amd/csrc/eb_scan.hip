@@ -112,7 +112,7 @@ __device__ __forceinline__ Planes load_planes(const eb_dev_index& x, uint64_t w)
 // lane's own word or in the previous one (the neighbour lane's registers) gets its symbol histogram from
 // popcounts on registers; only runs longer than that (and the two-BWT mode, whose symbols live in other
 // coordinates) take the memory path.  Persistent grid: counters are flushed once per wave.
-__global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, ScanParams p, uint64_t w_lo,
+__global__ void __launch_bounds__(256, 4) k_scan(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, ScanParams p, uint64_t w_lo,
                                              uint64_t w_count, Survivor* __restrict__ surv, uint64_t surv_cap,
                                              ScanCounters* __restrict__ cnt) {
     __shared__ unsigned int sh_hist[201];
@@ -129,35 +129,50 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
     const uint64_t n_bwt_words = (x1.n_blocks << 1); // 64-symbol words backed by the packed BWT
     uint64_t n_runs = 0, n_clusters = 0, n_bases = 0;
     const uint64_t tiles = (w_count + 255) / 256;
+    // Everything a lane needs for one tile; all loads are independent of each other (the extra "previous
+    // word" loads of lane 0 included), so they are in flight together.
+    struct TileData {
+        uint64_t fw, da_cur, l0_pfw, l0_da;
+        Planes cur, l0_prv;
+    };
+    const bool local_syms = p.mode != 2;
+    auto load_tile = [&](uint64_t tile) -> TileData {
+        TileData d;
+        d.fw = d.da_cur = d.l0_pfw = d.l0_da = 0;
+        d.cur = {0, 0};
+        d.l0_prv = {0, 0};
+        uint64_t t = tile * 256 + threadIdx.x;
+        if (tile < tiles && t < w_count) {
+            uint64_t w = w_lo + t;
+            d.fw = flag_word(f, w);
+            if (local_syms) {
+                if (w < n_bwt_words) d.cur = load_planes(x1, w);
+                if (p.mode == 3) d.da_cur = f.da[w];
+            }
+            if (lane == 0 && w > 0) {
+                d.l0_pfw = flag_word(f, w - 1);
+                if (local_syms) {
+                    d.l0_prv = load_planes(x1, w - 1);
+                    if (p.mode == 3) d.l0_da = f.da[w - 1];
+                }
+            }
+        }
+        return d;
+    };
     for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        TileData td = load_tile(tile);
         uint64_t t = tile * 256 + threadIdx.x;
         bool active = t < w_count;
         uint64_t w = w_lo + (active ? t : 0);
-        // ---- independent loads
-        uint64_t fw = flag_word(f, w);
-        Planes cur = {0, 0}, prv = {0, 0};
-        uint64_t da_cur = 0, da_prv = 0;
-        const bool local_syms = p.mode != 2;
-        if (local_syms) {
-            if (w < n_bwt_words) cur = load_planes(x1, w);
-            if (p.mode == 3) da_cur = f.da[w];
-        }
-        // previous word: neighbour lane's registers, lane 0 reads memory
+        uint64_t fw = td.fw;
+        Planes cur = td.cur, prv;
+        uint64_t da_cur = td.da_cur, da_prv;
+        // previous word: neighbour lane's registers; lane 0 fetched it from memory
         uint64_t pfw = __shfl_up((unsigned long long)fw, 1);
         prv.x = __shfl_up((unsigned long long)cur.x, 1);
         prv.y = __shfl_up((unsigned long long)cur.y, 1);
         da_prv = __shfl_up((unsigned long long)da_cur, 1);
-        if (lane == 0) {
-            if (w > 0) {
-                pfw = flag_word(f, w - 1);
-                if (local_syms) {
-                    prv = load_planes(x1, w - 1);
-                    if (p.mode == 3) da_prv = f.da[w - 1];
-                }
-            } else {
-                pfw = 0;
-            }
-        }
+        if (lane == 0) { pfw = td.l0_pfw; prv = td.l0_prv; da_prv = td.l0_da; }
         uint64_t ends = active ? ~fw & ((fw << 1) | (pfw >> 63)) : 0ull; // positions e with flag[e]=0 and flag[e-1]=1
         // keep closing positions inside [begin,end) and below n (a run still open at n-1 is dropped, ebwt2InDel.cpp:1609-1655)
         uint64_t base = w << 6;
@@ -302,9 +317,25 @@ __global__ void __launch_bounds__(256) k_surv_keys(const Survivor* __restrict__ 
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { keys[i] = s[i].b; idx[i] = (uint32_t)i; }
 }
-__global__ void __launch_bounds__(256) k_surv_gather(const Survivor* __restrict__ s, const uint32_t* __restrict__ idx, uint64_t n, Survivor* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_surv_gather(const Survivor* __restrict__ s, const uint32_t* __restrict__ idx, uint64_t n, Survivor* __restrict__ out,
+                                                    uint32_t* __restrict__ n_chains) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = s[idx[i]];
+    if (i < n) {
+        Survivor v = s[idx[i]];
+        out[i] = v;
+        n_chains[i] = (uint32_t)(__popc(v.fmask0) + __popc(v.fmask1));
+    }
+}
+// dense work list for k_extend: one entry (cluster << 3 | side*4 + letter) per frequent symbol
+__global__ void __launch_bounds__(256) k_chain_list(const Survivor* __restrict__ s, const uint32_t* __restrict__ offset, uint64_t n, uint64_t* __restrict__ chains) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Survivor v = s[i];
+    uint32_t o = offset[i];
+    for (uint32_t sidx = 0; sidx < 8; ++sidx) {
+        uint32_t fm = (sidx >> 2) ? v.fmask1 : v.fmask0;
+        if ((fm >> (sidx & 3u)) & 1u) chains[o++] = (i << 3) | sidx;
+    }
 }
 
 __device__ __forceinline__ uint64_t pick4(const uint64_t* F, uint32_t c) { return c == 0 ? F[0] : c == 1 ? F[1] : c == 2 ? F[2] : F[3]; }
@@ -312,18 +343,18 @@ __device__ __forceinline__ uint64_t pick4(const uint64_t* F, uint32_t c) { retur
 // Four lanes per chain.  extract_consensus(bwt,range,c,...) ebwt2InDel.cpp:303-319 -> LF(range,c), then
 // up to k_left-1 x { LF(range) ; consensus_letter } (:243-282).
 __global__ void __launch_bounds__(256) k_extend(eb_dev_index x1, eb_dev_index x2, ScanParams p, const Survivor* __restrict__ surv,
-                                               uint64_t nsurv, eb_cluster* __restrict__ recs, uint8_t* __restrict__ left,
-                                               ScanCounters* __restrict__ cnt) {
+                                               const uint64_t* __restrict__ chains, uint64_t n_chains, eb_cluster* __restrict__ recs,
+                                               uint8_t* __restrict__ left) {
     const uint32_t j = threadIdx.x & 3u;
     const uint32_t qbase = (threadIdx.x & 63u) & ~3u; // first lane of this quad inside the wave
-    uint64_t chain = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
-    uint64_t i = chain >> 3;
-    uint32_t sidx = (uint32_t)(chain & 7u);
-    if (i >= nsurv) return; // uniform inside a quad
+    uint64_t ch = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    if (ch >= n_chains) return; // uniform inside a quad
+    uint64_t item = chains[ch];
+    uint64_t i = item >> 3;
+    uint32_t sidx = (uint32_t)(item & 7u);
     Survivor s = surv[i];
     uint32_t side = sidx >> 2, c = sidx & 3u;
     uint32_t fm = side ? s.fmask1 : s.fmask0;
-    if (!((fm >> c) & 1u)) return;
     uint32_t slot = (side ? (uint32_t)__popc(s.fmask0) : 0u) + (uint32_t)__popc(fm & ((1u << c) - 1u));
     const bool second = p.mode == 2 && side == 1;
     const eb_dev_index& x = second ? x2 : x1;
@@ -464,7 +495,7 @@ extern "C" int eb_scan_clusters(eb_index* b1, eb_index* b2, eb_flags* f, uint64_
     for (auto& e : ev) EB_HIP(hipEventCreate(&e));
     struct EvGuard { hipEvent_t* e; ~EvGuard() { for (int i = 0; i < 5; ++i) (void)hipEventDestroy(e[i]); } } evg{ev};
 
-    DevMem d_cnt, d_surv, d_sorted, d_keys, d_keys2, d_idx, d_idx2, d_tmp, d_recs, d_left, d_right;
+    DevMem d_cnt, d_surv, d_sorted, d_keys, d_keys2, d_idx, d_idx2, d_tmp, d_recs, d_left, d_right, d_nch, d_choff, d_chains;
     int rc;
     if ((rc = d_cnt.alloc(sizeof(ScanCounters))) != EB_OK) return rc;
     uint64_t w_lo = begin >> 6, w_hi = (end + 63) >> 6;
@@ -505,7 +536,21 @@ extern "C" int eb_scan_clusters(eb_index* b1, eb_index* b2, eb_flags* f, uint64_
         if ((rc = d_tmp.alloc(tmp_bytes)) != EB_OK) return rc;
         EB_HIP(hipcub::DeviceRadixSort::SortPairs(d_tmp.p, tmp_bytes, d_keys.as<uint64_t>(), d_keys2.as<uint64_t>(), d_idx.as<uint32_t>(),
                                                   d_idx2.as<uint32_t>(), (int)ns, 0, 64, st));
-        hipLaunchKernelGGL(k_surv_gather, dim3(grid_of(ns)), dim3(256), 0, st, d_surv.as<Survivor>(), d_idx2.as<uint32_t>(), ns, d_sorted.as<Survivor>());
+        if ((rc = d_nch.alloc(ns * 4)) != EB_OK || (rc = d_choff.alloc((ns + 1) * 4)) != EB_OK) return rc;
+        hipLaunchKernelGGL(k_surv_gather, dim3(grid_of(ns)), dim3(256), 0, st, d_surv.as<Survivor>(), d_idx2.as<uint32_t>(), ns, d_sorted.as<Survivor>(),
+                           d_nch.as<uint32_t>());
+        // dense chain list: exclusive scan of the per-cluster chain counts
+        size_t scan_bytes = 0;
+        EB_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_nch.as<uint32_t>(), d_choff.as<uint32_t>(), (int)ns, st));
+        if (scan_bytes > tmp_bytes) { if ((rc = d_tmp.alloc(scan_bytes)) != EB_OK) return rc; tmp_bytes = scan_bytes; }
+        EB_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp.p, scan_bytes, d_nch.as<uint32_t>(), d_choff.as<uint32_t>(), (int)ns, st));
+        uint32_t last_off = 0, last_cnt = 0;
+        EB_HIP(hipMemcpyAsync(&last_off, d_choff.as<uint32_t>() + (ns - 1), 4, hipMemcpyDeviceToHost, st));
+        EB_HIP(hipMemcpyAsync(&last_cnt, d_nch.as<uint32_t>() + (ns - 1), 4, hipMemcpyDeviceToHost, st));
+        EB_HIP(hipStreamSynchronize(st));
+        const uint64_t n_chains = (uint64_t)last_off + last_cnt;
+        if ((rc = d_chains.alloc(n_chains * 8)) != EB_OK) return rc;
+        hipLaunchKernelGGL(k_chain_list, dim3(grid_of(ns)), dim3(256), 0, st, d_sorted.as<Survivor>(), d_choff.as<uint32_t>(), ns, d_chains.as<uint64_t>());
         size_t left_bytes = (size_t)ns * EB_MAX_SLOTS * (size_t)prm->k_left, right_bytes = (size_t)ns * (size_t)prm->k_right;
         if ((rc = d_recs.alloc(ns * sizeof(eb_cluster))) != EB_OK || (rc = d_left.alloc(left_bytes)) != EB_OK || (rc = d_right.alloc(right_bytes)) != EB_OK)
             return rc;
@@ -513,8 +558,9 @@ extern "C" int eb_scan_clusters(eb_index* b1, eb_index* b2, eb_flags* f, uint64_
         EB_HIP(hipMemsetAsync(d_left.p, 0, left_bytes, st));
         EB_HIP(hipMemsetAsync(d_right.p, 0, right_bytes, st));
         EB_HIP(hipEventRecord(ev[2], st));
-        hipLaunchKernelGGL(k_extend, dim3(grid_of(ns * 32)), dim3(256), 0, st, x1, x2, p, d_sorted.as<Survivor>(), ns, d_recs.as<eb_cluster>(),
-                           d_left.as<uint8_t>(), d_cnt.as<ScanCounters>());
+        if (n_chains)
+            hipLaunchKernelGGL(k_extend, dim3(grid_of(n_chains * 4)), dim3(256), 0, st, x1, x2, p, d_sorted.as<Survivor>(), d_chains.as<uint64_t>(), n_chains,
+                               d_recs.as<eb_cluster>(), d_left.as<uint8_t>());
         EB_HIP(hipEventRecord(ev[3], st));
         hipLaunchKernelGGL(k_right, dim3(grid_of(ns)), dim3(256), 0, st, x1, x2, df, p, d_sorted.as<Survivor>(), ns, d_recs.as<eb_cluster>(),
                            d_right.as<uint8_t>());
