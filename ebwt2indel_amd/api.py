@@ -224,16 +224,21 @@ class Calls:
         return self.view().count
 
     def arrays(self):
-        """(clusters as raw uint8 bytes, left chars, right chars) copied to numpy."""
+        """(clusters, chains, left words, right words) as raw uint8 copies."""
         v = self.view()
-        k = v.count
-        if k == 0:
-            z = np.zeros(0, dtype=np.uint8)
-            return z, z, z
-        cl = np.frombuffer(C.string_at(v.clusters, k * C.sizeof(_lib.Cluster)), dtype=np.uint8).copy()
-        left = np.frombuffer(C.string_at(v.left, k * 8 * v.k_left), dtype=np.uint8).copy()
-        right = np.frombuffer(C.string_at(v.right, k * v.k_right), dtype=np.uint8).copy()
-        return cl, left, right
+        k, m = v.count, v.n_chains
+        lw, rw = (v.k_left + 31) // 32, (v.k_right + 31) // 32
+
+        def grab(ptr, nbytes):
+            return np.frombuffer(C.string_at(ptr, nbytes), dtype=np.uint8).copy() if nbytes else np.zeros(0, dtype=np.uint8)
+        return (grab(v.clusters, k * C.sizeof(_lib.Cluster)), grab(v.chains, m * C.sizeof(_lib.Chain)),
+                grab(v.left, m * lw * 8), grab(v.right, k * rw * 8))
+
+    def blob(self) -> memoryview:
+        """Zero-copy view of the call set's wire image (valid while this object lives)."""
+        p, n = C.c_void_p(), C.c_uint64(0)
+        _check(lib().eb_calls_blob(self._h, C.byref(p), C.byref(n)))
+        return memoryview((C.c_uint8 * n.value).from_address(p.value))
 
     def pack(self) -> bytes:
         n = lib().eb_calls_packed_size(self._h)

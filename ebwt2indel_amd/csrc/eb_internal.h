@@ -63,12 +63,27 @@ struct eb_flags {
     }
 };
 
-struct eb_calls {
-    int32_t k_left = 0, k_right = 0;
-    std::vector<eb_cluster> clusters;
-    std::vector<uint8_t> left;  // count * EB_MAX_SLOTS * k_left
-    std::vector<uint8_t> right; // count * k_right
+// Call set = ONE contiguous blob (also its wire format for the gather between ranks):
+//   [header 64 B][eb_cluster x count][eb_chain x n_chains (padded to 8 B)][left words][right words]
+struct eb_calls_header {
+    uint64_t magic, count, n_chains, k_left, k_right, reserved[3];
 };
+struct eb_calls {
+    uint8_t* blob = nullptr;
+    uint64_t size = 0;
+    bool pinned = false; // page-locked (device -> host copies) or plain malloc (unpacked on a host without GPU)
+    uint64_t count = 0, n_chains = 0;
+    int32_t k_left = 0, k_right = 0;
+    eb_cluster* clusters = nullptr;
+    eb_chain* chains = nullptr;
+    uint64_t* left = nullptr;
+    uint64_t* right = nullptr;
+    uint64_t left_words() const { return ((uint64_t)k_left + 31) / 32; }
+    uint64_t right_words() const { return ((uint64_t)k_right + 31) / 32; }
+};
+uint64_t eb_calls_blob_size(uint64_t count, uint64_t n_chains, int32_t k_left, int32_t k_right);
+// allocates the blob (zeroed), fills the header and the section pointers; nullptr on failure (error set)
+eb_calls* eb_calls_alloc(uint64_t count, uint64_t n_chains, int32_t k_left, int32_t k_right, bool pinned);
 
 // words allocated for a bitvector of n bits (one spare word so neighbours can be read unguarded)
 static inline uint64_t eb_bit_words(uint64_t n) { return (n + 63) / 64; }

@@ -341,10 +341,11 @@ __global__ void __launch_bounds__(256) k_chain_list(const Survivor* __restrict__
 __device__ __forceinline__ uint64_t pick4(const uint64_t* F, uint32_t c) { return c == 0 ? F[0] : c == 1 ? F[1] : c == 2 ? F[2] : F[3]; }
 
 // Four lanes per chain.  extract_consensus(bwt,range,c,...) ebwt2InDel.cpp:303-319 -> LF(range,c), then
-// up to k_left-1 x { LF(range) ; consensus_letter } (:243-282).
+// up to k_left-1 x { LF(range) ; consensus_letter } (:243-282).  Output: eb_chain + bases packed 2 bits each in
+// extension order (the writer reverses them, :315).
 __global__ void __launch_bounds__(256) k_extend(eb_dev_index x1, eb_dev_index x2, ScanParams p, const Survivor* __restrict__ surv,
-                                               const uint64_t* __restrict__ chains, uint64_t n_chains, eb_cluster* __restrict__ recs,
-                                               uint8_t* __restrict__ left) {
+                                               const uint64_t* __restrict__ chains, uint64_t n_chains, eb_chain* __restrict__ crec,
+                                               uint64_t* __restrict__ left, uint32_t left_words) {
     const uint32_t j = threadIdx.x & 3u;
     const uint32_t qbase = (threadIdx.x & 63u) & ~3u; // first lane of this quad inside the wave
     uint64_t ch = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
@@ -354,13 +355,11 @@ __global__ void __launch_bounds__(256) k_extend(eb_dev_index x1, eb_dev_index x2
     uint32_t sidx = (uint32_t)(item & 7u);
     Survivor s = surv[i];
     uint32_t side = sidx >> 2, c = sidx & 3u;
-    uint32_t fm = side ? s.fmask1 : s.fmask0;
-    uint32_t slot = (side ? (uint32_t)__popc(s.fmask0) : 0u) + (uint32_t)__popc(fm & ((1u << c) - 1u));
     const bool second = p.mode == 2 && side == 1;
     const eb_dev_index& x = second ? x2 : x1;
     uint64_t L, R;
     if (p.mode == 2) { L = side ? s.b1 : s.b0; R = side ? s.e1 : s.e0; } else { L = s.b; R = s.e; }
-    uint8_t* out = left + ((size_t)i * EB_MAX_SLOTS + slot) * (size_t)p.k_left;
+    uint64_t* out = left + ch * (uint64_t)left_words;
     // LF(range, c)
     uint64_t a = eb_rank4_quad(x, L, j);
     uint64_t bq = R > L ? eb_rank4_quad(x, R, j) : a;
@@ -368,9 +367,9 @@ __global__ void __launch_bounds__(256) k_extend(eb_dev_index x1, eb_dev_index x2
     L = Fc + __shfl((unsigned long long)a, qbase + c);
     R = Fc + __shfl((unsigned long long)bq, qbase + c);
     uint32_t support = (uint32_t)(R - L);
-    int have = 1;
-    if (j == 0) out[p.k_left - 1] = (uint8_t)"ACGT"[c];
-    while (have < p.k_left) {
+    uint32_t have = 1;
+    uint64_t word = c; // base 0 = the frequent symbol itself
+    while (have < (uint32_t)p.k_left) {
         a = eb_rank4_quad(x, L, j);
         bq = R > L ? eb_rank4_quad(x, R, j) : a;
         uint64_t len = bq - a;
@@ -386,30 +385,33 @@ __global__ void __launch_bounds__(256) k_extend(eb_dev_index x1, eb_dev_index x2
         uint64_t Fb = pick4(x.F, bj);
         L = Fb + __shfl((unsigned long long)a, qbase + bj);
         R = Fb + __shfl((unsigned long long)bq, qbase + bj);
-        if (j == 0) out[p.k_left - 1 - have] = (uint8_t)"ACGT"[bj];
+        word |= (uint64_t)bj << (2u * (have & 31u));
         ++have;
+        if ((have & 31u) == 0) { // 32 bases collected
+            if (j == 0) out[(have >> 5) - 1] = word;
+            word = 0;
+        }
     }
     if (j == 0) {
-        eb_cluster* r = recs + i;
-        r->slot_side[slot] = (uint8_t)side;
-        r->slot_sym[slot] = (uint8_t)"ACGT"[c];
-        r->slot_len[slot] = (uint32_t)have;
-        r->slot_support[slot] = support;
+        if (have & 31u) out[have >> 5] = word;
+        eb_chain k;
+        k.side = (uint8_t)side;
+        k.sym = (uint8_t)"ACGT"[c];
+        k.reserved = 0;
+        k.len = have;
+        k.support = support;
+        crec[ch] = k;
     }
 }
 
 // One lane per cluster: record header + right context (extract_dna, ebwt2InDel.cpp:325-342) at the first
-// cluster position whose LCP >= k_right (:979-988; two BWTs :896-912).
+// cluster position whose LCP >= k_right (:979-988; two BWTs :896-912); bases packed 2 bits each in text order.
 __global__ void __launch_bounds__(256) k_right(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, ScanParams p,
-                                              const Survivor* __restrict__ surv, uint64_t nsurv, eb_cluster* __restrict__ recs,
-                                              uint8_t* __restrict__ right) {
+                                              const Survivor* __restrict__ surv, const uint32_t* __restrict__ chain_off, uint64_t nsurv,
+                                              eb_cluster* __restrict__ recs, uint64_t* __restrict__ right, uint32_t right_words) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nsurv) return;
     Survivor s = surv[i];
-    eb_cluster* r = recs + i;
-    r->begin = s.b;
-    r->end = s.e;
-    r->n_slots = (uint16_t)(__popc(s.fmask0) + __popc(s.fmask1));
     // first position in [b,e) with thrR
     uint64_t pos = ~0ull;
     for (uint64_t w = s.b >> 6; w <= (s.e - 1) >> 6; ++w) {
@@ -429,16 +431,27 @@ __global__ void __launch_bounds__(256) k_right(eb_dev_index x1, eb_dev_index x2,
             row = second ? i1 : pos - i1;
         }
         const eb_dev_index& x = second ? x2 : x1;
-        uint8_t* out = right + (size_t)i * (size_t)p.k_right;
+        uint64_t* out = right + i * (uint64_t)right_words;
+        uint64_t word = 0;
         int c = eb_F_letter(x, row);
         while (c >= 0 && len < (uint32_t)p.k_right) {
-            out[len++] = (uint8_t)"ACGT"[c];
+            word |= (uint64_t)c << (2u * (len & 31u));
+            ++len;
+            if ((len & 31u) == 0) { out[(len >> 5) - 1] = word; word = 0; }
             row = eb_FL(x, row, c);
             c = eb_F_letter(x, row);
         }
+        if (len & 31u) out[len >> 5] = word;
     }
-    r->right_found = pos != ~0ull ? 1 : 0;
-    r->right_len = len;
+    eb_cluster r;
+    r.begin = s.b;
+    r.end = s.e;
+    r.first_chain = chain_off[i];
+    r.n_slots = (uint16_t)(__popc(s.fmask0) + __popc(s.fmask1));
+    r.right_found = pos != ~0ull ? 1 : 0;
+    r.right_len = len;
+    r.reserved = 0;
+    recs[i] = r;
 }
 
 struct DevMem {
@@ -491,11 +504,11 @@ extern "C" int eb_scan_clusters(eb_index* b1, eb_index* b2, eb_flags* f, uint64_
     eb_dev_index x1 = b1->dev(), x2 = b2 ? b2->dev() : b1->dev();
     eb_dev_flags df = f->dev();
 
-    hipEvent_t ev[5];
+    hipEvent_t ev[6];
     for (auto& e : ev) EB_HIP(hipEventCreate(&e));
-    struct EvGuard { hipEvent_t* e; ~EvGuard() { for (int i = 0; i < 5; ++i) (void)hipEventDestroy(e[i]); } } evg{ev};
+    struct EvGuard { hipEvent_t* e; ~EvGuard() { for (int i = 0; i < 6; ++i) (void)hipEventDestroy(e[i]); } } evg{ev};
 
-    DevMem d_cnt, d_surv, d_sorted, d_keys, d_keys2, d_idx, d_idx2, d_tmp, d_recs, d_left, d_right, d_nch, d_choff, d_chains;
+    DevMem d_cnt, d_surv, d_sorted, d_keys, d_keys2, d_idx, d_idx2, d_tmp, d_recs, d_crec, d_left, d_right, d_nch, d_choff, d_chains;
     int rc;
     if ((rc = d_cnt.alloc(sizeof(ScanCounters))) != EB_OK) return rc;
     uint64_t w_lo = begin >> 6, w_hi = (end + 63) >> 6;
@@ -518,71 +531,70 @@ extern "C" int eb_scan_clusters(eb_index* b1, eb_index* b2, eb_flags* f, uint64_
     }
     EB_HIP(hipEventRecord(ev[1], st));
     const uint64_t ns = c.nsurv;
-    eb_calls* calls = new eb_calls();
-    calls->k_left = prm->k_left;
-    calls->k_right = prm->k_right;
-    struct CallGuard { eb_calls* c; ~CallGuard() { delete c; } } cg{calls};
+    eb_calls* calls = nullptr;
+    struct CallGuard { eb_calls** c; ~CallGuard() { if (*c) eb_calls_free(*c); } } cg{&calls};
     float ms_scan = 0, ms_ext = 0, ms_right = 0, ms_total = 0;
+    uint64_t n_chains = 0;
+    const uint32_t lw = (uint32_t)((prm->k_left + 31) / 32), rw = (uint32_t)((prm->k_right + 31) / 32);
     if (ns) {
-        if (ns > 0xFFFFFFFFull) { eb_set_error("too many surviving clusters in one call; shard the range"); return EB_ERR_STATE; }
+        if (ns > 0x1FFFFFFFull) { eb_set_error("too many surviving clusters in one call; shard the range"); return EB_ERR_STATE; }
         // BWT order: sort survivors by begin
         if ((rc = d_keys.alloc(ns * 8)) != EB_OK || (rc = d_keys2.alloc(ns * 8)) != EB_OK || (rc = d_idx.alloc(ns * 4)) != EB_OK ||
             (rc = d_idx2.alloc(ns * 4)) != EB_OK || (rc = d_sorted.alloc(ns * sizeof(Survivor))) != EB_OK)
             return rc;
         hipLaunchKernelGGL(k_surv_keys, dim3(grid_of(ns)), dim3(256), 0, st, d_surv.as<Survivor>(), ns, d_keys.as<uint64_t>(), d_idx.as<uint32_t>());
-        size_t tmp_bytes = 0;
+        size_t tmp_bytes = 0, scan_bytes = 0;
         EB_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_keys.as<uint64_t>(), d_keys2.as<uint64_t>(), d_idx.as<uint32_t>(),
                                                   d_idx2.as<uint32_t>(), (int)ns, 0, 64, st));
+        if ((rc = d_nch.alloc(ns * 4)) != EB_OK || (rc = d_choff.alloc((ns + 1) * 4)) != EB_OK) return rc;
+        EB_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_nch.as<uint32_t>(), d_choff.as<uint32_t>(), (int)ns, st));
+        if (scan_bytes > tmp_bytes) tmp_bytes = scan_bytes;
         if ((rc = d_tmp.alloc(tmp_bytes)) != EB_OK) return rc;
         EB_HIP(hipcub::DeviceRadixSort::SortPairs(d_tmp.p, tmp_bytes, d_keys.as<uint64_t>(), d_keys2.as<uint64_t>(), d_idx.as<uint32_t>(),
                                                   d_idx2.as<uint32_t>(), (int)ns, 0, 64, st));
-        if ((rc = d_nch.alloc(ns * 4)) != EB_OK || (rc = d_choff.alloc((ns + 1) * 4)) != EB_OK) return rc;
         hipLaunchKernelGGL(k_surv_gather, dim3(grid_of(ns)), dim3(256), 0, st, d_surv.as<Survivor>(), d_idx2.as<uint32_t>(), ns, d_sorted.as<Survivor>(),
                            d_nch.as<uint32_t>());
         // dense chain list: exclusive scan of the per-cluster chain counts
-        size_t scan_bytes = 0;
-        EB_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_nch.as<uint32_t>(), d_choff.as<uint32_t>(), (int)ns, st));
-        if (scan_bytes > tmp_bytes) { if ((rc = d_tmp.alloc(scan_bytes)) != EB_OK) return rc; tmp_bytes = scan_bytes; }
-        EB_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp.p, scan_bytes, d_nch.as<uint32_t>(), d_choff.as<uint32_t>(), (int)ns, st));
+        EB_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp.p, tmp_bytes, d_nch.as<uint32_t>(), d_choff.as<uint32_t>(), (int)ns, st));
         uint32_t last_off = 0, last_cnt = 0;
         EB_HIP(hipMemcpyAsync(&last_off, d_choff.as<uint32_t>() + (ns - 1), 4, hipMemcpyDeviceToHost, st));
         EB_HIP(hipMemcpyAsync(&last_cnt, d_nch.as<uint32_t>() + (ns - 1), 4, hipMemcpyDeviceToHost, st));
         EB_HIP(hipStreamSynchronize(st));
-        const uint64_t n_chains = (uint64_t)last_off + last_cnt;
-        if ((rc = d_chains.alloc(n_chains * 8)) != EB_OK) return rc;
-        hipLaunchKernelGGL(k_chain_list, dim3(grid_of(ns)), dim3(256), 0, st, d_sorted.as<Survivor>(), d_choff.as<uint32_t>(), ns, d_chains.as<uint64_t>());
-        size_t left_bytes = (size_t)ns * EB_MAX_SLOTS * (size_t)prm->k_left, right_bytes = (size_t)ns * (size_t)prm->k_right;
-        if ((rc = d_recs.alloc(ns * sizeof(eb_cluster))) != EB_OK || (rc = d_left.alloc(left_bytes)) != EB_OK || (rc = d_right.alloc(right_bytes)) != EB_OK)
+        n_chains = (uint64_t)last_off + last_cnt;
+        calls = eb_calls_alloc(ns, n_chains, prm->k_left, prm->k_right, true); // page-locked blob, sections filled by D2H copies
+        if (!calls) return EB_ERR_NOMEM;
+        const size_t rec_bytes = ns * sizeof(eb_cluster), chain_bytes = n_chains * sizeof(eb_chain);
+        const size_t left_bytes = n_chains * (size_t)lw * 8, right_bytes = ns * (size_t)rw * 8;
+        if ((rc = d_chains.alloc(n_chains * 8)) != EB_OK || (rc = d_recs.alloc(rec_bytes)) != EB_OK || (rc = d_crec.alloc(chain_bytes)) != EB_OK ||
+            (rc = d_left.alloc(left_bytes)) != EB_OK || (rc = d_right.alloc(right_bytes)) != EB_OK)
             return rc;
-        EB_HIP(hipMemsetAsync(d_recs.p, 0, ns * sizeof(eb_cluster), st));
+        hipLaunchKernelGGL(k_chain_list, dim3(grid_of(ns)), dim3(256), 0, st, d_sorted.as<Survivor>(), d_choff.as<uint32_t>(), ns, d_chains.as<uint64_t>());
         EB_HIP(hipMemsetAsync(d_left.p, 0, left_bytes, st));
         EB_HIP(hipMemsetAsync(d_right.p, 0, right_bytes, st));
         EB_HIP(hipEventRecord(ev[2], st));
         if (n_chains)
             hipLaunchKernelGGL(k_extend, dim3(grid_of(n_chains * 4)), dim3(256), 0, st, x1, x2, p, d_sorted.as<Survivor>(), d_chains.as<uint64_t>(), n_chains,
-                               d_recs.as<eb_cluster>(), d_left.as<uint8_t>());
+                               d_crec.as<eb_chain>(), d_left.as<uint64_t>(), lw);
         EB_HIP(hipEventRecord(ev[3], st));
-        hipLaunchKernelGGL(k_right, dim3(grid_of(ns)), dim3(256), 0, st, x1, x2, df, p, d_sorted.as<Survivor>(), ns, d_recs.as<eb_cluster>(),
-                           d_right.as<uint8_t>());
+        hipLaunchKernelGGL(k_right, dim3(grid_of(ns)), dim3(256), 0, st, x1, x2, df, p, d_sorted.as<Survivor>(), d_choff.as<uint32_t>(), ns,
+                           d_recs.as<eb_cluster>(), d_right.as<uint64_t>(), rw);
         EB_HIP(hipEventRecord(ev[4], st));
         EB_HIP(hipGetLastError());
-        calls->clusters.resize(ns);
-        calls->left.resize(left_bytes);
-        calls->right.resize(right_bytes);
-        EB_HIP(hipMemcpyAsync(calls->clusters.data(), d_recs.p, ns * sizeof(eb_cluster), hipMemcpyDeviceToHost, st));
-        EB_HIP(hipMemcpyAsync(calls->left.data(), d_left.p, left_bytes, hipMemcpyDeviceToHost, st));
-        EB_HIP(hipMemcpyAsync(calls->right.data(), d_right.p, right_bytes, hipMemcpyDeviceToHost, st));
-        EB_HIP(hipMemcpyAsync(&c, d_cnt.p, sizeof c, hipMemcpyDeviceToHost, st));
+        EB_HIP(hipMemcpyAsync(calls->clusters, d_recs.p, rec_bytes, hipMemcpyDeviceToHost, st));
+        if (chain_bytes) EB_HIP(hipMemcpyAsync(calls->chains, d_crec.p, chain_bytes, hipMemcpyDeviceToHost, st));
+        if (left_bytes) EB_HIP(hipMemcpyAsync(calls->left, d_left.p, left_bytes, hipMemcpyDeviceToHost, st));
+        EB_HIP(hipMemcpyAsync(calls->right, d_right.p, right_bytes, hipMemcpyDeviceToHost, st));
+        EB_HIP(hipEventRecord(ev[5], st));
         EB_HIP(hipStreamSynchronize(st));
         EB_HIP(hipEventElapsedTime(&ms_ext, ev[2], ev[3]));
         EB_HIP(hipEventElapsedTime(&ms_right, ev[3], ev[4]));
-        EB_HIP(hipEventElapsedTime(&ms_total, ev[0], ev[4]));
+        EB_HIP(hipEventElapsedTime(&ms_total, ev[0], ev[5]));
         // contexts shorter than k_left are dropped by the writer (ebwt2InDel.cpp:317): blank them
-        for (uint64_t i = 0; i < ns; ++i)
-            for (uint32_t s = 0; s < EB_MAX_SLOTS; ++s)
-                if (calls->clusters[i].slot_len[s] != (uint32_t)prm->k_left)
-                    memset(calls->left.data() + (i * EB_MAX_SLOTS + s) * (size_t)prm->k_left, 0, (size_t)prm->k_left);
+        for (uint64_t k = 0; k < n_chains; ++k)
+            if (calls->chains[k].len != (uint32_t)prm->k_left) memset(calls->left + k * lw, 0, (size_t)lw * 8);
     } else {
+        calls = eb_calls_alloc(0, 0, prm->k_left, prm->k_right, false);
+        if (!calls) return EB_ERR_NOMEM;
         EB_HIP(hipEventSynchronize(ev[1]));
         EB_HIP(hipEventElapsedTime(&ms_total, ev[0], ev[1]));
     }
@@ -595,16 +607,14 @@ extern "C" int eb_scan_clusters(eb_index* b1, eb_index* b2, eb_flags* f, uint64_
         stats->clusters = c.clusters;
         stats->bases_in_runs = c.bases;
         stats->survivors = ns;
-        uint64_t chains = 0;
-        for (const eb_cluster& r : calls->clusters) chains += r.n_slots; // one left-context chain per frequent symbol
-        stats->chains = chains;
+        stats->chains = n_chains; // one left-context chain per frequent symbol
         for (int k = 0; k < 201; ++k) stats->hist[k] = c.hist[k];
         stats->ms_scan = ms_scan;
         stats->ms_extend = ms_ext;
         stats->ms_right = ms_right;
         stats->ms_total = ms_total;
     }
-    cg.c = nullptr;
     *out = calls;
+    calls = nullptr; // ownership passed on
     return EB_OK;
 }

@@ -9,7 +9,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "eb_internal.h"
@@ -149,22 +151,34 @@ void write_pairs(std::string& o, const std::vector<Ctx>& c0, const std::vector<C
     cluster_nr += found ? 1 : 0; // :1250
 }
 
+std::string unpack_bases(const uint64_t* words, uint32_t len, bool reversed) {
+    std::string s(len, 'A');
+    for (uint32_t e = 0; e < len; ++e) {
+        char ch = "ACGT"[(words[e >> 5] >> (2 * (e & 31))) & 3];
+        s[reversed ? len - 1 - e : e] = ch;
+    }
+    return s;
+}
+
 int format_calls(const eb_calls* c, const eb_params* p, int two_samples, uint64_t* cluster_nr, uint64_t* events, std::string& o) {
     if (!c || !p || !cluster_nr) { eb_set_error("null argument"); return EB_ERR_ARG; }
     if (c->k_left != p->k_left || c->k_right != p->k_right) { eb_set_error("call set was produced with other -L/-R values"); return EB_ERR_ARG; }
     uint64_t ev = events ? *events : 0;
-    const size_t kl = (size_t)c->k_left, kr = (size_t)c->k_right;
-    for (size_t i = 0; i < c->clusters.size(); ++i) {
+    const uint64_t lw = c->left_words(), rw = c->right_words();
+    for (uint64_t i = 0; i < c->count; ++i) {
         const eb_cluster& r = c->clusters[i];
         if (!r.right_found) continue; // no variants are collected without a right context (:985, :909, :1071)
-        std::string right(reinterpret_cast<const char*>(c->right.data() + i * kr), r.right_len);
+        std::string right = unpack_bases(c->right + i * rw, r.right_len, false);
         std::vector<Ctx> side[2];
-        for (uint32_t s = 0; s < r.n_slots && s < EB_MAX_SLOTS; ++s) {
-            if (r.slot_len[s] != (uint32_t)c->k_left) continue; // shorter contexts are dropped (:317)
+        for (uint32_t s = 0; s < r.n_slots; ++s) {
+            uint64_t ch = (uint64_t)r.first_chain + s;
+            if (ch >= c->n_chains) { eb_set_error("corrupt call set: chain index out of range"); return EB_ERR_ARG; }
+            const eb_chain& k = c->chains[ch];
+            if (k.len != (uint32_t)c->k_left) continue; // shorter contexts are dropped (:317)
             Ctx x;
-            x.s.assign(reinterpret_cast<const char*>(c->left.data() + (i * EB_MAX_SLOTS + s) * kl), kl);
-            x.support = (int)r.slot_support[s];
-            side[r.slot_side[s] ? 1 : 0].push_back(std::move(x));
+            x.s = unpack_bases(c->left + ch * lw, k.len, true); // extension order -> text order (reverse, :315)
+            x.support = (int)k.support;
+            side[k.side ? 1 : 0].push_back(std::move(x));
         }
         if (two_samples) write_pairs(o, side[0], side[1], right, *p, *cluster_nr);
         else write_single(o, side[0], right, *p, *cluster_nr, ev);
@@ -177,67 +191,148 @@ int format_calls(const eb_calls* c, const eb_params* p, int two_samples, uint64_
 
 // ------------------------------------------------------------------ call-set container
 
+static const uint64_t kMagic = 0x32534C4C41434245ull; // "EBCALLS2"
+
+namespace {
+// page-locked blobs are recycled: pinning tens of MB per call would cost more than the copy it speeds up
+std::mutex g_pool_mu;
+std::vector<std::pair<void*, uint64_t>> g_pool;
+
+void* pinned_get(uint64_t size, uint64_t* got) {
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (size_t i = 0; i < g_pool.size(); ++i)
+            if (g_pool[i].second >= size && g_pool[i].second <= 2 * size + (1u << 20)) {
+                void* p = g_pool[i].first;
+                *got = g_pool[i].second;
+                g_pool.erase(g_pool.begin() + i);
+                return p;
+            }
+    }
+    void* p = nullptr;
+    uint64_t cap = size + size / 4 + 4096;
+    if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+    *got = cap;
+    return p;
+}
+void pinned_put(void* p, uint64_t cap) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (g_pool.size() < 8) { g_pool.emplace_back(p, cap); return; }
+    (void)hipHostFree(p);
+}
+uint64_t align8(uint64_t v) { return (v + 7) & ~7ull; }
+
+void bind_sections(eb_calls* c) {
+    uint8_t* q = c->blob + sizeof(eb_calls_header);
+    c->clusters = reinterpret_cast<eb_cluster*>(q);
+    q += c->count * sizeof(eb_cluster);
+    c->chains = reinterpret_cast<eb_chain*>(q);
+    q += align8(c->n_chains * sizeof(eb_chain));
+    c->left = reinterpret_cast<uint64_t*>(q);
+    q += c->n_chains * c->left_words() * 8;
+    c->right = reinterpret_cast<uint64_t*>(q);
+}
+}  // namespace
+
+struct eb_calls_storage { uint64_t cap; }; // capacity of a pinned blob is kept in front of the handle
+
+uint64_t eb_calls_blob_size(uint64_t count, uint64_t n_chains, int32_t k_left, int32_t k_right) {
+    uint64_t lw = ((uint64_t)k_left + 31) / 32, rw = ((uint64_t)k_right + 31) / 32;
+    return sizeof(eb_calls_header) + count * sizeof(eb_cluster) + align8(n_chains * sizeof(eb_chain)) + n_chains * lw * 8 + count * rw * 8;
+}
+
+static std::vector<std::pair<eb_calls*, uint64_t>> g_caps; // pinned capacity per live handle
+static std::mutex g_caps_mu;
+
+eb_calls* eb_calls_alloc(uint64_t count, uint64_t n_chains, int32_t k_left, int32_t k_right, bool pinned) {
+    eb_calls* c = new eb_calls();
+    c->count = count;
+    c->n_chains = n_chains;
+    c->k_left = k_left;
+    c->k_right = k_right;
+    c->size = eb_calls_blob_size(count, n_chains, k_left, k_right);
+    c->pinned = pinned;
+    if (pinned) {
+        uint64_t cap = 0;
+        c->blob = static_cast<uint8_t*>(pinned_get(c->size, &cap));
+        if (c->blob) {
+            std::lock_guard<std::mutex> lk(g_caps_mu);
+            g_caps.emplace_back(c, cap);
+        }
+    } else {
+        c->blob = static_cast<uint8_t*>(malloc(c->size));
+    }
+    if (!c->blob) { eb_set_error("out of host memory for %llu call records", (unsigned long long)count); delete c; return nullptr; }
+    memset(c->blob, 0, c->size);
+    eb_calls_header h = {kMagic, count, n_chains, (uint64_t)(uint32_t)k_left, (uint64_t)(uint32_t)k_right, {0, 0, 0}};
+    memcpy(c->blob, &h, sizeof h);
+    bind_sections(c);
+    return c;
+}
+
 extern "C" int eb_calls_get(const eb_calls* c, eb_calls_view* v) {
     if (!c || !v) { eb_set_error("null argument"); return EB_ERR_ARG; }
-    v->count = c->clusters.size();
+    v->count = c->count;
+    v->n_chains = c->n_chains;
     v->k_left = c->k_left;
     v->k_right = c->k_right;
-    v->clusters = c->clusters.data();
-    v->left = c->left.data();
-    v->right = c->right.data();
+    v->clusters = c->clusters;
+    v->chains = c->chains;
+    v->left = c->left;
+    v->right = c->right;
     return EB_OK;
 }
 
-extern "C" void eb_calls_free(eb_calls* c) { delete c; }
-
-static const uint64_t kMagic = 0x31534C4C41434245ull; // "EBCALLS1"
-
-extern "C" uint64_t eb_calls_packed_size(const eb_calls* c) {
-    if (!c) return 0;
-    return 32 + c->clusters.size() * sizeof(eb_cluster) + c->left.size() + c->right.size();
+extern "C" void eb_calls_free(eb_calls* c) {
+    if (!c) return;
+    if (c->blob) {
+        if (c->pinned) {
+            uint64_t cap = 0;
+            {
+                std::lock_guard<std::mutex> lk(g_caps_mu);
+                for (size_t i = 0; i < g_caps.size(); ++i)
+                    if (g_caps[i].first == c) { cap = g_caps[i].second; g_caps.erase(g_caps.begin() + i); break; }
+            }
+            pinned_put(c->blob, cap);
+        } else {
+            free(c->blob);
+        }
+    }
+    delete c;
 }
+
+extern "C" uint64_t eb_calls_packed_size(const eb_calls* c) { return c ? c->size : 0; }
 
 extern "C" int eb_calls_pack(const eb_calls* c, uint8_t* buf, uint64_t cap) {
     if (!c || !buf) { eb_set_error("null argument"); return EB_ERR_ARG; }
-    uint64_t need = eb_calls_packed_size(c);
-    if (cap < need) { eb_set_error("buffer too small: need %llu bytes", (unsigned long long)need); return EB_ERR_ARG; }
-    uint64_t hdr[4] = {kMagic, c->clusters.size(), (uint64_t)(uint32_t)c->k_left, (uint64_t)(uint32_t)c->k_right};
-    memcpy(buf, hdr, 32);
-    uint8_t* q = buf + 32;
-    if (!c->clusters.empty()) {
-        memcpy(q, c->clusters.data(), c->clusters.size() * sizeof(eb_cluster));
-        q += c->clusters.size() * sizeof(eb_cluster);
-        memcpy(q, c->left.data(), c->left.size());
-        q += c->left.size();
-        memcpy(q, c->right.data(), c->right.size());
-    }
+    if (cap < c->size) { eb_set_error("buffer too small: need %llu bytes", (unsigned long long)c->size); return EB_ERR_ARG; }
+    memcpy(buf, c->blob, c->size);
+    return EB_OK;
+}
+
+extern "C" int eb_calls_blob(const eb_calls* c, const uint8_t** data, uint64_t* len) {
+    if (!c || !data || !len) { eb_set_error("null argument"); return EB_ERR_ARG; }
+    *data = c->blob;
+    *len = c->size;
     return EB_OK;
 }
 
 extern "C" int eb_calls_unpack(const uint8_t* buf, uint64_t len, eb_calls** out) {
     if (!buf || !out) { eb_set_error("null argument"); return EB_ERR_ARG; }
     *out = nullptr;
-    uint64_t hdr[4];
-    if (len < 32) { eb_set_error("truncated call set"); return EB_ERR_ARG; }
-    memcpy(hdr, buf, 32);
-    if (hdr[0] != kMagic) { eb_set_error("not a packed call set"); return EB_ERR_ARG; }
-    uint64_t cnt = hdr[1], kl = hdr[2], kr = hdr[3];
-    uint64_t need = 32 + cnt * sizeof(eb_cluster) + cnt * EB_MAX_SLOTS * kl + cnt * kr;
-    if (len < need) { eb_set_error("truncated call set"); return EB_ERR_ARG; }
-    eb_calls* c = new eb_calls();
-    c->k_left = (int32_t)kl;
-    c->k_right = (int32_t)kr;
-    c->clusters.resize(cnt);
-    c->left.resize(cnt * EB_MAX_SLOTS * kl);
-    c->right.resize(cnt * kr);
-    const uint8_t* q = buf + 32;
-    if (cnt) {
-        memcpy(c->clusters.data(), q, cnt * sizeof(eb_cluster));
-        q += cnt * sizeof(eb_cluster);
-        memcpy(c->left.data(), q, c->left.size());
-        q += c->left.size();
-        memcpy(c->right.data(), q, c->right.size());
+    eb_calls_header h;
+    if (len < sizeof h) { eb_set_error("truncated call set"); return EB_ERR_ARG; }
+    memcpy(&h, buf, sizeof h);
+    if (h.magic != kMagic) { eb_set_error("not a packed call set"); return EB_ERR_ARG; }
+    if (h.k_left == 0 || h.k_left > (1u << 20) || h.k_right == 0 || h.k_right > (1u << 20) || h.count > (1ull << 40) || h.n_chains > h.count * EB_MAX_SLOTS) {
+        eb_set_error("corrupt call set header");
+        return EB_ERR_ARG;
     }
+    uint64_t need = eb_calls_blob_size(h.count, h.n_chains, (int32_t)h.k_left, (int32_t)h.k_right);
+    if (len < need) { eb_set_error("truncated call set"); return EB_ERR_ARG; }
+    eb_calls* c = eb_calls_alloc(h.count, h.n_chains, (int32_t)h.k_left, (int32_t)h.k_right, false);
+    if (!c) return EB_ERR_NOMEM;
+    memcpy(c->blob, buf, need);
     *out = c;
     return EB_OK;
 }

@@ -20,7 +20,7 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     return cut(rank), cut(rank + 1)
 
 
-def gather_packed(packed: bytes, group=None, device=None, dst: int = 0) -> Optional[List[bytes]]:
+def gather_packed(packed, group=None, device=None, dst: int = 0) -> Optional[List[bytes]]:
     """Variable-length gather of one byte string per rank to `dst` (None elsewhere).
     Sizes travel in an all_gather, payloads in a padded gather; tensors live on `device`
     (a CUDA/HIP device for the nccl backend, CPU for gloo)."""
@@ -36,8 +36,9 @@ def gather_packed(packed: bytes, group=None, device=None, dst: int = 0) -> Optio
     sizes = [int(s.item()) for s in sizes]
     cap = max(max(sizes), 1)
     buf = torch.zeros(cap, dtype=torch.uint8, device=dev)
-    if packed:
-        buf[: len(packed)] = torch.frombuffer(bytearray(packed), dtype=torch.uint8).to(dev)
+    if len(packed):
+        src = torch.frombuffer(packed, dtype=torch.uint8)      # bytes / memoryview (e.g. Calls.blob()): no extra host copy
+        buf[: len(packed)].copy_(src, non_blocking=False)
     outs = [torch.zeros(cap, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == dst else None
     dist.gather(buf, outs, dst=dst, group=group)
     if rank != dst:

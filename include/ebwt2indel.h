@@ -142,17 +142,28 @@ void eb_flags_destroy(eb_flags* f);
 
 /* ------------------------------------------------------------------ phase 4
  * One record per cluster that passed the length and frequent-symbol filters
- * (find_variants, ebwt2InDel.cpp:840-934, 941-1005, 1013-1096), in BWT order. */
+ * (find_variants, ebwt2InDel.cpp:840-934, 941-1005, 1013-1096), in BWT order, plus one
+ * record per left-context chain (one chain per frequent symbol: extract_consensus :303-319).
+ * Contexts are packed 2 bits per base (A=0 C=1 G=2 T=3), base e at bits 2*(e&31) of word e>>5:
+ *   left  -- ceil(k_left/32) words per chain, in EXTENSION order: base 0 is the frequent symbol
+ *            itself (the last character of the context), base e the e-th base prepended to it;
+ *   right -- ceil(k_right/32) words per cluster, in text order. */
 typedef struct {
     uint64_t begin, end;           /* cluster [begin,end) in merged coordinates (:1618,1632) */
-    uint16_t n_slots;              /* left-context chains started, side 0 first, A<C<G<T within a side */
+    uint32_t first_chain;          /* index of the cluster's first chain; side 0 first, A<C<G<T within a side */
+    uint16_t n_slots;              /* chains of this cluster (<= EB_MAX_SLOTS) */
     uint16_t right_found;          /* 1 iff some cluster position has LCP >= k_right (:982-985) */
-    uint32_t right_len;            /* chars of right context extracted there (k_right unless TERM was met) */
-    uint8_t  slot_side[EB_MAX_SLOTS];    /* 0/1 (always 0 in one-sample mode) */
-    uint8_t  slot_sym[EB_MAX_SLOTS];     /* 'A','C','G','T' */
-    uint32_t slot_len[EB_MAX_SLOTS];     /* chars obtained; a context is valid iff == k_left (:317) */
-    uint32_t slot_support[EB_MAX_SLOTS]; /* |LF(range,c)| (:308-310) */
+    uint32_t right_len;            /* bases of right context extracted there (k_right unless TERM was met) */
+    uint32_t reserved;
 } eb_cluster;
+
+typedef struct {
+    uint8_t  side;                 /* 0/1 (always 0 in one-sample mode) */
+    uint8_t  sym;                  /* 'A','C','G','T' */
+    uint16_t reserved;
+    uint32_t len;                  /* bases obtained; the context is valid iff == k_left (:317) */
+    uint32_t support;              /* |LF(range,c)| (:308-310) */
+} eb_chain;
 
 typedef struct {
     uint64_t begin, end;       /* scanned range */
@@ -174,11 +185,13 @@ int eb_scan_clusters(eb_index* b1, eb_index* b2, eb_flags* f, uint64_t begin, ui
                      eb_calls** out, eb_scan_stats* stats);
 
 typedef struct {
-    uint64_t count;
+    uint64_t count;                /* clusters */
+    uint64_t n_chains;             /* chains over all clusters */
     int32_t k_left, k_right;
     const eb_cluster* clusters;    /* count records */
-    const uint8_t* left;           /* count * EB_MAX_SLOTS * k_left ASCII bytes, slot-major per cluster */
-    const uint8_t* right;          /* count * k_right ASCII bytes */
+    const eb_chain* chains;        /* n_chains records */
+    const uint64_t* left;          /* n_chains * ceil(k_left/32) words */
+    const uint64_t* right;         /* count * ceil(k_right/32) words */
 } eb_calls_view;
 int eb_calls_get(const eb_calls* c, eb_calls_view* view);
 void eb_calls_free(eb_calls* c);
@@ -186,6 +199,8 @@ void eb_calls_free(eb_calls* c);
 uint64_t eb_calls_packed_size(const eb_calls* c);
 int eb_calls_pack(const eb_calls* c, uint8_t* buf, uint64_t cap);
 int eb_calls_unpack(const uint8_t* buf, uint64_t len, eb_calls** out);
+/* The call set IS one contiguous blob in that same format: zero-copy access (valid until eb_calls_free). */
+int eb_calls_blob(const eb_calls* c, const uint8_t** data, uint64_t* len);
 
 /* ------------------------------------------------------------------ event logic + KisSNP2 writer (host)
  * Replaces to_file (ebwt2InDel.cpp:1254-1330 one sample, :1149-1252 pairs) with distance (:192-240),

@@ -545,7 +545,7 @@ typedef struct {
     sbuf out;
     uint64_t cluster_nr, id_nr, events;
     /* optional record capture (same layout the HIP path emits) */
-    eb_cluster* recs; uint8_t* rec_left; uint8_t* rec_right; uint64_t nrecs, rec_cap;
+    eb_cluster* recs; eb_chain* rec_chains; uint64_t* rec_left; uint64_t* rec_right; uint64_t nrecs, rec_cap, nchains, chain_cap;
     int capture;
     uint64_t n_clusters, clust_size, runs_closed, chains;
     uint64_t hist[201];
@@ -709,22 +709,44 @@ static void write_pairs(orun* r, octx* c0, int n0, octx* c1, int n1, const char*
     r->cluster_nr += (uint64_t)found; /* :1250 */
 }
 
+/* record capture in the product ABI's layout (include/ebwt2indel.h): bases packed 2 bits each */
+static void pack_bases(uint64_t* words, const char* s, int len, int reversed) {
+    for (int e = 0; e < len; ++e) {
+        char ch = s[reversed ? len - 1 - e : e];
+        uint64_t code = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : 3;
+        words[e >> 5] |= code << (2 * (e & 31));
+    }
+}
 static eb_cluster* capture_new(orun* r, uint64_t begin, uint64_t end) {
     if (!r->capture) return NULL;
+    size_t rw = ((size_t)r->p->k_right + 31) / 32;
     if (r->nrecs == r->rec_cap) {
         r->rec_cap = r->rec_cap ? r->rec_cap * 2 : 1024;
         r->recs = (eb_cluster*)realloc(r->recs, r->rec_cap * sizeof(eb_cluster));
-        r->rec_left = (uint8_t*)realloc(r->rec_left, r->rec_cap * EB_MAX_SLOTS * (size_t)r->p->k_left);
-        r->rec_right = (uint8_t*)realloc(r->rec_right, r->rec_cap * (size_t)r->p->k_right);
+        r->rec_right = (uint64_t*)realloc(r->rec_right, r->rec_cap * rw * 8);
     }
     eb_cluster* c = &r->recs[r->nrecs];
     memset(c, 0, sizeof *c);
-    memset(r->rec_left + r->nrecs * EB_MAX_SLOTS * (size_t)r->p->k_left, 0, EB_MAX_SLOTS * (size_t)r->p->k_left);
-    memset(r->rec_right + r->nrecs * (size_t)r->p->k_right, 0, (size_t)r->p->k_right);
+    memset(r->rec_right + r->nrecs * rw, 0, rw * 8);
     c->begin = begin;
     c->end = end;
+    c->first_chain = (uint32_t)r->nchains;
     r->nrecs++;
     return c;
+}
+static void capture_chain(orun* r, int side, uint8_t sym, int len, int support, const char* ctx) {
+    size_t lw = ((size_t)r->p->k_left + 31) / 32;
+    if (r->nchains == r->chain_cap) {
+        r->chain_cap = r->chain_cap ? r->chain_cap * 2 : 2048;
+        r->rec_chains = (eb_chain*)realloc(r->rec_chains, r->chain_cap * sizeof(eb_chain));
+        r->rec_left = (uint64_t*)realloc(r->rec_left, r->chain_cap * lw * 8);
+    }
+    eb_chain* k = &r->rec_chains[r->nchains];
+    memset(k, 0, sizeof *k);
+    k->side = (uint8_t)side; k->sym = sym; k->len = (uint32_t)len; k->support = (uint32_t)support;
+    memset(r->rec_left + r->nchains * lw, 0, lw * 8);
+    if (len == r->p->k_left) pack_bases(r->rec_left + r->nchains * lw, ctx, len, 1); /* extension order = reversed text order */
+    r->nchains++;
 }
 
 /* One cluster.  mode 1: find_variants(bwt,range) ebwt2InDel.cpp:941-1005;
@@ -755,8 +777,7 @@ static void analyse_cluster(orun* r, int mode, uint64_t b, uint64_t e, uint64_t 
         if (nf[0] == 0 || nf[1] == 0 || (q > 0 && nf[0] > q) || (q > 0 && nf[1] > q)) return; /* :870-880, :1042-1052 */
     }
     eb_cluster* rec = capture_new(r, b, e);
-    uint8_t* rleft = rec ? r->rec_left + (r->nrecs - 1) * EB_MAX_SLOTS * (size_t)p->k_left : NULL;
-    uint8_t* rright = rec ? r->rec_right + (r->nrecs - 1) * (size_t)p->k_right : NULL;
+    uint64_t* rright = rec ? r->rec_right + (r->nrecs - 1) * (((size_t)p->k_right + 31) / 32) : NULL;
 
     octx ctx[2][4];
     int nctx[2] = {0, 0};
@@ -771,11 +792,7 @@ static void analyse_cluster(orun* r, int mode, uint64_t b, uint64_t e, uint64_t 
             int support = 0;
             int len = left_context(x, rng, fr[side][k], p->k_left, dst, &support);
             r->chains++;
-            if (rec) {
-                rec->slot_side[slot] = (uint8_t)side; rec->slot_sym[slot] = fr[side][k];
-                rec->slot_len[slot] = (uint32_t)len; rec->slot_support[slot] = (uint32_t)support;
-                if (len == p->k_left) memcpy(rleft + (size_t)slot * (size_t)p->k_left, dst, (size_t)len);
-            }
+            if (rec) capture_chain(r, side, fr[side][k], len, support, dst);
             if (len == p->k_left) { /* :317 */
                 octx* c = &ctx[side][nctx[side]++];
                 c->s = dst; c->len = len; c->support = support;
@@ -796,7 +813,7 @@ static void analyse_cluster(orun* r, int mode, uint64_t b, uint64_t e, uint64_t 
         while (i < e && !bit_get(r->f->thrR, i)) ++i;
         if (i < e) rlen = right_context(r->x1, i, p->k_right, right);
     }
-    if (rec && rlen >= 0) { rec->right_found = 1; rec->right_len = (uint32_t)rlen; memcpy(rright, right, (size_t)rlen); }
+    if (rec && rlen >= 0) { rec->right_found = 1; rec->right_len = (uint32_t)rlen; pack_bases(rright, right, rlen, 0); }
     if (rlen >= 0) {
         if (mode == 1) write_single(r, ctx[0], nctx[0], right, rlen);
         else write_pairs(r, ctx[0], nctx[0], ctx[1], nctx[1], right, rlen);
@@ -887,7 +904,8 @@ void orc_free(void* p) { free(p); }
  * in the product ABI's layout (used to test shard/gather/writer logic without a GPU). */
 char* orc_scan(const oindex* x1, const oindex* x2, oflags* f, const eb_params* p, uint64_t sb, uint64_t se,
                uint64_t* cluster_nr, uint64_t* events, uint64_t* out_len,
-               eb_cluster** recs_out, uint8_t** left_out, uint8_t** right_out, uint64_t* nrecs, uint64_t* stats5) {
+               eb_cluster** recs_out, eb_chain** chains_out, uint64_t** left_out, uint64_t** right_out, uint64_t* nrecs, uint64_t* nchains,
+               uint64_t* stats5) {
     orun r;
     memset(&r, 0, sizeof r);
     r.p = p; r.f = f; r.x1 = x1; r.x2 = x2; r.cluster_nr = cluster_nr ? *cluster_nr : 1; r.id_nr = 1;
@@ -898,7 +916,7 @@ char* orc_scan(const oindex* x1, const oindex* x2, oflags* f, const eb_params* p
     if (cluster_nr) *cluster_nr = r.cluster_nr;
     if (events) *events = r.events;
     if (out_len) *out_len = r.out.len;
-    if (recs_out) { *recs_out = r.recs; *left_out = r.rec_left; *right_out = r.rec_right; *nrecs = r.nrecs; }
+    if (recs_out) { *recs_out = r.recs; *chains_out = r.rec_chains; *left_out = r.rec_left; *right_out = r.rec_right; *nrecs = r.nrecs; *nchains = r.nchains; }
     if (stats5) { stats5[0] = r.runs_closed; stats5[1] = r.n_clusters; stats5[2] = r.clust_size; stats5[3] = r.nrecs; stats5[4] = r.chains; }
     return r.out.p;
 }

@@ -44,9 +44,13 @@ class Params(C.Structure):
 
 class Cluster(C.Structure):
     """Mirror of eb_cluster (include/ebwt2indel.h)."""
-    _fields_ = [("begin", C.c_uint64), ("end", C.c_uint64), ("n_slots", C.c_uint16), ("right_found", C.c_uint16), ("right_len", C.c_uint32),
-                ("slot_side", C.c_uint8 * 8), ("slot_sym", C.c_uint8 * 8), ("slot_len", C.c_uint32 * 8),
-                ("slot_support", C.c_uint32 * 8)]
+    _fields_ = [("begin", C.c_uint64), ("end", C.c_uint64), ("first_chain", C.c_uint32), ("n_slots", C.c_uint16),
+                ("right_found", C.c_uint16), ("right_len", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class Chain(C.Structure):
+    """Mirror of eb_chain (include/ebwt2indel.h)."""
+    _fields_ = [("side", C.c_uint8), ("sym", C.c_uint8), ("reserved", C.c_uint16), ("len", C.c_uint32), ("support", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -95,7 +99,7 @@ class Oracle:
         L.orc_run_mem.argtypes = [vp, u64, vp, u64, vp, u64, C.POINTER(Params), C.POINTER(u64), C.POINTER(Stats)]
         L.orc_scan.restype = vp
         L.orc_scan.argtypes = [vp, vp, vp, C.POINTER(Params), u64, u64, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64),
-                               C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(u64), vp]
+                               C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(u64), C.POINTER(u64), vp]
         L.orc_free.argtypes = [vp]
         L.orc_rank_bench.restype = C.c_double
         L.orc_rank_bench.argtypes = [vp, u64, u64, C.POINTER(u64)]
@@ -223,29 +227,38 @@ class OracleFlags:
         """Phase 4 over clusters starting in [begin,end).  Returns dict(text, cluster_nr, events, stats[, clusters, left, right])."""
         L = self.o.lib
         cn, ev, ln = C.c_uint64(cluster_nr), C.c_uint64(0), C.c_uint64(0)
-        recs, left, right, nrec = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64(0)
+        recs, chains, left, right = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        nrec, nch = C.c_uint64(0), C.c_uint64(0)
         st = np.zeros(5, dtype=np.uint64)
+        cap = (lambda x: C.byref(x)) if capture else (lambda x: None)
         ptr = L.orc_scan(self.idx1.h, self.idx2.h if self.idx2 is not None else None, self.h, C.byref(params), begin, end,
-                         C.byref(cn), C.byref(ev), C.byref(ln),
-                         C.byref(recs) if capture else None, C.byref(left) if capture else None,
-                         C.byref(right) if capture else None, C.byref(nrec) if capture else None, st.ctypes.data)
+                         C.byref(cn), C.byref(ev), C.byref(ln), cap(recs), cap(chains), cap(left), cap(right), cap(nrec), cap(nch),
+                         st.ctypes.data)
         text = C.string_at(ptr, ln.value)
         L.orc_free(ptr)
         out = dict(text=text, cluster_nr=cn.value, events=ev.value,
                    stats=dict(zip(("runs_closed", "clusters", "bases_in_runs", "survivors", "chains"), (int(x) for x in st))))
         if capture:
-            k = nrec.value
-            out["clusters"] = np.frombuffer(C.string_at(recs, k * C.sizeof(Cluster)), dtype=np.uint8).copy() if k else np.zeros(0, np.uint8)
-            out["left"] = np.frombuffer(C.string_at(left, k * 8 * params.k_left), dtype=np.uint8).copy() if k else np.zeros(0, np.uint8)
-            out["right"] = np.frombuffer(C.string_at(right, k * params.k_right), dtype=np.uint8).copy() if k else np.zeros(0, np.uint8)
-            out["count"] = k
-            for p_ in (recs, left, right):
+            k, m = nrec.value, nch.value
+            lw, rw = (params.k_left + 31) // 32, (params.k_right + 31) // 32
+
+            def grab(p_, nbytes):
+                return np.frombuffer(C.string_at(p_, nbytes), dtype=np.uint8).copy() if nbytes and p_.value else np.zeros(0, np.uint8)
+            out["clusters"] = grab(recs, k * C.sizeof(Cluster))
+            out["chains"] = grab(chains, m * C.sizeof(Chain))
+            out["left"] = grab(left, m * lw * 8)
+            out["right"] = grab(right, k * rw * 8)
+            out["count"], out["n_chains"] = k, m
+            for p_ in (recs, chains, left, right):
                 if p_.value:
                     L.orc_free(p_)
         return out
 
 
 def pack_calls(rec: dict, k_left: int, k_right: int) -> bytes:
-    """Byte image understood by eb_calls_unpack (csrc/eb_writer.cpp) from an oracle record capture."""
-    hdr = np.array([0x31534C4C41434245, rec["count"], k_left, k_right], dtype=np.uint64).tobytes()
-    return hdr + rec["clusters"].tobytes() + rec["left"].tobytes() + rec["right"].tobytes()
+    """Byte image understood by eb_calls_unpack (csrc/eb_writer.cpp) from an oracle record capture:
+    64-byte header, clusters, chains (padded to 8 bytes), left words, right words."""
+    hdr = np.array([0x32534C4C41434245, rec["count"], rec["n_chains"], k_left, k_right, 0, 0, 0], dtype=np.uint64).tobytes()
+    chains = rec["chains"].tobytes()
+    chains += b"\0" * ((-len(chains)) % 8)
+    return hdr + rec["clusters"].tobytes() + chains + rec["left"].tobytes() + rec["right"].tobytes()

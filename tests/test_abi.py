@@ -28,7 +28,9 @@ def test_every_declared_symbol_is_exported():
 
 
 def test_struct_layouts_match_header():
-    assert C.sizeof(_lib.Cluster) == 104
+    assert C.sizeof(_lib.Cluster) == 32
+    assert C.sizeof(_lib.Chain) == 12
+    assert C.sizeof(_lib.CallsView) == 56
     assert C.sizeof(_lib.Params) == 36
     assert C.sizeof(_lib.IndexInfo) == 64
 

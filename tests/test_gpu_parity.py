@@ -230,11 +230,13 @@ def test_cluster_records_match_oracle(oracle, case):
         for b, e in zip(cuts[:-1], cuts[1:]):
             want = of.scan(p, b, e, capture=True)
             calls = api.scan_clusters(g1, gf, pp, bwt2=g2, begin=b, end=e)
-            cl, left, right = calls.arrays()
+            cl, chains, left, right = calls.arrays()
             assert len(calls) == want["count"]
             assert np.array_equal(cl, want["clusters"])
+            assert np.array_equal(chains, want["chains"])
             assert np.array_equal(left, want["left"])
             assert np.array_equal(right, want["right"])
+            assert bytes(calls.blob()) == _oracle.pack_calls(want, p.k_left, p.k_right)   # wire image, byte for byte
             st = calls.stats
             assert dict(runs_closed=st.runs_closed, clusters=st.clusters, bases_in_runs=st.bases_in_runs,
                         survivors=st.survivors, chains=st.chains) == want["stats"]
