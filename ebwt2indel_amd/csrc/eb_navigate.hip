@@ -9,6 +9,7 @@
 // the top keeps the footprint of a depth-first walk; a batch of millions keeps HBM busy with
 // independent 64-byte block reads.  Bit writes are atomicOr on 64-bit words and are skipped when
 // the value is 0 (vectors start zeroed), i.e. for records shallower than K / k_right.
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -266,6 +267,8 @@ __global__ void __launch_bounds__(256) k_take_first(const uint64_t* __restrict__
     if (g < groups) out[g] = vec4[g * 4];
 }
 
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 template <typename Item>
 struct Drain {
     // Drains a LIFO work stack in HBM with batched launches.  `launch(in, count, out, out_cap)` must append
@@ -277,26 +280,23 @@ struct Drain {
     uint64_t cap = 0, batch = 0, top = 0;
     uint64_t launches = 0, max_top = 0;
 
-    int init(uint64_t n_bound, uint64_t batch_max) {
-        size_t free_b = 0, total_b = 0;
-        EB_HIP(hipMemGetInfo(&free_b, &total_b));
-        uint64_t budget = (uint64_t)(free_b * 0.6) / sizeof(Item);
+    // The stack and the batch buffer live in one arena shared by both phases (allocating HBM costs ~20 ms per GB,
+    // so the arena is sized from the batch, not from n).  A depth-first drain needs a few batches of room (observed:
+    // < 7 batches at 7.55 G positions); if the arena ever fills, run() shrinks the batch -- in the limit a plain
+    // depth-first walk that needs 4 x depth records -- so capacity never affects results.
+    int init(void* arena, uint64_t arena_bytes, uint64_t n_bound, uint64_t batch_max) {
         batch = batch_max;
         if (batch > n_bound / 2 + 64) batch = n_bound / 2 + 64;
-        cap = n_bound + 4 * batch + 64;             // every pending record is a distinct suffix-tree node/leaf
-        if (cap + batch > budget) {
-            if (budget < 8 * 1024) { eb_set_error("not enough device memory for the traversal stack"); return EB_ERR_NOMEM; }
-            if (batch > budget / 8) batch = budget / 8;
-            cap = budget - batch;
-        }
-        hipError_t e = hipMalloc(&d_stack, cap * sizeof(Item));
-        if (e == hipSuccess) e = hipMalloc(&d_in, batch * sizeof(Item));
-        if (e != hipSuccess) { eb_set_error("traversal stack allocation failed: %s", hipGetErrorString(e)); return EB_ERR_NOMEM; }
+        uint64_t records = arena_bytes / sizeof(Item);
+        if (records < 8 * 1024) { eb_set_error("traversal arena too small"); return EB_ERR_NOMEM; }
+        if (batch > records / 8) batch = records / 8;
+        cap = records - batch;
+        uint64_t need = n_bound + 4 * batch + 64;   // every pending record is a distinct suffix-tree node/leaf
+        if (cap > need) cap = need;
+        d_in = static_cast<Item*>(arena);
+        d_stack = d_in + batch;
+        if (getenv("EB_NAV_TRACE")) fprintf(stderr, "[nav] stack cap=%llu records (%.2f GB) batch=%llu\n", (unsigned long long)cap, cap * sizeof(Item) / 1e9, (unsigned long long)batch);
         return EB_OK;
-    }
-    ~Drain() {
-        if (d_stack) (void)hipFree(d_stack);
-        if (d_in) (void)hipFree(d_in);
     }
     int push_host(const Item& it) {
         EB_HIP(hipMemcpyAsync(d_stack + top, &it, sizeof(Item), hipMemcpyHostToDevice, stream));
@@ -306,6 +306,8 @@ struct Drain {
     }
     template <typename Launch>
     int run(NavCounters* d_cnt, unsigned long long* h_pushed /* pinned */, Launch launch) {
+        const bool trace = getenv("EB_NAV_TRACE") != nullptr;
+        const double t_start = now_s();
         while (top > 0) {
             uint64_t room = cap - top;
             uint64_t B = top < batch ? top : batch;
@@ -325,6 +327,7 @@ struct Drain {
             top = base + *h_pushed;
             if (top > max_top) max_top = top;
             ++launches;
+            if (trace && (launches % 200 == 0 || top == 0)) fprintf(stderr, "[nav] launch %llu: B=%llu pushed=%llu top=%llu max_top=%llu t=%.3fs\n", (unsigned long long)launches, (unsigned long long)B, (unsigned long long)*h_pushed, (unsigned long long)top, (unsigned long long)max_top, now_s() - t_start);
         }
         return EB_OK;
     }
@@ -342,8 +345,6 @@ uint64_t env_u64(const char* name, uint64_t dflt) {
     if (!s || !*s) return dflt;
     return strtoull(s, nullptr, 10);
 }
-
-double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 }  // namespace
 
@@ -412,6 +413,24 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
     NavParams p{K, k_right};
     hipStream_t st = f->stream;
     const uint64_t batch_max = env_u64("EB_NAV_BATCH", 4ull << 20);
+    // one arena for both traversals: (EB_NAV_STACK_BATCHES + 1) batches of the largest record
+    const uint64_t item_bytes = b2 ? sizeof(Node2) : sizeof(Node1);
+    uint64_t arena_batches = env_u64("EB_NAV_STACK_BATCHES", 24) + 1;
+    uint64_t eff_batch = batch_max < n / 2 + 64 ? batch_max : n / 2 + 64;
+    uint64_t arena_records = arena_batches * eff_batch + (n < (1ull << 20) ? n + 4 * eff_batch + 64 : 0);
+    if (arena_records < (1ull << 16)) arena_records = 1ull << 16;
+    uint64_t arena_bytes = arena_records * item_bytes + 65536;
+    {
+        size_t free_b = 0, total_b = 0;
+        EB_HIP(hipMemGetInfo(&free_b, &total_b));
+        if (arena_bytes > free_b / 2) arena_bytes = free_b / 2;
+    }
+    void* d_arena = nullptr;
+    {
+        hipError_t e = hipMalloc(&d_arena, arena_bytes);
+        if (e != hipSuccess) { eb_set_error("traversal arena allocation failed (%llu bytes): %s", (unsigned long long)arena_bytes, hipGetErrorString(e)); return EB_ERR_NOMEM; }
+    }
+    struct Guard3 { void* p; ~Guard3() { (void)hipFree(p); } } guard3{d_arena};
     eb_nav_stats s;
     memset(&s, 0, sizeof s);
     s.n = n;
@@ -422,7 +441,7 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
         { // phase 2 (ebwt2InDel.cpp:577-615); first_leaf = {[0,F_A), 0} (dna_bwt.hpp:313-317)
             Drain<Leaf1> d;
             d.device = b1->device; d.stream = st;
-            if ((rc = d.init(n, batch_max)) != EB_OK) return rc;
+            if ((rc = d.init(d_arena, arena_bytes, n, batch_max)) != EB_OK) return rc;
             if ((rc = d.push_host(Leaf1{0, b1->F[0], 0, 0})) != EB_OK) return rc;
             rc = d.run(d_cnt, h_pushed, [&](Leaf1* in, uint64_t cnt, Leaf1* o, uint64_t ocap) {
                 hipLaunchKernelGGL(k_leaves<1>, dim3(nav_grid(cnt)), dim3(256), 0, st, x1, x2, df, p, in, cnt, o, ocap, d_cnt);
@@ -435,7 +454,7 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
         { // phase 3 (ebwt2InDel.cpp:622-673); root (dna_bwt.hpp:296-308)
             Drain<Node1> d;
             d.device = b1->device; d.stream = st;
-            if ((rc = d.init(n, batch_max)) != EB_OK) return rc;
+            if ((rc = d.init(d_arena, arena_bytes, n, batch_max)) != EB_OK) return rc;
             Node1 root{{0, b1->F[0], b1->F[1], b1->F[2], b1->F[3], b1->n}, 0, 0};
             if ((rc = d.push_host(root)) != EB_OK) return rc;
             rc = d.run(d_cnt, h_pushed, [&](Node1* in, uint64_t cnt, Node1* o, uint64_t ocap) {
@@ -449,7 +468,7 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
         { // phase 2 (ebwt2InDel.cpp:708-756)
             Drain<Leaf2> d;
             d.device = b1->device; d.stream = st;
-            if ((rc = d.init(n, batch_max)) != EB_OK) return rc;
+            if ((rc = d.init(d_arena, arena_bytes, n, batch_max)) != EB_OK) return rc;
             if ((rc = d.push_host(Leaf2{0, b1->F[0], 0, b2->F[0], 0, {0, 0, 0}})) != EB_OK) return rc;
             rc = d.run(d_cnt, h_pushed, [&](Leaf2* in, uint64_t cnt, Leaf2* o, uint64_t ocap) {
                 hipLaunchKernelGGL(k_leaves<2>, dim3(nav_grid(cnt)), dim3(256), 0, st, x1, x2, df, p, in, cnt, o, ocap, d_cnt);
@@ -462,7 +481,7 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
         { // phase 3 (ebwt2InDel.cpp:764-823)
             Drain<Node2> d;
             d.device = b1->device; d.stream = st;
-            if ((rc = d.init(n, batch_max)) != EB_OK) return rc;
+            if ((rc = d.init(d_arena, arena_bytes, n, batch_max)) != EB_OK) return rc;
             Node2 root{{0, b1->F[0], b1->F[1], b1->F[2], b1->F[3], b1->n}, {0, b2->F[0], b2->F[1], b2->F[2], b2->F[3], b2->n}, 0, {0, 0, 0}};
             if ((rc = d.push_host(root)) != EB_OK) return rc;
             rc = d.run(d_cnt, h_pushed, [&](Node2* in, uint64_t cnt, Node2* o, uint64_t ocap) {
