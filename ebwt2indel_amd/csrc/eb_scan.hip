@@ -393,7 +393,12 @@ __global__ void __launch_bounds__(256) k_extend(eb_dev_index x1, eb_dev_index x2
         }
     }
     if (j == 0) {
-        if (have & 31u) out[have >> 5] = word;
+        if (have == (uint32_t)p.k_left) {
+            if (have & 31u) out[have >> 5] = word;
+        } else {
+            // a context shorter than k_left is dropped by the writer (ebwt2InDel.cpp:317): leave it blank
+            for (uint32_t wi = 0; wi < (have >> 5); ++wi) out[wi] = 0;
+        }
         eb_chain k;
         k.side = (uint8_t)side;
         k.sym = (uint8_t)"ACGT"[c];
@@ -504,9 +509,9 @@ extern "C" int eb_scan_clusters(eb_index* b1, eb_index* b2, eb_flags* f, uint64_
     eb_dev_index x1 = b1->dev(), x2 = b2 ? b2->dev() : b1->dev();
     eb_dev_flags df = f->dev();
 
-    hipEvent_t ev[6];
+    hipEvent_t ev[7];
     for (auto& e : ev) EB_HIP(hipEventCreate(&e));
-    struct EvGuard { hipEvent_t* e; ~EvGuard() { for (int i = 0; i < 6; ++i) (void)hipEventDestroy(e[i]); } } evg{ev};
+    struct EvGuard { hipEvent_t* e; ~EvGuard() { for (int i = 0; i < 7; ++i) (void)hipEventDestroy(e[i]); } } evg{ev};
 
     DevMem d_cnt, d_surv, d_sorted, d_keys, d_keys2, d_idx, d_idx2, d_tmp, d_recs, d_crec, d_left, d_right, d_nch, d_choff, d_chains;
     int rc;
@@ -571,13 +576,19 @@ extern "C" int eb_scan_clusters(eb_index* b1, eb_index* b2, eb_flags* f, uint64_
         hipLaunchKernelGGL(k_chain_list, dim3(grid_of(ns)), dim3(256), 0, st, d_sorted.as<Survivor>(), d_choff.as<uint32_t>(), ns, d_chains.as<uint64_t>());
         EB_HIP(hipMemsetAsync(d_left.p, 0, left_bytes, st));
         EB_HIP(hipMemsetAsync(d_right.p, 0, right_bytes, st));
+        // The two context kernels are independent dependent-load chains that leave most of the chip idle on their
+        // own: run k_right on the flags' stream next to k_extend on the index stream.
+        hipStream_t st2 = f->stream;
         EB_HIP(hipEventRecord(ev[2], st));
+        EB_HIP(hipStreamWaitEvent(st2, ev[2], 0));
+        hipLaunchKernelGGL(k_right, dim3(grid_of(ns)), dim3(256), 0, st2, x1, x2, df, p, d_sorted.as<Survivor>(), d_choff.as<uint32_t>(), ns,
+                           d_recs.as<eb_cluster>(), d_right.as<uint64_t>(), rw);
+        EB_HIP(hipEventRecord(ev[6], st2));
         if (n_chains)
             hipLaunchKernelGGL(k_extend, dim3(grid_of(n_chains * 4)), dim3(256), 0, st, x1, x2, p, d_sorted.as<Survivor>(), d_chains.as<uint64_t>(), n_chains,
                                d_crec.as<eb_chain>(), d_left.as<uint64_t>(), lw);
         EB_HIP(hipEventRecord(ev[3], st));
-        hipLaunchKernelGGL(k_right, dim3(grid_of(ns)), dim3(256), 0, st, x1, x2, df, p, d_sorted.as<Survivor>(), d_choff.as<uint32_t>(), ns,
-                           d_recs.as<eb_cluster>(), d_right.as<uint64_t>(), rw);
+        EB_HIP(hipStreamWaitEvent(st, ev[6], 0));
         EB_HIP(hipEventRecord(ev[4], st));
         EB_HIP(hipGetLastError());
         EB_HIP(hipMemcpyAsync(calls->clusters, d_recs.p, rec_bytes, hipMemcpyDeviceToHost, st));
@@ -587,11 +598,8 @@ extern "C" int eb_scan_clusters(eb_index* b1, eb_index* b2, eb_flags* f, uint64_
         EB_HIP(hipEventRecord(ev[5], st));
         EB_HIP(hipStreamSynchronize(st));
         EB_HIP(hipEventElapsedTime(&ms_ext, ev[2], ev[3]));
-        EB_HIP(hipEventElapsedTime(&ms_right, ev[3], ev[4]));
+        EB_HIP(hipEventElapsedTime(&ms_right, ev[2], ev[6])); // runs concurrently with k_extend
         EB_HIP(hipEventElapsedTime(&ms_total, ev[0], ev[5]));
-        // contexts shorter than k_left are dropped by the writer (ebwt2InDel.cpp:317): blank them
-        for (uint64_t k = 0; k < n_chains; ++k)
-            if (calls->chains[k].len != (uint32_t)prm->k_left) memset(calls->left + k * lw, 0, (size_t)lw * 8);
     } else {
         calls = eb_calls_alloc(0, 0, prm->k_left, prm->k_right, false);
         if (!calls) return EB_ERR_NOMEM;

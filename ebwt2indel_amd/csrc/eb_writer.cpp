@@ -263,10 +263,11 @@ eb_calls* eb_calls_alloc(uint64_t count, uint64_t n_chains, int32_t k_left, int3
         c->blob = static_cast<uint8_t*>(malloc(c->size));
     }
     if (!c->blob) { eb_set_error("out of host memory for %llu call records", (unsigned long long)count); delete c; return nullptr; }
-    memset(c->blob, 0, c->size);
+    if (!pinned) memset(c->blob, 0, c->size); // a page-locked blob is overwritten section by section by device copies
     eb_calls_header h = {kMagic, count, n_chains, (uint64_t)(uint32_t)k_left, (uint64_t)(uint32_t)k_right, {0, 0, 0}};
     memcpy(c->blob, &h, sizeof h);
     bind_sections(c);
+    if (pinned && (n_chains * sizeof(eb_chain)) % 8) memset(reinterpret_cast<uint8_t*>(c->chains) + n_chains * sizeof(eb_chain), 0, 8 - (n_chains * sizeof(eb_chain)) % 8);
     return c;
 }
 
