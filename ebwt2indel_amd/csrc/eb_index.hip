@@ -54,6 +54,60 @@ extern "C" void eb_index_bad_symbol(uint8_t* symbol, uint64_t* position) {
     if (position) *position = g_bad_pos;
 }
 
+// ------------------------------------------------------------------ scratch cache
+
+#include <mutex>
+#include <vector>
+
+namespace {
+struct ScratchBlock { int device; void* p; size_t cap; };
+std::mutex g_scratch_mu;
+std::vector<ScratchBlock> g_scratch;
+}  // namespace
+
+void* eb_scratch_get(int device, size_t bytes, size_t* capacity) {
+    if (bytes == 0) bytes = 1;
+    {
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        size_t best = g_scratch.size();
+        for (size_t i = 0; i < g_scratch.size(); ++i)
+            if (g_scratch[i].device == device && g_scratch[i].cap >= bytes && g_scratch[i].cap <= 2 * bytes + (1u << 20) &&
+                (best == g_scratch.size() || g_scratch[i].cap < g_scratch[best].cap))
+                best = i;
+        if (best != g_scratch.size()) {
+            void* p = g_scratch[best].p;
+            *capacity = g_scratch[best].cap;
+            g_scratch.erase(g_scratch.begin() + best);
+            return p;
+        }
+    }
+    size_t cap = bytes + bytes / 8 + 256;
+    void* p = nullptr;
+    if (hipMalloc(&p, cap) != hipSuccess) {
+        eb_scratch_release(device); // give cached blocks back and retry once
+        if (hipMalloc(&p, cap) != hipSuccess) return nullptr;
+    }
+    *capacity = cap;
+    return p;
+}
+
+void eb_scratch_put(int device, void* p, size_t capacity) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (g_scratch.size() < 64) { g_scratch.push_back({device, p, capacity}); return; }
+    (void)hipFree(p);
+}
+
+void eb_scratch_release(int device) {
+    std::vector<ScratchBlock> mine;
+    {
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        for (size_t i = 0; i < g_scratch.size();)
+            if (g_scratch[i].device == device) { mine.push_back(g_scratch[i]); g_scratch.erase(g_scratch.begin() + i); } else ++i;
+    }
+    for (auto& b : mine) (void)hipFree(b.p);
+}
+
 // ------------------------------------------------------------------ kernels
 
 // One thread packs 32 symbols into one chunk (planes only; counter filled later).
@@ -355,6 +409,8 @@ extern "C" void eb_index_destroy(eb_index* h) {
     if (h->d_chunks) (void)hipFree(h->d_chunks);
     if (h->d_super) (void)hipFree(h->d_super);
     if (h->d_sel_dir) (void)hipFree(h->d_sel_dir);
+    for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
+    eb_scratch_release(h->device);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }

@@ -31,6 +31,7 @@ struct eb_index {
     uint64_t F[4] = {0, 0, 0, 0};
     uint8_t term = '#';
     uint64_t device_bytes = 0;
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // timing / ordering events, created on first use
     eb_dev_index dev() const {
         eb_dev_index d;
         d.chunks = d_chunks;
@@ -97,3 +98,9 @@ int eb_scan4_exclusive(uint64_t* d_vec4, uint64_t count, uint64_t* d_tmp, hipStr
 // (re)builds d_da_rank from d_da
 int eb_flags_build_da_rank(eb_flags* f);
 int eb_flags_alloc(uint64_t n, int device, bool with_da, eb_flags** out);
+
+// Caching device-scratch allocator (eb_index.hip).  hipMalloc / hipFree cost 0.1-1 ms each and hipFree synchronises
+// the device, so the per-call temporaries of the phase-4 driver are recycled instead of returned to the runtime.
+void* eb_scratch_get(int device, size_t bytes, size_t* capacity);
+void eb_scratch_put(int device, void* p, size_t capacity);
+void eb_scratch_release(int device); // frees everything cached for the device

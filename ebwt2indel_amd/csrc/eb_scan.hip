@@ -459,13 +459,16 @@ __global__ void __launch_bounds__(256) k_right(eb_dev_index x1, eb_dev_index x2,
     recs[i] = r;
 }
 
-struct DevMem {
+struct DevMem { // per-call temporary from the caching scratch allocator
     void* p = nullptr;
-    ~DevMem() { if (p) (void)hipFree(p); }
+    size_t cap = 0;
+    int device = 0;
+    ~DevMem() { if (p) eb_scratch_put(device, p, cap); }
     int alloc(size_t bytes) {
-        if (p) { (void)hipFree(p); p = nullptr; }
-        hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
-        if (e != hipSuccess) { eb_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return EB_ERR_NOMEM; }
+        if (p && cap >= bytes) return EB_OK;
+        if (p) { eb_scratch_put(device, p, cap); p = nullptr; }
+        p = eb_scratch_get(device, bytes, &cap);
+        if (!p) { eb_set_error("device scratch allocation of %zu bytes failed", bytes); return EB_ERR_NOMEM; }
         return EB_OK;
     }
     template <typename T> T* as() { return static_cast<T*>(p); }
@@ -509,11 +512,13 @@ extern "C" int eb_scan_clusters(eb_index* b1, eb_index* b2, eb_flags* f, uint64_
     eb_dev_index x1 = b1->dev(), x2 = b2 ? b2->dev() : b1->dev();
     eb_dev_flags df = f->dev();
 
-    hipEvent_t ev[7];
-    for (auto& e : ev) EB_HIP(hipEventCreate(&e));
-    struct EvGuard { hipEvent_t* e; ~EvGuard() { for (int i = 0; i < 7; ++i) (void)hipEventDestroy(e[i]); } } evg{ev};
+    hipEvent_t* ev = b1->ev; // cached in the handle
+    for (int i = 0; i < 7; ++i)
+        if (!ev[i]) EB_HIP(hipEventCreate(&ev[i]));
 
     DevMem d_cnt, d_surv, d_sorted, d_keys, d_keys2, d_idx, d_idx2, d_tmp, d_recs, d_crec, d_left, d_right, d_nch, d_choff, d_chains;
+    for (DevMem* m : {&d_cnt, &d_surv, &d_sorted, &d_keys, &d_keys2, &d_idx, &d_idx2, &d_tmp, &d_recs, &d_crec, &d_left, &d_right, &d_nch, &d_choff, &d_chains})
+        m->device = b1->device;
     int rc;
     if ((rc = d_cnt.alloc(sizeof(ScanCounters))) != EB_OK) return rc;
     uint64_t w_lo = begin >> 6, w_hi = (end + 63) >> 6;
