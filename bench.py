@@ -48,11 +48,26 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # EB_BENCH_BACKEND=gloo: rehearsal of the N>1 path on a box with fewer GPUs than ranks (ranks share devices,
+    # records travel as CPU tensors); the real multi-GPU run uses nccl (= RCCL over xGMI), one GPU per rank.
+    backend = os.environ.get("EB_BENCH_BACKEND", "nccl")
+    ndev = max(1, torch.cuda.device_count())
+    if backend == "nccl" and world > ndev:
+        raise SystemExit(f"{world} ranks but {ndev} GPU(s): one GPU per rank is required with nccl")
+    local = local % ndev
+    use_dist = world > 1 or os.environ.get("EB_BENCH_FORCE_DIST") == "1"   # the latter: exercise the collectives with one rank
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local}"))
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group(backend=backend)
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
+    comm_dev = dev if backend == "nccl" else torch.device("cpu")
 
     from ebwt2indel_amd import api, sim
     from ebwt2indel_amd import distributed as ebd
@@ -103,11 +118,11 @@ def main():
 
     def step():
         calls = api.scan_clusters(bwt, flags, p, begin=begin, end=end)     # records land in page-locked host memory
-        parts = ebd.gather_packed(calls.blob(), device=dev) if world > 1 else None
+        parts = ebd.gather_packed(calls.blob(), device=comm_dev) if use_dist else None
         return calls, parts
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -125,8 +140,8 @@ def main():
         tot_ms.append(st.ms_total)
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
@@ -211,7 +226,7 @@ def main():
         }
         line.update(out)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

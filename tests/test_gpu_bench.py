@@ -1,0 +1,49 @@
+"""bench.py end to end on the GPU at reduced size: the JSON contract, and the N=2 path (two ranks sharing the one
+GPU of the test box, records gathered over gloo) producing the same .snp as N=1."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ARGS = ["--reads", "300000", "--steps", "2", "--warmup", "1", "--rank-queries", "1048576"]
+
+
+def _last_json(out: str):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    return json.loads(lines[0])
+
+
+def test_bench_contract_single_gpu():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-sample-reads", "20000"] + ARGS,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["peak"] == 8000.0
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["snp_identical_to_gpu"]
+    assert d["snp_records"] > 1000
+    pytest.single_gpu_sha = d["snp_sha256"]
+
+
+def test_bench_two_ranks_share_the_gpu_same_snp():
+    env = dict(os.environ, EB_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cpu-sample-reads", "0"] + ARGS
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-sample-reads", "0"] + ARGS, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = _last_json(one.stdout)
+    assert d["snp_sha256"] == d1["snp_sha256"] and d["snp_records"] == d1["snp_records"]
+    assert d["clusters_emitted"] == d1["clusters_emitted"]
