@@ -159,6 +159,7 @@ __global__ void __launch_bounds__(256, 4) k_scan(eb_dev_index x1, eb_dev_index x
         }
         return d;
     };
+    uint32_t trips = 0;
     for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         TileData td = load_tile(tile);
         uint64_t t = tile * 256 + threadIdx.x;
@@ -226,10 +227,15 @@ __global__ void __launch_bounds__(256, 4) k_scan(eb_dev_index x1, eb_dev_index x
             if (len < p.min_len) continue;
             ++n_clusters;
             if (p.mode == 1 && in_regs) {
-                uint64_t xc = cur.x & mcur, xp = prv.x & mprv, yc = cur.y & mcur, yp = prv.y & mprv;
-                bool px = (xc == mcur && xp == mprv) || ((xc | xp) == 0);
-                bool py = (yc == mcur && yp == mprv) || ((yc | yp) == 0);
-                if (px && py) continue;
+                // Two letters with >= mcov rows each need >= mcov rows that differ from the majority letter, and a row
+                // that differs does so in code plane x or y: (minority of x) + (minority of y) >= mcov is necessary.
+                // One-letter clusters and clusters with a stray TERM or two fall out here with two popcounts.
+                uint32_t ones_x = (uint32_t)__popcll(cur.x & mcur) + (uint32_t)__popcll(prv.x & mprv);
+                uint32_t ones_y = (uint32_t)__popcll(cur.y & mcur) + (uint32_t)__popcll(prv.y & mprv);
+                uint32_t l32 = (uint32_t)len;
+                uint32_t dx = ones_x < l32 - ones_x ? ones_x : l32 - ones_x;
+                uint32_t dy = ones_y < l32 - ones_y ? ones_y : l32 - ones_y;
+                if (dx + dy < p.mcov) continue;
             }
             todo |= 1ull << bit;
         }
@@ -286,12 +292,12 @@ __global__ void __launch_bounds__(256, 4) k_scan(eb_dev_index x1, eb_dev_index x
                 }
             }
         }
-        // block-uniform flush decision: look at the fill level between two barriers
-        __syncthreads();
-        uint32_t filled = s_count;
-        __syncthreads();
-        if (filled >= (uint32_t)STAGE / 2) {
-            if (threadIdx.x == 0 && filled > (uint32_t)STAGE) s_count = STAGE; // overflowing records went to the list directly
+        // Survivors are rare (~1 per 10^4 positions = ~2 per tile): empty the staging buffer every 16 tiles.  No
+        // barrier in between (they would serialise the tiles of a workgroup); a buffer that fills up earlier sends
+        // the excess straight to the list (above), so the schedule never affects the result.
+        if ((++trips & 15u) == 0) {
+            __syncthreads();
+            if (threadIdx.x == 0 && s_count > (uint32_t)STAGE) s_count = STAGE;
             stage.flush(surv, surv_cap, &cnt->nsurv);
         }
     }
