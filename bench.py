@@ -61,10 +61,26 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local}"))
-        else:
-            dist.init_process_group(backend=backend)
+        # RCCL prints a version banner on stdout when the first communicator comes up; stdout must carry exactly one
+        # JSON line, so fd 1 points at stderr until the communicator exists.
+        sys.stdout.flush()
+        saved_out = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                torch.cuda.set_device(local)
+                dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local}"))
+                dist.barrier()
+                warm = torch.zeros(1, device=f"cuda:{local}")
+                dist.all_reduce(warm)
+                torch.cuda.synchronize()
+            else:
+                dist.init_process_group(backend=backend)
+                dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_out, 1)
+            os.close(saved_out)
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
     comm_dev = dev if backend == "nccl" else torch.device("cpu")

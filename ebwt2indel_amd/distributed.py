@@ -20,30 +20,56 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     return cut(rank), cut(rank + 1)
 
 
-def gather_packed(packed, group=None, device=None, dst: int = 0) -> Optional[List[bytes]]:
-    """Variable-length gather of one byte string per rank to `dst` (None elsewhere).
-    Sizes travel in an all_gather, payloads in a padded gather; tensors live on `device`
-    (a CUDA/HIP device for the nccl backend, CPU for gloo)."""
+_bufs = {}
+
+
+def _buffers(world: int, cap: int, dev, root: bool):
+    """Staging tensors reused across steps: send buffer on `dev`; on the root a [world, cap] receive buffer on `dev`
+    and a page-locked host mirror."""
+    import torch
+
+    key = (world, str(dev), root)
+    cur = _bufs.get(key)
+    if cur is None or cur["cap"] < cap:
+        cur = {"cap": cap, "send": torch.empty(cap, dtype=torch.uint8, device=dev)}
+        if root:
+            cur["recv"] = torch.empty(world * cap, dtype=torch.uint8, device=dev)
+            cur["host"] = torch.empty(world * cap, dtype=torch.uint8, pin_memory=True) if dev.type == "cuda" else cur["recv"]
+        _bufs[key] = cur
+    return cur
+
+
+def gather_packed(packed, group=None, device=None, dst: int = 0) -> Optional[List[memoryview]]:
+    """Variable-length gather of one byte string (bytes / memoryview, e.g. Calls.blob()) per rank to `dst`
+    (None elsewhere).  One small all_gather tells every rank all sizes (so all derive the same padded length), one
+    gather moves the payloads; tensors live on `device` (the rank's GPU for nccl = RCCL over xGMI, CPU for gloo).
+    On the root the result is a list of views into a reused page-locked host buffer: valid until the next call."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    dev = torch.device("cpu") if device is None else device
-    size = torch.tensor([len(packed)], dtype=torch.int64, device=dev)
-    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(sizes, size, group=group)
-    sizes = [int(s.item()) for s in sizes]
-    cap = max(max(sizes), 1)
-    buf = torch.zeros(cap, dtype=torch.uint8, device=dev)
-    if len(packed):
-        src = torch.frombuffer(packed, dtype=torch.uint8)      # bytes / memoryview (e.g. Calls.blob()): no extra host copy
-        buf[: len(packed)].copy_(src, non_blocking=False)
-    outs = [torch.zeros(cap, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == dst else None
-    dist.gather(buf, outs, dst=dst, group=group)
+    dev = torch.device("cpu") if device is None else torch.device(device)
+    n = len(packed)
+    sizes_t = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(sizes_t, torch.tensor([n], dtype=torch.int64, device=dev), group=group)
+    sizes = [int(x) for x in sizes_t.tolist()]
+    cap = (max(max(sizes), 1) + 0xFFFF) & ~0xFFFF          # same on every rank
+    buf = _buffers(world, cap + cap // 4, dev, rank == dst)  # grow with some slack, slice to the agreed length
+    send = buf["send"][:cap]
+    if n:
+        send[:n].copy_(torch.frombuffer(packed, dtype=torch.uint8))
+    outs = [buf["recv"][r * cap:(r + 1) * cap] for r in range(world)] if rank == dst else None
+    dist.gather(send, outs, dst=dst, group=group)
     if rank != dst:
         return None
-    return [bytes(o[:s].cpu().numpy().tobytes()) for o, s in zip(outs, sizes)]
+    host = buf["host"]
+    if dev.type == "cuda":
+        for r in range(world):
+            host[r * cap: r * cap + sizes[r]].copy_(outs[r][: sizes[r]], non_blocking=True)
+        torch.cuda.current_stream(dev).synchronize()
+    base = host.numpy()
+    return [memoryview(base[r * cap: r * cap + sizes[r]]) for r in range(world)]
 
 
 def write_gathered(parts: List[bytes], params, two_samples: bool):
@@ -53,7 +79,7 @@ def write_gathered(parts: List[bytes], params, two_samples: bool):
     text, cluster_nr, events = b"", 1, 0
     total = 0
     for part in parts:
-        calls = api.Calls.unpack(part)
+        calls = api.Calls.unpack(bytes(part) if not isinstance(part, (bytes, bytearray)) else part)
         total += len(calls)
         t, cluster_nr, events = calls.format_snp(params, two_samples, cluster_nr, events)
         text += t
