@@ -52,7 +52,7 @@ __device__ __forceinline__ uint64_t pick4(const uint64_t* F, uint32_t c) { retur
 // (dna_bwt.hpp:358-379; two BWTs: ebwt2InDel.cpp:452-472).  Four lanes per leaf: lane j owns letter j --
 // it loads the j-th chunk of each rank query and builds the child leaf obtained by prepending "ACGT"[j].
 template <int NB>
-__global__ void __launch_bounds__(256) k_leaves(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, NavParams p, const void* in_,
+__global__ void __launch_bounds__(256) k_leaves(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, uint64_t* __restrict__ kr, NavParams p, const void* in_,
                                                uint64_t count, void* out_, uint64_t out_cap, NavCounters* cnt) {
     using Leaf = typename std::conditional<NB == 1, Leaf1, Leaf2>::type;
     constexpr int STAGE = 1024;
@@ -93,8 +93,8 @@ __global__ void __launch_bounds__(256) k_leaves(eb_dev_index x1, eb_dev_index x2
                         uint64_t m = ~0ull;
                         if (w == w0) m &= ~0ull << (lo & 63u);
                         if (w == w1) m &= ~0ull >> (63u - ((hi - 1) & 63u));
-                        if (setK) atomicOr(reinterpret_cast<unsigned long long*>(f.thrK + w), m);
-                        if (setR) atomicOr(reinterpret_cast<unsigned long long*>(f.thrR + w), m);
+                        if (setK) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * w), m);
+                        if (setR) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * w + 1), m);
                     }
                 }
                 if (j == 0) n_lcp += hi - lo;
@@ -122,8 +122,8 @@ __global__ void __launch_bounds__(256) k_leaves(eb_dev_index x1, eb_dev_index x2
                     };
                     uint64_t md = span(s2, e), ml = span(s1 + 1, e);
                     if (md) atomicOr(reinterpret_cast<unsigned long long*>(f.da + w), md);
-                    if (ml && setK) atomicOr(reinterpret_cast<unsigned long long*>(f.thrK + w), ml);
-                    if (ml && setR) atomicOr(reinterpret_cast<unsigned long long*>(f.thrR + w), ml);
+                    if (ml && setK) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * w), ml);
+                    if (ml && setR) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * w + 1), ml);
                 }
                 if (j == 0) {
                     ++n_leaf;
@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(256) k_leaves(eb_dev_index x1, eb_dev_index x2
 // six boundary blocks (one coalesced 64-byte segment per rank query), owns letter j, i.e. the Weiner-link
 // child "ACGT"[j] + W, and writes border j's LCP / minimum bits.
 template <int NB>
-__global__ void __launch_bounds__(256) k_nodes(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, NavParams p, const void* in_,
+__global__ void __launch_bounds__(256) k_nodes(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, uint64_t* __restrict__ kr, NavParams p, const void* in_,
                                               uint64_t count, void* out_, uint64_t out_cap, NavCounters* cnt) {
     using Node = typename std::conditional<NB == 1, Node1, Node2>::type;
     constexpr int STAGE = NB == 1 ? 768 : 512;
@@ -184,8 +184,9 @@ __global__ void __launch_bounds__(256) k_nodes(eb_dev_index x1, eb_dev_index x2,
             uint64_t lo = 0, hi = 0;
             for (int k = 0; k < 4; ++k) if (j == (uint32_t)k) { lo = m[k]; hi = m[k + 1]; }
             if (hi > lo && hi != m[5]) {
-                if ((int64_t)N.depth >= p.K) eb_bit_set_atomic(f.thrK, hi);
-                if ((int64_t)N.depth >= p.k_right) eb_bit_set_atomic(f.thrR, hi);
+                // the two threshold bits of a position sit in adjacent words of the same line (second atomic hits in L2)
+                if ((int64_t)N.depth >= p.K) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * (hi >> 6)), 1ull << (hi & 63u));
+                if ((int64_t)N.depth >= p.k_right) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * (hi >> 6) + 1), 1ull << (hi & 63u));
                 ++n_lcp;
             }
             // a local LCP minimum follows each child A,C,G of size >= 2 that ends before last-1
@@ -247,6 +248,15 @@ __global__ void __launch_bounds__(256) k_nodes(eb_dev_index x1, eb_dev_index x2,
     flush_stat(&cnt->minima, n_min);
     flush_stat(&cnt->ranks, n_rank);
     if constexpr (NB == 2) flush_stat(&cnt->da_values, n_da);
+}
+
+// after navigation: kr[2w], kr[2w+1] -> thrK[w], thrR[w] (streaming, ~1 ms per 7.5 G positions)
+__global__ void __launch_bounds__(256) k_split_kr(const uint4* __restrict__ kr, uint64_t words, uint64_t* __restrict__ thrK, uint64_t* __restrict__ thrR) {
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < words; w += (uint64_t)gridDim.x * blockDim.x) {
+        uint4 v = kr[w];
+        thrK[w] = (uint64_t)v.x | ((uint64_t)v.y << 32);
+        thrR[w] = (uint64_t)v.z | ((uint64_t)v.w << 32);
+    }
 }
 
 // ones in each group of 8 DA words -> exclusive prefix = ones before the group
@@ -431,6 +441,11 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
         if (e != hipSuccess) { eb_set_error("traversal arena allocation failed (%llu bytes): %s", (unsigned long long)arena_bytes, hipGetErrorString(e)); return EB_ERR_NOMEM; }
     }
     struct Guard3 { void* p; ~Guard3() { (void)hipFree(p); } } guard3{d_arena};
+    // threshold bits are collected interleaved (one HBM line per position for both vectors) and split afterwards
+    uint64_t* d_kr = nullptr;
+    EB_HIP(hipMalloc(&d_kr, eb_bit_alloc_words(n) * 16));
+    struct Guard4 { void* p; ~Guard4() { (void)hipFree(p); } } guard4{d_kr};
+    EB_HIP(hipMemsetAsync(d_kr, 0, eb_bit_alloc_words(n) * 16, f->stream));
     eb_nav_stats s;
     memset(&s, 0, sizeof s);
     s.n = n;
@@ -444,7 +459,7 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
             if ((rc = d.init(d_arena, arena_bytes, n, batch_max)) != EB_OK) return rc;
             if ((rc = d.push_host(Leaf1{0, b1->F[0], 0, 0})) != EB_OK) return rc;
             rc = d.run(d_cnt, h_pushed, [&](Leaf1* in, uint64_t cnt, Leaf1* o, uint64_t ocap) {
-                hipLaunchKernelGGL(k_leaves<1>, dim3(nav_grid(cnt)), dim3(256), 0, st, x1, x2, df, p, in, cnt, o, ocap, d_cnt);
+                hipLaunchKernelGGL(k_leaves<1>, dim3(nav_grid(cnt)), dim3(256), 0, st, x1, x2, df, d_kr, p, in, cnt, o, ocap, d_cnt);
             });
             if (rc != EB_OK) return rc;
             launches += d.launches;
@@ -458,7 +473,7 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
             Node1 root{{0, b1->F[0], b1->F[1], b1->F[2], b1->F[3], b1->n}, 0, 0};
             if ((rc = d.push_host(root)) != EB_OK) return rc;
             rc = d.run(d_cnt, h_pushed, [&](Node1* in, uint64_t cnt, Node1* o, uint64_t ocap) {
-                hipLaunchKernelGGL(k_nodes<1>, dim3(nav_grid(cnt)), dim3(256), 0, st, x1, x2, df, p, in, cnt, o, ocap, d_cnt);
+                hipLaunchKernelGGL(k_nodes<1>, dim3(nav_grid(cnt)), dim3(256), 0, st, x1, x2, df, d_kr, p, in, cnt, o, ocap, d_cnt);
             });
             if (rc != EB_OK) return rc;
             launches += d.launches;
@@ -471,7 +486,7 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
             if ((rc = d.init(d_arena, arena_bytes, n, batch_max)) != EB_OK) return rc;
             if ((rc = d.push_host(Leaf2{0, b1->F[0], 0, b2->F[0], 0, {0, 0, 0}})) != EB_OK) return rc;
             rc = d.run(d_cnt, h_pushed, [&](Leaf2* in, uint64_t cnt, Leaf2* o, uint64_t ocap) {
-                hipLaunchKernelGGL(k_leaves<2>, dim3(nav_grid(cnt)), dim3(256), 0, st, x1, x2, df, p, in, cnt, o, ocap, d_cnt);
+                hipLaunchKernelGGL(k_leaves<2>, dim3(nav_grid(cnt)), dim3(256), 0, st, x1, x2, df, d_kr, p, in, cnt, o, ocap, d_cnt);
             });
             if (rc != EB_OK) return rc;
             launches += d.launches;
@@ -485,7 +500,7 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
             Node2 root{{0, b1->F[0], b1->F[1], b1->F[2], b1->F[3], b1->n}, {0, b2->F[0], b2->F[1], b2->F[2], b2->F[3], b2->n}, 0, {0, 0, 0}};
             if ((rc = d.push_host(root)) != EB_OK) return rc;
             rc = d.run(d_cnt, h_pushed, [&](Node2* in, uint64_t cnt, Node2* o, uint64_t ocap) {
-                hipLaunchKernelGGL(k_nodes<2>, dim3(nav_grid(cnt)), dim3(256), 0, st, x1, x2, df, p, in, cnt, o, ocap, d_cnt);
+                hipLaunchKernelGGL(k_nodes<2>, dim3(nav_grid(cnt)), dim3(256), 0, st, x1, x2, df, d_kr, p, in, cnt, o, ocap, d_cnt);
             });
             if (rc != EB_OK) return rc;
             launches += d.launches;
@@ -493,6 +508,9 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
         s.seconds_nodes = now_s() - t1;
         if ((rc = eb_flags_build_da_rank(f)) != EB_OK) return rc;
     }
+    hipLaunchKernelGGL(k_split_kr, dim3(2048), dim3(256), 0, st, reinterpret_cast<const uint4*>(d_kr), f->words, f->d_thrK, f->d_thrR);
+    EB_HIP(hipStreamSynchronize(st));
+    EB_HIP(hipGetLastError());
     NavCounters c;
     EB_HIP(hipMemcpy(&c, d_cnt, sizeof c, hipMemcpyDeviceToHost));
     s.leaves = c.leaves;
