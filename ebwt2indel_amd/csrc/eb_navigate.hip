@@ -34,6 +34,7 @@ struct NavCounters {
 
 struct NavParams {
     int K, k_right;
+    uint8_t* lcpb; // one byte per position (bit 0: LCP >= K, bit 1: LCP >= k_right) or null -> interleaved bit words `kr`
 };
 
 __device__ __forceinline__ uint64_t wave_sum(uint64_t v) {
@@ -87,7 +88,10 @@ __global__ void __launch_bounds__(256) k_leaves(eb_dev_index x1, eb_dev_index x2
                 // LCP slots l+1 .. r-1 of the leaf: the quad splits the touched words
                 uint64_t lo = L.l + 1, hi = L.r;
                 bool setK = (int64_t)L.depth >= p.K, setR = (int64_t)L.depth >= p.k_right;
-                if (setK || setR) {
+                if ((setK || setR) && p.lcpb) {
+                    uint8_t v = (uint8_t)((setK ? 1 : 0) | (setR ? 2 : 0));
+                    for (uint64_t i2 = lo + j; i2 < hi; i2 += 4) p.lcpb[i2] = v; // every position has one writer: plain byte stores
+                } else if (setK || setR) {
                     uint64_t w0 = lo >> 6, w1 = (hi - 1) >> 6;
                     for (uint64_t w = w0 + j; w <= w1; w += 4) {
                         uint64_t m = ~0ull;
@@ -122,8 +126,14 @@ __global__ void __launch_bounds__(256) k_leaves(eb_dev_index x1, eb_dev_index x2
                     };
                     uint64_t md = span(s2, e), ml = span(s1 + 1, e);
                     if (md) atomicOr(reinterpret_cast<unsigned long long*>(f.da + w), md);
-                    if (ml && setK) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * w), ml);
-                    if (ml && setR) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * w + 1), ml);
+                    if (!p.lcpb) {
+                        if (ml && setK) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * w), ml);
+                        if (ml && setR) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * w + 1), ml);
+                    }
+                }
+                if (p.lcpb && (setK || setR)) {
+                    uint8_t v = (uint8_t)((setK ? 1 : 0) | (setR ? 2 : 0));
+                    for (uint64_t i2 = s1 + 1 + j; i2 < e; i2 += 4) p.lcpb[i2] = v;
                 }
                 if (j == 0) {
                     ++n_leaf;
@@ -185,8 +195,15 @@ __global__ void __launch_bounds__(256) k_nodes(eb_dev_index x1, eb_dev_index x2,
             for (int k = 0; k < 4; ++k) if (j == (uint32_t)k) { lo = m[k]; hi = m[k + 1]; }
             if (hi > lo && hi != m[5]) {
                 // the two threshold bits of a position sit in adjacent words of the same line (second atomic hits in L2)
-                if ((int64_t)N.depth >= p.K) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * (hi >> 6)), 1ull << (hi & 63u));
-                if ((int64_t)N.depth >= p.k_right) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * (hi >> 6) + 1), 1ull << (hi & 63u));
+                if (p.lcpb) {
+                    // each LCP slot has exactly one writer (ebwt2InDel.cpp:617,670): a plain byte store replaces two
+                    // memory-side atomics (integer atomics on random lines cost ~2x a store and bypass L2)
+                    uint8_t v = (uint8_t)(((int64_t)N.depth >= p.K ? 1 : 0) | ((int64_t)N.depth >= p.k_right ? 2 : 0));
+                    if (v) p.lcpb[hi] = v;
+                } else {
+                    if ((int64_t)N.depth >= p.K) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * (hi >> 6)), 1ull << (hi & 63u));
+                    if ((int64_t)N.depth >= p.k_right) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * (hi >> 6) + 1), 1ull << (hi & 63u));
+                }
                 ++n_lcp;
             }
             // a local LCP minimum follows each child A,C,G of size >= 2 that ends before last-1
@@ -256,6 +273,26 @@ __global__ void __launch_bounds__(256) k_split_kr(const uint4* __restrict__ kr, 
         uint4 v = kr[w];
         thrK[w] = (uint64_t)v.x | ((uint64_t)v.y << 32);
         thrR[w] = (uint64_t)v.z | ((uint64_t)v.w << 32);
+    }
+}
+
+// after navigation: 64 bytes -> one word of thrK and one of thrR
+__global__ void __launch_bounds__(256) k_pack_lcp(const uint4* __restrict__ lcpb, uint64_t words, uint64_t* __restrict__ thrK, uint64_t* __restrict__ thrR) {
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < words; w += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t k = 0, r = 0;
+        for (int q = 0; q < 4; ++q) {
+            uint4 v = lcpb[w * 4 + q];
+            uint32_t d[4] = {v.x, v.y, v.z, v.w};
+            for (int t = 0; t < 4; ++t)
+                for (int b = 0; b < 4; ++b) {
+                    uint32_t byte = (d[t] >> (8 * b)) & 0xFFu;
+                    uint32_t pos = q * 16 + t * 4 + b;
+                    k |= (uint64_t)(byte & 1u) << pos;
+                    r |= (uint64_t)((byte >> 1) & 1u) << pos;
+                }
+        }
+        thrK[w] = k;
+        thrR[w] = r;
     }
 }
 
@@ -420,7 +457,7 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
 
     eb_dev_index x1 = b1->dev(), x2 = b2 ? b2->dev() : b1->dev();
     eb_dev_flags df = f->dev();
-    NavParams p{K, k_right};
+    NavParams p{K, k_right, nullptr};
     hipStream_t st = f->stream;
     const uint64_t batch_max = env_u64("EB_NAV_BATCH", 4ull << 20);
     // one arena for both traversals: (EB_NAV_STACK_BATCHES + 1) batches of the largest record
@@ -441,11 +478,22 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
         if (e != hipSuccess) { eb_set_error("traversal arena allocation failed (%llu bytes): %s", (unsigned long long)arena_bytes, hipGetErrorString(e)); return EB_ERR_NOMEM; }
     }
     struct Guard3 { void* p; ~Guard3() { (void)hipFree(p); } } guard3{d_arena};
-    // threshold bits are collected interleaved (one HBM line per position for both vectors) and split afterwards
+    // Threshold bits are collected either as one byte per position (plain stores; needs n bytes of spare HBM) or, when
+    // memory is short, as interleaved bit words set with atomics; both are converted to the two bit vectors afterwards.
     uint64_t* d_kr = nullptr;
-    EB_HIP(hipMalloc(&d_kr, eb_bit_alloc_words(n) * 16));
-    struct Guard4 { void* p; ~Guard4() { (void)hipFree(p); } } guard4{d_kr};
-    EB_HIP(hipMemsetAsync(d_kr, 0, eb_bit_alloc_words(n) * 16, f->stream));
+    uint8_t* d_lcpb = nullptr;
+    const size_t lcpb_bytes = eb_bit_alloc_words(n) * 64;
+    {
+        size_t free_b = 0, total_b = 0;
+        EB_HIP(hipMemGetInfo(&free_b, &total_b));
+        bool want_bytes = env_u64("EB_NAV_BYTES", 1) != 0 && lcpb_bytes + (4ull << 30) < free_b;
+        if (want_bytes && hipMalloc(&d_lcpb, lcpb_bytes) != hipSuccess) d_lcpb = nullptr;
+        if (!d_lcpb) EB_HIP(hipMalloc(&d_kr, eb_bit_alloc_words(n) * 16));
+    }
+    struct Guard4 { void* a; void* b; ~Guard4() { if (a) (void)hipFree(a); if (b) (void)hipFree(b); } } guard4{d_kr, d_lcpb};
+    if (d_lcpb) EB_HIP(hipMemsetAsync(d_lcpb, 0, lcpb_bytes, f->stream));
+    else EB_HIP(hipMemsetAsync(d_kr, 0, eb_bit_alloc_words(n) * 16, f->stream));
+    p.lcpb = d_lcpb;
     eb_nav_stats s;
     memset(&s, 0, sizeof s);
     s.n = n;
@@ -508,7 +556,8 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
         s.seconds_nodes = now_s() - t1;
         if ((rc = eb_flags_build_da_rank(f)) != EB_OK) return rc;
     }
-    hipLaunchKernelGGL(k_split_kr, dim3(2048), dim3(256), 0, st, reinterpret_cast<const uint4*>(d_kr), f->words, f->d_thrK, f->d_thrR);
+    if (d_lcpb) hipLaunchKernelGGL(k_pack_lcp, dim3(4096), dim3(256), 0, st, reinterpret_cast<const uint4*>(d_lcpb), f->words, f->d_thrK, f->d_thrR);
+    else hipLaunchKernelGGL(k_split_kr, dim3(2048), dim3(256), 0, st, reinterpret_cast<const uint4*>(d_kr), f->words, f->d_thrK, f->d_thrR);
     EB_HIP(hipStreamSynchronize(st));
     EB_HIP(hipGetLastError());
     NavCounters c;
