@@ -40,8 +40,10 @@ struct alignas(16) Survivor {
     uint64_t pad;
 };
 
+#define EB_NEEDS_HIST 0x80000000u
+
 struct ScanCounters {
-    unsigned long long nsurv, runs_closed, clusters, bases, chains;
+    unsigned long long nsurv, runs_closed, clusters, bases, n_long, dropped;
     unsigned long long hist[201];
 };
 
@@ -112,7 +114,8 @@ __device__ __forceinline__ Planes load_planes(const eb_dev_index& x, uint64_t w)
 // lane's own word or in the previous one (the neighbour lane's registers) gets its symbol histogram from
 // popcounts on registers; only runs longer than that (and the two-BWT mode, whose symbols live in other
 // coordinates) take the memory path.  Persistent grid: counters are flushed once per wave.
-__global__ void __launch_bounds__(256, 4) k_scan(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, ScanParams p, uint64_t w_lo,
+template <int MODE>
+__global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, ScanParams p, uint64_t w_lo,
                                              uint64_t w_count, Survivor* __restrict__ surv, uint64_t surv_cap,
                                              ScanCounters* __restrict__ cnt) {
     __shared__ unsigned int sh_hist[201];
@@ -135,7 +138,7 @@ __global__ void __launch_bounds__(256, 4) k_scan(eb_dev_index x1, eb_dev_index x
         uint64_t fw, da_cur, l0_pfw, l0_da;
         Planes cur, l0_prv;
     };
-    const bool local_syms = p.mode != 2;
+    constexpr bool local_syms = MODE != 2;
     auto load_tile = [&](uint64_t tile) -> TileData {
         TileData d;
         d.fw = d.da_cur = d.l0_pfw = d.l0_da = 0;
@@ -147,13 +150,13 @@ __global__ void __launch_bounds__(256, 4) k_scan(eb_dev_index x1, eb_dev_index x
             d.fw = flag_word(f, w);
             if (local_syms) {
                 if (w < n_bwt_words) d.cur = load_planes(x1, w);
-                if (p.mode == 3) d.da_cur = f.da[w];
+                if (MODE == 3) d.da_cur = f.da[w];
             }
             if (lane == 0 && w > 0) {
                 d.l0_pfw = flag_word(f, w - 1);
                 if (local_syms) {
                     d.l0_prv = load_planes(x1, w - 1);
-                    if (p.mode == 3) d.l0_da = f.da[w - 1];
+                    if (MODE == 3) d.l0_da = f.da[w - 1];
                 }
             }
         }
@@ -226,7 +229,7 @@ __global__ void __launch_bounds__(256, 4) k_scan(eb_dev_index x1, eb_dev_index x
             if (len <= 200 && !(p.dbg & 1u)) atomicAdd(&sh_hist[len], 1u);
             if (len < p.min_len) continue;
             ++n_clusters;
-            if (p.mode == 1 && in_regs) {
+            if (MODE == 1 && in_regs) {
                 // Two letters with >= mcov rows each need >= mcov rows that differ from the majority letter, and a row
                 // that differs does so in code plane x or y: (minority of x) + (minority of y) >= mcov is necessary.
                 // One-letter clusters and clusters with a stray TERM or two fall out here with two popcounts.
@@ -248,37 +251,40 @@ __global__ void __launch_bounds__(256, 4) k_scan(eb_dev_index x1, eb_dev_index x
             bool in_regs = run_at(bit, b, mcur, mprv);
             uint64_t e = base + bit;
             Survivor s;
-            s.b = b; s.e = e; s.b0 = s.e0 = s.b1 = s.e1 = 0; s.fmask0 = s.fmask1 = 0;
+            s.b = b; s.e = e; s.b0 = s.e0 = s.b1 = s.e1 = 0; s.fmask0 = s.fmask1 = 0; s.pad = 0;
             uint32_t c0[4], c1[4];
             bool keep;
-            if (p.mode == 1) {
-                if (in_regs) {
-                    for (int c = 0; c < 4; ++c) c0[c] = (uint32_t)__popcll(cur.letter(c) & mcur) + (uint32_t)__popcll(prv.letter(c) & mprv);
-                } else {
-                    hist_by_rank(x1, b, e, c0);
-                }
+            if constexpr (MODE == 2) {
+                // symbols live in the two BWTs' own coordinates: rank differences on both
+                s.b1 = da_rank(f, b); s.e1 = da_rank(f, e);
+                s.b0 = b - s.b1; s.e0 = e - s.e1;
+                hist_by_rank(x1, s.b0, s.e0, c0);
+                hist_by_rank(x2, s.b1, s.e1, c1);
+                s.fmask0 = frequent_mask(c0, p.mcov);
+                s.fmask1 = frequent_mask(c1, p.mcov);
+                int n0 = __popc(s.fmask0), n1 = __popc(s.fmask1);
+                keep = n0 > 0 && n1 > 0 && !(p.q > 0 && (n0 > p.q || n1 > p.q)); // :870-880
+            } else if (!in_regs) {
+                // run longer than the lane's two words: its histogram needs memory; k_long_runs does that later so
+                // that the streaming kernel carries no rank code (registers) for this rare case
+                s.fmask0 = EB_NEEDS_HIST;
+                keep = true;
+                atomicAdd(&cnt->n_long, 1ull);
+            } else if constexpr (MODE == 1) {
+                for (int c = 0; c < 4; ++c) c0[c] = (uint32_t)__popcll(cur.letter(c) & mcur) + (uint32_t)__popcll(prv.letter(c) & mprv);
                 s.fmask0 = frequent_mask(c0, p.mcov);
                 int nf = __popc(s.fmask0);
                 keep = nf >= 2 && !(p.q > 0 && nf > p.q); // ebwt2InDel.cpp:961-966
             } else {
-                if (p.mode == 2) {
-                    s.b1 = da_rank(f, b); s.e1 = da_rank(f, e);
-                    s.b0 = b - s.b1; s.e0 = e - s.e1;
-                    hist_by_rank(x1, s.b0, s.e0, c0);
-                    hist_by_rank(x2, s.b1, s.e1, c1);
-                } else if (in_regs) {
-                    for (int c = 0; c < 4; ++c) {
-                        uint64_t lc = cur.letter(c) & mcur, lp = prv.letter(c) & mprv;
-                        c1[c] = (uint32_t)__popcll(lc & da_cur) + (uint32_t)__popcll(lp & da_prv);
-                        c0[c] = (uint32_t)__popcll(lc & ~da_cur) + (uint32_t)__popcll(lp & ~da_prv);
-                    }
-                } else {
-                    hist_by_da(x1, f, b, e, c0, c1);
+                for (int c = 0; c < 4; ++c) {
+                    uint64_t lc = cur.letter(c) & mcur, lp = prv.letter(c) & mprv;
+                    c1[c] = (uint32_t)__popcll(lc & da_cur) + (uint32_t)__popcll(lp & da_prv);
+                    c0[c] = (uint32_t)__popcll(lc & ~da_cur) + (uint32_t)__popcll(lp & ~da_prv);
                 }
                 s.fmask0 = frequent_mask(c0, p.mcov);
                 s.fmask1 = frequent_mask(c1, p.mcov);
                 int n0 = __popc(s.fmask0), n1 = __popc(s.fmask1);
-                keep = n0 > 0 && n1 > 0 && !(p.q > 0 && (n0 > p.q || n1 > p.q)); // :870-880, :1042-1052
+                keep = n0 > 0 && n1 > 0 && !(p.q > 0 && (n0 > p.q || n1 > p.q)); // :1042-1052
             }
             if (keep) {
                 // LDS staging (no per-survivor global atomic); a full buffer spills straight to the list
@@ -317,6 +323,36 @@ __global__ void __launch_bounds__(256, 4) k_scan(eb_dev_index x1, eb_dev_index x
     __syncthreads();
     for (int k = threadIdx.x; k < 201; k += blockDim.x)
         if (sh_hist[k]) atomicAdd(&cnt->hist[k], (unsigned long long)sh_hist[k] * (unsigned long long)k); // CLUST_SIZES[len] += len
+}
+
+// Histogram + frequent-symbol filter of the clusters k_scan could not analyse from registers (runs longer than
+// 64..128 positions).  Dropped ones get begin = ~0, which the sort moves behind the real survivors.
+__global__ void __launch_bounds__(256) k_long_runs(eb_dev_index x1, eb_dev_flags f, ScanParams p, Survivor* __restrict__ surv, uint64_t n,
+                                                  unsigned long long* __restrict__ dropped) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Survivor s = surv[i];
+    if (s.fmask0 != EB_NEEDS_HIST) return;
+    uint32_t c0[4], c1[4];
+    bool keep;
+    if (p.mode == 1) {
+        hist_by_rank(x1, s.b, s.e, c0);
+        s.fmask0 = frequent_mask(c0, p.mcov);
+        int nf = __popc(s.fmask0);
+        keep = nf >= 2 && !(p.q > 0 && nf > p.q);
+    } else {
+        hist_by_da(x1, f, s.b, s.e, c0, c1);
+        s.fmask0 = frequent_mask(c0, p.mcov);
+        s.fmask1 = frequent_mask(c1, p.mcov);
+        int n0 = __popc(s.fmask0), n1 = __popc(s.fmask1);
+        keep = n0 > 0 && n1 > 0 && !(p.q > 0 && (n0 > p.q || n1 > p.q));
+    }
+    if (!keep) {
+        s.b = ~0ull;
+        s.fmask0 = s.fmask1 = 0;
+        atomicAdd(dropped, 1ull);
+    }
+    surv[i] = s;
 }
 
 __global__ void __launch_bounds__(256) k_surv_keys(const Survivor* __restrict__ s, uint64_t n, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx) {
@@ -535,9 +571,11 @@ extern "C" int eb_scan_clusters(eb_index* b1, eb_index* b2, eb_flags* f, uint64_
     for (;;) {
         if ((rc = d_surv.alloc(cap * sizeof(Survivor))) != EB_OK) return rc;
         EB_HIP(hipMemsetAsync(d_cnt.p, 0, sizeof(ScanCounters), st));
-        if (w_count)
-            hipLaunchKernelGGL(k_scan, dim3(scan_grid(w_count)), dim3(256), 0, st, x1, x2, df, p, w_lo, w_count, d_surv.as<Survivor>(), cap,
+        if (w_count) {
+            auto kern = p.mode == 1 ? k_scan<1> : (p.mode == 2 ? k_scan<2> : k_scan<3>);
+            hipLaunchKernelGGL(kern, dim3(scan_grid(w_count)), dim3(256), 0, st, x1, x2, df, p, w_lo, w_count, d_surv.as<Survivor>(), cap,
                                d_cnt.as<ScanCounters>());
+        }
         EB_HIP(hipGetLastError());
         EB_HIP(hipMemcpyAsync(&c, d_cnt.p, sizeof c, hipMemcpyDeviceToHost, st));
         EB_HIP(hipStreamSynchronize(st));
@@ -546,28 +584,37 @@ extern "C" int eb_scan_clusters(eb_index* b1, eb_index* b2, eb_flags* f, uint64_
         EB_HIP(hipEventRecord(ev[0], st));
     }
     EB_HIP(hipEventRecord(ev[1], st));
-    const uint64_t ns = c.nsurv;
+    const uint64_t ns_raw = c.nsurv; // entries in the survivor list, long-run candidates included
+    uint64_t ns = ns_raw;
+    if (c.n_long) {
+        hipLaunchKernelGGL(k_long_runs, dim3(grid_of(ns_raw)), dim3(256), 0, st, x1, df, p, d_surv.as<Survivor>(), ns_raw,
+                           &d_cnt.as<ScanCounters>()->dropped);
+        EB_HIP(hipMemcpyAsync(&c, d_cnt.p, sizeof c, hipMemcpyDeviceToHost, st));
+        EB_HIP(hipStreamSynchronize(st));
+        EB_HIP(hipGetLastError());
+        ns = ns_raw - c.dropped; // dropped candidates carry begin = ~0 and sort behind the survivors
+    }
     eb_calls* calls = nullptr;
     struct CallGuard { eb_calls** c; ~CallGuard() { if (*c) eb_calls_free(*c); } } cg{&calls};
     float ms_scan = 0, ms_ext = 0, ms_right = 0, ms_total = 0;
     uint64_t n_chains = 0;
     const uint32_t lw = (uint32_t)((prm->k_left + 31) / 32), rw = (uint32_t)((prm->k_right + 31) / 32);
     if (ns) {
-        if (ns > 0x1FFFFFFFull) { eb_set_error("too many surviving clusters in one call; shard the range"); return EB_ERR_STATE; }
+        if (ns_raw > 0x1FFFFFFFull) { eb_set_error("too many surviving clusters in one call; shard the range"); return EB_ERR_STATE; }
         // BWT order: sort survivors by begin
-        if ((rc = d_keys.alloc(ns * 8)) != EB_OK || (rc = d_keys2.alloc(ns * 8)) != EB_OK || (rc = d_idx.alloc(ns * 4)) != EB_OK ||
-            (rc = d_idx2.alloc(ns * 4)) != EB_OK || (rc = d_sorted.alloc(ns * sizeof(Survivor))) != EB_OK)
+        if ((rc = d_keys.alloc(ns_raw * 8)) != EB_OK || (rc = d_keys2.alloc(ns_raw * 8)) != EB_OK || (rc = d_idx.alloc(ns_raw * 4)) != EB_OK ||
+            (rc = d_idx2.alloc(ns_raw * 4)) != EB_OK || (rc = d_sorted.alloc(ns * sizeof(Survivor))) != EB_OK)
             return rc;
-        hipLaunchKernelGGL(k_surv_keys, dim3(grid_of(ns)), dim3(256), 0, st, d_surv.as<Survivor>(), ns, d_keys.as<uint64_t>(), d_idx.as<uint32_t>());
+        hipLaunchKernelGGL(k_surv_keys, dim3(grid_of(ns_raw)), dim3(256), 0, st, d_surv.as<Survivor>(), ns_raw, d_keys.as<uint64_t>(), d_idx.as<uint32_t>());
         size_t tmp_bytes = 0, scan_bytes = 0;
         EB_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_keys.as<uint64_t>(), d_keys2.as<uint64_t>(), d_idx.as<uint32_t>(),
-                                                  d_idx2.as<uint32_t>(), (int)ns, 0, 64, st));
+                                                  d_idx2.as<uint32_t>(), (int)ns_raw, 0, 64, st));
         if ((rc = d_nch.alloc(ns * 4)) != EB_OK || (rc = d_choff.alloc((ns + 1) * 4)) != EB_OK) return rc;
         EB_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_nch.as<uint32_t>(), d_choff.as<uint32_t>(), (int)ns, st));
         if (scan_bytes > tmp_bytes) tmp_bytes = scan_bytes;
         if ((rc = d_tmp.alloc(tmp_bytes)) != EB_OK) return rc;
         EB_HIP(hipcub::DeviceRadixSort::SortPairs(d_tmp.p, tmp_bytes, d_keys.as<uint64_t>(), d_keys2.as<uint64_t>(), d_idx.as<uint32_t>(),
-                                                  d_idx2.as<uint32_t>(), (int)ns, 0, 64, st));
+                                                  d_idx2.as<uint32_t>(), (int)ns_raw, 0, 64, st));
         hipLaunchKernelGGL(k_surv_gather, dim3(grid_of(ns)), dim3(256), 0, st, d_surv.as<Survivor>(), d_idx2.as<uint32_t>(), ns, d_sorted.as<Survivor>(),
                            d_nch.as<uint32_t>());
         // dense chain list: exclusive scan of the per-cluster chain counts

@@ -333,3 +333,32 @@ def test_properties_at_larger_size():
     assert calls.stats.survivors == len(calls) > 500
     text, cluster_nr, events = calls.format_snp(api.make_params(), False)
     assert events == text.count(b">") and events > 500
+
+
+def test_long_clusters_take_the_memory_path(oracle):
+    """Clusters longer than the 128 positions a lane holds in registers (deep coverage, repeats) go through k_long_runs;
+    results must not depend on which path analysed a cluster (modes 1 and 3)."""
+    rng = _rng(77)
+    unit = sim.BASES[rng.integers(0, 4, size=400)]
+    g = np.concatenate([sim.BASES[rng.integers(0, 4, size=1500)], unit, unit, unit, sim.BASES[rng.integers(0, 4, size=1500)]])
+    h2 = g.copy()
+    for pos in (700, 1700, 2100, 2500, 3300):
+        h2[pos] = ord("A") if g[pos] != ord("A") else ord("C")
+    reads = sim.sample_reads([g, h2], 9000, 100, seed=78)           # ~200x: every locus cluster is > 128 rows
+    e = sim.build_ebwt(reads)
+    p = _oracle.Params.from_args([])
+    want, st = oracle.run(e, params=p)
+    assert api.run_one_dataset(e) == want
+    o1 = oracle.index(e)
+    of = _oracle.OracleFlags(oracle, o1, None, p.K, p.k_right)
+    rec = of.scan(p, 0, len(e), capture=True)
+    cl = np.frombuffer(rec["clusters"].tobytes(), dtype=np.uint64).reshape(-1, 4)
+    assert ((cl[:, 1] - cl[:, 0]) > 130).sum() > 10              # long surviving clusters exist
+    g1 = api.DnaBwt(e)
+    calls = api.scan_clusters(g1, api.Flags.from_host(len(e), *of.export()), api.make_params())
+    assert bytes(calls.blob()) == _oracle.pack_calls(rec, p.k_left, p.k_right)
+    # same reads as two samples through a document array (mode 3)
+    r0, r1 = reads[:4500], reads[4500:]
+    m, da = sim.build_merged_ebwt(r0, r1)
+    want3, _ = oracle.run(m, da=da, params=p)
+    assert api.run_two_datasets_da(m, da) == want3
