@@ -409,7 +409,7 @@ extern "C" void eb_index_destroy(eb_index* h) {
     if (h->d_chunks) (void)hipFree(h->d_chunks);
     if (h->d_super) (void)hipFree(h->d_super);
     if (h->d_sel_dir) (void)hipFree(h->d_sel_dir);
-    for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
+    eb_scan_ctx_destroy(h->scan_ctx);
     eb_scratch_release(h->device);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;

@@ -20,6 +20,14 @@ void eb_set_error(const char* fmt, ...);
         }                                                                                         \
     } while (0)
 
+// streams / events / pinned counters of the pipelined phase-4 driver (eb_scan.hip), created on first use
+struct eb_scan_ctx {
+    hipStream_t prep = nullptr, ext = nullptr, right = nullptr, copy = nullptr;
+    std::vector<hipEvent_t> events;
+    void* h_pinned = nullptr;
+};
+void eb_scan_ctx_destroy(eb_scan_ctx* c);
+
 struct eb_index {
     int device = -1;
     hipStream_t stream = nullptr;
@@ -31,7 +39,7 @@ struct eb_index {
     uint64_t F[4] = {0, 0, 0, 0};
     uint8_t term = '#';
     uint64_t device_bytes = 0;
-    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // timing / ordering events, created on first use
+    eb_scan_ctx* scan_ctx = nullptr;
     eb_dev_index dev() const {
         eb_dev_index d;
         d.chunks = d_chunks;

@@ -454,7 +454,7 @@ __global__ void __launch_bounds__(256) k_extend(eb_dev_index x1, eb_dev_index x2
 // One lane per cluster: record header + right context (extract_dna, ebwt2InDel.cpp:325-342) at the first
 // cluster position whose LCP >= k_right (:979-988; two BWTs :896-912); bases packed 2 bits each in text order.
 __global__ void __launch_bounds__(256) k_right(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, ScanParams p,
-                                              const Survivor* __restrict__ surv, const uint32_t* __restrict__ chain_off, uint64_t nsurv,
+                                              const Survivor* __restrict__ surv, const uint32_t* __restrict__ chain_off, uint32_t chain_base, uint64_t nsurv,
                                               eb_cluster* __restrict__ recs, uint64_t* __restrict__ right, uint32_t right_words) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nsurv) return;
@@ -493,7 +493,7 @@ __global__ void __launch_bounds__(256) k_right(eb_dev_index x1, eb_dev_index x2,
     eb_cluster r;
     r.begin = s.b;
     r.end = s.e;
-    r.first_chain = chain_off[i];
+    r.first_chain = chain_off[i] + chain_base;
     r.n_slots = (uint16_t)(__popc(s.fmask0) + __popc(s.fmask1));
     r.right_found = pos != ~0ull ? 1 : 0;
     r.right_len = len;
@@ -526,6 +526,15 @@ unsigned scan_grid(uint64_t words) {
 
 }  // namespace
 
+void eb_scan_ctx_destroy(eb_scan_ctx* c) {
+    if (!c) return;
+    for (hipStream_t st : {c->prep, c->ext, c->right, c->copy})
+        if (st) (void)hipStreamDestroy(st);
+    for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    delete c;
+}
+
 extern "C" int eb_scan_clusters(eb_index* b1, eb_index* b2, eb_flags* f, uint64_t begin, uint64_t end, const eb_params* prm,
                                 eb_calls** out, eb_scan_stats* stats) {
     if (!b1 || !f || !prm || !out) { eb_set_error("null argument"); return EB_ERR_ARG; }
@@ -538,7 +547,6 @@ extern "C" int eb_scan_clusters(eb_index* b1, eb_index* b2, eb_flags* f, uint64_
     if (end > n) end = n;
     if (begin > end) begin = end;
     EB_HIP(hipSetDevice(b1->device));
-    hipStream_t st = b1->stream;
 
     ScanParams p;
     p.mode = b2 ? 2 : (f->d_da ? 3 : 1);
@@ -554,117 +562,201 @@ extern "C" int eb_scan_clusters(eb_index* b1, eb_index* b2, eb_flags* f, uint64_
     eb_dev_index x1 = b1->dev(), x2 = b2 ? b2->dev() : b1->dev();
     eb_dev_flags df = f->dev();
 
-    hipEvent_t* ev = b1->ev; // cached in the handle
-    for (int i = 0; i < 7; ++i)
-        if (!ev[i]) EB_HIP(hipEventCreate(&ev[i]));
-
-    DevMem d_cnt, d_surv, d_sorted, d_keys, d_keys2, d_idx, d_idx2, d_tmp, d_recs, d_crec, d_left, d_right, d_nch, d_choff, d_chains;
-    for (DevMem* m : {&d_cnt, &d_surv, &d_sorted, &d_keys, &d_keys2, &d_idx, &d_idx2, &d_tmp, &d_recs, &d_crec, &d_left, &d_right, &d_nch, &d_choff, &d_chains})
-        m->device = b1->device;
-    int rc;
-    if ((rc = d_cnt.alloc(sizeof(ScanCounters))) != EB_OK) return rc;
+    // ---- pipelined driver.  The range is cut into sub-shards; their scans are queued back to back on the index
+    // stream while, for each finished scan, survivors are sorted on a preparation stream and the two context kernels
+    // run on two more streams.  The streaming scan of shard k+1 thus overlaps the dependent-load chains of shard k,
+    // and the record download of shard k overlaps the chains of shard k+1.
+    eb_scan_ctx* ctx = b1->scan_ctx;
+    if (!ctx) {
+        ctx = new eb_scan_ctx();
+        b1->scan_ctx = ctx;
+        EB_HIP(hipStreamCreateWithFlags(&ctx->prep, hipStreamNonBlocking));
+        EB_HIP(hipStreamCreateWithFlags(&ctx->ext, hipStreamNonBlocking));
+        EB_HIP(hipStreamCreateWithFlags(&ctx->right, hipStreamNonBlocking));
+        EB_HIP(hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking));
+        EB_HIP(hipHostMalloc(&ctx->h_pinned, 16 * (sizeof(ScanCounters) + 64), hipHostMallocDefault));
+    }
+    const hipStream_t sA = b1->stream, sP = ctx->prep, sB = ctx->ext, sC = ctx->right, sD = ctx->copy;
     uint64_t w_lo = begin >> 6, w_hi = (end + 63) >> 6;
-    uint64_t w_count = w_hi > w_lo ? w_hi - w_lo : 0;
-    uint64_t cap = w_count / 16 + 4096; // survivors are ~1e-4 per position; grown on demand
-    ScanCounters c;
-    EB_HIP(hipEventRecord(ev[0], st));
-    for (;;) {
-        if ((rc = d_surv.alloc(cap * sizeof(Survivor))) != EB_OK) return rc;
-        EB_HIP(hipMemsetAsync(d_cnt.p, 0, sizeof(ScanCounters), st));
-        if (w_count) {
-            auto kern = p.mode == 1 ? k_scan<1> : (p.mode == 2 ? k_scan<2> : k_scan<3>);
-            hipLaunchKernelGGL(kern, dim3(scan_grid(w_count)), dim3(256), 0, st, x1, x2, df, p, w_lo, w_count, d_surv.as<Survivor>(), cap,
-                               d_cnt.as<ScanCounters>());
-        }
-        EB_HIP(hipGetLastError());
-        EB_HIP(hipMemcpyAsync(&c, d_cnt.p, sizeof c, hipMemcpyDeviceToHost, st));
-        EB_HIP(hipStreamSynchronize(st));
-        if (c.nsurv <= cap) break;
-        cap = c.nsurv + 1024; // rare: rerun the scan with room for every survivor
-        EB_HIP(hipEventRecord(ev[0], st));
+    uint64_t w_total = w_hi > w_lo ? w_hi - w_lo : 0;
+    // Measured at 7.55 G positions (EB_SCAN_SUBSHARDS=1/2/4/8): 6.5 / 6.1 / 6.4 / 11.0 ms per call -- the streaming scan and
+    // the random-access chains compete for the same memory request rate, so overlap buys little and slows each kernel.
+    // Default: one shard (kernels run alone, cleanest timings); the knob stays for experiments.
+    int S = 1;
+    if (const char* e = getenv("EB_SCAN_SUBSHARDS")) { int v = atoi(e); if (v >= 1 && v <= 16) S = v; }
+    if ((uint64_t)S > w_total) S = w_total ? (int)w_total : 1;
+
+    struct SubShard {
+        uint64_t begin = 0, end = 0, w_lo = 0, w_count = 0, cap = 0;
+        DevMem cnt, surv, sorted, keys, keys2, idx, idx2, tmp, nch, choff, chains, recs, crec, left, right;
+        uint64_t ns_raw = 0, ns = 0, n_chains = 0, rec_base = 0, chain_base = 0;
+        hipEvent_t e[9]; // scan_t0, scan_t1, scan_done, prep_cnt, prep_done, ext_t0, ext_done, right_t0, right_done
+        ScanCounters* h_cnt = nullptr;
+        uint32_t* h_last = nullptr;
+    };
+    enum { E_SCAN0, E_SCAN1, E_SCAN_DONE, E_PREP_CNT, E_PREP_DONE, E_EXT0, E_EXT_DONE, E_RIGHT0, E_RIGHT_DONE };
+    std::vector<SubShard> sh((size_t)S);
+    const size_t n_events = 2 + 9 * (size_t)S;
+    while (ctx->events.size() < n_events) {
+        hipEvent_t e = nullptr;
+        EB_HIP(hipEventCreate(&e));
+        ctx->events.push_back(e);
     }
-    EB_HIP(hipEventRecord(ev[1], st));
-    const uint64_t ns_raw = c.nsurv; // entries in the survivor list, long-run candidates included
-    uint64_t ns = ns_raw;
-    if (c.n_long) {
-        hipLaunchKernelGGL(k_long_runs, dim3(grid_of(ns_raw)), dim3(256), 0, st, x1, df, p, d_surv.as<Survivor>(), ns_raw,
-                           &d_cnt.as<ScanCounters>()->dropped);
-        EB_HIP(hipMemcpyAsync(&c, d_cnt.p, sizeof c, hipMemcpyDeviceToHost, st));
-        EB_HIP(hipStreamSynchronize(st));
+    hipEvent_t ev_begin = ctx->events[0], ev_end = ctx->events[1];
+    int rc;
+    auto kern = p.mode == 1 ? k_scan<1> : (p.mode == 2 ? k_scan<2> : k_scan<3>);
+    auto launch_scan = [&](SubShard& x) -> int {
+        ScanParams q = p;
+        q.begin = x.begin;
+        q.end = x.end;
+        int r;
+        if ((r = x.surv.alloc(x.cap * sizeof(Survivor))) != EB_OK) return r;
+        EB_HIP(hipMemsetAsync(x.cnt.p, 0, sizeof(ScanCounters), sA));
+        EB_HIP(hipEventRecord(x.e[E_SCAN0], sA));
+        if (x.w_count)
+            hipLaunchKernelGGL(kern, dim3(scan_grid(x.w_count)), dim3(256), 0, sA, x1, x2, df, q, x.w_lo, x.w_count, x.surv.as<Survivor>(), x.cap,
+                               x.cnt.as<ScanCounters>());
+        EB_HIP(hipEventRecord(x.e[E_SCAN1], sA));
+        EB_HIP(hipMemcpyAsync(x.h_cnt, x.cnt.p, sizeof(ScanCounters), hipMemcpyDeviceToHost, sA));
+        EB_HIP(hipEventRecord(x.e[E_SCAN_DONE], sA));
         EB_HIP(hipGetLastError());
-        ns = ns_raw - c.dropped; // dropped candidates carry begin = ~0 and sort behind the survivors
+        return EB_OK;
+    };
+    EB_HIP(hipEventRecord(ev_begin, sA));
+    for (int k = 0; k < S; ++k) {
+        SubShard& x = sh[(size_t)k];
+        for (DevMem* m : {&x.cnt, &x.surv, &x.sorted, &x.keys, &x.keys2, &x.idx, &x.idx2, &x.tmp, &x.nch, &x.choff, &x.chains, &x.recs, &x.crec, &x.left, &x.right})
+            m->device = b1->device;
+        for (int i = 0; i < 9; ++i) x.e[i] = ctx->events[2 + 9 * (size_t)k + (size_t)i];
+        x.h_cnt = reinterpret_cast<ScanCounters*>(static_cast<uint8_t*>(ctx->h_pinned) + (size_t)k * (sizeof(ScanCounters) + 64));
+        x.h_last = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(x.h_cnt) + sizeof(ScanCounters));
+        // cut on flag-word boundaries; clusters belong to the sub-shard that holds their closing position
+        uint64_t wa = w_lo + w_total * (uint64_t)k / (uint64_t)S, wb = w_lo + w_total * (uint64_t)(k + 1) / (uint64_t)S;
+        x.w_lo = wa;
+        x.w_count = wb - wa;
+        x.begin = k == 0 ? begin : wa << 6;
+        x.end = k == S - 1 ? end : wb << 6;
+        x.cap = x.w_count / 16 + 4096; // survivors are ~1e-4 per position; grown on demand
+        if ((rc = x.cnt.alloc(sizeof(ScanCounters))) != EB_OK) return rc;
+        if ((rc = launch_scan(x)) != EB_OK) return rc;
     }
-    eb_calls* calls = nullptr;
-    struct CallGuard { eb_calls** c; ~CallGuard() { if (*c) eb_calls_free(*c); } } cg{&calls};
-    float ms_scan = 0, ms_ext = 0, ms_right = 0, ms_total = 0;
-    uint64_t n_chains = 0;
+
     const uint32_t lw = (uint32_t)((prm->k_left + 31) / 32), rw = (uint32_t)((prm->k_right + 31) / 32);
-    if (ns) {
-        if (ns_raw > 0x1FFFFFFFull) { eb_set_error("too many surviving clusters in one call; shard the range"); return EB_ERR_STATE; }
+    uint64_t rec_total = 0, chain_total = 0;
+    ScanCounters c;
+    memset(&c, 0, sizeof c);
+    for (int k = 0; k < S; ++k) {
+        SubShard& x = sh[(size_t)k];
+        for (;;) {
+            EB_HIP(hipEventSynchronize(x.e[E_SCAN_DONE]));
+            if (x.h_cnt->nsurv <= x.cap) break;
+            x.cap = x.h_cnt->nsurv + 1024; // rare: rerun this sub-shard's scan with room for every survivor
+            if ((rc = launch_scan(x)) != EB_OK) return rc;
+        }
+        ScanCounters hc = *x.h_cnt;
+        x.ns_raw = hc.nsurv;
+        x.ns = x.ns_raw;
+        if (x.ns_raw > 0x1FFFFFFFull) { eb_set_error("too many surviving clusters in one call; shard the range"); return EB_ERR_STATE; }
+        EB_HIP(hipStreamWaitEvent(sP, x.e[E_SCAN_DONE], 0));
+        if (hc.n_long) {
+            hipLaunchKernelGGL(k_long_runs, dim3(grid_of(x.ns_raw)), dim3(256), 0, sP, x1, df, p, x.surv.as<Survivor>(), x.ns_raw,
+                               &x.cnt.as<ScanCounters>()->dropped);
+            EB_HIP(hipMemcpyAsync(x.h_cnt, x.cnt.p, sizeof(ScanCounters), hipMemcpyDeviceToHost, sP));
+            EB_HIP(hipStreamSynchronize(sP));
+            EB_HIP(hipGetLastError());
+            x.ns = x.ns_raw - x.h_cnt->dropped; // dropped candidates carry begin = ~0 and sort behind the survivors
+        }
+        c.runs_closed += hc.runs_closed;
+        c.clusters += hc.clusters;
+        c.bases += hc.bases;
+        for (int i = 0; i < 201; ++i) c.hist[i] += hc.hist[i];
+        x.rec_base = rec_total;
+        x.chain_base = chain_total;
+        if (x.ns == 0) continue;
         // BWT order: sort survivors by begin
-        if ((rc = d_keys.alloc(ns_raw * 8)) != EB_OK || (rc = d_keys2.alloc(ns_raw * 8)) != EB_OK || (rc = d_idx.alloc(ns_raw * 4)) != EB_OK ||
-            (rc = d_idx2.alloc(ns_raw * 4)) != EB_OK || (rc = d_sorted.alloc(ns * sizeof(Survivor))) != EB_OK)
+        if ((rc = x.keys.alloc(x.ns_raw * 8)) != EB_OK || (rc = x.keys2.alloc(x.ns_raw * 8)) != EB_OK || (rc = x.idx.alloc(x.ns_raw * 4)) != EB_OK ||
+            (rc = x.idx2.alloc(x.ns_raw * 4)) != EB_OK || (rc = x.sorted.alloc(x.ns * sizeof(Survivor))) != EB_OK ||
+            (rc = x.nch.alloc(x.ns * 4)) != EB_OK || (rc = x.choff.alloc((x.ns + 1) * 4)) != EB_OK)
             return rc;
-        hipLaunchKernelGGL(k_surv_keys, dim3(grid_of(ns_raw)), dim3(256), 0, st, d_surv.as<Survivor>(), ns_raw, d_keys.as<uint64_t>(), d_idx.as<uint32_t>());
+        hipLaunchKernelGGL(k_surv_keys, dim3(grid_of(x.ns_raw)), dim3(256), 0, sP, x.surv.as<Survivor>(), x.ns_raw, x.keys.as<uint64_t>(), x.idx.as<uint32_t>());
         size_t tmp_bytes = 0, scan_bytes = 0;
-        EB_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_keys.as<uint64_t>(), d_keys2.as<uint64_t>(), d_idx.as<uint32_t>(),
-                                                  d_idx2.as<uint32_t>(), (int)ns_raw, 0, 64, st));
-        if ((rc = d_nch.alloc(ns * 4)) != EB_OK || (rc = d_choff.alloc((ns + 1) * 4)) != EB_OK) return rc;
-        EB_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_nch.as<uint32_t>(), d_choff.as<uint32_t>(), (int)ns, st));
+        EB_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, x.keys.as<uint64_t>(), x.keys2.as<uint64_t>(), x.idx.as<uint32_t>(),
+                                                  x.idx2.as<uint32_t>(), (int)x.ns_raw, 0, 64, sP));
+        EB_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, x.nch.as<uint32_t>(), x.choff.as<uint32_t>(), (int)x.ns, sP));
         if (scan_bytes > tmp_bytes) tmp_bytes = scan_bytes;
-        if ((rc = d_tmp.alloc(tmp_bytes)) != EB_OK) return rc;
-        EB_HIP(hipcub::DeviceRadixSort::SortPairs(d_tmp.p, tmp_bytes, d_keys.as<uint64_t>(), d_keys2.as<uint64_t>(), d_idx.as<uint32_t>(),
-                                                  d_idx2.as<uint32_t>(), (int)ns_raw, 0, 64, st));
-        hipLaunchKernelGGL(k_surv_gather, dim3(grid_of(ns)), dim3(256), 0, st, d_surv.as<Survivor>(), d_idx2.as<uint32_t>(), ns, d_sorted.as<Survivor>(),
-                           d_nch.as<uint32_t>());
+        if ((rc = x.tmp.alloc(tmp_bytes)) != EB_OK) return rc;
+        EB_HIP(hipcub::DeviceRadixSort::SortPairs(x.tmp.p, tmp_bytes, x.keys.as<uint64_t>(), x.keys2.as<uint64_t>(), x.idx.as<uint32_t>(),
+                                                  x.idx2.as<uint32_t>(), (int)x.ns_raw, 0, 64, sP));
+        hipLaunchKernelGGL(k_surv_gather, dim3(grid_of(x.ns)), dim3(256), 0, sP, x.surv.as<Survivor>(), x.idx2.as<uint32_t>(), x.ns, x.sorted.as<Survivor>(),
+                           x.nch.as<uint32_t>());
         // dense chain list: exclusive scan of the per-cluster chain counts
-        EB_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp.p, tmp_bytes, d_nch.as<uint32_t>(), d_choff.as<uint32_t>(), (int)ns, st));
-        uint32_t last_off = 0, last_cnt = 0;
-        EB_HIP(hipMemcpyAsync(&last_off, d_choff.as<uint32_t>() + (ns - 1), 4, hipMemcpyDeviceToHost, st));
-        EB_HIP(hipMemcpyAsync(&last_cnt, d_nch.as<uint32_t>() + (ns - 1), 4, hipMemcpyDeviceToHost, st));
-        EB_HIP(hipStreamSynchronize(st));
-        n_chains = (uint64_t)last_off + last_cnt;
-        calls = eb_calls_alloc(ns, n_chains, prm->k_left, prm->k_right, true); // page-locked blob, sections filled by D2H copies
-        if (!calls) return EB_ERR_NOMEM;
-        const size_t rec_bytes = ns * sizeof(eb_cluster), chain_bytes = n_chains * sizeof(eb_chain);
-        const size_t left_bytes = n_chains * (size_t)lw * 8, right_bytes = ns * (size_t)rw * 8;
-        if ((rc = d_chains.alloc(n_chains * 8)) != EB_OK || (rc = d_recs.alloc(rec_bytes)) != EB_OK || (rc = d_crec.alloc(chain_bytes)) != EB_OK ||
-            (rc = d_left.alloc(left_bytes)) != EB_OK || (rc = d_right.alloc(right_bytes)) != EB_OK)
+        EB_HIP(hipcub::DeviceScan::ExclusiveSum(x.tmp.p, tmp_bytes, x.nch.as<uint32_t>(), x.choff.as<uint32_t>(), (int)x.ns, sP));
+        EB_HIP(hipMemcpyAsync(&x.h_last[0], x.choff.as<uint32_t>() + (x.ns - 1), 4, hipMemcpyDeviceToHost, sP));
+        EB_HIP(hipMemcpyAsync(&x.h_last[1], x.nch.as<uint32_t>() + (x.ns - 1), 4, hipMemcpyDeviceToHost, sP));
+        EB_HIP(hipEventRecord(x.e[E_PREP_CNT], sP));
+        EB_HIP(hipEventSynchronize(x.e[E_PREP_CNT]));
+        x.n_chains = (uint64_t)x.h_last[0] + x.h_last[1];
+        if (chain_total + x.n_chains > 0xFFFFFFFFull) { eb_set_error("too many chains in one call; shard the range"); return EB_ERR_STATE; }
+        const size_t left_bytes = x.n_chains * (size_t)lw * 8, right_bytes = x.ns * (size_t)rw * 8;
+        if ((rc = x.chains.alloc(x.n_chains * 8)) != EB_OK || (rc = x.recs.alloc(x.ns * sizeof(eb_cluster))) != EB_OK ||
+            (rc = x.crec.alloc(x.n_chains * sizeof(eb_chain))) != EB_OK || (rc = x.left.alloc(left_bytes)) != EB_OK || (rc = x.right.alloc(right_bytes)) != EB_OK)
             return rc;
-        hipLaunchKernelGGL(k_chain_list, dim3(grid_of(ns)), dim3(256), 0, st, d_sorted.as<Survivor>(), d_choff.as<uint32_t>(), ns, d_chains.as<uint64_t>());
-        EB_HIP(hipMemsetAsync(d_left.p, 0, left_bytes, st));
-        EB_HIP(hipMemsetAsync(d_right.p, 0, right_bytes, st));
-        // The two context kernels are independent dependent-load chains that leave most of the chip idle on their
-        // own: run k_right on the flags' stream next to k_extend on the index stream.
-        hipStream_t st2 = f->stream;
-        EB_HIP(hipEventRecord(ev[2], st));
-        EB_HIP(hipStreamWaitEvent(st2, ev[2], 0));
-        hipLaunchKernelGGL(k_right, dim3(grid_of(ns)), dim3(256), 0, st2, x1, x2, df, p, d_sorted.as<Survivor>(), d_choff.as<uint32_t>(), ns,
-                           d_recs.as<eb_cluster>(), d_right.as<uint64_t>(), rw);
-        EB_HIP(hipEventRecord(ev[6], st2));
-        if (n_chains)
-            hipLaunchKernelGGL(k_extend, dim3(grid_of(n_chains * 4)), dim3(256), 0, st, x1, x2, p, d_sorted.as<Survivor>(), d_chains.as<uint64_t>(), n_chains,
-                               d_crec.as<eb_chain>(), d_left.as<uint64_t>(), lw);
-        EB_HIP(hipEventRecord(ev[3], st));
-        EB_HIP(hipStreamWaitEvent(st, ev[6], 0));
-        EB_HIP(hipEventRecord(ev[4], st));
+        hipLaunchKernelGGL(k_chain_list, dim3(grid_of(x.ns)), dim3(256), 0, sP, x.sorted.as<Survivor>(), x.choff.as<uint32_t>(), x.ns, x.chains.as<uint64_t>());
+        EB_HIP(hipMemsetAsync(x.left.p, 0, left_bytes, sP));
+        EB_HIP(hipMemsetAsync(x.right.p, 0, right_bytes, sP));
+        EB_HIP(hipEventRecord(x.e[E_PREP_DONE], sP));
+        // the two context kernels are independent dependent-load chains: one stream each
+        EB_HIP(hipStreamWaitEvent(sB, x.e[E_PREP_DONE], 0));
+        EB_HIP(hipEventRecord(x.e[E_EXT0], sB));
+        if (x.n_chains)
+            hipLaunchKernelGGL(k_extend, dim3(grid_of(x.n_chains * 4)), dim3(256), 0, sB, x1, x2, p, x.sorted.as<Survivor>(), x.chains.as<uint64_t>(), x.n_chains,
+                               x.crec.as<eb_chain>(), x.left.as<uint64_t>(), lw);
+        EB_HIP(hipEventRecord(x.e[E_EXT_DONE], sB));
+        EB_HIP(hipStreamWaitEvent(sC, x.e[E_PREP_DONE], 0));
+        EB_HIP(hipEventRecord(x.e[E_RIGHT0], sC));
+        hipLaunchKernelGGL(k_right, dim3(grid_of(x.ns)), dim3(256), 0, sC, x1, x2, df, p, x.sorted.as<Survivor>(), x.choff.as<uint32_t>(), (uint32_t)x.chain_base,
+                           x.ns, x.recs.as<eb_cluster>(), x.right.as<uint64_t>(), rw);
+        EB_HIP(hipEventRecord(x.e[E_RIGHT_DONE], sC));
         EB_HIP(hipGetLastError());
-        EB_HIP(hipMemcpyAsync(calls->clusters, d_recs.p, rec_bytes, hipMemcpyDeviceToHost, st));
-        if (chain_bytes) EB_HIP(hipMemcpyAsync(calls->chains, d_crec.p, chain_bytes, hipMemcpyDeviceToHost, st));
-        if (left_bytes) EB_HIP(hipMemcpyAsync(calls->left, d_left.p, left_bytes, hipMemcpyDeviceToHost, st));
-        EB_HIP(hipMemcpyAsync(calls->right, d_right.p, right_bytes, hipMemcpyDeviceToHost, st));
-        EB_HIP(hipEventRecord(ev[5], st));
-        EB_HIP(hipStreamSynchronize(st));
-        EB_HIP(hipEventElapsedTime(&ms_ext, ev[2], ev[3]));
-        EB_HIP(hipEventElapsedTime(&ms_right, ev[2], ev[6])); // runs concurrently with k_extend
-        EB_HIP(hipEventElapsedTime(&ms_total, ev[0], ev[5]));
-    } else {
-        calls = eb_calls_alloc(0, 0, prm->k_left, prm->k_right, false);
-        if (!calls) return EB_ERR_NOMEM;
-        EB_HIP(hipEventSynchronize(ev[1]));
-        EB_HIP(hipEventElapsedTime(&ms_total, ev[0], ev[1]));
+        rec_total += x.ns;
+        chain_total += x.n_chains;
     }
-    EB_HIP(hipEventElapsedTime(&ms_scan, ev[0], ev[1]));
+    const uint64_t ns = rec_total, n_chains = chain_total;
+
+    // ---- one blob for the whole call; each sub-shard's sections are copied as soon as its kernels are done
+    eb_calls* calls = eb_calls_alloc(ns, n_chains, prm->k_left, prm->k_right, ns != 0);
+    if (!calls) return EB_ERR_NOMEM;
+    struct CallGuard { eb_calls** c; ~CallGuard() { if (*c) eb_calls_free(*c); } } cg{&calls};
+    EB_HIP(hipStreamWaitEvent(sD, sh[(size_t)S - 1].e[E_SCAN_DONE], 0));
+    for (int k = 0; k < S; ++k) {
+        SubShard& x = sh[(size_t)k];
+        if (x.ns == 0) continue;
+        EB_HIP(hipStreamWaitEvent(sD, x.e[E_EXT_DONE], 0));
+        EB_HIP(hipStreamWaitEvent(sD, x.e[E_RIGHT_DONE], 0));
+        EB_HIP(hipMemcpyAsync(calls->clusters + x.rec_base, x.recs.p, x.ns * sizeof(eb_cluster), hipMemcpyDeviceToHost, sD));
+        EB_HIP(hipMemcpyAsync(calls->right + x.rec_base * rw, x.right.p, x.ns * (size_t)rw * 8, hipMemcpyDeviceToHost, sD));
+        if (x.n_chains) {
+            EB_HIP(hipMemcpyAsync(calls->chains + x.chain_base, x.crec.p, x.n_chains * sizeof(eb_chain), hipMemcpyDeviceToHost, sD));
+            EB_HIP(hipMemcpyAsync(calls->left + x.chain_base * lw, x.left.p, x.n_chains * (size_t)lw * 8, hipMemcpyDeviceToHost, sD));
+        }
+    }
+    EB_HIP(hipEventRecord(ev_end, sD));
+    EB_HIP(hipEventSynchronize(ev_end));
+    EB_HIP(hipStreamSynchronize(sB));
+    EB_HIP(hipStreamSynchronize(sC));
+    float ms_scan = 0, ms_ext = 0, ms_right = 0, ms_total = 0;
+    EB_HIP(hipEventElapsedTime(&ms_total, ev_begin, ev_end));
+    for (int k = 0; k < S; ++k) {
+        SubShard& x = sh[(size_t)k];
+        float t = 0;
+        EB_HIP(hipEventElapsedTime(&t, x.e[E_SCAN0], x.e[E_SCAN1]));
+        ms_scan += t;
+        if (x.ns == 0) continue;
+        EB_HIP(hipEventElapsedTime(&t, x.e[E_EXT0], x.e[E_EXT_DONE]));
+        ms_ext += t;
+        EB_HIP(hipEventElapsedTime(&t, x.e[E_RIGHT0], x.e[E_RIGHT_DONE]));
+        ms_right += t;
+    }
     if (stats) {
         memset(stats, 0, sizeof *stats);
         stats->begin = begin;
@@ -679,6 +771,7 @@ extern "C" int eb_scan_clusters(eb_index* b1, eb_index* b2, eb_flags* f, uint64_
         stats->ms_extend = ms_ext;
         stats->ms_right = ms_right;
         stats->ms_total = ms_total;
+        stats->scan_launches = (uint32_t)S;
     }
     *out = calls;
     calls = nullptr; // ownership passed on

@@ -173,7 +173,10 @@ typedef struct {
     uint64_t survivors;        /* records emitted */
     uint64_t chains;           /* left-context chains extended */
     uint64_t hist[201];        /* CLUST_SIZES (:1604,1627) */
-    float    ms_scan, ms_extend, ms_right, ms_total; /* HIP-event times on the handle's stream */
+    float    ms_scan, ms_extend, ms_right; /* HIP-event kernel times summed over the sub-shard launches */
+    float    ms_total;                     /* first scan launch .. last record byte in host memory */
+    uint32_t scan_launches;                /* k_scan launches (sub-shards) behind ms_scan */
+    uint32_t reserved;
 } eb_scan_stats;
 
 /* Replaces the phase-4 loops run_one_dataset (:1609-1655), run_two_datasets (:1395-1445)
