@@ -228,6 +228,18 @@ def main():
                "e2e_positions_per_s": round(len(se) / (st.t_nav + st.t_scan), 1),
                "rank_queries_per_s": round(20_000_000 / rt, 1), "snp_identical_to_gpu": True}
 
+    # HBM traffic of the dominant kernel from the PMC passes committed under profiles/ (FETCH_SIZE / WRITE_SIZE cannot be
+    # collected from inside this process); used only when it was measured on the same launch size.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+            pmc = json.load(fh)
+        ks = pmc["kernels"]["k_scan<1>"]
+        if abs(pmc["workload_positions"] - positions_per_launch) <= 0.01 * positions_per_launch and scan_avg_ms > 0:
+            traffic = round(ks["hbm_bytes_per_launch_corrected"] / (scan_avg_ms * 1e-3) / 1e9, 2)   # GB/s, same unit as `achieved`
+    except Exception:
+        traffic = None
+
     if rank == 0:
         line = {
             "metric": "BWT positions scanned/sec (whole node)", "value": round(value, 1), "unit": "positions/s",
@@ -236,7 +248,7 @@ def main():
             "config": {"workload": workload, "mode": 1, "options": "-L31 -R30 -k16 -g10 -v2 -m3 -c20 -q0",
                        "parallelism": f"scan range split over {world} GPU(s), BWT+flags replicated, gather of cluster records to rank 0"},
             "roofline": {"bound": "hbm", "achieved": round(scan_gbs, 2), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(scan_gbs / 8000.0, 5), "traffic": None, "kernel": "k_scan",
+                         "frac": round(scan_gbs / 8000.0, 5), "traffic": traffic, "kernel": "k_scan",
                          "avg_launch_ms": round(scan_avg_ms, 4), "launches_per_step": scan_launches, "positions_per_launch": int(positions_per_launch),
                          "algorithmic_bytes_per_position": 0.75},
             "rank_roofline": rank_info,
