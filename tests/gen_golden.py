@@ -191,9 +191,20 @@ def main():
     tiny = sim.build_ebwt([b"ACGTACGGTCA", b"TTGACCA"]).tobytes()
     add_case("m1_tiny_nocluster", 1, {"bwt1": ("tiny.ebwt", tiny)}, [])
 
+    # ---- filter_snp (post-filter of the one-sample pipeline): reference outputs on two of the .snp files above
+    filt = []
+    FREF = os.path.join(ROOT, "oracle", "_ref", "filter_snp_ref")
+    for src, fargs in (("m1_default", ["5"]), ("m1_default", ["3", "8"]), ("m3_het_default", ["4", "12"]), ("m1_edge_default", ["1"])):
+        snp_path = os.path.join(tmp, src + ".snp")
+        out = subprocess.run([FREF, snp_path] + fargs, capture_output=True).stdout
+        name = f"filter_{src}_{'_'.join(fargs)}.txt"
+        put(name, out)
+        filt.append({"snp": src + ".snp", "args": fargs, "out": name, "records": out.count(b">")})
+        print(f"{name:40s} records={out.count(b'>')}")
+
     with open(os.path.join(GOLD, "manifest.json"), "w") as f:
         json.dump({"generator": "tests/gen_golden.py", "reference": "oracle/_ref/ebwt2InDel_ref (upstream Release flags)",
-                   "cases": cases}, f, indent=1)
+                   "cases": cases, "filter_snp": filt}, f, indent=1)
     total = sum(os.path.getsize(os.path.join(GOLD, x)) for x in os.listdir(GOLD))
     print(f"{len(cases)} cases, {total / 1e6:.2f} MB in {GOLD}")
 
