@@ -61,7 +61,8 @@ ABI_SYMBOLS = [
     "eb_index_create", "eb_index_create_from_file", "eb_index_create_from_device", "eb_index_destroy", "eb_index_bad_symbol",
     "eb_index_info", "eb_rank4_batch", "eb_access_batch", "eb_lf_range_batch", "eb_lf_range_sym_batch", "eb_fl_batch",
     "eb_lf_node_batch", "eb_rank4_batch_device", "eb_flags_build", "eb_flags_set_da", "eb_flags_words", "eb_flags_has_da",
-    "eb_flags_export", "eb_flags_import", "eb_flags_destroy", "eb_scan_clusters", "eb_calls_get", "eb_calls_free",
+    "eb_flags_export", "eb_flags_import", "eb_flags_destroy", "eb_scan_clusters", "eb_scan_clusters_begin", "eb_scan_clusters_end",
+    "eb_scan_clusters_cancel", "eb_calls_get", "eb_calls_free",
     "eb_calls_packed_size", "eb_calls_pack", "eb_calls_unpack", "eb_calls_blob", "eb_write_snp", "eb_format_snp", "eb_free",
 ]
 
@@ -82,6 +83,8 @@ def load():
     # If torch is imported AFTER this library has pulled in the system runtime, the process ends up with two
     # runtimes and the second finds no GPU.  So when torch is present, let it load its runtime first; the
     # library then binds to that one.  EB_NO_TORCH=1 skips this (pure C / CLI use binds to /opt/rocm).
+    # five streams per handle: give the HIP runtime enough hardware queues (only effective before HIP initialises)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     if os.environ.get("EB_NO_TORCH", "0") != "1":
         try:
             import torch  # noqa: F401
@@ -115,6 +118,10 @@ def load():
     L.eb_flags_destroy.argtypes = [vp]
     L.eb_flags_destroy.restype = None
     L.eb_scan_clusters.argtypes = [vp, vp, vp, u64, u64, P(Params), P(vp), P(ScanStats)]
+    L.eb_scan_clusters_begin.argtypes = [vp, vp, vp, u64, u64, P(Params), P(vp)]
+    L.eb_scan_clusters_end.argtypes = [vp, P(vp), P(ScanStats)]
+    L.eb_scan_clusters_cancel.argtypes = [vp]
+    L.eb_scan_clusters_cancel.restype = None
     L.eb_calls_get.argtypes = [vp, P(CallsView)]
     L.eb_calls_free.argtypes = [vp]
     L.eb_calls_free.restype = None

@@ -290,6 +290,37 @@ def scan_clusters(bwt1: DnaBwt, flags: Flags, params: Params, bwt2: Optional[Dna
     return Calls(h, st)
 
 
+class ScanJob:
+    """A phase-4 call in flight (eb_scan_clusters_begin); finish() waits for it and returns the Calls."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def finish(self) -> Calls:
+        h, self._h = self._h, None
+        out = C.c_void_p()
+        st = _lib.ScanStats()
+        _check(lib().eb_scan_clusters_end(h, C.byref(out), C.byref(st)))
+        return Calls(out, st)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().eb_scan_clusters_cancel(self._h)
+        except Exception:
+            pass
+
+
+def scan_clusters_begin(bwt1: DnaBwt, flags: Flags, params: Params, bwt2: Optional[DnaBwt] = None, begin: int = 0,
+                        end: Optional[int] = None) -> ScanJob:
+    """Enqueue phase 4 and return at once; the record download overlaps whatever the caller launches next."""
+    n = bwt1.n + (bwt2.n if bwt2 is not None else 0)
+    h = C.c_void_p()
+    _check(lib().eb_scan_clusters_begin(bwt1._h, bwt2._h if bwt2 is not None else None, flags._h, begin, n if end is None else end,
+                                        C.byref(params), C.byref(h)))
+    return ScanJob(h)
+
+
 # ---- the three entry points of the reference's main() (ebwt2InDel.cpp:1805-1821), returning .snp bytes
 
 def navigate_one_bwt(bwt: DnaBwt, params: Params) -> Flags:

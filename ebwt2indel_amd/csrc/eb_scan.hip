@@ -526,6 +526,30 @@ unsigned scan_grid(uint64_t words) {
 
 }  // namespace
 
+namespace {
+struct SubShard {
+    uint64_t begin = 0, end = 0, w_lo = 0, w_count = 0, cap = 0;
+    DevMem cnt, surv, sorted, keys, keys2, idx, idx2, tmp, nch, choff, chains, recs, crec, left, right;
+    uint64_t ns_raw = 0, ns = 0, n_chains = 0, rec_base = 0, chain_base = 0;
+    hipEvent_t e[9]; // scan_t0, scan_t1, scan_done, prep_cnt, prep_done, ext_t0, ext_done, right_t0, right_done
+    ScanCounters* h_cnt = nullptr;
+    uint32_t* h_last = nullptr;
+};
+enum { E_SCAN0, E_SCAN1, E_SCAN_DONE, E_PREP_CNT, E_PREP_DONE, E_EXT0, E_EXT_DONE, E_RIGHT0, E_RIGHT_DONE };
+}  // namespace
+
+// A phase-4 call in flight: everything is enqueued, the record copies to host may still be running.
+struct eb_scan_job {
+    eb_index* b1 = nullptr;
+    std::vector<SubShard> sh;
+    std::vector<hipEvent_t> events; // owned until the job ends, then returned to the context's pool
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    eb_calls* calls = nullptr;
+    ScanCounters c;
+    uint64_t begin = 0, end = 0, ns = 0, n_chains = 0;
+    int S = 1;
+};
+
 void eb_scan_ctx_destroy(eb_scan_ctx* c) {
     if (!c) return;
     for (hipStream_t st : {c->prep, c->ext, c->right, c->copy})
@@ -535,10 +559,10 @@ void eb_scan_ctx_destroy(eb_scan_ctx* c) {
     delete c;
 }
 
-extern "C" int eb_scan_clusters(eb_index* b1, eb_index* b2, eb_flags* f, uint64_t begin, uint64_t end, const eb_params* prm,
-                                eb_calls** out, eb_scan_stats* stats) {
-    if (!b1 || !f || !prm || !out) { eb_set_error("null argument"); return EB_ERR_ARG; }
-    *out = nullptr;
+extern "C" int eb_scan_clusters_begin(eb_index* b1, eb_index* b2, eb_flags* f, uint64_t begin, uint64_t end, const eb_params* prm,
+                                      eb_scan_job** out_job) {
+    if (!b1 || !f || !prm || !out_job) { eb_set_error("null argument"); return EB_ERR_ARG; }
+    *out_job = nullptr;
     const uint64_t n = b1->n + (b2 ? b2->n : 0);
     if (f->n != n) { eb_set_error("flag vectors cover %llu positions, BWT has %llu", (unsigned long long)f->n, (unsigned long long)n); return EB_ERR_ARG; }
     if (b1->device != f->device || (b2 && b2->device != b1->device)) { eb_set_error("handles live on different devices"); return EB_ERR_ARG; }
@@ -586,23 +610,34 @@ extern "C" int eb_scan_clusters(eb_index* b1, eb_index* b2, eb_flags* f, uint64_
     if (const char* e = getenv("EB_SCAN_SUBSHARDS")) { int v = atoi(e); if (v >= 1 && v <= 16) S = v; }
     if ((uint64_t)S > w_total) S = w_total ? (int)w_total : 1;
 
-    struct SubShard {
-        uint64_t begin = 0, end = 0, w_lo = 0, w_count = 0, cap = 0;
-        DevMem cnt, surv, sorted, keys, keys2, idx, idx2, tmp, nch, choff, chains, recs, crec, left, right;
-        uint64_t ns_raw = 0, ns = 0, n_chains = 0, rec_base = 0, chain_base = 0;
-        hipEvent_t e[9]; // scan_t0, scan_t1, scan_done, prep_cnt, prep_done, ext_t0, ext_done, right_t0, right_done
-        ScanCounters* h_cnt = nullptr;
-        uint32_t* h_last = nullptr;
-    };
-    enum { E_SCAN0, E_SCAN1, E_SCAN_DONE, E_PREP_CNT, E_PREP_DONE, E_EXT0, E_EXT_DONE, E_RIGHT0, E_RIGHT_DONE };
-    std::vector<SubShard> sh((size_t)S);
+    eb_scan_job* job = new eb_scan_job();
+    struct JobGuard {
+        eb_scan_job** j;
+        eb_scan_ctx* ctx;
+        ~JobGuard() {
+            if (!*j) return;
+            (void)hipDeviceSynchronize(); // nothing may still use the job's buffers
+            for (hipEvent_t e : (*j)->events) ctx->events.push_back(e);
+            if ((*j)->calls) eb_calls_free((*j)->calls);
+            delete *j;
+        }
+    } job_guard{&job, ctx};
+    job->b1 = b1;
+    job->S = S;
+    job->begin = begin;
+    job->end = end;
+    job->sh.resize((size_t)S);
+    std::vector<SubShard>& sh = job->sh;
     const size_t n_events = 2 + 9 * (size_t)S;
-    while (ctx->events.size() < n_events) {
+    for (size_t i = 0; i < n_events; ++i) { // events are recycled through the context's pool
         hipEvent_t e = nullptr;
-        EB_HIP(hipEventCreate(&e));
-        ctx->events.push_back(e);
+        if (!ctx->events.empty()) { e = ctx->events.back(); ctx->events.pop_back(); }
+        else EB_HIP(hipEventCreate(&e));
+        job->events.push_back(e);
     }
-    hipEvent_t ev_begin = ctx->events[0], ev_end = ctx->events[1];
+    hipEvent_t ev_begin = job->events[0], ev_end = job->events[1];
+    job->ev_begin = ev_begin;
+    job->ev_end = ev_end;
     int rc;
     auto kern = p.mode == 1 ? k_scan<1> : (p.mode == 2 ? k_scan<2> : k_scan<3>);
     auto launch_scan = [&](SubShard& x) -> int {
@@ -627,7 +662,7 @@ extern "C" int eb_scan_clusters(eb_index* b1, eb_index* b2, eb_flags* f, uint64_
         SubShard& x = sh[(size_t)k];
         for (DevMem* m : {&x.cnt, &x.surv, &x.sorted, &x.keys, &x.keys2, &x.idx, &x.idx2, &x.tmp, &x.nch, &x.choff, &x.chains, &x.recs, &x.crec, &x.left, &x.right})
             m->device = b1->device;
-        for (int i = 0; i < 9; ++i) x.e[i] = ctx->events[2 + 9 * (size_t)k + (size_t)i];
+        for (int i = 0; i < 9; ++i) x.e[i] = job->events[2 + 9 * (size_t)k + (size_t)i];
         x.h_cnt = reinterpret_cast<ScanCounters*>(static_cast<uint8_t*>(ctx->h_pinned) + (size_t)k * (sizeof(ScanCounters) + 64));
         x.h_last = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(x.h_cnt) + sizeof(ScanCounters));
         // cut on flag-word boundaries; clusters belong to the sub-shard that holds their closing position
@@ -741,39 +776,80 @@ extern "C" int eb_scan_clusters(eb_index* b1, eb_index* b2, eb_flags* f, uint64_
         }
     }
     EB_HIP(hipEventRecord(ev_end, sD));
-    EB_HIP(hipEventSynchronize(ev_end));
-    EB_HIP(hipStreamSynchronize(sB));
-    EB_HIP(hipStreamSynchronize(sC));
+    job->calls = calls;
+    calls = nullptr; // owned by the job from here on
+    job->c = c;
+    job->ns = ns;
+    job->n_chains = n_chains;
+    *out_job = job;
+    job = nullptr;
+    return EB_OK;
+}
+
+extern "C" int eb_scan_clusters_end(eb_scan_job* job, eb_calls** out, eb_scan_stats* stats) {
+    if (!job || !out) { eb_set_error("null argument"); return EB_ERR_ARG; }
+    *out = nullptr;
+    eb_index* b1 = job->b1;
+    eb_scan_ctx* ctx = b1->scan_ctx;
+    EB_HIP(hipSetDevice(b1->device));
+    hipError_t werr = hipEventSynchronize(job->ev_end);
+    if (werr == hipSuccess) werr = hipStreamSynchronize(ctx->ext);
+    if (werr == hipSuccess) werr = hipStreamSynchronize(ctx->right);
     float ms_scan = 0, ms_ext = 0, ms_right = 0, ms_total = 0;
-    EB_HIP(hipEventElapsedTime(&ms_total, ev_begin, ev_end));
-    for (int k = 0; k < S; ++k) {
-        SubShard& x = sh[(size_t)k];
-        float t = 0;
-        EB_HIP(hipEventElapsedTime(&t, x.e[E_SCAN0], x.e[E_SCAN1]));
-        ms_scan += t;
-        if (x.ns == 0) continue;
-        EB_HIP(hipEventElapsedTime(&t, x.e[E_EXT0], x.e[E_EXT_DONE]));
-        ms_ext += t;
-        EB_HIP(hipEventElapsedTime(&t, x.e[E_RIGHT0], x.e[E_RIGHT_DONE]));
-        ms_right += t;
+    if (werr == hipSuccess) {
+        (void)hipEventElapsedTime(&ms_total, job->ev_begin, job->ev_end);
+        for (int k = 0; k < job->S; ++k) {
+            SubShard& x = job->sh[(size_t)k];
+            float t = 0;
+            (void)hipEventElapsedTime(&t, x.e[E_SCAN0], x.e[E_SCAN1]);
+            ms_scan += t;
+            if (x.ns == 0) continue;
+            (void)hipEventElapsedTime(&t, x.e[E_EXT0], x.e[E_EXT_DONE]);
+            ms_ext += t;
+            (void)hipEventElapsedTime(&t, x.e[E_RIGHT0], x.e[E_RIGHT_DONE]);
+            ms_right += t;
+        }
     }
-    if (stats) {
+    if (stats && werr == hipSuccess) {
         memset(stats, 0, sizeof *stats);
-        stats->begin = begin;
-        stats->end = end;
-        stats->runs_closed = c.runs_closed;
-        stats->clusters = c.clusters;
-        stats->bases_in_runs = c.bases;
-        stats->survivors = ns;
-        stats->chains = n_chains; // one left-context chain per frequent symbol
-        for (int k = 0; k < 201; ++k) stats->hist[k] = c.hist[k];
+        stats->begin = job->begin;
+        stats->end = job->end;
+        stats->runs_closed = job->c.runs_closed;
+        stats->clusters = job->c.clusters;
+        stats->bases_in_runs = job->c.bases;
+        stats->survivors = job->ns;
+        stats->chains = job->n_chains; // one left-context chain per frequent symbol
+        for (int k = 0; k < 201; ++k) stats->hist[k] = job->c.hist[k];
         stats->ms_scan = ms_scan;
         stats->ms_extend = ms_ext;
         stats->ms_right = ms_right;
         stats->ms_total = ms_total;
-        stats->scan_launches = (uint32_t)S;
+        stats->scan_launches = (uint32_t)job->S;
+    }
+    for (hipEvent_t e : job->events) ctx->events.push_back(e);
+    eb_calls* calls = job->calls;
+    delete job; // releases the device scratch to the cache
+    if (werr != hipSuccess) {
+        eb_set_error("phase-4 job failed: %s", hipGetErrorString(werr));
+        if (calls) eb_calls_free(calls);
+        return EB_ERR_DEVICE;
     }
     *out = calls;
-    calls = nullptr; // ownership passed on
     return EB_OK;
+}
+
+extern "C" void eb_scan_clusters_cancel(eb_scan_job* job) {
+    eb_calls* c = nullptr;
+    if (job) (void)eb_scan_clusters_end(job, &c, nullptr);
+    if (c) eb_calls_free(c);
+}
+
+extern "C" int eb_scan_clusters(eb_index* b1, eb_index* b2, eb_flags* f, uint64_t begin, uint64_t end, const eb_params* prm,
+                                eb_calls** out, eb_scan_stats* stats) {
+    if (!out) { eb_set_error("null argument"); return EB_ERR_ARG; }
+    *out = nullptr;
+    eb_scan_job* job = nullptr;
+    int rc = eb_scan_clusters_begin(b1, b2, f, begin, end, prm, &job);
+    if (rc != EB_OK) return rc;
+    return eb_scan_clusters_end(job, out, stats);
 }

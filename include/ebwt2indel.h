@@ -187,6 +187,15 @@ typedef struct {
 int eb_scan_clusters(eb_index* b1, eb_index* b2, eb_flags* f, uint64_t begin, uint64_t end, const eb_params* p,
                      eb_calls** out, eb_scan_stats* stats);
 
+/* Split form for callers that pipeline calls (the record download of one call overlaps the kernels of the next):
+ * _begin returns once everything is enqueued on the handles' streams; _end waits and hands over the results.
+ * Several jobs may be in flight on the same handles; each must be ended (or cancelled) exactly once, in any order. */
+typedef struct eb_scan_job eb_scan_job;
+int eb_scan_clusters_begin(eb_index* b1, eb_index* b2, eb_flags* f, uint64_t begin, uint64_t end, const eb_params* p,
+                           eb_scan_job** job);
+int eb_scan_clusters_end(eb_scan_job* job, eb_calls** out, eb_scan_stats* stats);
+void eb_scan_clusters_cancel(eb_scan_job* job);
+
 typedef struct {
     uint64_t count;                /* clusters */
     uint64_t n_chains;             /* chains over all clusters */

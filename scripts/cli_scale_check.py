@@ -1,0 +1,20 @@
+"""Check the ebwt2InDel executable on a large file: GPU-generated eBWT -> /tmp file -> CLI -> .snp, against the in-process path."""
+import hashlib, os, subprocess, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ebwt2indel_amd import sim, api, _lib
+n_reads = int(sys.argv[1]); L = 150
+glen = int(n_reads * L / 30)
+g = sim.random_genome(glen, 1); h2 = sim.mutate_haplotype(g, 1)
+text, offs = sim.haplotype_text([g, h2]); starts = sim.sample_read_starts([g, h2], offs, n_reads, L, 1)
+dev = sim.build_ebwt_gpu(text, starts, L)
+ebwt, _ = dev.to_host(); dev.free()
+path = "/tmp/scale.ebwt"; ebwt.tofile(path)
+p = api.make_params()
+t = time.time(); want = api.run_one_dataset(ebwt, p); t_api = time.time() - t
+t = time.time()
+r = subprocess.run([_lib.CLI_PATH, "-1", path, "-o", "/tmp/scale.snp"], capture_output=True, text=True)
+t_cli = time.time() - t
+got = open("/tmp/scale.snp", "rb").read()
+print(f"n={len(ebwt)} api {t_api:.2f}s cli {t_cli:.2f}s rc={r.returncode} identical={got == want} records={got.count(b'>')} sha={hashlib.sha256(got).hexdigest()[:16]}")
+print(r.stdout.splitlines()[-1])
+os.remove(path); os.remove("/tmp/scale.snp")
