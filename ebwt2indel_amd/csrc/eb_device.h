@@ -107,44 +107,45 @@ __device__ __forceinline__ uint64_t eb_block_count(const eb_dev_index& x, uint64
 
 // select (dna_string.hpp:182-188,254-272): position of the r-th (0-based) letter c.  The reference
 // bisects [0,n) with ~log2(n) full rank queries (33 at n = 7.55 G).  Here a small directory (block of every
-// 1024th occurrence, n/1024 bytes) brackets the answer to ~32 blocks; letters are locally uniform, so one
-// interpolated probe of the per-block counters lands within a block or two of the answer and a short walk over
-// neighbouring blocks finishes -- the same unique answer in ~3 dependent 64-byte reads.
+// 1024th occurrence, n/1024 bytes) brackets the answer to ~32 blocks; letters are locally uniform, so an
+// interpolated guess lands within a block or two.  Each probe loads the WHOLE 64-byte block (one line): its
+// counter says how many c precede it, its planes how many it holds, so the block that contains the answer is
+// recognised without probing its neighbour, and the in-block select needs no further memory access.
+// Same unique answer as the reference's bisection in ~2.3 dependent 64-byte reads.
 __device__ __forceinline__ uint64_t eb_select(const eb_dev_index& x, uint64_t r, int c) {
     const uint32_t* dir = x.sel_dir + (uint64_t)c * x.sel_stride;
     uint64_t m = r >> EB_SEL_SHIFT;
-    uint64_t lo = dir[m], hi = dir[m + 1]; // count(lo) <= m*1024 <= r, and the answer block is <= hi
+    uint64_t lo = dir[m], hi = dir[m + 1]; // the answer lies in a block of [lo, hi]
     uint64_t g = lo + (((r - (m << EB_SEL_SHIFT)) * (hi - lo + 1)) >> EB_SEL_SHIFT);
     if (g > hi) g = hi;
-    uint64_t cg = eb_block_count(x, g, c);
-    if (cg <= r) {
-        while (g < hi) { // forward while the next block still starts at or before occurrence r
-            uint64_t c1 = eb_block_count(x, g + 1, c);
-            if (c1 > r) break;
-            ++g;
-            cg = c1;
+    for (;;) {
+        const uint4* b = x.chunks + (g << 2);
+        uint4 ch0 = b[0], ch1 = b[1], ch2 = b[2], ch3 = b[3];
+        uint32_t w = c == 0 ? ch0.w : c == 1 ? ch1.w : c == 2 ? ch2.w : ch3.w;
+        uint64_t before = x.super[((g >> 25) << 2) + c] + w; // occurrences of c before block g
+        uint32_t m0 = ~ch0.z & ((c & 2) ? ch0.y : ~ch0.y) & ((c & 1) ? ch0.x : ~ch0.x);
+        uint32_t m1 = ~ch1.z & ((c & 2) ? ch1.y : ~ch1.y) & ((c & 1) ? ch1.x : ~ch1.x);
+        uint32_t m2 = ~ch2.z & ((c & 2) ? ch2.y : ~ch2.y) & ((c & 1) ? ch2.x : ~ch2.x);
+        uint32_t m3 = ~ch3.z & ((c & 2) ? ch3.y : ~ch3.y) & ((c & 1) ? ch3.x : ~ch3.x);
+        uint32_t k0 = (uint32_t)__popc(m0), k1 = (uint32_t)__popc(m1), k2 = (uint32_t)__popc(m2), k3 = (uint32_t)__popc(m3);
+        uint32_t k = k0 + k1 + k2 + k3;
+        if (r < before) {                      // answer lies earlier: at least ceil((before - r) / 128) blocks back
+            g -= ((before - r - 1) >> 7) + 1;
+            continue;
         }
-    } else {
-        do { // backward; count(lo) <= r guarantees termination at or above lo
-            --g;
-            cg = eb_block_count(x, g, c);
-        } while (cg > r);
-    }
-    uint32_t need = (uint32_t)(r - cg); // occurrences to skip inside block g
-    const uint4* b = x.chunks + (g << 2);
-    uint32_t off = 0;
-    for (uint32_t j = 0; j < 4; ++j) {
-        uint4 ch = b[j];
-        uint32_t mk = ~ch.z & ((c & 2) ? ch.y : ~ch.y) & ((c & 1) ? ch.x : ~ch.x);
-        uint32_t k = (uint32_t)__popc(mk);
-        if (need < k) {
-            for (uint32_t t = 0; t < need; ++t) mk &= mk - 1; // drop the `need` lowest set bits
-            off = j * 32u + (uint32_t)__ffs((int)mk) - 1u;
-            break;
+        if (r >= before + k) {                 // answer lies later: a block holds at most 128 occurrences
+            g += ((r - before - k) >> 7) + 1;
+            continue;
         }
-        need -= k;
+        uint32_t need = (uint32_t)(r - before); // occurrences to skip inside block g
+        uint32_t mk, base;
+        if (need < k0) { mk = m0; base = 0; }
+        else if (need < k0 + k1) { mk = m1; base = 32; need -= k0; }
+        else if (need < k0 + k1 + k2) { mk = m2; base = 64; need -= k0 + k1; }
+        else { mk = m3; base = 96; need -= k0 + k1 + k2; }
+        for (uint32_t t = 0; t < need; ++t) mk &= mk - 1; // drop the `need` lowest set bits
+        return (g << 7) + base + (uint32_t)__ffs((int)mk) - 1u;
     }
-    return (g << 7) + off;
 }
 
 // FL(i) (dna_bwt.hpp:115-133); i must not be a TERM row.

@@ -677,6 +677,8 @@ extern "C" int eb_scan_clusters_begin(eb_index* b1, eb_index* b2, eb_flags* f, u
     }
 
     const uint32_t lw = (uint32_t)((prm->k_left + 31) / 32), rw = (uint32_t)((prm->k_right + 31) / 32);
+    int key_bits = 1;
+    while (key_bits < 64 && (n >> key_bits)) ++key_bits; // cluster begins are < n: fewer radix passes than 64 bits
     uint64_t rec_total = 0, chain_total = 0;
     ScanCounters c;
     memset(&c, 0, sizeof c);
@@ -715,13 +717,14 @@ extern "C" int eb_scan_clusters_begin(eb_index* b1, eb_index* b2, eb_flags* f, u
             return rc;
         hipLaunchKernelGGL(k_surv_keys, dim3(grid_of(x.ns_raw)), dim3(256), 0, sP, x.surv.as<Survivor>(), x.ns_raw, x.keys.as<uint64_t>(), x.idx.as<uint32_t>());
         size_t tmp_bytes = 0, scan_bytes = 0;
+        const int end_bit = hc.n_long ? 64 : key_bits; // dropped long-run candidates carry begin = ~0 and must sort last
         EB_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, x.keys.as<uint64_t>(), x.keys2.as<uint64_t>(), x.idx.as<uint32_t>(),
-                                                  x.idx2.as<uint32_t>(), (int)x.ns_raw, 0, 64, sP));
+                                                  x.idx2.as<uint32_t>(), (int)x.ns_raw, 0, end_bit, sP));
         EB_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, x.nch.as<uint32_t>(), x.choff.as<uint32_t>(), (int)x.ns, sP));
         if (scan_bytes > tmp_bytes) tmp_bytes = scan_bytes;
         if ((rc = x.tmp.alloc(tmp_bytes)) != EB_OK) return rc;
         EB_HIP(hipcub::DeviceRadixSort::SortPairs(x.tmp.p, tmp_bytes, x.keys.as<uint64_t>(), x.keys2.as<uint64_t>(), x.idx.as<uint32_t>(),
-                                                  x.idx2.as<uint32_t>(), (int)x.ns_raw, 0, 64, sP));
+                                                  x.idx2.as<uint32_t>(), (int)x.ns_raw, 0, end_bit, sP));
         hipLaunchKernelGGL(k_surv_gather, dim3(grid_of(x.ns)), dim3(256), 0, sP, x.surv.as<Survivor>(), x.idx2.as<uint32_t>(), x.ns, x.sorted.as<Survivor>(),
                            x.nch.as<uint32_t>());
         // dense chain list: exclusive scan of the per-cluster chain counts
