@@ -264,6 +264,7 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
                 s.fmask1 = frequent_mask(c1, p.mcov);
                 int n0 = __popc(s.fmask0), n1 = __popc(s.fmask1);
                 keep = n0 > 0 && n1 > 0 && !(p.q > 0 && (n0 > p.q || n1 > p.q)); // :870-880
+                keep = keep && __popc(s.fmask0 | s.fmask1) > 1; // see can_emit_pairs() below
             } else if (!in_regs) {
                 // run longer than the lane's two words: its histogram needs memory; k_long_runs does that later so
                 // that the streaming kernel carries no rank code (registers) for this rare case
@@ -285,6 +286,10 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
                 s.fmask1 = frequent_mask(c1, p.mcov);
                 int n0 = __popc(s.fmask0), n1 = __popc(s.fmask1);
                 keep = n0 > 0 && n1 > 0 && !(p.q > 0 && (n0 > p.q || n1 > p.q)); // :1042-1052
+                // Pairs are emitted only for contexts whose last characters -- the frequent symbols themselves -- differ
+                // (:921, :1083), and an empty pair list leaves cluster_nr untouched (:1250): a cluster whose two sides
+                // share one single frequent letter can never reach the output, so its contexts are not computed.
+                keep = keep && __popc(s.fmask0 | s.fmask1) > 1;
             }
             if (keep) {
                 // LDS staging (no per-survivor global atomic); a full buffer spills straight to the list
@@ -345,7 +350,7 @@ __global__ void __launch_bounds__(256) k_long_runs(eb_dev_index x1, eb_dev_flags
         s.fmask0 = frequent_mask(c0, p.mcov);
         s.fmask1 = frequent_mask(c1, p.mcov);
         int n0 = __popc(s.fmask0), n1 = __popc(s.fmask1);
-        keep = n0 > 0 && n1 > 0 && !(p.q > 0 && (n0 > p.q || n1 > p.q));
+        keep = n0 > 0 && n1 > 0 && !(p.q > 0 && (n0 > p.q || n1 > p.q)) && __popc(s.fmask0 | s.fmask1) > 1;
     }
     if (!keep) {
         s.b = ~0ull;

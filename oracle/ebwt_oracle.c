@@ -776,7 +776,18 @@ static void analyse_cluster(orun* r, int mode, uint64_t b, uint64_t e, uint64_t 
     } else {
         if (nf[0] == 0 || nf[1] == 0 || (q > 0 && nf[0] > q) || (q > 0 && nf[1] > q)) return; /* :870-880, :1042-1052 */
     }
-    eb_cluster* rec = capture_new(r, b, e);
+    /* Record capture follows the product's definition of a surviving cluster: it passed the reference's filter AND can
+     * reach the output.  With two samples, pairs are emitted only when the last characters (= the frequent symbols)
+     * differ (:921,:1083) and an empty list leaves cluster_nr untouched (:1250), so a cluster whose sides share one single
+     * frequent letter is output-neutral; the text path below still runs the reference's algorithm on it. */
+    int can_emit = 1;
+    if (mode != 1) {
+        unsigned um = 0;
+        for (int k = 0; k < nf[0]; ++k) um |= 1u << sym_code(fr[0][k], 0);
+        for (int k = 0; k < nf[1]; ++k) um |= 1u << sym_code(fr[1][k], 0);
+        can_emit = __builtin_popcount(um) > 1;
+    }
+    eb_cluster* rec = can_emit ? capture_new(r, b, e) : NULL;
     uint64_t* rright = rec ? r->rec_right + (r->nrecs - 1) * (((size_t)p->k_right + 31) / 32) : NULL;
 
     octx ctx[2][4];
@@ -791,7 +802,7 @@ static void analyse_cluster(orun* r, int mode, uint64_t b, uint64_t e, uint64_t 
             char* dst = store + (size_t)slot * ((size_t)p->k_left + 1);
             int support = 0;
             int len = left_context(x, rng, fr[side][k], p->k_left, dst, &support);
-            r->chains++;
+            if (can_emit) r->chains++;
             if (rec) capture_chain(r, side, fr[side][k], len, support, dst);
             if (len == p->k_left) { /* :317 */
                 octx* c = &ctx[side][nctx[side]++];
