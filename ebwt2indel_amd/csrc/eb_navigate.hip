@@ -575,16 +575,47 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
     return EB_OK;
 }
 
+// '1' -> 1, anything else -> 0: 64 ASCII bytes -> one word (ebwt2InDel.cpp:1503-1508)
+__global__ void __launch_bounds__(256) k_pack_da(const uint8_t* __restrict__ ascii, uint64_t len, uint64_t first_word, uint64_t n_words,
+                                                uint64_t* __restrict__ da) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_words) return;
+    uint64_t off = t * 64, w = 0;
+    if (off + 64 <= len) {
+        const uint4* p4 = reinterpret_cast<const uint4*>(ascii + off);
+        for (int q = 0; q < 4; ++q) {
+            uint4 v = p4[q];
+            uint32_t d[4] = {v.x, v.y, v.z, v.w};
+            for (int k = 0; k < 4; ++k)
+                for (int b = 0; b < 4; ++b)
+                    w |= (uint64_t)(((d[k] >> (8 * b)) & 0xFFu) == '1') << (q * 16 + k * 4 + b);
+        }
+    } else {
+        for (uint64_t k = 0; k < 64 && off + k < len; ++k) w |= (uint64_t)(ascii[off + k] == '1') << k;
+    }
+    da[first_word + t] = w;
+}
+
 extern "C" int eb_flags_set_da(eb_flags* f, const uint8_t* ascii01, uint64_t n) {
     if (!f || (!ascii01 && n)) { eb_set_error("null argument"); return EB_ERR_ARG; }
     EB_HIP(hipSetDevice(f->device));
     // '1' -> 1, anything else (and anything past the end of the file) -> 0  (ebwt2InDel.cpp:1503-1508)
-    std::vector<uint64_t> bits(eb_bit_alloc_words(f->n), 0);
-    uint64_t lim = n < f->n ? n : f->n;
-    for (uint64_t i = 0; i < lim; ++i)
-        if (ascii01[i] == '1') bits[i >> 6] |= 1ull << (i & 63);
-    if (!f->d_da) EB_HIP(hipMalloc(&f->d_da, bits.size() * 8));
-    EB_HIP(hipMemcpy(f->d_da, bits.data(), bits.size() * 8, hipMemcpyHostToDevice));
+    const size_t bytes = eb_bit_alloc_words(f->n) * 8;
+    if (!f->d_da) EB_HIP(hipMalloc(&f->d_da, bytes));
+    EB_HIP(hipMemsetAsync(f->d_da, 0, bytes, f->stream));
+    const uint64_t lim = n < f->n ? n : f->n;
+    const uint64_t PIECE = 256ull << 20; // multiple of 64 positions
+    uint8_t* d_stage = nullptr;
+    EB_HIP(hipMalloc(&d_stage, lim < PIECE ? (lim ? lim : 1) : PIECE));
+    struct G { void* p; ~G() { (void)hipFree(p); } } g{d_stage};
+    for (uint64_t pos = 0; pos < lim; pos += PIECE) {
+        uint64_t len = lim - pos < PIECE ? lim - pos : PIECE;
+        EB_HIP(hipMemcpyAsync(d_stage, ascii01 + pos, len, hipMemcpyHostToDevice, f->stream));
+        uint64_t n_words = (len + 63) / 64;
+        hipLaunchKernelGGL(k_pack_da, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, f->stream, d_stage, len, pos / 64, n_words, f->d_da);
+        EB_HIP(hipStreamSynchronize(f->stream)); // the staging buffer is reused
+    }
+    EB_HIP(hipGetLastError());
     return eb_flags_build_da_rank(f);
 }
 
