@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--rank-queries", type=int, default=1 << 27)
     ap.add_argument("--cpu-sample-reads", type=int, default=130_000, help="reads in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-pipeline", action="store_true", help="finish every step before the next begins (profiling: under rocprofv3 the "
+                    "overlapped record download runs as a blit kernel and slows the scan it overlaps)")
     args = ap.parse_args()
 
     import torch
@@ -154,6 +156,13 @@ def main():
         torch.cuda.synchronize()
 
     def run_steps(k, record=None):
+        if args.no_pipeline:
+            last = None
+            for _ in range(k):
+                last = finish_step(begin_step())
+                if record is not None:
+                    record(last[0].stats)
+            return last
         job = begin_step()
         last = None
         for _ in range(k - 1):
@@ -273,7 +282,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": workload, "mode": 1, "options": "-L31 -R30 -k16 -g10 -v2 -m3 -c20 -q0",
-                       "parallelism": f"scan range split over {world} GPU(s), BWT+flags replicated, gather of cluster records to rank 0; steps pipelined one deep"},
+                       "parallelism": f"scan range split over {world} GPU(s), BWT+flags replicated, gather of cluster records to rank 0; " + ("steps back to back" if args.no_pipeline else "steps pipelined one deep")},
             "roofline": {"bound": "hbm", "achieved": round(scan_gbs, 2), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(scan_gbs / 8000.0, 5), "traffic": traffic, "kernel": "k_scan",
                          "avg_launch_ms": round(scan_avg_ms, 4), "launches_per_step": scan_launches, "positions_per_launch": int(positions_per_launch),

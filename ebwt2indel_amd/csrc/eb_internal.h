@@ -24,6 +24,7 @@ void eb_set_error(const char* fmt, ...);
 struct eb_scan_ctx {
     hipStream_t prep = nullptr, ext = nullptr, right = nullptr, copy = nullptr;
     std::vector<hipEvent_t> events;
+    hipEvent_t last_ext = nullptr, last_right = nullptr; // end of the most recent job's context kernels
     void* h_pinned = nullptr;
 };
 void eb_scan_ctx_destroy(eb_scan_ctx* c);

@@ -560,6 +560,8 @@ void eb_scan_ctx_destroy(eb_scan_ctx* c) {
     for (hipStream_t st : {c->prep, c->ext, c->right, c->copy})
         if (st) (void)hipStreamDestroy(st);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+    if (c->last_ext) (void)hipEventDestroy(c->last_ext);
+    if (c->last_right) (void)hipEventDestroy(c->last_right);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     delete c;
 }
@@ -604,6 +606,10 @@ extern "C" int eb_scan_clusters_begin(eb_index* b1, eb_index* b2, eb_flags* f, u
         EB_HIP(hipStreamCreateWithFlags(&ctx->right, hipStreamNonBlocking));
         EB_HIP(hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking));
         EB_HIP(hipHostMalloc(&ctx->h_pinned, 16 * (sizeof(ScanCounters) + 64), hipHostMallocDefault));
+        EB_HIP(hipEventCreateWithFlags(&ctx->last_ext, hipEventDisableTiming));
+        EB_HIP(hipEventCreateWithFlags(&ctx->last_right, hipEventDisableTiming));
+        EB_HIP(hipEventRecord(ctx->last_ext, ctx->ext));
+        EB_HIP(hipEventRecord(ctx->last_right, ctx->right));
     }
     const hipStream_t sA = b1->stream, sP = ctx->prep, sB = ctx->ext, sC = ctx->right, sD = ctx->copy;
     uint64_t w_lo = begin >> 6, w_hi = (end + 63) >> 6;
@@ -662,6 +668,10 @@ extern "C" int eb_scan_clusters_begin(eb_index* b1, eb_index* b2, eb_flags* f, u
         EB_HIP(hipGetLastError());
         return EB_OK;
     };
+    // A caller that pipelines jobs gets the record download of job i under the kernels of job i+1; the streaming scan
+    // itself starts only after job i's context kernels (they would just slow each other down: same memory system).
+    EB_HIP(hipStreamWaitEvent(sA, ctx->last_ext, 0));
+    EB_HIP(hipStreamWaitEvent(sA, ctx->last_right, 0));
     EB_HIP(hipEventRecord(ev_begin, sA));
     for (int k = 0; k < S; ++k) {
         SubShard& x = sh[(size_t)k];
@@ -755,11 +765,13 @@ extern "C" int eb_scan_clusters_begin(eb_index* b1, eb_index* b2, eb_flags* f, u
             hipLaunchKernelGGL(k_extend, dim3(grid_of(x.n_chains * 4)), dim3(256), 0, sB, x1, x2, p, x.sorted.as<Survivor>(), x.chains.as<uint64_t>(), x.n_chains,
                                x.crec.as<eb_chain>(), x.left.as<uint64_t>(), lw);
         EB_HIP(hipEventRecord(x.e[E_EXT_DONE], sB));
+        EB_HIP(hipEventRecord(ctx->last_ext, sB));
         EB_HIP(hipStreamWaitEvent(sC, x.e[E_PREP_DONE], 0));
         EB_HIP(hipEventRecord(x.e[E_RIGHT0], sC));
         hipLaunchKernelGGL(k_right, dim3(grid_of(x.ns)), dim3(256), 0, sC, x1, x2, df, p, x.sorted.as<Survivor>(), x.choff.as<uint32_t>(), (uint32_t)x.chain_base,
                            x.ns, x.recs.as<eb_cluster>(), x.right.as<uint64_t>(), rw);
         EB_HIP(hipEventRecord(x.e[E_RIGHT_DONE], sC));
+        EB_HIP(hipEventRecord(ctx->last_right, sC));
         EB_HIP(hipGetLastError());
         rec_total += x.ns;
         chain_total += x.n_chains;
