@@ -362,3 +362,37 @@ def test_long_clusters_take_the_memory_path(oracle):
     m, da = sim.build_merged_ebwt(r0, r1)
     want3, _ = oracle.run(m, da=da, params=p)
     assert api.run_two_datasets_da(m, da) == want3
+
+
+DEGENERATE = {
+    "empty": [],
+    "one_base": [b"A"],
+    "same_base_x4": [b"A"] * 4,
+    "one_read": [b"ACGTTGCAACGT"],
+    "identical_reads": [b"ACGTACGGTCAATCGGCTAAGCTTAGCCTAGGATCCA"] * 12,
+    "length_one_reads": [b"A", b"C", b"G", b"T"] * 5,
+    "homopolymer": [b"A" * 60] * 8 + [b"A" * 59 + b"C"] * 8,
+}
+
+
+@pytest.mark.parametrize("name", list(DEGENERATE), ids=list(DEGENERATE))
+def test_degenerate_inputs(oracle, name):
+    """Empty, single-symbol, duplicate-only and homopolymer collections: index, flag vectors and .snp against the oracle."""
+    reads = DEGENERATE[name]
+    e = sim.build_ebwt(reads).tobytes() if reads else b""
+    p = _oracle.Params.from_args([])
+    want, st = oracle.run(e, params=p)
+    got = api.run_one_dataset(e)
+    assert got == want
+    g = api.DnaBwt(e)
+    assert g.size() == len(e)
+    o = oracle.index(e)
+    assert g.F_arr == [int(x) for x in o.F()]
+    pos = np.arange(len(e) + 1, dtype=np.uint64)
+    assert np.array_equal(g.parallel_rank(pos), o.rank4(pos))
+    gf = api.Flags.build(g, None, p.K, p.k_right)
+    of = _oracle.OracleFlags(oracle, o, None, p.K, p.k_right)
+    for a, b in zip(gf.export()[:3], of.export()[:3]):
+        assert np.array_equal(a, b)
+    oc = of.counters()
+    assert (gf.stats.leaves, gf.stats.nodes, gf.stats.lcp_values) == (oc["leaves"], oc["nodes"], oc["lcp_values"])
