@@ -318,63 +318,67 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 
 template <typename Item>
 struct Drain {
-    // Drains a LIFO work stack in HBM with batched launches.  `launch(in, count, out, out_cap)` must append
-    // children through NavCounters::pushed.
+    // Drains LIFO work stacks in HBM with batched launches.  `launch(in, count, out, out_cap)` must append children
+    // through NavCounters::pushed.  TWO stacks alternate: a batch is popped from the top of one and expanded in place
+    // (the kernel reads it where it lies -- no staging copy), its children are pushed onto the other, which becomes
+    // the one to pop from next.  Popping the most recently pushed records first keeps a depth-first footprint.
     int device;
     hipStream_t stream;
-    Item* d_stack = nullptr;
-    Item* d_in = nullptr;
-    uint64_t cap = 0, batch = 0, top = 0;
+    Item* d_stack[2] = {nullptr, nullptr};
+    uint64_t cap = 0, batch = 0, top[2] = {0, 0};
     uint64_t launches = 0, max_top = 0;
 
-    // The stack and the batch buffer live in one arena shared by both phases (allocating HBM costs ~20 ms per GB,
-    // so the arena is sized from the batch, not from n).  A depth-first drain needs a few batches of room (observed:
-    // < 7 batches at 7.55 G positions); if the arena ever fills, run() shrinks the batch -- in the limit a plain
-    // depth-first walk that needs 4 x depth records -- so capacity never affects results.
+    // The stacks live in one arena shared by both phases (allocating HBM costs ~20 ms per GB, so the arena is sized from
+    // the batch, not from n).  A depth-first drain needs a few batches of room (observed: < 7 batches at 7.55 G
+    // positions); if a stack ever fills, run() shrinks the batch -- in the limit a plain depth-first walk that needs
+    // 4 x depth records -- so capacity never affects results.
     int init(void* arena, uint64_t arena_bytes, uint64_t n_bound, uint64_t batch_max) {
         batch = batch_max;
         if (batch > n_bound / 2 + 64) batch = n_bound / 2 + 64;
         uint64_t records = arena_bytes / sizeof(Item);
-        if (records < 8 * 1024) { eb_set_error("traversal arena too small"); return EB_ERR_NOMEM; }
-        if (batch > records / 8) batch = records / 8;
-        cap = records - batch;
+        if (records < 16 * 1024) { eb_set_error("traversal arena too small"); return EB_ERR_NOMEM; }
+        cap = records / 2;
+        if (batch > cap / 8) batch = cap / 8;
         uint64_t need = n_bound + 4 * batch + 64;   // every pending record is a distinct suffix-tree node/leaf
         if (cap > need) cap = need;
-        d_in = static_cast<Item*>(arena);
-        d_stack = d_in + batch;
-        if (getenv("EB_NAV_TRACE")) fprintf(stderr, "[nav] stack cap=%llu records (%.2f GB) batch=%llu\n", (unsigned long long)cap, cap * sizeof(Item) / 1e9, (unsigned long long)batch);
+        d_stack[0] = static_cast<Item*>(arena);
+        d_stack[1] = d_stack[0] + cap;
+        top[0] = top[1] = 0;
+        if (getenv("EB_NAV_TRACE")) fprintf(stderr, "[nav] 2 stacks x %llu records (%.2f GB) batch=%llu\n", (unsigned long long)cap, 2 * cap * sizeof(Item) / 1e9, (unsigned long long)batch);
         return EB_OK;
     }
     int push_host(const Item& it) {
-        EB_HIP(hipMemcpyAsync(d_stack + top, &it, sizeof(Item), hipMemcpyHostToDevice, stream));
+        EB_HIP(hipMemcpyAsync(d_stack[0] + top[0], &it, sizeof(Item), hipMemcpyHostToDevice, stream));
         EB_HIP(hipStreamSynchronize(stream));
-        ++top;
+        ++top[0];
         return EB_OK;
     }
     template <typename Launch>
     int run(NavCounters* d_cnt, unsigned long long* h_pushed /* pinned */, Launch launch) {
         const bool trace = getenv("EB_NAV_TRACE") != nullptr;
         const double t_start = now_s();
-        while (top > 0) {
-            uint64_t room = cap - top;
-            uint64_t B = top < batch ? top : batch;
-            if (B > 1 && 3 * B > room + 0) { // children (<= 4B) go where the popped B were, plus `room`
-                uint64_t fit = room / 3;
-                B = fit < 1 ? 1 : (fit < B ? fit : B);
-            }
-            if (top - B + 4 * B > cap) { eb_set_error("traversal stack capacity exceeded (cap %llu records)", (unsigned long long)cap); return EB_ERR_NOMEM; }
-            uint64_t base = top - B;
-            EB_HIP(hipMemcpyAsync(d_in, d_stack + base, B * sizeof(Item), hipMemcpyDeviceToDevice, stream));
+        int recent = 0; // stack that received records last
+        while (top[0] + top[1] > 0) {
+            const int src = top[recent] > 0 ? recent : 1 - recent, dst = 1 - src;
+            uint64_t room = cap - top[dst];
+            uint64_t B = top[src] < batch ? top[src] : batch;
+            if (4 * B > room) B = room / 4; // a record has at most four children
+            if (B == 0) { eb_set_error("traversal stack capacity exceeded (cap %llu records)", (unsigned long long)cap); return EB_ERR_NOMEM; }
+            const uint64_t base = top[src] - B;
             EB_HIP(hipMemsetAsync(&d_cnt->pushed, 0, sizeof(unsigned long long), stream));
-            launch(d_in, B, d_stack + base, cap - base);
+            launch(d_stack[src] + base, B, d_stack[dst] + top[dst], room);
             EB_HIP(hipGetLastError());
             EB_HIP(hipMemcpyAsync(h_pushed, &d_cnt->pushed, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
             EB_HIP(hipStreamSynchronize(stream));
-            if (*h_pushed > cap - base) { eb_set_error("traversal stack overflow"); return EB_ERR_STATE; }
-            top = base + *h_pushed;
-            if (top > max_top) max_top = top;
+            if (*h_pushed > room) { eb_set_error("traversal stack overflow"); return EB_ERR_STATE; }
+            top[src] = base;
+            top[dst] += *h_pushed;
+            if (*h_pushed) recent = dst;
+            if (top[0] + top[1] > max_top) max_top = top[0] + top[1];
             ++launches;
-            if (trace && (launches % 200 == 0 || top == 0)) fprintf(stderr, "[nav] launch %llu: B=%llu pushed=%llu top=%llu max_top=%llu t=%.3fs\n", (unsigned long long)launches, (unsigned long long)B, (unsigned long long)*h_pushed, (unsigned long long)top, (unsigned long long)max_top, now_s() - t_start);
+            if (trace && (launches % 200 == 0 || top[0] + top[1] == 0))
+                fprintf(stderr, "[nav] launch %llu: B=%llu pushed=%llu pending=%llu max=%llu t=%.3fs\n", (unsigned long long)launches, (unsigned long long)B,
+                        (unsigned long long)*h_pushed, (unsigned long long)(top[0] + top[1]), (unsigned long long)max_top, now_s() - t_start);
         }
         return EB_OK;
     }
@@ -459,8 +463,8 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
     eb_dev_flags df = f->dev();
     NavParams p{K, k_right, nullptr};
     hipStream_t st = f->stream;
-    const uint64_t batch_max = env_u64("EB_NAV_BATCH", 4ull << 20);
-    // one arena for both traversals: (EB_NAV_STACK_BATCHES + 1) batches of the largest record
+    const uint64_t batch_max = env_u64("EB_NAV_BATCH", 8ull << 20);
+    // one arena for both traversals: two stacks of EB_NAV_STACK_BATCHES / 2 batches of the largest record each
     const uint64_t item_bytes = b2 ? sizeof(Node2) : sizeof(Node1);
     uint64_t arena_batches = env_u64("EB_NAV_STACK_BATCHES", 24) + 1;
     uint64_t eff_batch = batch_max < n / 2 + 64 ? batch_max : n / 2 + 64;
