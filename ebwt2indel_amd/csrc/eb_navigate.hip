@@ -463,10 +463,10 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
     eb_dev_flags df = f->dev();
     NavParams p{K, k_right, nullptr};
     hipStream_t st = f->stream;
-    const uint64_t batch_max = env_u64("EB_NAV_BATCH", 8ull << 20);
+    const uint64_t batch_max = env_u64("EB_NAV_BATCH", 16ull << 20);
     // one arena for both traversals: two stacks of EB_NAV_STACK_BATCHES / 2 batches of the largest record each
     const uint64_t item_bytes = b2 ? sizeof(Node2) : sizeof(Node1);
-    uint64_t arena_batches = env_u64("EB_NAV_STACK_BATCHES", 24) + 1;
+    uint64_t arena_batches = env_u64("EB_NAV_STACK_BATCHES", 12) + 1; // observed peak: 5 batches pending
     uint64_t eff_batch = batch_max < n / 2 + 64 ? batch_max : n / 2 + 64;
     uint64_t arena_records = arena_batches * eff_batch + (n < (1ull << 20) ? n + 4 * eff_batch + 64 : 0);
     if (arena_records < (1ull << 16)) arena_records = 1ull << 16;
