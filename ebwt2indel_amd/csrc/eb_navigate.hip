@@ -42,9 +42,20 @@ __device__ __forceinline__ uint64_t wave_sum(uint64_t v) {
     return v;
 }
 
-__device__ __forceinline__ void flush_stat(unsigned long long* dst, uint64_t v) {
-    v = wave_sum(v);
-    if ((threadIdx.x & 63u) == 0 && v) atomicAdd(dst, (unsigned long long)v);
+// Statistics: every workgroup owns one row of counters in HBM and adds its totals with plain read-modify-writes
+// (launches are sequential; rows are summed on the host at the end) -- no per-wave atomics on shared words.
+#define EB_NAV_STATS 6 /* leaves, nodes, lcp_values, da_values, minima, ranks */
+__device__ __forceinline__ void flush_stats(unsigned long long* rows, const uint64_t* v /* EB_NAV_STATS values of this lane */) {
+    __shared__ unsigned long long sh[EB_NAV_STATS][4];
+    for (int k = 0; k < EB_NAV_STATS; ++k) {
+        uint64_t s = wave_sum(v[k]);
+        if ((threadIdx.x & 63u) == 0) sh[k][threadIdx.x >> 6] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < EB_NAV_STATS) {
+        unsigned long long* p = rows + (uint64_t)blockIdx.x * EB_NAV_STATS + threadIdx.x;
+        *p += sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
+    }
 }
 
 __device__ __forceinline__ uint64_t pick4(const uint64_t* F, uint32_t c) { return c == 0 ? F[0] : c == 1 ? F[1] : c == 2 ? F[2] : F[3]; }
@@ -54,7 +65,7 @@ __device__ __forceinline__ uint64_t pick4(const uint64_t* F, uint32_t c) { retur
 // it loads the j-th chunk of each rank query and builds the child leaf obtained by prepending "ACGT"[j].
 template <int NB>
 __global__ void __launch_bounds__(256) k_leaves(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, uint64_t* __restrict__ kr, NavParams p, const void* in_,
-                                               uint64_t count, void* out_, uint64_t out_cap, NavCounters* cnt) {
+                                               uint64_t count, void* out_, uint64_t out_cap, NavCounters* cnt, unsigned long long* __restrict__ stat_rows) {
     using Leaf = typename std::conditional<NB == 1, Leaf1, Leaf2>::type;
     constexpr int STAGE = 1024;
     __shared__ uint4 s_buf[STAGE * (sizeof(Leaf) / 16)];
@@ -149,10 +160,8 @@ __global__ void __launch_bounds__(256) k_leaves(eb_dev_index x1, eb_dev_index x2
         if (++trips % (STAGE / 256) == 0) stage.flush(out, out_cap, &cnt->pushed);
     }
     stage.flush(out, out_cap, &cnt->pushed);
-    flush_stat(&cnt->leaves, n_leaf);
-    flush_stat(&cnt->lcp_values, n_lcp);
-    flush_stat(&cnt->ranks, n_rank);
-    if constexpr (NB == 2) flush_stat(&cnt->da_values, n_da);
+    const uint64_t st[EB_NAV_STATS] = {n_leaf, 0, n_lcp, n_da, 0, n_rank};
+    flush_stats(stat_rows, st);
 }
 
 // ---- phase 3: right-maximal nodes.  update_lcp_threshold (include.hpp:826-860), update_lcp_minima
@@ -162,7 +171,7 @@ __global__ void __launch_bounds__(256) k_leaves(eb_dev_index x1, eb_dev_index x2
 // child "ACGT"[j] + W, and writes border j's LCP / minimum bits.
 template <int NB>
 __global__ void __launch_bounds__(256) k_nodes(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, uint64_t* __restrict__ kr, NavParams p, const void* in_,
-                                              uint64_t count, void* out_, uint64_t out_cap, NavCounters* cnt) {
+                                              uint64_t count, void* out_, uint64_t out_cap, NavCounters* cnt, unsigned long long* __restrict__ stat_rows) {
     using Node = typename std::conditional<NB == 1, Node1, Node2>::type;
     constexpr int STAGE = NB == 1 ? 768 : 512;
     __shared__ uint4 s_buf[STAGE * (sizeof(Node) / 16)];
@@ -260,11 +269,8 @@ __global__ void __launch_bounds__(256) k_nodes(eb_dev_index x1, eb_dev_index x2,
         if (++trips % (STAGE / 256) == 0) stage.flush(out, out_cap, &cnt->pushed);
     }
     stage.flush(out, out_cap, &cnt->pushed);
-    flush_stat(&cnt->nodes, n_node);
-    flush_stat(&cnt->lcp_values, n_lcp);
-    flush_stat(&cnt->minima, n_min);
-    flush_stat(&cnt->ranks, n_rank);
-    if constexpr (NB == 2) flush_stat(&cnt->da_values, n_da);
+    const uint64_t st[EB_NAV_STATS] = {0, n_node, n_lcp, n_da, n_min, n_rank};
+    flush_stats(stat_rows, st);
 }
 
 // after navigation: kr[2w], kr[2w+1] -> thrK[w], thrR[w] (streaming, ~1 ms per 7.5 G positions)
@@ -457,6 +463,10 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
     EB_HIP(hipMalloc(&d_cnt, sizeof(NavCounters)));
     EB_HIP(hipMemset(d_cnt, 0, sizeof(NavCounters)));
     EB_HIP(hipHostMalloc(&h_pushed, sizeof(unsigned long long)));
+    unsigned long long* d_rows = nullptr; // EB_NAV_STATS counters per workgroup (nav_grid() launches at most 2048)
+    EB_HIP(hipMalloc(&d_rows, 2048 * EB_NAV_STATS * sizeof(unsigned long long)));
+    EB_HIP(hipMemset(d_rows, 0, 2048 * EB_NAV_STATS * sizeof(unsigned long long)));
+    struct GuardR { void* p; ~GuardR() { (void)hipFree(p); } } guard_r{d_rows};
     struct Guard2 { NavCounters* c; unsigned long long* h; ~Guard2() { (void)hipFree(c); (void)hipHostFree(h); } } guard2{d_cnt, h_pushed};
 
     eb_dev_index x1 = b1->dev(), x2 = b2 ? b2->dev() : b1->dev();
@@ -511,7 +521,7 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
             if ((rc = d.init(d_arena, arena_bytes, n, batch_max)) != EB_OK) return rc;
             if ((rc = d.push_host(Leaf1{0, b1->F[0], 0, 0})) != EB_OK) return rc;
             rc = d.run(d_cnt, h_pushed, [&](Leaf1* in, uint64_t cnt, Leaf1* o, uint64_t ocap) {
-                hipLaunchKernelGGL(k_leaves<1>, dim3(nav_grid(cnt)), dim3(256), 0, st, x1, x2, df, d_kr, p, in, cnt, o, ocap, d_cnt);
+                hipLaunchKernelGGL(k_leaves<1>, dim3(nav_grid(cnt)), dim3(256), 0, st, x1, x2, df, d_kr, p, in, cnt, o, ocap, d_cnt, d_rows);
             });
             if (rc != EB_OK) return rc;
             launches += d.launches;
@@ -525,7 +535,7 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
             Node1 root{{0, b1->F[0], b1->F[1], b1->F[2], b1->F[3], b1->n}, 0, 0};
             if ((rc = d.push_host(root)) != EB_OK) return rc;
             rc = d.run(d_cnt, h_pushed, [&](Node1* in, uint64_t cnt, Node1* o, uint64_t ocap) {
-                hipLaunchKernelGGL(k_nodes<1>, dim3(nav_grid(cnt)), dim3(256), 0, st, x1, x2, df, d_kr, p, in, cnt, o, ocap, d_cnt);
+                hipLaunchKernelGGL(k_nodes<1>, dim3(nav_grid(cnt)), dim3(256), 0, st, x1, x2, df, d_kr, p, in, cnt, o, ocap, d_cnt, d_rows);
             });
             if (rc != EB_OK) return rc;
             launches += d.launches;
@@ -538,7 +548,7 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
             if ((rc = d.init(d_arena, arena_bytes, n, batch_max)) != EB_OK) return rc;
             if ((rc = d.push_host(Leaf2{0, b1->F[0], 0, b2->F[0], 0, {0, 0, 0}})) != EB_OK) return rc;
             rc = d.run(d_cnt, h_pushed, [&](Leaf2* in, uint64_t cnt, Leaf2* o, uint64_t ocap) {
-                hipLaunchKernelGGL(k_leaves<2>, dim3(nav_grid(cnt)), dim3(256), 0, st, x1, x2, df, d_kr, p, in, cnt, o, ocap, d_cnt);
+                hipLaunchKernelGGL(k_leaves<2>, dim3(nav_grid(cnt)), dim3(256), 0, st, x1, x2, df, d_kr, p, in, cnt, o, ocap, d_cnt, d_rows);
             });
             if (rc != EB_OK) return rc;
             launches += d.launches;
@@ -552,7 +562,7 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
             Node2 root{{0, b1->F[0], b1->F[1], b1->F[2], b1->F[3], b1->n}, {0, b2->F[0], b2->F[1], b2->F[2], b2->F[3], b2->n}, 0, {0, 0, 0}};
             if ((rc = d.push_host(root)) != EB_OK) return rc;
             rc = d.run(d_cnt, h_pushed, [&](Node2* in, uint64_t cnt, Node2* o, uint64_t ocap) {
-                hipLaunchKernelGGL(k_nodes<2>, dim3(nav_grid(cnt)), dim3(256), 0, st, x1, x2, df, d_kr, p, in, cnt, o, ocap, d_cnt);
+                hipLaunchKernelGGL(k_nodes<2>, dim3(nav_grid(cnt)), dim3(256), 0, st, x1, x2, df, d_kr, p, in, cnt, o, ocap, d_cnt, d_rows);
             });
             if (rc != EB_OK) return rc;
             launches += d.launches;
@@ -565,7 +575,19 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
     EB_HIP(hipStreamSynchronize(st));
     EB_HIP(hipGetLastError());
     NavCounters c;
-    EB_HIP(hipMemcpy(&c, d_cnt, sizeof c, hipMemcpyDeviceToHost));
+    memset(&c, 0, sizeof c);
+    {
+        std::vector<unsigned long long> rows(2048 * EB_NAV_STATS);
+        EB_HIP(hipMemcpy(rows.data(), d_rows, rows.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (size_t r = 0; r < 2048; ++r) {
+            c.leaves += rows[r * EB_NAV_STATS + 0];
+            c.nodes += rows[r * EB_NAV_STATS + 1];
+            c.lcp_values += rows[r * EB_NAV_STATS + 2];
+            c.da_values += rows[r * EB_NAV_STATS + 3];
+            c.minima += rows[r * EB_NAV_STATS + 4];
+            c.ranks += rows[r * EB_NAV_STATS + 5];
+        }
+    }
     s.leaves = c.leaves;
     s.nodes = c.nodes;
     s.lcp_values = c.lcp_values + 1; // the reference starts its counter at 1 (ebwt2InDel.cpp:575)

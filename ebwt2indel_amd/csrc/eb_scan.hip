@@ -41,6 +41,7 @@ struct alignas(16) Survivor {
 };
 
 #define EB_NEEDS_HIST 0x80000000u
+#define EB_SCAN_PARTIAL 204 /* runs, clusters, bases, hist[201] */
 
 struct ScanCounters {
     unsigned long long nsurv, runs_closed, clusters, bases, n_long, dropped;
@@ -117,7 +118,7 @@ __device__ __forceinline__ Planes load_planes(const eb_dev_index& x, uint64_t w)
 template <int MODE>
 __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, ScanParams p, uint64_t w_lo,
                                              uint64_t w_count, Survivor* __restrict__ surv, uint64_t surv_cap,
-                                             ScanCounters* __restrict__ cnt) {
+                                             ScanCounters* __restrict__ cnt, unsigned long long* __restrict__ partial) {
     __shared__ unsigned int sh_hist[201];
     constexpr int STAGE = 256; // survivors are ~1 per 10^4 positions: a workgroup rarely fills this before its last tile
     __shared__ uint4 s_buf[STAGE * (sizeof(Survivor) / 16)];
@@ -315,19 +316,37 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
     __syncthreads();
     if (threadIdx.x == 0 && s_count > (uint32_t)STAGE) s_count = STAGE;
     stage.flush(surv, surv_cap, &cnt->nsurv);
+    // Statistics leave the kernel as one row of plain stores per workgroup (k_scan_reduce adds the rows up): thousands of
+    // waves hammering three counters in one cache line with atomics cost ~0.25 ms per launch, whatever the range size.
     for (int o = 32; o > 0; o >>= 1) {
         n_runs += __shfl_xor((unsigned long long)n_runs, o);
         n_clusters += __shfl_xor((unsigned long long)n_clusters, o);
         n_bases += __shfl_xor((unsigned long long)n_bases, o);
     }
-    if (lane == 0) {
-        if (n_runs) atomicAdd(&cnt->runs_closed, (unsigned long long)n_runs);
-        if (n_clusters) atomicAdd(&cnt->clusters, (unsigned long long)n_clusters);
-        if (n_bases) atomicAdd(&cnt->bases, (unsigned long long)n_bases);
-    }
+    __shared__ unsigned long long sh_red[3][4];
+    if (lane == 0) { sh_red[0][threadIdx.x >> 6] = n_runs; sh_red[1][threadIdx.x >> 6] = n_clusters; sh_red[2][threadIdx.x >> 6] = n_bases; }
     __syncthreads();
-    for (int k = threadIdx.x; k < 201; k += blockDim.x)
-        if (sh_hist[k]) atomicAdd(&cnt->hist[k], (unsigned long long)sh_hist[k] * (unsigned long long)k); // CLUST_SIZES[len] += len
+    unsigned long long* row = partial + (uint64_t)blockIdx.x * EB_SCAN_PARTIAL;
+    if (threadIdx.x < 3) row[threadIdx.x] = sh_red[threadIdx.x][0] + sh_red[threadIdx.x][1] + sh_red[threadIdx.x][2] + sh_red[threadIdx.x][3];
+    for (int k = threadIdx.x; k < 201; k += blockDim.x) row[3 + k] = (unsigned long long)sh_hist[k] * (unsigned long long)k; // CLUST_SIZES[len] += len
+}
+
+// column sums of the per-workgroup statistics rows -> ScanCounters (one workgroup per column)
+__global__ void __launch_bounds__(256) k_scan_reduce(const unsigned long long* __restrict__ partial, uint32_t rows, ScanCounters* __restrict__ cnt) {
+    __shared__ unsigned long long sh[4];
+    const uint32_t col = blockIdx.x;
+    unsigned long long s = 0;
+    for (uint32_t r = threadIdx.x; r < rows; r += blockDim.x) s += partial[(uint64_t)r * EB_SCAN_PARTIAL + col];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63u) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s = sh[0] + sh[1] + sh[2] + sh[3];
+        if (col == 0) cnt->runs_closed = s;
+        else if (col == 1) cnt->clusters = s;
+        else if (col == 2) cnt->bases = s;
+        else cnt->hist[col - 3] = s;
+    }
 }
 
 // Histogram + frequent-symbol filter of the clusters k_scan could not analyse from registers (runs longer than
@@ -534,7 +553,7 @@ unsigned scan_grid(uint64_t words) {
 namespace {
 struct SubShard {
     uint64_t begin = 0, end = 0, w_lo = 0, w_count = 0, cap = 0;
-    DevMem cnt, surv, sorted, keys, keys2, idx, idx2, tmp, nch, choff, chains, recs, crec, left, right;
+    DevMem cnt, part, surv, sorted, keys, keys2, idx, idx2, tmp, nch, choff, chains, recs, crec, left, right;
     uint64_t ns_raw = 0, ns = 0, n_chains = 0, rec_base = 0, chain_base = 0;
     hipEvent_t e[9]; // scan_t0, scan_t1, scan_done, prep_cnt, prep_done, ext_t0, ext_done, right_t0, right_done
     ScanCounters* h_cnt = nullptr;
@@ -659,9 +678,13 @@ extern "C" int eb_scan_clusters_begin(eb_index* b1, eb_index* b2, eb_flags* f, u
         if ((r = x.surv.alloc(x.cap * sizeof(Survivor))) != EB_OK) return r;
         EB_HIP(hipMemsetAsync(x.cnt.p, 0, sizeof(ScanCounters), sA));
         EB_HIP(hipEventRecord(x.e[E_SCAN0], sA));
-        if (x.w_count)
-            hipLaunchKernelGGL(kern, dim3(scan_grid(x.w_count)), dim3(256), 0, sA, x1, x2, df, q, x.w_lo, x.w_count, x.surv.as<Survivor>(), x.cap,
-                               x.cnt.as<ScanCounters>());
+        if (x.w_count) {
+            const unsigned grid = scan_grid(x.w_count);
+            if ((r = x.part.alloc((size_t)grid * EB_SCAN_PARTIAL * 8)) != EB_OK) return r;
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, sA, x1, x2, df, q, x.w_lo, x.w_count, x.surv.as<Survivor>(), x.cap,
+                               x.cnt.as<ScanCounters>(), x.part.as<unsigned long long>());
+            hipLaunchKernelGGL(k_scan_reduce, dim3(EB_SCAN_PARTIAL), dim3(256), 0, sA, x.part.as<unsigned long long>(), grid, x.cnt.as<ScanCounters>());
+        }
         EB_HIP(hipEventRecord(x.e[E_SCAN1], sA));
         EB_HIP(hipMemcpyAsync(x.h_cnt, x.cnt.p, sizeof(ScanCounters), hipMemcpyDeviceToHost, sA));
         EB_HIP(hipEventRecord(x.e[E_SCAN_DONE], sA));
@@ -675,7 +698,7 @@ extern "C" int eb_scan_clusters_begin(eb_index* b1, eb_index* b2, eb_flags* f, u
     EB_HIP(hipEventRecord(ev_begin, sA));
     for (int k = 0; k < S; ++k) {
         SubShard& x = sh[(size_t)k];
-        for (DevMem* m : {&x.cnt, &x.surv, &x.sorted, &x.keys, &x.keys2, &x.idx, &x.idx2, &x.tmp, &x.nch, &x.choff, &x.chains, &x.recs, &x.crec, &x.left, &x.right})
+        for (DevMem* m : {&x.cnt, &x.part, &x.surv, &x.sorted, &x.keys, &x.keys2, &x.idx, &x.idx2, &x.tmp, &x.nch, &x.choff, &x.chains, &x.recs, &x.crec, &x.left, &x.right})
             m->device = b1->device;
         for (int i = 0; i < 9; ++i) x.e[i] = job->events[2 + 9 * (size_t)k + (size_t)i];
         x.h_cnt = reinterpret_cast<ScanCounters*>(static_cast<uint8_t*>(ctx->h_pinned) + (size_t)k * (sizeof(ScanCounters) + 64));
