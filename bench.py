@@ -142,10 +142,19 @@ def main():
     # next pass is enqueued (eb_scan_clusters_begin) before the previous one's records are waited for / gathered, so
     # the PCIe download and the RCCL gather of step i overlap the kernels of step i+1.  Exactly `steps` passes start
     # and finish between the two barriers.
+    # With RCCL the call set never visits a non-root host: each rank's device image goes GPU -> GPU over xGMI and rank 0
+    # downloads once.  (gloo rehearsal / single GPU: records are downloaded by the library into page-locked memory.)
+    device_gather = use_dist and comm_dev.type == "cuda" and os.environ.get("EB_BENCH_HOST_GATHER", "0") != "1"
+
     def begin_step():
-        return api.scan_clusters_begin(bwt, flags, p, begin=begin, end=end)
+        return api.scan_clusters_begin(bwt, flags, p, begin=begin, end=end, device_only=device_gather)
 
     def finish_step(job):
+        if device_gather:
+            job.wait()
+            ptr, length = job.device_blob()
+            parts = ebd.gather_device(ptr, length, comm_dev)
+            return job.finish(), parts
         calls = job.finish()                                             # records now in page-locked host memory
         parts = ebd.gather_packed(calls.blob(), device=comm_dev) if use_dist else None
         return calls, parts

@@ -297,11 +297,23 @@ class ScanJob:
         self._h = handle
 
     def finish(self) -> Calls:
+        """Waits, releases the job and returns the Calls (handle None -- only .stats -- for a device-only job)."""
         h, self._h = self._h, None
         out = C.c_void_p()
         st = _lib.ScanStats()
         _check(lib().eb_scan_clusters_end(h, C.byref(out), C.byref(st)))
-        return Calls(out, st)
+        return Calls(out if out.value else None, st)
+
+    def wait(self) -> None:
+        """Blocks until the job's kernels and copies are complete; the job stays valid."""
+        _check(lib().eb_scan_job_wait(self._h))
+
+    def device_blob(self):
+        """(device pointer, length) of the call set as one contiguous image in HBM -- the format of Calls.blob().
+        Valid until finish()."""
+        ptr, ln = C.c_void_p(), C.c_uint64()
+        _check(lib().eb_scan_job_device_blob(self._h, C.byref(ptr), C.byref(ln)))
+        return int(ptr.value or 0), int(ln.value)
 
     def __del__(self):
         try:
@@ -311,13 +323,17 @@ class ScanJob:
             pass
 
 
+SCAN_DEVICE_ONLY = 1
+
+
 def scan_clusters_begin(bwt1: DnaBwt, flags: Flags, params: Params, bwt2: Optional[DnaBwt] = None, begin: int = 0,
-                        end: Optional[int] = None) -> ScanJob:
-    """Enqueue phase 4 and return at once; the record download overlaps whatever the caller launches next."""
+                        end: Optional[int] = None, device_only: bool = False) -> ScanJob:
+    """Enqueue phase 4 and return at once; the record download overlaps whatever the caller launches next.
+    device_only: keep the call set in HBM (ScanJob.device_blob) -- for ranks that forward it with RCCL."""
     n = bwt1.n + (bwt2.n if bwt2 is not None else 0)
     h = C.c_void_p()
-    _check(lib().eb_scan_clusters_begin(bwt1._h, bwt2._h if bwt2 is not None else None, flags._h, begin, n if end is None else end,
-                                        C.byref(params), C.byref(h)))
+    _check(lib().eb_scan_clusters_begin_ex(bwt1._h, bwt2._h if bwt2 is not None else None, flags._h, begin, n if end is None else end,
+                                           C.byref(params), SCAN_DEVICE_ONLY if device_only else 0, C.byref(h)))
     return ScanJob(h)
 
 

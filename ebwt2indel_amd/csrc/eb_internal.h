@@ -78,6 +78,7 @@ struct eb_flags {
 struct eb_calls_header {
     uint64_t magic, count, n_chains, k_left, k_right, reserved[3];
 };
+static const uint64_t EB_CALLS_MAGIC = 0x32534C4C41434245ull; // "EBCALLS2"
 struct eb_calls {
     uint8_t* blob = nullptr;
     uint64_t size = 0;

@@ -453,9 +453,18 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
     *out = nullptr;
     EB_HIP(hipSetDevice(b1->device));
     const uint64_t n = b1->n + (b2 ? b2->n : 0);
+    const bool trace_alloc = getenv("EB_NAV_TRACE") != nullptr;
+    double ta = now_s();
+    auto lap = [&](const char* what) {
+        if (!trace_alloc) return;
+        double t = now_s();
+        fprintf(stderr, "[nav] %s: %.1f ms\n", what, (t - ta) * 1e3);
+        ta = t;
+    };
     eb_flags* f = nullptr;
     int rc = eb_flags_alloc(n, b1->device, b2 != nullptr, &f);
     if (rc != EB_OK) return rc;
+    lap("flag vectors allocated + cleared");
     struct Guard { eb_flags* f; ~Guard() { if (f) eb_flags_destroy(f); } } guard{f};
 
     NavCounters* d_cnt = nullptr;
@@ -492,6 +501,7 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
         if (e != hipSuccess) { eb_set_error("traversal arena allocation failed (%llu bytes): %s", (unsigned long long)arena_bytes, hipGetErrorString(e)); return EB_ERR_NOMEM; }
     }
     struct Guard3 { void* p; ~Guard3() { (void)hipFree(p); } } guard3{d_arena};
+    lap("arena allocated");
     // Threshold bits are collected either as one byte per position (plain stores; needs n bytes of spare HBM) or, when
     // memory is short, as interleaved bit words set with atomics; both are converted to the two bit vectors afterwards.
     uint64_t* d_kr = nullptr;
@@ -508,6 +518,7 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
     if (d_lcpb) EB_HIP(hipMemsetAsync(d_lcpb, 0, lcpb_bytes, f->stream));
     else EB_HIP(hipMemsetAsync(d_kr, 0, eb_bit_alloc_words(n) * 16, f->stream));
     p.lcpb = d_lcpb;
+    if (trace_alloc) { EB_HIP(hipStreamSynchronize(f->stream)); lap("threshold bytes allocated + cleared"); }
     eb_nav_stats s;
     memset(&s, 0, sizeof s);
     s.n = n;
@@ -572,8 +583,10 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
     }
     if (d_lcpb) hipLaunchKernelGGL(k_pack_lcp, dim3(4096), dim3(256), 0, st, reinterpret_cast<const uint4*>(d_lcpb), f->words, f->d_thrK, f->d_thrR);
     else hipLaunchKernelGGL(k_split_kr, dim3(2048), dim3(256), 0, st, reinterpret_cast<const uint4*>(d_kr), f->words, f->d_thrK, f->d_thrR);
+    lap("traversals");
     EB_HIP(hipStreamSynchronize(st));
     EB_HIP(hipGetLastError());
+    lap("threshold bits packed");
     NavCounters c;
     memset(&c, 0, sizeof c);
     {

@@ -553,7 +553,10 @@ unsigned scan_grid(uint64_t words) {
 namespace {
 struct SubShard {
     uint64_t begin = 0, end = 0, w_lo = 0, w_count = 0, cap = 0;
-    DevMem cnt, part, surv, sorted, keys, keys2, idx, idx2, tmp, nch, choff, chains, recs, crec, left, right;
+    DevMem cnt, part, surv, sorted, keys, keys2, idx, idx2, tmp, nch, choff, chains, recs, crec, left, right, blob;
+    eb_cluster* d_recs = nullptr; // sections: inside `blob` (one shard) or the separate buffers above (sub-shards)
+    eb_chain* d_crec = nullptr;
+    uint64_t *d_left = nullptr, *d_right = nullptr;
     uint64_t ns_raw = 0, ns = 0, n_chains = 0, rec_base = 0, chain_base = 0;
     hipEvent_t e[9]; // scan_t0, scan_t1, scan_done, prep_cnt, prep_done, ext_t0, ext_done, right_t0, right_done
     ScanCounters* h_cnt = nullptr;
@@ -572,7 +575,17 @@ struct eb_scan_job {
     ScanCounters c;
     uint64_t begin = 0, end = 0, ns = 0, n_chains = 0;
     int S = 1;
+    uint32_t options = 0;
+    bool has_blob = false;      // sh[0].blob holds the contiguous device image
+    uint64_t blob_bytes = 0;
+    eb_calls_header header;     // first 64 bytes of the device image
 };
+
+// first 64 bytes of the device image of a call set
+__global__ void k_blob_header(eb_calls_header h, uint64_t* dst) {
+    const uint64_t v[8] = {h.magic, h.count, h.n_chains, h.k_left, h.k_right, 0, 0, 0};
+    if (threadIdx.x < 8) dst[threadIdx.x] = v[threadIdx.x];
+}
 
 void eb_scan_ctx_destroy(eb_scan_ctx* c) {
     if (!c) return;
@@ -585,8 +598,8 @@ void eb_scan_ctx_destroy(eb_scan_ctx* c) {
     delete c;
 }
 
-extern "C" int eb_scan_clusters_begin(eb_index* b1, eb_index* b2, eb_flags* f, uint64_t begin, uint64_t end, const eb_params* prm,
-                                      eb_scan_job** out_job) {
+extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f, uint64_t begin, uint64_t end, const eb_params* prm,
+                                         uint32_t options, eb_scan_job** out_job) {
     if (!b1 || !f || !prm || !out_job) { eb_set_error("null argument"); return EB_ERR_ARG; }
     *out_job = nullptr;
     const uint64_t n = b1->n + (b2 ? b2->n : 0);
@@ -654,6 +667,7 @@ extern "C" int eb_scan_clusters_begin(eb_index* b1, eb_index* b2, eb_flags* f, u
     } job_guard{&job, ctx};
     job->b1 = b1;
     job->S = S;
+    job->options = options;
     job->begin = begin;
     job->end = end;
     job->sh.resize((size_t)S);
@@ -698,7 +712,7 @@ extern "C" int eb_scan_clusters_begin(eb_index* b1, eb_index* b2, eb_flags* f, u
     EB_HIP(hipEventRecord(ev_begin, sA));
     for (int k = 0; k < S; ++k) {
         SubShard& x = sh[(size_t)k];
-        for (DevMem* m : {&x.cnt, &x.part, &x.surv, &x.sorted, &x.keys, &x.keys2, &x.idx, &x.idx2, &x.tmp, &x.nch, &x.choff, &x.chains, &x.recs, &x.crec, &x.left, &x.right})
+        for (DevMem* m : {&x.cnt, &x.part, &x.surv, &x.sorted, &x.keys, &x.keys2, &x.idx, &x.idx2, &x.tmp, &x.nch, &x.choff, &x.chains, &x.recs, &x.crec, &x.left, &x.right, &x.blob})
             m->device = b1->device;
         for (int i = 0; i < 9; ++i) x.e[i] = job->events[2 + 9 * (size_t)k + (size_t)i];
         x.h_cnt = reinterpret_cast<ScanCounters*>(static_cast<uint8_t*>(ctx->h_pinned) + (size_t)k * (sizeof(ScanCounters) + 64));
@@ -774,25 +788,49 @@ extern "C" int eb_scan_clusters_begin(eb_index* b1, eb_index* b2, eb_flags* f, u
         x.n_chains = (uint64_t)x.h_last[0] + x.h_last[1];
         if (chain_total + x.n_chains > 0xFFFFFFFFull) { eb_set_error("too many chains in one call; shard the range"); return EB_ERR_STATE; }
         const size_t left_bytes = x.n_chains * (size_t)lw * 8, right_bytes = x.ns * (size_t)rw * 8;
-        if ((rc = x.chains.alloc(x.n_chains * 8)) != EB_OK || (rc = x.recs.alloc(x.ns * sizeof(eb_cluster))) != EB_OK ||
-            (rc = x.crec.alloc(x.n_chains * sizeof(eb_chain))) != EB_OK || (rc = x.left.alloc(left_bytes)) != EB_OK || (rc = x.right.alloc(right_bytes)) != EB_OK)
-            return rc;
+        if ((rc = x.chains.alloc(x.n_chains * 8)) != EB_OK) return rc;
+        if (S == 1) {
+            // one shard: the kernels write straight into a contiguous image of the call set (the wire / host format)
+            const uint64_t bytes = eb_calls_blob_size(x.ns, x.n_chains, prm->k_left, prm->k_right);
+            if ((rc = x.blob.alloc(bytes)) != EB_OK) return rc;
+            uint8_t* q = x.blob.as<uint8_t>() + sizeof(eb_calls_header);
+            x.d_recs = reinterpret_cast<eb_cluster*>(q);
+            q += x.ns * sizeof(eb_cluster);
+            x.d_crec = reinterpret_cast<eb_chain*>(q);
+            q += (x.n_chains * sizeof(eb_chain) + 7) & ~(size_t)7;
+            x.d_left = reinterpret_cast<uint64_t*>(q);
+            q += left_bytes;
+            x.d_right = reinterpret_cast<uint64_t*>(q);
+            job->has_blob = true;
+            job->blob_bytes = bytes;
+            job->header = eb_calls_header{EB_CALLS_MAGIC, x.ns, x.n_chains, (uint64_t)(uint32_t)prm->k_left, (uint64_t)(uint32_t)prm->k_right, {0, 0, 0}};
+            EB_HIP(hipMemsetAsync(x.blob.p, 0, bytes, sP));
+            hipLaunchKernelGGL(k_blob_header, dim3(1), dim3(64), 0, sP, job->header, x.blob.as<uint64_t>());
+        } else {
+            if ((rc = x.recs.alloc(x.ns * sizeof(eb_cluster))) != EB_OK || (rc = x.crec.alloc(x.n_chains * sizeof(eb_chain))) != EB_OK ||
+                (rc = x.left.alloc(left_bytes)) != EB_OK || (rc = x.right.alloc(right_bytes)) != EB_OK)
+                return rc;
+            x.d_recs = x.recs.as<eb_cluster>();
+            x.d_crec = x.crec.as<eb_chain>();
+            x.d_left = x.left.as<uint64_t>();
+            x.d_right = x.right.as<uint64_t>();
+            EB_HIP(hipMemsetAsync(x.left.p, 0, left_bytes, sP));
+            EB_HIP(hipMemsetAsync(x.right.p, 0, right_bytes, sP));
+        }
         hipLaunchKernelGGL(k_chain_list, dim3(grid_of(x.ns)), dim3(256), 0, sP, x.sorted.as<Survivor>(), x.choff.as<uint32_t>(), x.ns, x.chains.as<uint64_t>());
-        EB_HIP(hipMemsetAsync(x.left.p, 0, left_bytes, sP));
-        EB_HIP(hipMemsetAsync(x.right.p, 0, right_bytes, sP));
         EB_HIP(hipEventRecord(x.e[E_PREP_DONE], sP));
         // the two context kernels are independent dependent-load chains: one stream each
         EB_HIP(hipStreamWaitEvent(sB, x.e[E_PREP_DONE], 0));
         EB_HIP(hipEventRecord(x.e[E_EXT0], sB));
         if (x.n_chains)
             hipLaunchKernelGGL(k_extend, dim3(grid_of(x.n_chains * 4)), dim3(256), 0, sB, x1, x2, p, x.sorted.as<Survivor>(), x.chains.as<uint64_t>(), x.n_chains,
-                               x.crec.as<eb_chain>(), x.left.as<uint64_t>(), lw);
+                               x.d_crec, x.d_left, lw);
         EB_HIP(hipEventRecord(x.e[E_EXT_DONE], sB));
         EB_HIP(hipEventRecord(ctx->last_ext, sB));
         EB_HIP(hipStreamWaitEvent(sC, x.e[E_PREP_DONE], 0));
         EB_HIP(hipEventRecord(x.e[E_RIGHT0], sC));
         hipLaunchKernelGGL(k_right, dim3(grid_of(x.ns)), dim3(256), 0, sC, x1, x2, df, p, x.sorted.as<Survivor>(), x.choff.as<uint32_t>(), (uint32_t)x.chain_base,
-                           x.ns, x.recs.as<eb_cluster>(), x.right.as<uint64_t>(), rw);
+                           x.ns, x.d_recs, x.d_right, rw);
         EB_HIP(hipEventRecord(x.e[E_RIGHT_DONE], sC));
         EB_HIP(hipEventRecord(ctx->last_right, sC));
         EB_HIP(hipGetLastError());
@@ -801,9 +839,19 @@ extern "C" int eb_scan_clusters_begin(eb_index* b1, eb_index* b2, eb_flags* f, u
     }
     const uint64_t ns = rec_total, n_chains = chain_total;
 
-    // ---- one blob for the whole call; each sub-shard's sections are copied as soon as its kernels are done
-    eb_calls* calls = eb_calls_alloc(ns, n_chains, prm->k_left, prm->k_right, ns != 0);
-    if (!calls) return EB_ERR_NOMEM;
+    // ---- the call set in host memory (unless the caller keeps it on the device): one page-locked blob; with one shard
+    // the device image is copied in one piece, with sub-shards each shard's sections as soon as its kernels are done
+    const bool device_only = (options & EB_SCAN_DEVICE_ONLY) != 0;
+    if (ns == 0 && S == 1 && !job->has_blob) {
+        // nothing survived: the device image is just a header
+        SubShard& x = sh[0];
+        if ((rc = x.blob.alloc(sizeof(eb_calls_header))) != EB_OK) return rc;
+        job->has_blob = true;
+        job->blob_bytes = sizeof(eb_calls_header);
+        job->header = eb_calls_header{EB_CALLS_MAGIC, 0, 0, (uint64_t)(uint32_t)prm->k_left, (uint64_t)(uint32_t)prm->k_right, {0, 0, 0}};
+        hipLaunchKernelGGL(k_blob_header, dim3(1), dim3(64), 0, sD, job->header, x.blob.as<uint64_t>());
+    }
+    eb_calls* calls = nullptr;
     struct CallGuard { eb_calls** c; ~CallGuard() { if (*c) eb_calls_free(*c); } } cg{&calls};
     EB_HIP(hipStreamWaitEvent(sD, sh[(size_t)S - 1].e[E_SCAN_DONE], 0));
     for (int k = 0; k < S; ++k) {
@@ -811,11 +859,23 @@ extern "C" int eb_scan_clusters_begin(eb_index* b1, eb_index* b2, eb_flags* f, u
         if (x.ns == 0) continue;
         EB_HIP(hipStreamWaitEvent(sD, x.e[E_EXT_DONE], 0));
         EB_HIP(hipStreamWaitEvent(sD, x.e[E_RIGHT_DONE], 0));
-        EB_HIP(hipMemcpyAsync(calls->clusters + x.rec_base, x.recs.p, x.ns * sizeof(eb_cluster), hipMemcpyDeviceToHost, sD));
-        EB_HIP(hipMemcpyAsync(calls->right + x.rec_base * rw, x.right.p, x.ns * (size_t)rw * 8, hipMemcpyDeviceToHost, sD));
-        if (x.n_chains) {
-            EB_HIP(hipMemcpyAsync(calls->chains + x.chain_base, x.crec.p, x.n_chains * sizeof(eb_chain), hipMemcpyDeviceToHost, sD));
-            EB_HIP(hipMemcpyAsync(calls->left + x.chain_base * lw, x.left.p, x.n_chains * (size_t)lw * 8, hipMemcpyDeviceToHost, sD));
+    }
+    if (!device_only) {
+        calls = eb_calls_alloc(ns, n_chains, prm->k_left, prm->k_right, ns != 0);
+        if (!calls) return EB_ERR_NOMEM;
+        if (job->has_blob && ns) {
+            EB_HIP(hipMemcpyAsync(calls->blob, sh[0].blob.p, job->blob_bytes, hipMemcpyDeviceToHost, sD));
+        } else {
+            for (int k = 0; k < S; ++k) {
+                SubShard& x = sh[(size_t)k];
+                if (x.ns == 0) continue;
+                EB_HIP(hipMemcpyAsync(calls->clusters + x.rec_base, x.d_recs, x.ns * sizeof(eb_cluster), hipMemcpyDeviceToHost, sD));
+                EB_HIP(hipMemcpyAsync(calls->right + x.rec_base * rw, x.d_right, x.ns * (size_t)rw * 8, hipMemcpyDeviceToHost, sD));
+                if (x.n_chains) {
+                    EB_HIP(hipMemcpyAsync(calls->chains + x.chain_base, x.d_crec, x.n_chains * sizeof(eb_chain), hipMemcpyDeviceToHost, sD));
+                    EB_HIP(hipMemcpyAsync(calls->left + x.chain_base * lw, x.d_left, x.n_chains * (size_t)lw * 8, hipMemcpyDeviceToHost, sD));
+                }
+            }
         }
     }
     EB_HIP(hipEventRecord(ev_end, sD));
@@ -830,8 +890,8 @@ extern "C" int eb_scan_clusters_begin(eb_index* b1, eb_index* b2, eb_flags* f, u
 }
 
 extern "C" int eb_scan_clusters_end(eb_scan_job* job, eb_calls** out, eb_scan_stats* stats) {
-    if (!job || !out) { eb_set_error("null argument"); return EB_ERR_ARG; }
-    *out = nullptr;
+    if (!job) { eb_set_error("null argument"); return EB_ERR_ARG; }
+    if (out) *out = nullptr;
     eb_index* b1 = job->b1;
     eb_scan_ctx* ctx = b1->scan_ctx;
     EB_HIP(hipSetDevice(b1->device));
@@ -877,7 +937,28 @@ extern "C" int eb_scan_clusters_end(eb_scan_job* job, eb_calls** out, eb_scan_st
         if (calls) eb_calls_free(calls);
         return EB_ERR_DEVICE;
     }
-    *out = calls;
+    if (out) *out = calls;
+    else if (calls) eb_calls_free(calls);
+    return EB_OK;
+}
+
+extern "C" int eb_scan_clusters_begin(eb_index* b1, eb_index* b2, eb_flags* f, uint64_t begin, uint64_t end, const eb_params* prm,
+                                      eb_scan_job** out_job) {
+    return eb_scan_clusters_begin_ex(b1, b2, f, begin, end, prm, 0u, out_job);
+}
+
+extern "C" int eb_scan_job_wait(eb_scan_job* job) {
+    if (!job) { eb_set_error("null argument"); return EB_ERR_ARG; }
+    EB_HIP(hipSetDevice(job->b1->device));
+    EB_HIP(hipEventSynchronize(job->ev_end));
+    return EB_OK;
+}
+
+extern "C" int eb_scan_job_device_blob(eb_scan_job* job, const void** d_data, uint64_t* len) {
+    if (!job || !d_data || !len) { eb_set_error("null argument"); return EB_ERR_ARG; }
+    if (!job->has_blob) { eb_set_error("the job was split into sub-shards: no contiguous device image"); return EB_ERR_STATE; }
+    *d_data = job->sh[0].blob.p;
+    *len = job->blob_bytes;
     return EB_OK;
 }
 

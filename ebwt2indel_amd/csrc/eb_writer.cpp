@@ -191,7 +191,7 @@ int format_calls(const eb_calls* c, const eb_params* p, int two_samples, uint64_
 
 // ------------------------------------------------------------------ call-set container
 
-static const uint64_t kMagic = 0x32534C4C41434245ull; // "EBCALLS2"
+static const uint64_t kMagic = EB_CALLS_MAGIC;
 
 namespace {
 // page-locked blobs are recycled: pinning tens of MB per call would cost more than the copy it speeds up

@@ -39,8 +39,26 @@ def _buffers(world: int, cap: int, dev, root: bool):
     return cur
 
 
+class _DeviceBytes:
+    """`length` bytes of device memory at `ptr`, for torch.as_tensor (no copy)."""
+
+    def __init__(self, ptr: int, length: int):
+        self.__cuda_array_interface__ = {"shape": (length,), "typestr": "|u1", "data": (ptr, False), "version": 3, "strides": None}
+
+
+def gather_device(ptr: int, length: int, device, group=None, dst: int = 0) -> Optional[List[memoryview]]:
+    """gather_packed for a call set that is still in HBM (ScanJob.device_blob): the image goes GPU -> GPU over
+    xGMI without touching this rank's host memory; only the root downloads, once, into its reused page-locked buffer.
+    The caller must have waited for the job (ScanJob.wait) and keeps it alive until this returns."""
+    import torch
+
+    dev = torch.device(device)
+    src = torch.as_tensor(_DeviceBytes(ptr, length), device=dev) if length else torch.empty(0, dtype=torch.uint8, device=dev)
+    return gather_packed(src, group=group, device=dev, dst=dst)
+
+
 def gather_packed(packed, group=None, device=None, dst: int = 0) -> Optional[List[memoryview]]:
-    """Variable-length gather of one byte string (bytes / memoryview, e.g. Calls.blob()) per rank to `dst`
+    """Variable-length gather of one byte string (bytes / memoryview, e.g. Calls.blob(), or a uint8 tensor on `device`) per rank to `dst`
     (None elsewhere).  One small all_gather tells every rank all sizes (so all derive the same padded length), one
     gather moves the payloads; tensors live on `device` (the rank's GPU for nccl = RCCL over xGMI, CPU for gloo).
     On the root the result is a list of views into a reused page-locked host buffer: valid until the next call."""
@@ -50,7 +68,9 @@ def gather_packed(packed, group=None, device=None, dst: int = 0) -> Optional[Lis
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = torch.device("cpu") if device is None else torch.device(device)
-    n = len(packed)
+    import torch as _t
+    on_device = isinstance(packed, _t.Tensor)
+    n = int(packed.numel()) if on_device else len(packed)
     sizes_t = torch.empty(world, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(sizes_t, torch.tensor([n], dtype=torch.int64, device=dev), group=group)
     sizes = [int(x) for x in sizes_t.tolist()]
@@ -58,10 +78,12 @@ def gather_packed(packed, group=None, device=None, dst: int = 0) -> Optional[Lis
     buf = _buffers(world, cap + cap // 4, dev, rank == dst)  # grow with some slack, slice to the agreed length
     send = buf["send"][:cap]
     if n:
-        send[:n].copy_(torch.frombuffer(packed, dtype=torch.uint8))
+        send[:n].copy_(packed if on_device else torch.frombuffer(packed, dtype=torch.uint8))
     outs = [buf["recv"][r * cap:(r + 1) * cap] for r in range(world)] if rank == dst else None
     dist.gather(send, outs, dst=dst, group=group)
     if rank != dst:
+        if on_device:
+            torch.cuda.current_stream(dev).synchronize()  # the source image may be released once this returns
         return None
     host = buf["host"]
     if dev.type == "cuda":

@@ -195,6 +195,16 @@ int eb_scan_clusters_begin(eb_index* b1, eb_index* b2, eb_flags* f, uint64_t beg
                            eb_scan_job** job);
 int eb_scan_clusters_end(eb_scan_job* job, eb_calls** out, eb_scan_stats* stats);
 void eb_scan_clusters_cancel(eb_scan_job* job);
+/* Options for _begin_ex.  EB_SCAN_DEVICE_ONLY: leave the call set in device memory only (no copy to the host) -- for
+ * ranks that forward it to rank 0 with RCCL; _end then returns *out = NULL. */
+#define EB_SCAN_DEVICE_ONLY 1u
+int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f, uint64_t begin, uint64_t end, const eb_params* p,
+                              uint32_t options, eb_scan_job** job);
+/* Blocks until the job's kernels and copies are complete; the job stays valid. */
+int eb_scan_job_wait(eb_scan_job* job);
+/* The job's call set as one contiguous image in DEVICE memory (same format as eb_calls_blob), valid until _end.
+ * EB_ERR_STATE when the job was split into sub-shards (EB_SCAN_SUBSHARDS > 1). */
+int eb_scan_job_device_blob(eb_scan_job* job, const void** d_data, uint64_t* len);
 
 typedef struct {
     uint64_t count;                /* clusters */

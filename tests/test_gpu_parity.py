@@ -396,3 +396,26 @@ def test_degenerate_inputs(oracle, name):
         assert np.array_equal(a, b)
     oc = of.counters()
     assert (gf.stats.leaves, gf.stats.nodes, gf.stats.lcp_values) == (oc["leaves"], oc["nodes"], oc["lcp_values"])
+
+
+def test_device_image_equals_host_blob(dip):
+    """A device-only job (EB_SCAN_DEVICE_ONLY) leaves the call set in HBM as one contiguous image: byte-identical to the
+    blob a normal job downloads, for a full range, a shard and an empty range."""
+    e, g, _ = dip
+    n = len(e)
+    p = api.make_params()
+    fl = api.navigate_one_bwt(g, p)
+    for begin, end in [(0, n), (n // 3 // 64 * 64, n // 3 * 2 // 64 * 64), (64, 64)]:
+        host = api.scan_clusters_begin(g, fl, p, begin=begin, end=end).finish()
+        want = bytes(host.blob())
+        job = api.scan_clusters_begin(g, fl, p, begin=begin, end=end, device_only=True)
+        job.wait()
+        ptr, length = job.device_blob()
+        assert length == len(want)
+        got = np.empty(length, dtype=np.uint8)
+        sim._hip_copy_to_host(got, ptr, length)
+        done = job.finish()
+        assert done._h is None and done.stats.survivors == len(host)
+        assert got.tobytes() == want
+        back = api.Calls.unpack(got.tobytes())
+        assert back.format_snp(p, False)[0] == host.format_snp(p, False)[0]
