@@ -5,7 +5,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_build", "libebwt2indel.so")
+LIB_PATH = os.environ.get("EB_LIB_PATH") or os.path.join(_HERE, "_build", "libebwt2indel.so")  # EB_LIB_PATH: A/B builds
 CLI_PATH = os.path.join(_HERE, "_build", "ebwt2InDel")
 CSRC = os.path.join(_HERE, "csrc")
 

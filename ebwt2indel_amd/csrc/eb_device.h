@@ -16,7 +16,9 @@
 
 #define EB_BLOCK_SYMS 128u
 #define EB_SUPER_SHIFT 32 /* 2^32 symbols per superblock (dna_string.hpp:36) */
-#define EB_SEL_SHIFT 10   /* select directory samples every 1024th occurrence of a letter */
+#ifndef EB_SEL_SHIFT
+#define EB_SEL_SHIFT 7    /* select directory samples every 128th occurrence of a letter */
+#endif
 
 struct eb_dev_index {
     const uint4* chunks;    // 4 * n_blocks chunks
@@ -25,7 +27,7 @@ struct eb_dev_index {
     uint64_t n_blocks;      // ceil((n+1)/128)
     uint64_t F[4];          // F_A,F_C,F_G,F_T
     const uint32_t* sel_dir; // select directory: block of every EB_SEL_SAMPLE-th occurrence of each letter
-    uint64_t sel_stride;     // entries per letter
+    uint64_t sel_off[4];     // first directory entry of each letter
     uint32_t term;          // ASCII terminator
 };
 
@@ -83,6 +85,22 @@ __device__ __forceinline__ uint64_t eb_rank4_quad(const eb_dev_index& x, uint64_
     return x.super[((i >> EB_SUPER_SHIFT) << 2) + j] + c.w + ((p >> (8u * j)) & 0xFFu);
 }
 
+// Ranks at both ends of an interval [lo, hi] by one quad: a narrow interval (the usual case when following a
+// cluster's left context, width ~ coverage) lies in ONE block, which is then loaded once.
+__device__ __forceinline__ void eb_rank4_quad_pair(const eb_dev_index& x, uint64_t lo, uint64_t hi, uint32_t j, uint64_t& a, uint64_t& b) {
+    uint4 c = x.chunks[((lo >> 7) << 2) + j];
+    uint4 d = c;
+    if ((hi >> 7) != (lo >> 7)) d = x.chunks[((hi >> 7) << 2) + j]; // uniform inside the quad
+    uint32_t p = eb_chunk_counts(c, eb_prefix_mask32((uint32_t)(lo & 127u), j));
+    uint32_t q = eb_chunk_counts(d, eb_prefix_mask32((uint32_t)(hi & 127u), j));
+    p += (uint32_t)__shfl_xor((int)p, 1);
+    q += (uint32_t)__shfl_xor((int)q, 1);
+    p += (uint32_t)__shfl_xor((int)p, 2);
+    q += (uint32_t)__shfl_xor((int)q, 2);
+    a = x.super[((lo >> EB_SUPER_SHIFT) << 2) + j] + c.w + ((p >> (8u * j)) & 0xFFu);
+    b = x.super[((hi >> EB_SUPER_SHIFT) << 2) + j] + d.w + ((q >> (8u * j)) & 0xFFu);
+}
+
 // operator[] (dna_string.hpp:113-135): 3-bit code of symbol i.
 __device__ __forceinline__ uint32_t eb_code(const eb_dev_index& x, uint64_t i) {
     uint4 c = x.chunks[i >> 5];
@@ -106,14 +124,14 @@ __device__ __forceinline__ uint64_t eb_block_count(const eb_dev_index& x, uint64
 }
 
 // select (dna_string.hpp:182-188,254-272): position of the r-th (0-based) letter c.  The reference
-// bisects [0,n) with ~log2(n) full rank queries (33 at n = 7.55 G).  Here a small directory (block of every
-// 1024th occurrence, n/1024 bytes) brackets the answer to ~32 blocks; letters are locally uniform, so an
-// interpolated guess lands within a block or two.  Each probe loads the WHOLE 64-byte block (one line): its
+// bisects [0,n) with ~log2(n) full rank queries (33 at n = 7.55 G).  Here a directory (block of every
+// 128th occurrence of each letter, n/32 bytes in all) brackets the answer to a handful of blocks; letters are locally
+// uniform, so an interpolated guess usually lands on the right block at once.  Each probe loads the WHOLE 64-byte block (one line): its
 // counter says how many c precede it, its planes how many it holds, so the block that contains the answer is
 // recognised without probing its neighbour, and the in-block select needs no further memory access.
 // Same unique answer as the reference's bisection in ~2.3 dependent 64-byte reads.
 __device__ __forceinline__ uint64_t eb_select(const eb_dev_index& x, uint64_t r, int c) {
-    const uint32_t* dir = x.sel_dir + (uint64_t)c * x.sel_stride;
+    const uint32_t* dir = x.sel_dir + (c == 0 ? x.sel_off[0] : c == 1 ? x.sel_off[1] : c == 2 ? x.sel_off[2] : x.sel_off[3]);
     uint64_t m = r >> EB_SEL_SHIFT;
     uint64_t lo = dir[m], hi = dir[m + 1]; // the answer lies in a block of [lo, hi]
     uint64_t g = lo + (((r - (m << EB_SEL_SHIFT)) * (hi - lo + 1)) >> EB_SEL_SHIFT);

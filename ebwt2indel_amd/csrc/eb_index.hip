@@ -81,7 +81,8 @@ void* eb_scratch_get(int device, size_t bytes, size_t* capacity) {
             return p;
         }
     }
-    size_t cap = bytes + bytes / 8 + 256;
+    size_t slack = bytes / 8 < (64u << 20) ? bytes / 8 : (64u << 20); // room to be reused by a slightly larger request
+    size_t cap = bytes + slack + 256;
     void* p = nullptr;
     if (hipMalloc(&p, cap) != hipSuccess) {
         eb_scratch_release(device); // give cached blocks back and retry once
@@ -207,15 +208,16 @@ __global__ void __launch_bounds__(TILE_BLOCKS) k_write_counters(uint4* __restric
 
 // Select directory: for each letter, the block that holds its (m * 1024)-th occurrence.  A block holds at most
 // 128 occurrences, so at most one sample per letter falls into it.
-__global__ void __launch_bounds__(256) k_select_dir(eb_dev_index x, uint32_t* __restrict__ dir, uint64_t stride) {
+__global__ void __launch_bounds__(256) k_select_dir(eb_dev_index x, uint32_t* __restrict__ dir) {
     uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= x.n_blocks) return;
     uint32_t p = block_letter_counts(x.chunks + (b << 2));
     for (int c = 0; c < 4; ++c) {
         uint64_t before = eb_block_count(x, b, c);
         uint64_t in_block = (p >> (8 * c)) & 0xFFu;
-        uint64_t m = (before + (1ull << EB_SEL_SHIFT) - 1) >> EB_SEL_SHIFT; // first sample index >= before
-        if ((m << EB_SEL_SHIFT) < before + in_block) dir[(uint64_t)c * stride + m] = (uint32_t)b;
+        // samples m * 2^EB_SEL_SHIFT that fall on an occurrence inside this block
+        for (uint64_t m = (before + (1ull << EB_SEL_SHIFT) - 1) >> EB_SEL_SHIFT; (m << EB_SEL_SHIFT) < before + in_block; ++m)
+            dir[x.sel_off[c] + m] = (uint32_t)b;
     }
 }
 __global__ void __launch_bounds__(256) k_fill_u32(uint32_t* __restrict__ p, uint64_t n, uint32_t v) {
@@ -309,11 +311,15 @@ static int finish_index(eb_index* h, unsigned long long* d_bad, const uint8_t* d
     EB_HIP(hipFree(d_tmp));
     // select directory (eb_select): samples beyond a letter's last occurrence point at the last block
     if (h->n_blocks > 0xFFFFFFFFull) { eb_set_error("BWT too large for the 32-bit select directory"); return EB_ERR_ARG; }
-    h->sel_stride = (h->n >> EB_SEL_SHIFT) + 3;
-    EB_HIP(hipMalloc(&h->d_sel_dir, 4 * h->sel_stride * sizeof(uint32_t)));
-    h->device_bytes += 4 * h->sel_stride * sizeof(uint32_t);
-    hipLaunchKernelGGL(k_fill_u32, dim3(1024), dim3(256), 0, h->stream, h->d_sel_dir, 4 * h->sel_stride, (uint32_t)(h->n_blocks - 1));
-    hipLaunchKernelGGL(k_select_dir, dim3((unsigned)((h->n_blocks + 255) / 256)), dim3(256), 0, h->stream, h->dev(), h->d_sel_dir, h->sel_stride);
+    uint64_t sel_entries = 0;
+    for (int c = 0; c < 4; ++c) {
+        h->sel_off[c] = sel_entries;
+        sel_entries += (tot[c] >> EB_SEL_SHIFT) + 3;
+    }
+    EB_HIP(hipMalloc(&h->d_sel_dir, sel_entries * sizeof(uint32_t)));
+    h->device_bytes += sel_entries * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_fill_u32, dim3(1024), dim3(256), 0, h->stream, h->d_sel_dir, sel_entries, (uint32_t)(h->n_blocks - 1));
+    hipLaunchKernelGGL(k_select_dir, dim3((unsigned)((h->n_blocks + 255) / 256)), dim3(256), 0, h->stream, h->dev(), h->d_sel_dir);
     EB_HIP(hipStreamSynchronize(h->stream));
     EB_HIP(hipGetLastError());
     uint64_t n_term = h->n - (tot[0] + tot[1] + tot[2] + tot[3]);

@@ -34,8 +34,8 @@ struct eb_index {
     hipStream_t stream = nullptr;
     uint4* d_chunks = nullptr;
     uint64_t* d_super = nullptr;
-    uint32_t* d_sel_dir = nullptr; // 4 * sel_stride entries
-    uint64_t sel_stride = 0;
+    uint32_t* d_sel_dir = nullptr; // select directory, letter c at sel_off[c]
+    uint64_t sel_off[4] = {0, 0, 0, 0};
     uint64_t n = 0, n_blocks = 0, n_super = 0;
     uint64_t F[4] = {0, 0, 0, 0};
     uint8_t term = '#';
@@ -49,7 +49,7 @@ struct eb_index {
         d.n_blocks = n_blocks;
         for (int i = 0; i < 4; ++i) d.F[i] = F[i];
         d.sel_dir = d_sel_dir;
-        d.sel_stride = sel_stride;
+        for (int i = 0; i < 4; ++i) d.sel_off[i] = sel_off[i];
         d.term = term;
         return d;
     }

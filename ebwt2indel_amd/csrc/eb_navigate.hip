@@ -495,26 +495,32 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
         EB_HIP(hipMemGetInfo(&free_b, &total_b));
         if (arena_bytes > free_b / 2) arena_bytes = free_b / 2;
     }
-    void* d_arena = nullptr;
-    {
-        hipError_t e = hipMalloc(&d_arena, arena_bytes);
-        if (e != hipSuccess) { eb_set_error("traversal arena allocation failed (%llu bytes): %s", (unsigned long long)arena_bytes, hipGetErrorString(e)); return EB_ERR_NOMEM; }
-    }
-    struct Guard3 { void* p; ~Guard3() { (void)hipFree(p); } } guard3{d_arena};
+    // The traversal's temporaries come from the library's scratch cache and go back to it: a freed multi-GB block is wiped by
+    // the driver, and the next large hipMalloc in the process then waits for that wipe (seconds -- measured 3.4 s for
+    // the 7.55 GB below right after a previous call's hipFree); recycled blocks cost nothing and phase 4 reuses them.
+    const int device = b1->device;
+    size_t arena_cap = 0;
+    void* d_arena = eb_scratch_get(device, arena_bytes, &arena_cap);
+    if (!d_arena) { eb_set_error("traversal arena allocation failed (%llu bytes)", (unsigned long long)arena_bytes); return EB_ERR_NOMEM; }
+    struct Guard3 { int dev; void* p; size_t cap; ~Guard3() { eb_scratch_put(dev, p, cap); } } guard3{device, d_arena, arena_cap};
     lap("arena allocated");
     // Threshold bits are collected either as one byte per position (plain stores; needs n bytes of spare HBM) or, when
     // memory is short, as interleaved bit words set with atomics; both are converted to the two bit vectors afterwards.
     uint64_t* d_kr = nullptr;
     uint8_t* d_lcpb = nullptr;
     const size_t lcpb_bytes = eb_bit_alloc_words(n) * 64;
+    size_t thr_cap = 0;
     {
         size_t free_b = 0, total_b = 0;
         EB_HIP(hipMemGetInfo(&free_b, &total_b));
         bool want_bytes = env_u64("EB_NAV_BYTES", 1) != 0 && lcpb_bytes + (4ull << 30) < free_b;
-        if (want_bytes && hipMalloc(&d_lcpb, lcpb_bytes) != hipSuccess) d_lcpb = nullptr;
-        if (!d_lcpb) EB_HIP(hipMalloc(&d_kr, eb_bit_alloc_words(n) * 16));
+        if (want_bytes) d_lcpb = static_cast<uint8_t*>(eb_scratch_get(device, lcpb_bytes, &thr_cap));
+        if (!d_lcpb) {
+            d_kr = static_cast<uint64_t*>(eb_scratch_get(device, eb_bit_alloc_words(n) * 16, &thr_cap));
+            if (!d_kr) { eb_set_error("threshold word allocation failed"); return EB_ERR_NOMEM; }
+        }
     }
-    struct Guard4 { void* a; void* b; ~Guard4() { if (a) (void)hipFree(a); if (b) (void)hipFree(b); } } guard4{d_kr, d_lcpb};
+    struct Guard4 { int dev; void* p; size_t cap; ~Guard4() { eb_scratch_put(dev, p, cap); } } guard4{device, d_lcpb ? (void*)d_lcpb : (void*)d_kr, thr_cap};
     if (d_lcpb) EB_HIP(hipMemsetAsync(d_lcpb, 0, lcpb_bytes, f->stream));
     else EB_HIP(hipMemsetAsync(d_kr, 0, eb_bit_alloc_words(n) * 16, f->stream));
     p.lcpb = d_lcpb;

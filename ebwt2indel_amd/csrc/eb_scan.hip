@@ -427,8 +427,8 @@ __global__ void __launch_bounds__(256) k_extend(eb_dev_index x1, eb_dev_index x2
     if (p.mode == 2) { L = side ? s.b1 : s.b0; R = side ? s.e1 : s.e0; } else { L = s.b; R = s.e; }
     uint64_t* out = left + ch * (uint64_t)left_words;
     // LF(range, c)
-    uint64_t a = eb_rank4_quad(x, L, j);
-    uint64_t bq = R > L ? eb_rank4_quad(x, R, j) : a;
+    uint64_t a, bq;
+    eb_rank4_quad_pair(x, L, R, j, a, bq);
     uint64_t Fc = pick4(x.F, c);
     L = Fc + __shfl((unsigned long long)a, qbase + c);
     R = Fc + __shfl((unsigned long long)bq, qbase + c);
@@ -436,8 +436,7 @@ __global__ void __launch_bounds__(256) k_extend(eb_dev_index x1, eb_dev_index x2
     uint32_t have = 1;
     uint64_t word = c; // base 0 = the frequent symbol itself
     while (have < (uint32_t)p.k_left) {
-        a = eb_rank4_quad(x, L, j);
-        bq = R > L ? eb_rank4_quad(x, R, j) : a;
+        eb_rank4_quad_pair(x, L, R, j, a, bq);
         uint64_t len = bq - a;
         // arg-max over the quad, ties to the smaller letter (stable descending sort, ebwt2InDel.cpp:252-255)
         uint64_t bl = len;
