@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--coverage", type=float, default=30.0)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--rank-queries", type=int, default=1 << 27)
+    ap.add_argument("--rank-queries", type=int, default=1 << 28)   # SURVEY.md §8(d) metric 2: 2^28 uniform random positions
     ap.add_argument("--cpu-sample-reads", type=int, default=130_000, help="reads in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-pipeline", action="store_true", help="finish every step before the next begins (profiling: under rocprofv3 the "
                     "overlapped record download runs as a blit kernel and slows the scan it overlaps)")
@@ -127,7 +127,11 @@ def main():
     sim._hip_copy_to_host(head, dev_ebwt.ptr, probe_len)
     dev_ebwt.free()
     t1 = time.time()
-    flags = api.navigate_one_bwt(bwt, p)
+    # N > 1: the traversal itself is split over the ranks (Weiner-link subtrees) and the bit vectors are combined by
+    # one all-reduce each; N = 1: the plain build.
+    flags = ebd.navigate_sharded(bwt, p, device=comm_dev) if use_dist else api.navigate_one_bwt(bwt, p)
+    if use_dist:
+        dist.barrier()
     t_nav = time.time() - t1
     ns = flags.stats
     if rank == 0:
@@ -302,7 +306,7 @@ def main():
             "cpu_baseline": cpu,
             "phase4_device_ms": {"scan": round(scan_sum_ms, 4), "extend": round(float(np.mean(ext_ms)), 4),
                                  "right": round(float(np.mean(right_ms)), 4), "total": round(float(np.mean(tot_ms)), 4)},
-            "phases23_gpu": {"seconds": round(t_nav, 4), "traversal_seconds": round(float(ns.seconds_leaves + ns.seconds_nodes), 4),
+            "phases23_gpu": {"seconds": round(t_nav, 4), "traversal_shards": world if use_dist else 1, "traversal_seconds": round(float(ns.seconds_leaves + ns.seconds_nodes), 4),
                              "rank_gq_per_s": round(ns.rank_queries / max(ns.seconds_leaves + ns.seconds_nodes, 1e-9) / 1e9, 2), "nodes": int(ns.nodes), "leaves": int(ns.leaves), "rank_queries": int(ns.rank_queries),
                              "launches": int(ns.batches), "e2e_positions_per_s": round(n / (t_nav + ms_per_step * 1e-3), 1)},
         }

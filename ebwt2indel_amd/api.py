@@ -170,6 +170,25 @@ class Flags:
         return cls(h, st)
 
     @classmethod
+    def build_shard(cls, bwt1: DnaBwt, bwt2: Optional[DnaBwt], K: int, k_right: int, shard: int, n_shards: int) -> "Flags":
+        """This shard's share of phases 2-3 (eb_flags_build_shard): the vectors of all shards must be summed and
+        finalize() called before use -- distributed.navigate_sharded does both."""
+        h = C.c_void_p()
+        st = _lib.NavStats()
+        _check(lib().eb_flags_build_shard(bwt1._h, bwt2._h if bwt2 is not None else None, K, k_right, shard, n_shards, C.byref(h), C.byref(st)))
+        return cls(h, st)
+
+    def device_vectors(self):
+        """([thrK, thrR, minima, da] device pointers, 0 where absent; words per vector)."""
+        ptrs = (C.c_void_p * 4)()
+        w = C.c_uint64()
+        _check(lib().eb_flags_device_vectors(self._h, ptrs, C.byref(w)))
+        return [int(p or 0) for p in ptrs], int(w.value)
+
+    def finalize(self):
+        _check(lib().eb_flags_finalize(self._h))
+
+    @classmethod
     def from_host(cls, n: int, thrK, thrR, minima, da=None, device: int = 0) -> "Flags":
         h = C.c_void_p()
         arrs = [np.ascontiguousarray(a, dtype=np.uint64) if a is not None else None for a in (thrK, thrR, minima, da)]

@@ -34,6 +34,7 @@ struct NavCounters {
 
 struct NavParams {
     int K, k_right;
+    int write;     // 0: expand only (the shared top of the tree on shards other than 0): no bit writes, no statistics
     uint8_t* lcpb; // one byte per position (bit 0: LCP >= K, bit 1: LCP >= k_right) or null -> interleaved bit words `kr`
 };
 
@@ -95,7 +96,7 @@ __global__ void __launch_bounds__(256) k_leaves(eb_dev_index x1, eb_dev_index x2
             uint64_t Fj = pick4(x1.F, j);
             child.l = Fj + a; child.r = Fj + b; child.depth = L.depth + 1;
             keep = active && (b - a >= 2);
-            if (active && L.r > L.l + 1) {
+            if (active && p.write && L.r > L.l + 1) {
                 // LCP slots l+1 .. r-1 of the leaf: the quad splits the touched words
                 uint64_t lo = L.l + 1, hi = L.r;
                 bool setK = (int64_t)L.depth >= p.K, setR = (int64_t)L.depth >= p.k_right;
@@ -114,14 +115,14 @@ __global__ void __launch_bounds__(256) k_leaves(eb_dev_index x1, eb_dev_index x2
                 }
                 if (j == 0) n_lcp += hi - lo;
             }
-            if (active && j == 0) { ++n_leaf; n_rank += L.r > L.l ? 2 : 1; }
+            if (active && p.write && j == 0) { ++n_leaf; n_rank += L.r > L.l ? 2 : 1; }
         } else {
             uint64_t a1 = eb_rank4_quad(x1, L.l1, j), b1 = eb_rank4_quad(x1, L.r1 > L.l1 ? L.r1 : L.l1, j);
             uint64_t a2 = eb_rank4_quad(x2, L.l2, j), b2 = eb_rank4_quad(x2, L.r2 > L.l2 ? L.r2 : L.l2, j);
             uint64_t F1 = pick4(x1.F, j), F2 = pick4(x2.F, j);
             child.l1 = F1 + a1; child.r1 = F1 + b1; child.l2 = F2 + a2; child.r2 = F2 + b2; child.depth = L.depth + 1;
             keep = active && ((b1 - a1) + (b2 - a2) >= 2);
-            if (active) {
+            if (active && p.write) {
                 uint64_t s1 = L.l1 + L.l2, s2 = L.l2 + L.r1, e = L.r1 + L.r2;
                 bool setK = (int64_t)L.depth >= p.K, setR = (int64_t)L.depth >= p.k_right;
                 // words of [s1, e): DA = 1 on [s2,e) (second collection), LCP bits on [s1+1, e)
@@ -198,7 +199,7 @@ __global__ void __launch_bounds__(256) k_nodes(eb_dev_index x1, eb_dev_index x2,
         } else {
             for (int k = 0; k < 6; ++k) m[k] = N.a[k] + N.b[k];
         }
-        if (active) {
+        if (active && p.write) {
             // lane j looks after border j (right end of child TERM,A,C,G)
             uint64_t lo = 0, hi = 0;
             for (int k = 0; k < 4; ++k) if (j == (uint32_t)k) { lo = m[k]; hi = m[k + 1]; }
@@ -242,7 +243,7 @@ __global__ void __launch_bounds__(256) k_nodes(eb_dev_index x1, eb_dev_index x2,
             for (int k = 0; k < 5; ++k) kids += child.b[k + 1] > child.b[k];
             child.depth = N.depth + 1;
             keep = active && kids >= 2; // number_of_children (include.hpp:760-768)
-            if (active && j == 0) {
+            if (active && p.write && j == 0) {
                 ++n_node;
                 n_rank += 1;
                 for (int k = 1; k < 6; ++k) n_rank += N.b[k] != N.b[k - 1]; // the reference shares the query of equal neighbours
@@ -257,7 +258,7 @@ __global__ void __launch_bounds__(256) k_nodes(eb_dev_index x1, eb_dev_index x2,
             for (int k = 0; k < 5; ++k) kids += (child.a[k + 1] > child.a[k]) || (child.b[k + 1] > child.b[k]); // include.hpp:784-792
             child.depth = N.depth + 1;
             keep = active && kids >= 2;
-            if (active && j == 0) {
+            if (active && p.write && j == 0) {
                 ++n_node;
                 n_rank += 2;
                 for (int k = 1; k < 6; ++k) n_rank += (N.a[k] != N.a[k - 1]) + (N.b[k] != N.b[k - 1]);
@@ -271,6 +272,38 @@ __global__ void __launch_bounds__(256) k_nodes(eb_dev_index x1, eb_dev_index x2,
     stage.flush(out, out_cap, &cnt->pushed);
     const uint64_t st[EB_NAV_STATS] = {0, n_node, n_lcp, n_da, n_min, n_rank};
     flush_stats(stat_rows, st);
+}
+
+// Sharded traversal: at the first level wide enough, every shard keeps the records whose interval start
+// hashes to it -- content-addressed, so all shards agree whatever order their own launches left the level in.
+// W2 >= 0: second word added to the key (two-BWT records: the merged interval start).
+template <typename Item, int W2>
+__global__ void __launch_bounds__(256) k_keep_shard(const Item* __restrict__ in, uint64_t count, Item* __restrict__ out, uint32_t shard, uint32_t n_shards,
+                                                   NavCounters* cnt) {
+    const uint64_t total = (uint64_t)gridDim.x * blockDim.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < count; base += total) {
+        uint64_t i = base + threadIdx.x;
+        bool keep = false;
+        if (i < count) {
+            const uint64_t* w = reinterpret_cast<const uint64_t*>(in + i);
+            uint64_t key = w[0];
+            if (W2 >= 0) key += w[W2 < 0 ? 0 : W2];
+            uint64_t h = key * 0x9E3779B97F4A7C15ull;
+            h ^= h >> 29;
+            keep = (uint32_t)(h % n_shards) == shard;
+        }
+        unsigned long long mask = __ballot(keep);
+        unsigned long long wbase = 0;
+        if (lane == 0 && mask) wbase = atomicAdd(&cnt->pushed, (unsigned long long)__popcll(mask));
+        wbase = __shfl(wbase, 0);
+        if (keep) {
+            uint64_t slot = wbase + (uint64_t)__popcll(mask & ((1ull << lane) - 1ull));
+            const uint4* src = reinterpret_cast<const uint4*>(in + i);
+            uint4* dst = reinterpret_cast<uint4*>(out + slot);
+            for (int k = 0; k < (int)(sizeof(Item) / 16); ++k) dst[k] = src[k];
+        }
+    }
 }
 
 // after navigation: kr[2w], kr[2w+1] -> thrK[w], thrR[w] (streaming, ~1 ms per 7.5 G positions)
@@ -333,6 +366,11 @@ struct Drain {
     Item* d_stack[2] = {nullptr, nullptr};
     uint64_t cap = 0, batch = 0, top[2] = {0, 0};
     uint64_t launches = 0, max_top = 0;
+    // sharded traversal: the tree is walked breadth-first (identically on every shard, bits written by shard 0 only)
+    // down to the first level of at least split_min * n_shards records, which is then cut by k_keep_shard
+    uint32_t shard = 0, n_shards = 1;
+    uint64_t split_min = 4096;
+    bool split_done = false;
 
     // The stacks live in one arena shared by both phases (allocating HBM costs ~20 ms per GB, so the arena is sized from
     // the batch, not from n).  A depth-first drain needs a few batches of room (observed: < 7 batches at 7.55 G
@@ -359,20 +397,37 @@ struct Drain {
         ++top[0];
         return EB_OK;
     }
-    template <typename Launch>
+    template <int W2, typename Launch>
     int run(NavCounters* d_cnt, unsigned long long* h_pushed /* pinned */, Launch launch) {
         const bool trace = getenv("EB_NAV_TRACE") != nullptr;
         const double t_start = now_s();
         int recent = 0; // stack that received records last
         while (top[0] + top[1] > 0) {
             const int src = top[recent] > 0 ? recent : 1 - recent, dst = 1 - src;
+            if (n_shards > 1 && !split_done && top[dst] == 0 && top[src] >= split_min * n_shards) {
+                // so far every launch expanded one whole level: cut it
+                EB_HIP(hipMemsetAsync(&d_cnt->pushed, 0, sizeof(unsigned long long), stream));
+                uint64_t blocks = (top[src] + 255) / 256;
+                hipLaunchKernelGGL((k_keep_shard<Item, W2>), dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, stream, d_stack[src], top[src],
+                                   d_stack[dst], shard, n_shards, d_cnt);
+                EB_HIP(hipGetLastError());
+                EB_HIP(hipMemcpyAsync(h_pushed, &d_cnt->pushed, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+                EB_HIP(hipStreamSynchronize(stream));
+                if (trace) fprintf(stderr, "[nav] shard %u/%u keeps %llu of %llu records\n", shard, n_shards, (unsigned long long)*h_pushed, (unsigned long long)top[src]);
+                top[src] = 0;
+                top[dst] = *h_pushed;
+                recent = dst;
+                split_done = true;
+                continue;
+            }
+            const int write = (n_shards == 1 || split_done || shard == 0) ? 1 : 0;
             uint64_t room = cap - top[dst];
             uint64_t B = top[src] < batch ? top[src] : batch;
             if (4 * B > room) B = room / 4; // a record has at most four children
             if (B == 0) { eb_set_error("traversal stack capacity exceeded (cap %llu records)", (unsigned long long)cap); return EB_ERR_NOMEM; }
             const uint64_t base = top[src] - B;
             EB_HIP(hipMemsetAsync(&d_cnt->pushed, 0, sizeof(unsigned long long), stream));
-            launch(d_stack[src] + base, B, d_stack[dst] + top[dst], room);
+            launch(d_stack[src] + base, B, d_stack[dst] + top[dst], room, write);
             EB_HIP(hipGetLastError());
             EB_HIP(hipMemcpyAsync(h_pushed, &d_cnt->pushed, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
             EB_HIP(hipStreamSynchronize(stream));
@@ -447,8 +502,10 @@ int eb_flags_build_da_rank(eb_flags* f) {
     return EB_OK;
 }
 
-extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_right, eb_flags** out, eb_nav_stats* stats) {
+static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_right, uint32_t shard, uint32_t n_shards, eb_flags** out,
+                            eb_nav_stats* stats) {
     if (!b1 || !out) { eb_set_error("null argument"); return EB_ERR_ARG; }
+    if (n_shards == 0 || shard >= n_shards) { eb_set_error("shard %u of %u", shard, n_shards); return EB_ERR_ARG; }
     if (b2 && b2->device != b1->device) { eb_set_error("both indexes must live on the same device"); return EB_ERR_ARG; }
     *out = nullptr;
     EB_HIP(hipSetDevice(b1->device));
@@ -480,7 +537,8 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
 
     eb_dev_index x1 = b1->dev(), x2 = b2 ? b2->dev() : b1->dev();
     eb_dev_flags df = f->dev();
-    NavParams p{K, k_right, nullptr};
+    NavParams p{K, k_right, 1, nullptr};
+    const uint64_t split_min = env_u64("EB_NAV_SPLIT_MIN", 4096);
     hipStream_t st = f->stream;
     const uint64_t batch_max = env_u64("EB_NAV_BATCH", 16ull << 20);
     // one arena for both traversals: two stacks of EB_NAV_STACK_BATCHES / 2 batches of the largest record each
@@ -535,10 +593,13 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
         { // phase 2 (ebwt2InDel.cpp:577-615); first_leaf = {[0,F_A), 0} (dna_bwt.hpp:313-317)
             Drain<Leaf1> d;
             d.device = b1->device; d.stream = st;
+            d.shard = shard; d.n_shards = n_shards; d.split_min = split_min;
             if ((rc = d.init(d_arena, arena_bytes, n, batch_max)) != EB_OK) return rc;
             if ((rc = d.push_host(Leaf1{0, b1->F[0], 0, 0})) != EB_OK) return rc;
-            rc = d.run(d_cnt, h_pushed, [&](Leaf1* in, uint64_t cnt, Leaf1* o, uint64_t ocap) {
-                hipLaunchKernelGGL(k_leaves<1>, dim3(nav_grid(cnt)), dim3(256), 0, st, x1, x2, df, d_kr, p, in, cnt, o, ocap, d_cnt, d_rows);
+            rc = d.run<-1>(d_cnt, h_pushed, [&](Leaf1* in, uint64_t cnt, Leaf1* o, uint64_t ocap, int write) {
+                NavParams q = p;
+                q.write = write;
+                hipLaunchKernelGGL(k_leaves<1>, dim3(nav_grid(cnt)), dim3(256), 0, st, x1, x2, df, d_kr, q, in, cnt, o, ocap, d_cnt, d_rows);
             });
             if (rc != EB_OK) return rc;
             launches += d.launches;
@@ -548,11 +609,14 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
         { // phase 3 (ebwt2InDel.cpp:622-673); root (dna_bwt.hpp:296-308)
             Drain<Node1> d;
             d.device = b1->device; d.stream = st;
+            d.shard = shard; d.n_shards = n_shards; d.split_min = split_min;
             if ((rc = d.init(d_arena, arena_bytes, n, batch_max)) != EB_OK) return rc;
             Node1 root{{0, b1->F[0], b1->F[1], b1->F[2], b1->F[3], b1->n}, 0, 0};
             if ((rc = d.push_host(root)) != EB_OK) return rc;
-            rc = d.run(d_cnt, h_pushed, [&](Node1* in, uint64_t cnt, Node1* o, uint64_t ocap) {
-                hipLaunchKernelGGL(k_nodes<1>, dim3(nav_grid(cnt)), dim3(256), 0, st, x1, x2, df, d_kr, p, in, cnt, o, ocap, d_cnt, d_rows);
+            rc = d.run<-1>(d_cnt, h_pushed, [&](Node1* in, uint64_t cnt, Node1* o, uint64_t ocap, int write) {
+                NavParams q = p;
+                q.write = write;
+                hipLaunchKernelGGL(k_nodes<1>, dim3(nav_grid(cnt)), dim3(256), 0, st, x1, x2, df, d_kr, q, in, cnt, o, ocap, d_cnt, d_rows);
             });
             if (rc != EB_OK) return rc;
             launches += d.launches;
@@ -562,10 +626,13 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
         { // phase 2 (ebwt2InDel.cpp:708-756)
             Drain<Leaf2> d;
             d.device = b1->device; d.stream = st;
+            d.shard = shard; d.n_shards = n_shards; d.split_min = split_min;
             if ((rc = d.init(d_arena, arena_bytes, n, batch_max)) != EB_OK) return rc;
             if ((rc = d.push_host(Leaf2{0, b1->F[0], 0, b2->F[0], 0, {0, 0, 0}})) != EB_OK) return rc;
-            rc = d.run(d_cnt, h_pushed, [&](Leaf2* in, uint64_t cnt, Leaf2* o, uint64_t ocap) {
-                hipLaunchKernelGGL(k_leaves<2>, dim3(nav_grid(cnt)), dim3(256), 0, st, x1, x2, df, d_kr, p, in, cnt, o, ocap, d_cnt, d_rows);
+            rc = d.run<2>(d_cnt, h_pushed, [&](Leaf2* in, uint64_t cnt, Leaf2* o, uint64_t ocap, int write) {
+                NavParams q = p;
+                q.write = write;
+                hipLaunchKernelGGL(k_leaves<2>, dim3(nav_grid(cnt)), dim3(256), 0, st, x1, x2, df, d_kr, q, in, cnt, o, ocap, d_cnt, d_rows);
             });
             if (rc != EB_OK) return rc;
             launches += d.launches;
@@ -575,17 +642,20 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
         { // phase 3 (ebwt2InDel.cpp:764-823)
             Drain<Node2> d;
             d.device = b1->device; d.stream = st;
+            d.shard = shard; d.n_shards = n_shards; d.split_min = split_min;
             if ((rc = d.init(d_arena, arena_bytes, n, batch_max)) != EB_OK) return rc;
             Node2 root{{0, b1->F[0], b1->F[1], b1->F[2], b1->F[3], b1->n}, {0, b2->F[0], b2->F[1], b2->F[2], b2->F[3], b2->n}, 0, {0, 0, 0}};
             if ((rc = d.push_host(root)) != EB_OK) return rc;
-            rc = d.run(d_cnt, h_pushed, [&](Node2* in, uint64_t cnt, Node2* o, uint64_t ocap) {
-                hipLaunchKernelGGL(k_nodes<2>, dim3(nav_grid(cnt)), dim3(256), 0, st, x1, x2, df, d_kr, p, in, cnt, o, ocap, d_cnt, d_rows);
+            rc = d.run<6>(d_cnt, h_pushed, [&](Node2* in, uint64_t cnt, Node2* o, uint64_t ocap, int write) {
+                NavParams q = p;
+                q.write = write;
+                hipLaunchKernelGGL(k_nodes<2>, dim3(nav_grid(cnt)), dim3(256), 0, st, x1, x2, df, d_kr, q, in, cnt, o, ocap, d_cnt, d_rows);
             });
             if (rc != EB_OK) return rc;
             launches += d.launches;
         }
         s.seconds_nodes = now_s() - t1;
-        if ((rc = eb_flags_build_da_rank(f)) != EB_OK) return rc;
+        if (n_shards == 1 && (rc = eb_flags_build_da_rank(f)) != EB_OK) return rc; // shards: eb_flags_finalize, after the reduction
     }
     if (d_lcpb) hipLaunchKernelGGL(k_pack_lcp, dim3(4096), dim3(256), 0, st, reinterpret_cast<const uint4*>(d_lcpb), f->words, f->d_thrK, f->d_thrR);
     else hipLaunchKernelGGL(k_split_kr, dim3(2048), dim3(256), 0, st, reinterpret_cast<const uint4*>(d_kr), f->words, f->d_thrK, f->d_thrR);
@@ -609,7 +679,7 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
     }
     s.leaves = c.leaves;
     s.nodes = c.nodes;
-    s.lcp_values = c.lcp_values + 1; // the reference starts its counter at 1 (ebwt2InDel.cpp:575)
+    s.lcp_values = c.lcp_values + (shard == 0 ? 1 : 0); // the reference starts its counter at 1 (ebwt2InDel.cpp:575)
     s.da_values = c.da_values;
     s.minima = c.minima;
     s.rank_queries = c.ranks;
@@ -618,6 +688,30 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
     guard.f = nullptr;
     *out = f;
     return EB_OK;
+}
+
+extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_right, eb_flags** out, eb_nav_stats* stats) {
+    return flags_build_impl(b1, b2, K, k_right, 0, 1, out, stats);
+}
+
+extern "C" int eb_flags_build_shard(eb_index* b1, eb_index* b2, int32_t K, int32_t k_right, uint32_t shard, uint32_t n_shards, eb_flags** out,
+                                    eb_nav_stats* stats) {
+    return flags_build_impl(b1, b2, K, k_right, shard, n_shards, out, stats);
+}
+
+extern "C" int eb_flags_device_vectors(eb_flags* f, uint64_t* d_vectors[4], uint64_t* words) {
+    if (!f || !d_vectors || !words) { eb_set_error("null argument"); return EB_ERR_ARG; }
+    d_vectors[0] = f->d_thrK;
+    d_vectors[1] = f->d_thrR;
+    d_vectors[2] = f->d_min;
+    d_vectors[3] = f->d_da;
+    *words = f->words;
+    return EB_OK;
+}
+
+extern "C" int eb_flags_finalize(eb_flags* f) {
+    if (!f) { eb_set_error("null argument"); return EB_ERR_ARG; }
+    return eb_flags_build_da_rank(f);
 }
 
 // '1' -> 1, anything else -> 0: 64 ASCII bytes -> one word (ebwt2InDel.cpp:1503-1508)

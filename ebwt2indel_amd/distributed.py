@@ -94,6 +94,60 @@ def gather_packed(packed, group=None, device=None, dst: int = 0) -> Optional[Lis
     return [memoryview(base[r * cap: r * cap + sizes[r]]) for r in range(world)]
 
 
+class _DeviceWords:
+    """`words` int64 words of device memory at `ptr`, for torch.as_tensor (no copy)."""
+
+    def __init__(self, ptr: int, words: int):
+        self.__cuda_array_interface__ = {"shape": (words,), "typestr": "<i8", "data": (ptr, False), "version": 3, "strides": None}
+
+
+_NAV_COUNTERS = ("leaves", "nodes", "lcp_values", "da_values", "minima", "rank_queries", "batches")
+
+
+def navigate_sharded(bwt1, params, bwt2=None, group=None, device=None):
+    """Phases 2-3 split over the ranks: each rank walks its share of the Weiner-link subtrees
+    (eb_flags_build_shard), then ONE all-reduce per bit vector combines them -- every bit has a single writer over all
+    ranks, so integer SUM == OR (RCCL has no bitwise OR).  `device`: the rank's GPU for nccl (vectors are reduced in
+    place in HBM over xGMI); CPU for gloo (vectors staged through host memory: rehearsal only).  Every rank returns
+    complete Flags; stats hold the job totals (seconds: slowest rank)."""
+    import torch
+    import torch.distributed as dist
+    from . import api
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    fl = api.Flags.build_shard(bwt1, bwt2, params.K, params.k_right, rank, world)
+    if world == 1:
+        fl.finalize()
+        return fl
+    st = fl.stats
+    dev = torch.device("cpu") if device is None else torch.device(device)
+    if dev.type == "cuda":
+        ptrs, words = fl.device_vectors()
+        for ptr in ptrs:
+            if ptr:
+                dist.all_reduce(torch.as_tensor(_DeviceWords(ptr, words), device=dev), op=dist.ReduceOp.SUM, group=group)
+        torch.cuda.current_stream(dev).synchronize()
+        fl.finalize()
+    else:
+        vecs = fl.export()
+        for v in vecs:
+            if v is not None:
+                dist.all_reduce(torch.from_numpy(v.view(np.int64)), op=dist.ReduceOp.SUM, group=group)
+        n = bwt1.n + (bwt2.n if bwt2 is not None else 0)
+        fl.close()
+        fl = api.Flags.from_host(n, *vecs, device=bwt1.device)
+        fl.stats = st
+    cnt = torch.tensor([int(getattr(st, k)) for k in _NAV_COUNTERS], dtype=torch.int64, device=dev)
+    sec = torch.tensor([st.seconds_leaves, st.seconds_nodes], dtype=torch.float64, device=dev)
+    dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(sec, op=dist.ReduceOp.MAX, group=group)
+    for k, v in zip(_NAV_COUNTERS, cnt.tolist()):
+        setattr(st, k, int(v))
+    st.seconds_leaves, st.seconds_nodes = float(sec[0]), float(sec[1])
+    return fl
+
+
 def write_gathered(parts: List[bytes], params, two_samples: bool):
     """Rank 0: shard call sets in rank order -> one .snp text with a running cluster_nr (ebwt2InDel.cpp:52)."""
     from . import api

@@ -129,6 +129,18 @@ typedef struct {
     double   seconds_leaves, seconds_nodes;
 } eb_nav_stats;
 int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_right, eb_flags** out, eb_nav_stats* stats);
+/* Phases 2-3 split over GPUs (no reference counterpart; the reference is one process).  Shard `shard` of `n_shards`
+ * walks its share of the Weiner-link subtrees: all shards expand the top of the tree breadth-first, the first level of
+ * at least 4096 * n_shards records (EB_NAV_SPLIT_MIN) is cut by a hash of each record's interval start, and from there
+ * on a shard follows only its own records.  Above the cut only shard 0 sets bits and counts, below it only the owner:
+ * every bit and every counter has ONE writer over all shards, so the vectors (and eb_nav_stats' counters) of the shards
+ * combine with an integer SUM (== OR) all-reduce -- RCCL has no bitwise OR.  Then call eb_flags_finalize on every rank. */
+int eb_flags_build_shard(eb_index* b1, eb_index* b2, int32_t K, int32_t k_right, uint32_t shard, uint32_t n_shards, eb_flags** out,
+                         eb_nav_stats* stats);
+/* Device pointers of thrK, thrR, minima, da (NULL in one-BWT mode), eb_flags_words() words each, for the reduction. */
+int eb_flags_device_vectors(eb_flags* f, uint64_t* d_vectors[4], uint64_t* words);
+/* After the vectors of a sharded build were combined: rebuilds what is derived from them (the DA rank directory). */
+int eb_flags_finalize(eb_flags* f);
 /* Mode 3: ASCII '0'/'1' document array, '1' -> 1, anything else -> 0 (ebwt2InDel.cpp:1503-1508). */
 int eb_flags_set_da(eb_flags* f, const uint8_t* ascii01, uint64_t n);
 /* Bit i of each vector is bit (i & 63) of word (i >> 6).  Any pointer may be NULL.

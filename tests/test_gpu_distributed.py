@@ -1,0 +1,109 @@
+"""Multi-GPU path on the one-GPU box: (1) the shards of phases 2-3 (eb_flags_build_shard) partition the bit vectors --
+disjoint, union bit-exact equal to the unsharded build, counters add up; (2) two gloo ranks sharing GPU 0 run the whole
+N>1 pipeline of the product (sharded traversal + vector reduction, sharded scan, gather, writer) and rank 0 must
+reproduce the reference's .snp byte for byte.  (RCCL refuses two ranks on one device, so the collectives are
+rehearsed with gloo; the nccl leg differs only in where the tensors live.)"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from ebwt2indel_amd import api
+from tests.conftest import CASES, golden_bytes
+
+pytestmark = pytest.mark.gpu
+
+_COUNTERS = ("leaves", "nodes", "lcp_values", "da_values", "minima", "rank_queries")
+
+
+def _case(name):
+    return [c for c in CASES if c["name"] == name][0]
+
+
+@pytest.mark.parametrize("name", ["m1_default", "m2_het_default"])
+@pytest.mark.parametrize("n_shards,split_min", [(2, 1), (3, 4), (8, 16), (2, 1 << 40)])
+def test_shards_partition_the_flag_vectors(monkeypatch, name, n_shards, split_min):
+    case = _case(name)
+    inp = case["inputs"]
+    p = api.make_params(case["args"])
+    b1 = api.DnaBwt(golden_bytes(inp["bwt1"]), term=p.term)
+    b2 = api.DnaBwt(golden_bytes(inp["bwt2"]), term=p.term) if case["mode"] == 2 else None
+    whole = api.Flags.build(b1, b2, p.K, p.k_right)
+    want = whole.export()
+    monkeypatch.setenv("EB_NAV_SPLIT_MIN", str(split_min))      # tiny inputs: cut the tree after a handful of records
+    acc = [np.zeros_like(v) if v is not None else None for v in want]
+    totals = dict.fromkeys(_COUNTERS, 0)
+    busy = 0
+    for s in range(n_shards):
+        part = api.Flags.build_shard(b1, b2, p.K, p.k_right, s, n_shards)
+        vecs = part.export()
+        for a, v in zip(acc, vecs):
+            if a is not None:
+                assert not (a & v).any(), "a bit was written by two shards"
+                a |= v
+        for k in _COUNTERS:
+            totals[k] += int(getattr(part.stats, k))
+        busy += int(part.stats.nodes > 0)
+    for a, w in zip(acc, want):
+        if w is not None:
+            assert np.array_equal(a, w)
+    for k in _COUNTERS:
+        assert totals[k] == int(getattr(whole.stats, k)), k
+    if split_min < 100:
+        assert busy == n_shards                                   # the cut really spread the work
+    else:
+        assert busy == 1                                          # tree never wide enough: shard 0 alone writes
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, case, out_path):
+    import torch.distributed as dist
+
+    from ebwt2indel_amd import distributed as ebd
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["EB_NAV_SPLIT_MIN"] = "8"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        inp = case["inputs"]
+        p = api.make_params(case["args"])
+        b1 = api.DnaBwt(golden_bytes(inp["bwt1"]), term=p.term)
+        b2 = api.DnaBwt(golden_bytes(inp["bwt2"]), term=p.term) if case["mode"] == 2 else None
+        fl = ebd.navigate_sharded(b1, p, b2)                       # sharded traversal + SUM all-reduce of the vectors
+        whole = api.Flags.build(b1, b2, p.K, p.k_right)
+        for got, want in zip(fl.export(), whole.export()):
+            assert (got is None) == (want is None)
+            if want is not None:
+                assert np.array_equal(got, want)
+        for k in _COUNTERS:
+            assert int(getattr(fl.stats, k)) == int(getattr(whole.stats, k)), k
+        if case["mode"] == 3:
+            fl.set_da(golden_bytes(inp["da"]))
+        n = b1.n + (b2.n if b2 is not None else 0)
+        b, e = ebd.shard_range(n, rank, world)
+        calls = api.scan_clusters(b1, fl, p, bwt2=b2, begin=b, end=e)
+        parts = ebd.gather_packed(calls.blob())
+        if rank == 0:
+            text, cluster_nr, events, total = ebd.write_gathered(parts, p, case["mode"] != 1)
+            with open(out_path, "wb") as f:
+                f.write(text)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["m1_default", "m2_het_default", "m3_hom_default"])
+def test_two_ranks_one_gpu_reproduce_golden(tmp_path, name):
+    import torch.multiprocessing as mp
+
+    case = _case(name)
+    out = tmp_path / "out.snp"
+    mp.spawn(_worker, args=(2, _free_port(), case, str(out)), nprocs=2, join=True)
+    assert out.read_bytes() == golden_bytes(case["snp"])
