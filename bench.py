@@ -137,8 +137,7 @@ def main():
     if rank == 0:
         log(f"[bench] index {t_index*1e3:.1f} ms ({bwt.device_bytes/1e9:.2f} GB); phases 2-3 on GPU {t_nav:.3f}s: {ns.nodes} nodes, {ns.leaves} leaves, "
             f"{ns.rank_queries} rank queries in {ns.batches} launches; traversals {ns.seconds_leaves + ns.seconds_nodes:.3f}s -> "
-            f"{ns.rank_queries/max(ns.seconds_leaves + ns.seconds_nodes,1e-9)/1e9:.2f} GQ/s in situ (the rest of the wall time is HBM allocation: a large "
-            f"hipMalloc right after the generator's hipFree waits for the driver to wipe the freed memory)")
+            f"{ns.rank_queries/max(ns.seconds_leaves + ns.seconds_nodes,1e-9)/1e9:.2f} GQ/s in situ (wall time also covers HBM allocation and, for N > 1, the all-reduce of the bit vectors)")
     assert ns.lcp_values == n, "phases 2-3 did not cover every LCP slot"
 
     begin, end = ebd.shard_range(n, rank, world)
