@@ -26,6 +26,7 @@ struct eb_dev_index {
     uint64_t n;             // symbols
     uint64_t n_blocks;      // ceil((n+1)/128)
     uint64_t F[4];          // F_A,F_C,F_G,F_T
+    const uint4* xy;         // code planes x,y of every 64 positions {x lo, x hi, y lo, y hi}: the scan's 2-bit view (may be null)
     const uint32_t* sel_dir; // select directory: block of every EB_SEL_SAMPLE-th occurrence of each letter
     uint64_t sel_off[4];     // first directory entry of each letter
     uint32_t term;          // ASCII terminator
@@ -35,6 +36,7 @@ struct eb_dev_flags {
     uint64_t* thrK;   // LCP[i] >= K
     uint64_t* thrR;   // LCP[i] >= k_right
     uint64_t* minima; // local LCP minimum
+    const uint64_t* flag; // thrK & ~minima, the only combination phase 4 reads (derived once, eb_flags_derive)
     uint64_t* da;     // document array (may be null)
     const uint64_t* da_rank; // ones before each group of 8 words (two-BWT mode), may be null
     uint64_t n;

@@ -224,7 +224,29 @@ __global__ void __launch_bounds__(256) k_fill_u32(uint32_t* __restrict__ p, uint
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) p[i] = v;
 }
 
+// scan planes: the x and y code planes of each 64 positions, side by side (16 bytes), without the TERM plane and the
+// counters the streaming scan never looks at
+__global__ void __launch_bounds__(256) k_scan_planes(const uint4* __restrict__ chunks, uint64_t n_words, uint4* __restrict__ xy) {
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
+        uint4 c0 = chunks[2 * w], c1 = chunks[2 * w + 1];
+        xy[w] = make_uint4(c0.x, c1.x, c0.y, c1.y);
+    }
+}
+
 // ------------------------------------------------------------------ host side
+
+int eb_index_scan_planes(eb_index* h) {
+    if (h->d_xy) return EB_OK;
+    EB_HIP(hipSetDevice(h->device));
+    const uint64_t n_words = h->n_blocks * 2;
+    hipError_t e = hipMalloc(&h->d_xy, n_words * sizeof(uint4));
+    if (e != hipSuccess) { eb_set_error("scan plane allocation failed (%llu bytes): %s", (unsigned long long)(n_words * 16), hipGetErrorString(e)); return EB_ERR_NOMEM; }
+    hipLaunchKernelGGL(k_scan_planes, dim3(4096), dim3(256), 0, h->stream, h->d_chunks, n_words, h->d_xy);
+    EB_HIP(hipStreamSynchronize(h->stream));
+    EB_HIP(hipGetLastError());
+    h->device_bytes += n_words * sizeof(uint4);
+    return EB_OK;
+}
 
 static int index_alloc(uint64_t n, uint8_t term, int device, eb_index** out) {
     int ndev = eb_device_count();
@@ -415,6 +437,7 @@ extern "C" void eb_index_destroy(eb_index* h) {
     if (h->d_chunks) (void)hipFree(h->d_chunks);
     if (h->d_super) (void)hipFree(h->d_super);
     if (h->d_sel_dir) (void)hipFree(h->d_sel_dir);
+    if (h->d_xy) (void)hipFree(h->d_xy);
     eb_scan_ctx_destroy(h->scan_ctx);
     eb_scratch_release(h->device);
     if (h->stream) (void)hipStreamDestroy(h->stream);

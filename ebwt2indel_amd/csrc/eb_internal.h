@@ -34,6 +34,7 @@ struct eb_index {
     hipStream_t stream = nullptr;
     uint4* d_chunks = nullptr;
     uint64_t* d_super = nullptr;
+    uint4* d_xy = nullptr;         // scan planes (eb_index_scan_planes), built on first use by phase 4 in modes 1 / 3
     uint32_t* d_sel_dir = nullptr; // select directory, letter c at sel_off[c]
     uint64_t sel_off[4] = {0, 0, 0, 0};
     uint64_t n = 0, n_blocks = 0, n_super = 0;
@@ -48,6 +49,7 @@ struct eb_index {
         d.n = n;
         d.n_blocks = n_blocks;
         for (int i = 0; i < 4; ++i) d.F[i] = F[i];
+        d.xy = d_xy;
         d.sel_dir = d_sel_dir;
         for (int i = 0; i < 4; ++i) d.sel_off[i] = sel_off[i];
         d.term = term;
@@ -60,11 +62,14 @@ struct eb_flags {
     hipStream_t stream = nullptr;
     uint64_t n = 0, words = 0;
     uint64_t *d_thrK = nullptr, *d_thrR = nullptr, *d_min = nullptr, *d_da = nullptr, *d_da_rank = nullptr;
+    uint64_t* d_flag = nullptr; // thrK & ~minima
+    bool derived = false;       // d_flag / d_da_rank match the vectors (false between a sharded build and eb_flags_finalize)
     eb_dev_flags dev() const {
         eb_dev_flags f;
         f.thrK = d_thrK;
         f.thrR = d_thrR;
         f.minima = d_min;
+        f.flag = d_flag;
         f.da = d_da;
         f.da_rank = d_da_rank;
         f.n = n;
@@ -107,6 +112,10 @@ int eb_scan4_exclusive(uint64_t* d_vec4, uint64_t count, uint64_t* d_tmp, hipStr
 
 // (re)builds d_da_rank from d_da
 int eb_flags_build_da_rank(eb_flags* f);
+// (re)builds everything derived from the vectors: d_flag and d_da_rank
+int eb_flags_derive(eb_flags* f);
+// builds the scan planes of an index if absent (eb_index.hip)
+int eb_index_scan_planes(eb_index* h);
 int eb_flags_alloc(uint64_t n, int device, bool with_da, eb_flags** out);
 
 // Caching device-scratch allocator (eb_index.hip).  hipMalloc / hipFree cost 0.1-1 ms each and hipFree synchronises

@@ -471,8 +471,8 @@ int eb_flags_alloc(uint64_t n, int device, bool with_da, eb_flags** out) {
     f->words = eb_bit_words(n);
     size_t bytes = eb_bit_alloc_words(n) * 8;
     hipError_t e = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking);
-    uint64_t** vecs[4] = {&f->d_thrK, &f->d_thrR, &f->d_min, with_da ? &f->d_da : nullptr};
-    for (int i = 0; i < 4 && e == hipSuccess; ++i) {
+    uint64_t** vecs[5] = {&f->d_thrK, &f->d_thrR, &f->d_min, with_da ? &f->d_da : nullptr, &f->d_flag};
+    for (int i = 0; i < 5 && e == hipSuccess; ++i) {
         if (!vecs[i]) continue;
         e = hipMalloc(vecs[i], bytes);
         if (e == hipSuccess) e = hipMemsetAsync(*vecs[i], 0, bytes, f->stream);
@@ -499,6 +499,23 @@ int eb_flags_build_da_rank(eb_flags* f) {
     EB_HIP(hipStreamSynchronize(f->stream));
     EB_HIP(hipGetLastError());
     EB_HIP(hipFree(d_vec));
+    return EB_OK;
+}
+
+__global__ void __launch_bounds__(256) k_fuse_flags(const uint64_t* __restrict__ thrK, const uint64_t* __restrict__ minima, uint64_t words,
+                                                   uint64_t* __restrict__ flag) {
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < words; w += (uint64_t)gridDim.x * blockDim.x) flag[w] = thrK[w] & ~minima[w];
+}
+
+int eb_flags_derive(eb_flags* f) {
+    EB_HIP(hipSetDevice(f->device));
+    // phase 4 reads LCP_threshold[2i] only as `LCP_threshold[2i] && !LCP_minima[i]` (ebwt2InDel.cpp:1618,1632): one word instead of two
+    hipLaunchKernelGGL(k_fuse_flags, dim3(2048), dim3(256), 0, f->stream, f->d_thrK, f->d_min, eb_bit_alloc_words(f->n), f->d_flag);
+    EB_HIP(hipStreamSynchronize(f->stream));
+    EB_HIP(hipGetLastError());
+    int rc = eb_flags_build_da_rank(f);
+    if (rc != EB_OK) return rc;
+    f->derived = true;
     return EB_OK;
 }
 
@@ -655,7 +672,6 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
             launches += d.launches;
         }
         s.seconds_nodes = now_s() - t1;
-        if (n_shards == 1 && (rc = eb_flags_build_da_rank(f)) != EB_OK) return rc; // shards: eb_flags_finalize, after the reduction
     }
     if (d_lcpb) hipLaunchKernelGGL(k_pack_lcp, dim3(4096), dim3(256), 0, st, reinterpret_cast<const uint4*>(d_lcpb), f->words, f->d_thrK, f->d_thrR);
     else hipLaunchKernelGGL(k_split_kr, dim3(2048), dim3(256), 0, st, reinterpret_cast<const uint4*>(d_kr), f->words, f->d_thrK, f->d_thrR);
@@ -663,6 +679,7 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
     EB_HIP(hipStreamSynchronize(st));
     EB_HIP(hipGetLastError());
     lap("threshold bits packed");
+    if (n_shards == 1 && (rc = eb_flags_derive(f)) != EB_OK) return rc; // shards: eb_flags_finalize, after the reduction
     NavCounters c;
     memset(&c, 0, sizeof c);
     {
@@ -711,7 +728,7 @@ extern "C" int eb_flags_device_vectors(eb_flags* f, uint64_t* d_vectors[4], uint
 
 extern "C" int eb_flags_finalize(eb_flags* f) {
     if (!f) { eb_set_error("null argument"); return EB_ERR_ARG; }
-    return eb_flags_build_da_rank(f);
+    return eb_flags_derive(f);
 }
 
 // '1' -> 1, anything else -> 0: 64 ASCII bytes -> one word (ebwt2InDel.cpp:1503-1508)
@@ -788,7 +805,7 @@ extern "C" int eb_flags_import(uint64_t n, int device, const uint64_t* thrK, con
     if (e == hipSuccess) e = hipMemcpy(f->d_min, minima, bytes, hipMemcpyHostToDevice);
     if (e == hipSuccess && da) e = hipMemcpy(f->d_da, da, bytes, hipMemcpyHostToDevice);
     if (e != hipSuccess) { eb_set_error("flag upload failed: %s", hipGetErrorString(e)); eb_flags_destroy(f); return EB_ERR_DEVICE; }
-    if (da && (rc = eb_flags_build_da_rank(f)) != EB_OK) { eb_flags_destroy(f); return rc; }
+    if ((rc = eb_flags_derive(f)) != EB_OK) { eb_flags_destroy(f); return rc; }
     *out = f;
     return EB_OK;
 }
@@ -796,7 +813,7 @@ extern "C" int eb_flags_import(uint64_t n, int device, const uint64_t* thrK, con
 extern "C" void eb_flags_destroy(eb_flags* f) {
     if (!f) return;
     if (f->device >= 0) (void)hipSetDevice(f->device);
-    uint64_t* v[5] = {f->d_thrK, f->d_thrR, f->d_min, f->d_da, f->d_da_rank};
+    uint64_t* v[6] = {f->d_thrK, f->d_thrR, f->d_min, f->d_da, f->d_da_rank, f->d_flag};
     for (auto p : v)
         if (p) (void)hipFree(p);
     if (f->stream) (void)hipStreamDestroy(f->stream);

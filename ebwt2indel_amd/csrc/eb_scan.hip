@@ -48,7 +48,7 @@ struct ScanCounters {
     unsigned long long hist[201];
 };
 
-__device__ __forceinline__ uint64_t flag_word(const eb_dev_flags& f, uint64_t w) { return f.thrK[w] & ~f.minima[w]; }
+__device__ __forceinline__ uint64_t flag_word(const eb_dev_flags& f, uint64_t w) { return f.flag[w]; }
 
 // ones in DA[0,p)
 __device__ __forceinline__ uint64_t da_rank(const eb_dev_flags& f, uint64_t p) {
@@ -102,10 +102,10 @@ struct Planes {
 };
 
 __device__ __forceinline__ Planes load_planes(const eb_dev_index& x, uint64_t w) {
-    uint4 c0 = x.chunks[2 * w], c1 = x.chunks[2 * w + 1];
+    uint4 v = x.xy[w]; // scan planes: 16 bytes instead of the two 16-byte chunks (TERM plane and counters are not needed here)
     Planes p;
-    p.x = (uint64_t)c0.x | ((uint64_t)c1.x << 32);
-    p.y = (uint64_t)c0.y | ((uint64_t)c1.y << 32);
+    p.x = (uint64_t)v.x | ((uint64_t)v.y << 32);
+    p.y = (uint64_t)v.z | ((uint64_t)v.w << 32);
     return p;
 }
 
@@ -214,35 +214,70 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
             }
             return false;
         };
-        // ---- pass 1 over the closing positions: run statistics, and which clusters need their histogram.
-        // Most clusters hold one letter only (no variant, no read start): both code planes are constant over
-        // the cluster, at most one letter can be frequent and the one-sample filter drops it (:961).  Keeping
-        // the rare others for a second loop means the wave does not drag every lane through the analysis.
-        uint64_t todo = 0;
-        while (ends) {
-            uint32_t bit = (uint32_t)__ffsll((long long)ends) - 1u;
-            ends &= ends - 1;
-            uint64_t b, mcur, mprv;
-            bool in_regs = run_at(bit, b, mcur, mprv);
-            uint64_t len = base + bit - b;
-            ++n_runs;
-            n_bases += len;
-            if (len <= 200 && !(p.dbg & 1u)) atomicAdd(&sh_hist[len], 1u);
-            if (len < p.min_len) continue;
-            ++n_clusters;
-            if (MODE == 1 && in_regs) {
-                // Two letters with >= mcov rows each need >= mcov rows that differ from the majority letter, and a row
-                // that differs does so in code plane x or y: (minority of x) + (minority of y) >= mcov is necessary.
-                // One-letter clusters and clusters with a stray TERM or two fall out here with two popcounts.
-                uint32_t ones_x = (uint32_t)__popcll(cur.x & mcur) + (uint32_t)__popcll(prv.x & mprv);
-                uint32_t ones_y = (uint32_t)__popcll(cur.y & mcur) + (uint32_t)__popcll(prv.y & mprv);
-                uint32_t l32 = (uint32_t)len;
-                uint32_t dx = ones_x < l32 - ones_x ? ones_x : l32 - ones_x;
-                uint32_t dy = ones_y < l32 - ones_y ? ones_y : l32 - ones_y;
-                if (dx + dy < p.mcov) continue;
-            }
-            todo |= 1ull << bit;
+        // ---- pass 1a, bit-parallel: which closing runs contain a change of symbol at all.  A cluster whose rows all carry
+        // the same symbol (no variant, no read start: ~4 of 5) has at most one frequent letter and can never be kept
+        // (:961; two-sample modes need two distinct frequent letters to print anything, see below).  chg marks the
+        // positions i, i+1 of one run that differ; added to the run masks it carries out into exactly the closing
+        // positions of the runs that hold such a pair (a run's mask plus any non-empty subset of it reaches the zero
+        // that ends it and never passes it).
+        uint64_t hot = ends;
+        if (MODE != 2) {
+            uint64_t chg = ((cur.x ^ (cur.x >> 1)) | (cur.y ^ (cur.y >> 1))) & fw & (fw >> 1) & ~(1ull << 63);
+            // the part of a run that lies in the previous word (its top run, bits zbp..63)
+            uint64_t pz = ~pfw;
+            uint32_t zbp = pz ? 64u - (uint32_t)__clzll((long long)pz) : 0u;
+            uint64_t pchg = ((prv.x ^ (prv.x >> 1)) | (prv.y ^ (prv.y >> 1))) & pfw & (pfw >> 1) & ~(1ull << 63);
+            bool prv_hot = !pz || (zbp < 64 && (pchg >> zbp) != 0);          // run reaches beyond the two words: decided later
+            bool joint = (((prv.x >> 63) ^ cur.x) | ((prv.y >> 63) ^ cur.y)) & 1ull; // rows 63 | 0 differ
+            uint64_t inj = ((fw & 1ull) && (pfw >> 63) && (prv_hot || joint)) ? 1ull : 0ull;
+            hot = (fw + chg + inj) & ends;
+            if ((ends & 1ull) && prv_hot) hot |= 1ull;                       // a run that lies in the previous word and closes at bit 0
         }
+        // ---- pass 1b over all closing positions: run statistics only (CLUST_SIZES, counters)
+        n_runs += (uint64_t)__popcll(ends);
+        {
+            const uint64_t pz = ~pfw;
+            const uint32_t plen = pz ? (uint32_t)__clzll((long long)pz) : 64u; // flagged rows at the top of the previous word
+            uint64_t rest = ends;
+            while (rest) {
+                uint32_t bit = (uint32_t)__ffsll((long long)rest) - 1u;
+                rest &= rest - 1;
+                uint64_t zeros = ~fw & ((1ull << bit) - 1ull);
+                uint64_t len;
+                if (zeros) len = bit - (64u - (uint32_t)__clzll((long long)zeros));
+                else if (pz) len = bit + plen;
+                else {
+                    uint64_t b0, m0, m1;
+                    run_at(bit, b0, m0, m1); // walks back through memory
+                    len = base + bit - b0;
+                }
+                n_bases += len;
+                if (len <= 200 && !(p.dbg & 1u)) atomicAdd(&sh_hist[len], 1u);
+                if (len >= p.min_len) ++n_clusters;
+                else hot &= ~(1ull << bit);
+            }
+        }
+        // ---- pass 1c over the clusters that hold a change: two letters with >= mcov rows each need >= mcov rows that
+        // differ from the majority letter, and a row that differs does so in code plane x or y:
+        // (minority of x) + (minority of y) >= mcov is necessary.  Clusters with a stray TERM or two fall out here.
+        uint64_t todo = 0;
+        if (MODE == 2) todo = hot;
+        else
+            while (hot) {
+                uint32_t bit = (uint32_t)__ffsll((long long)hot) - 1u;
+                hot &= hot - 1;
+                uint64_t b, mcur, mprv;
+                bool in_regs = run_at(bit, b, mcur, mprv);
+                if (in_regs) {
+                    uint32_t l32 = (uint32_t)(base + bit - b);
+                    uint32_t ones_x = (uint32_t)__popcll(cur.x & mcur) + (uint32_t)__popcll(prv.x & mprv);
+                    uint32_t ones_y = (uint32_t)__popcll(cur.y & mcur) + (uint32_t)__popcll(prv.y & mprv);
+                    uint32_t dx = ones_x < l32 - ones_x ? ones_x : l32 - ones_x;
+                    uint32_t dy = ones_y < l32 - ones_y ? ones_y : l32 - ones_y;
+                    if (dx + dy < p.mcov) continue;
+                }
+                todo |= 1ull << bit;
+            }
         if (p.dbg & 2u) todo = 0;
         // ---- pass 2: histogram + frequent-symbol filter of the remaining clusters
         while (todo) {
@@ -606,9 +641,14 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
     if (b1->device != f->device || (b2 && b2->device != b1->device)) { eb_set_error("handles live on different devices"); return EB_ERR_ARG; }
     if (b2 && !f->d_da) { eb_set_error("two-BWT mode needs flags built from both indexes"); return EB_ERR_STATE; }
     if (prm->k_left < 1 || prm->k_right < 1 || prm->mcov_out < 1) { eb_set_error("parameters not resolved (call eb_params_resolve)"); return EB_ERR_ARG; }
+    if (!f->derived) { eb_set_error("flags of a sharded build must be combined and finalised first (eb_flags_finalize)"); return EB_ERR_STATE; }
     if (end > n) end = n;
     if (begin > end) begin = end;
     EB_HIP(hipSetDevice(b1->device));
+    if (!b2) { // modes 1 / 3 read symbols in the scan: 2-bit planes, derived from the index on first use
+        int rcp = eb_index_scan_planes(b1);
+        if (rcp != EB_OK) return rcp;
+    }
 
     ScanParams p;
     p.mode = b2 ? 2 : (f->d_da ? 3 : 1);
