@@ -109,56 +109,235 @@ __device__ __forceinline__ Planes load_planes(const eb_dev_index& x, uint64_t w)
     return p;
 }
 
-// K3+K4 fused.  One lane per 64 positions, all loads issued up front and independent of each other:
-// the two flag words (16 B), the two BWT chunks of the same 64 positions (32 B) and, with a document
-// array, its word (8 B) -- 0.75 B (0.875 B) per position, streamed once.  A cluster that begins in the
-// lane's own word or in the previous one (the neighbour lane's registers) gets its symbol histogram from
-// popcounts on registers; only runs longer than that (and the two-BWT mode, whose symbols live in other
-// coordinates) take the memory path.  Persistent grid: counters are flushed once per wave.
+// Geometry of the run that closes at bit `bit` of word w: its begin, and which bits of the word itself (mcur) and of
+// the previous word (mprv) it covers; in_regs = false when it starts further back (then b comes from walking the flag
+// words in memory and the masks are not meaningful).
+struct RunGeom {
+    uint64_t b, mcur, mprv;
+    bool in_regs;
+};
+__device__ __forceinline__ RunGeom run_geometry(const eb_dev_flags& f, uint64_t w, uint64_t fw, uint64_t pfw, uint32_t bit) {
+    RunGeom g;
+    const uint64_t base = w << 6;
+    uint64_t below = (1ull << bit) - 1ull;
+    uint64_t zeros = ~fw & below;
+    g.mprv = 0;
+    if (zeros) {
+        uint32_t zb = 64u - (uint32_t)__clzll((long long)zeros); // first flagged bit after the nearest 0
+        g.b = base + zb;
+        g.mcur = below & (~0ull << zb);
+        g.in_regs = true;
+        return g;
+    }
+    if (~pfw) {
+        uint32_t zb = 64u - (uint32_t)__clzll((long long)~pfw);   // 1..64
+        g.b = base - 64 + zb;
+        g.mcur = below;
+        g.mprv = zb < 64 ? ~0ull << zb : 0ull;
+        g.in_regs = true;
+        return g;
+    }
+    // run longer than the two words at hand: walk back through memory
+    g.mcur = 0;
+    g.in_regs = false;
+    uint64_t ww = w - 1;
+    g.b = 0;
+    while (ww > 0) {
+        --ww;
+        uint64_t z = ~flag_word(f, ww);
+        if (z) { g.b = (ww << 6) + (64u - (uint32_t)__clzll((long long)z)); break; }
+    }
+    return g;
+}
+
+// K3+K4 fused.  One lane per 64 positions; all loads of a tile are issued up front and are independent of each other:
+// the fused flag word (8 B), the scan planes of the same 64 positions (16 B) and, with a document array, its word
+// (8 B).  What every run needs (CLUST_SIZES, counters) is done by the lane that streams the word, with bit tricks on
+// registers.  What only a few runs need is NOT done there -- a wave would wait for its few busy lanes -- but handed
+// over through two small per-wave queues in LDS and worked off 64 at a time, one run per lane:
+//   hot queue : clusters that contain a change of symbol (found bit-parallel, ~1 in 5)   -> two-popcount necessary test
+//   todo queue: clusters that pass it (~1 in 30)                                         -> histogram, frequent letters, record
+// A queued run is a (word, bit) pair; its lane reloads the two flag words and planes (cache hits: just streamed).
+// Runs longer than the two words (and the two-BWT mode, whose symbols live in other coordinates) take the memory path.
+// Persistent grid; statistics leave as one row per workgroup.
 template <int MODE>
 __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, ScanParams p, uint64_t w_lo,
                                              uint64_t w_count, Survivor* __restrict__ surv, uint64_t surv_cap,
                                              ScanCounters* __restrict__ cnt, unsigned long long* __restrict__ partial) {
     __shared__ unsigned int sh_hist[201];
-    constexpr int STAGE = 256; // survivors are ~1 per 10^4 positions: a workgroup rarely fills this before its last tile
+    constexpr int STAGE = 128; // survivors are ~1 per 10^4 positions: a workgroup rarely fills this before its next flush
     __shared__ uint4 s_buf[STAGE * (sizeof(Survivor) / 16)];
     __shared__ uint32_t s_count;
     __shared__ unsigned long long s_base;
+    __shared__ unsigned long long q_hot[4][128], q_todo[4][128]; // per wave; entry = word << 6 | bit
     Stager<Survivor, STAGE> stage{s_buf, &s_count, &s_base};
     for (int k = threadIdx.x; k < 201; k += blockDim.x) sh_hist[k] = 0;
     if (threadIdx.x == 0) s_count = 0;
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
     const uint64_t hi_pos = p.end < p.n ? p.end : p.n;
     const uint64_t n_bwt_words = (x1.n_blocks << 1); // 64-symbol words backed by the packed BWT
     uint64_t n_runs = 0, n_clusters = 0, n_bases = 0;
+    uint32_t hot_n = 0, todo_n = 0;                   // queue fill, the same in every lane of the wave
     const uint64_t tiles = (w_count + 255) / 256;
+    constexpr bool local_syms = MODE != 2;
+
+    // ---- a queued cluster: histogram + frequent-symbol filter -> survivor record
+    auto analyse = [&](bool have, unsigned long long entry) {
+        if (!have) return;
+        const uint64_t w = entry >> 6;
+        const uint32_t bit = (uint32_t)(entry & 63u);
+        const uint64_t fw = flag_word(f, w), pfw = w ? flag_word(f, w - 1) : 0ull;
+        RunGeom g = run_geometry(f, w, fw, pfw, bit);
+        Survivor s;
+        s.b = g.b; s.e = (w << 6) + bit; s.b0 = s.e0 = s.b1 = s.e1 = 0; s.fmask0 = s.fmask1 = 0; s.pad = 0;
+        uint32_t c0[4], c1[4];
+        bool keep;
+        if constexpr (MODE == 2) {
+            // symbols live in the two BWTs' own coordinates: rank differences on both
+            s.b1 = da_rank(f, s.b); s.e1 = da_rank(f, s.e);
+            s.b0 = s.b - s.b1; s.e0 = s.e - s.e1;
+            hist_by_rank(x1, s.b0, s.e0, c0);
+            hist_by_rank(x2, s.b1, s.e1, c1);
+            s.fmask0 = frequent_mask(c0, p.mcov);
+            s.fmask1 = frequent_mask(c1, p.mcov);
+            int n0 = __popc(s.fmask0), n1 = __popc(s.fmask1);
+            keep = n0 > 0 && n1 > 0 && !(p.q > 0 && (n0 > p.q || n1 > p.q)); // :870-880
+            keep = keep && __popc(s.fmask0 | s.fmask1) > 1; // see can_emit_pairs() below
+        } else if (!g.in_regs) {
+            // run longer than two words: its histogram needs memory; k_long_runs does that later so that the
+            // streaming kernel carries no rank code (registers) for this rare case
+            s.fmask0 = EB_NEEDS_HIST;
+            keep = true;
+            atomicAdd(&cnt->n_long, 1ull);
+        } else {
+            Planes cur = {0, 0}, prv = {0, 0};
+            if (w < n_bwt_words) cur = load_planes(x1, w);
+            if (g.mprv) prv = load_planes(x1, w - 1);
+            if constexpr (MODE == 1) {
+                for (int c = 0; c < 4; ++c) c0[c] = (uint32_t)__popcll(cur.letter(c) & g.mcur) + (uint32_t)__popcll(prv.letter(c) & g.mprv);
+                s.fmask0 = frequent_mask(c0, p.mcov);
+                int nf = __popc(s.fmask0);
+                keep = nf >= 2 && !(p.q > 0 && nf > p.q); // ebwt2InDel.cpp:961-966
+            } else {
+                const uint64_t da_cur = f.da[w], da_prv = g.mprv ? f.da[w - 1] : 0ull;
+                for (int c = 0; c < 4; ++c) {
+                    uint64_t lc = cur.letter(c) & g.mcur, lp = prv.letter(c) & g.mprv;
+                    c1[c] = (uint32_t)__popcll(lc & da_cur) + (uint32_t)__popcll(lp & da_prv);
+                    c0[c] = (uint32_t)__popcll(lc & ~da_cur) + (uint32_t)__popcll(lp & ~da_prv);
+                }
+                s.fmask0 = frequent_mask(c0, p.mcov);
+                s.fmask1 = frequent_mask(c1, p.mcov);
+                int n0 = __popc(s.fmask0), n1 = __popc(s.fmask1);
+                keep = n0 > 0 && n1 > 0 && !(p.q > 0 && (n0 > p.q || n1 > p.q)); // :1042-1052
+                // Pairs are emitted only for contexts whose last characters -- the frequent symbols themselves -- differ
+                // (:921, :1083), and an empty pair list leaves cluster_nr untouched (:1250): a cluster whose two sides
+                // share one single frequent letter can never reach the output, so its contexts are not computed.
+                keep = keep && __popc(s.fmask0 | s.fmask1) > 1;
+            }
+        }
+        if (keep) {
+            // LDS staging (no per-survivor global atomic); a full buffer spills straight to the list
+            uint32_t slot = atomicAdd(&s_count, 1u);
+            if (slot < (uint32_t)STAGE) {
+                const uint4* src = reinterpret_cast<const uint4*>(&s);
+                for (int k = 0; k < (int)(sizeof(Survivor) / 16); ++k) s_buf[slot * (sizeof(Survivor) / 16) + k] = src[k];
+            } else {
+                unsigned long long gl = atomicAdd(&cnt->nsurv, 1ull);
+                if (gl < surv_cap) surv[gl] = s;
+            }
+        }
+    };
+    // Queue primitives.  Only this wave touches its queues and every lane executes every call (wave-uniform control
+    // flow), so the fill counters live in registers; LDS operations of one wave complete in order.
+    auto todo_push = [&](bool have, unsigned long long entry) {
+        unsigned long long m = __ballot(have);
+        if (have) q_todo[wave][todo_n + (uint32_t)__popcll(m & lanes_below)] = entry;
+        todo_n += (uint32_t)__popcll(m);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (todo_n >= 64u) {
+            todo_n -= 64u;
+            unsigned long long e = q_todo[wave][todo_n + lane];
+            __builtin_amdgcn_wave_barrier();
+            if (!(p.dbg & 2u)) analyse(true, e);
+        }
+    };
+    // a queued cluster that holds a change of symbol: two letters with >= mcov rows each need >= mcov rows that differ
+    // from the majority letter, and a row that differs does so in code plane x or y:
+    // (minority of x) + (minority of y) >= mcov is necessary.  Clusters with a stray TERM or two fall out here.
+    auto filter = [&](bool have, unsigned long long entry) {
+        bool pass = false;
+        if (have) {
+            const uint64_t w = entry >> 6;
+            const uint32_t bit = (uint32_t)(entry & 63u);
+            const uint64_t fw = flag_word(f, w), pfw = w ? flag_word(f, w - 1) : 0ull;
+            // geometry without the memory walk: a run that fills the whole previous word goes on unfiltered
+            const uint64_t below = (1ull << bit) - 1ull;
+            const uint64_t zeros = ~fw & below;
+            uint64_t mcur = below, mprv = 0;
+            uint32_t len;
+            pass = true;
+            bool in_regs = true;
+            if (zeros) {
+                uint32_t zb = 64u - (uint32_t)__clzll((long long)zeros);
+                mcur = below & (~0ull << zb);
+                len = bit - zb;
+            } else if (~pfw) {
+                uint32_t zb = 64u - (uint32_t)__clzll((long long)~pfw);
+                mprv = zb < 64 ? ~0ull << zb : 0ull;
+                len = bit + 64u - zb;
+            } else {
+                in_regs = false;
+                len = 0;
+            }
+            if (in_regs) {
+                Planes cur = {0, 0}, prv = {0, 0};
+                if (w < n_bwt_words) cur = load_planes(x1, w);
+                if (mprv) prv = load_planes(x1, w - 1);
+                uint32_t ones_x = (uint32_t)__popcll(cur.x & mcur) + (uint32_t)__popcll(prv.x & mprv);
+                uint32_t ones_y = (uint32_t)__popcll(cur.y & mcur) + (uint32_t)__popcll(prv.y & mprv);
+                uint32_t dx = ones_x < len - ones_x ? ones_x : len - ones_x;
+                uint32_t dy = ones_y < len - ones_y ? ones_y : len - ones_y;
+                pass = dx + dy >= p.mcov;
+            }
+        }
+        todo_push(pass, entry);
+    };
+    auto hot_push = [&](bool have, unsigned long long entry) {
+        unsigned long long m = __ballot(have);
+        if (have) q_hot[wave][hot_n + (uint32_t)__popcll(m & lanes_below)] = entry;
+        hot_n += (uint32_t)__popcll(m);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (hot_n >= 64u) {
+            hot_n -= 64u;
+            unsigned long long e = q_hot[wave][hot_n + lane];
+            __builtin_amdgcn_wave_barrier();
+            filter(true, e);
+        }
+    };
+
     // Everything a lane needs for one tile; all loads are independent of each other (the extra "previous
     // word" loads of lane 0 included), so they are in flight together.
     struct TileData {
-        uint64_t fw, da_cur, l0_pfw, l0_da;
+        uint64_t fw, l0_pfw;
         Planes cur, l0_prv;
     };
-    constexpr bool local_syms = MODE != 2;
     auto load_tile = [&](uint64_t tile) -> TileData {
         TileData d;
-        d.fw = d.da_cur = d.l0_pfw = d.l0_da = 0;
+        d.fw = d.l0_pfw = 0;
         d.cur = {0, 0};
         d.l0_prv = {0, 0};
         uint64_t t = tile * 256 + threadIdx.x;
         if (tile < tiles && t < w_count) {
             uint64_t w = w_lo + t;
             d.fw = flag_word(f, w);
-            if (local_syms) {
-                if (w < n_bwt_words) d.cur = load_planes(x1, w);
-                if (MODE == 3) d.da_cur = f.da[w];
-            }
+            if (local_syms && w < n_bwt_words) d.cur = load_planes(x1, w);
             if (lane == 0 && w > 0) {
                 d.l0_pfw = flag_word(f, w - 1);
-                if (local_syms) {
-                    d.l0_prv = load_planes(x1, w - 1);
-                    if (MODE == 3) d.l0_da = f.da[w - 1];
-                }
+                if (local_syms) d.l0_prv = load_planes(x1, w - 1);
             }
         }
         return d;
@@ -171,52 +350,22 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
         uint64_t w = w_lo + (active ? t : 0);
         uint64_t fw = td.fw;
         Planes cur = td.cur, prv;
-        uint64_t da_cur = td.da_cur, da_prv;
         // previous word: neighbour lane's registers; lane 0 fetched it from memory
         uint64_t pfw = __shfl_up((unsigned long long)fw, 1);
         prv.x = __shfl_up((unsigned long long)cur.x, 1);
         prv.y = __shfl_up((unsigned long long)cur.y, 1);
-        da_prv = __shfl_up((unsigned long long)da_cur, 1);
-        if (lane == 0) { pfw = td.l0_pfw; prv = td.l0_prv; da_prv = td.l0_da; }
-        uint64_t ends = active ? ~fw & ((fw << 1) | (pfw >> 63)) : 0ull; // positions e with flag[e]=0 and flag[e-1]=1
+        if (lane == 0) { pfw = td.l0_pfw; prv = td.l0_prv; }
+        const uint64_t ea = active ? ~fw & ((fw << 1) | (pfw >> 63)) : 0ull; // positions e with flag[e]=0 and flag[e-1]=1
         // keep closing positions inside [begin,end) and below n (a run still open at n-1 is dropped, ebwt2InDel.cpp:1609-1655)
+        uint64_t ends = ea;
         uint64_t base = w << 6;
         if (base < p.begin) ends &= (p.begin - base >= 64) ? 0ull : (~0ull << (p.begin - base));
         if (base + 64 > hi_pos) ends &= (hi_pos <= base) ? 0ull : (~0ull >> (base + 64 - hi_pos));
-        if (p.dbg & 4u) { n_runs += (uint64_t)__popcll(ends); ends = 0; }
-        // Geometry of the run that closes at bit `bit`: begin, and which bits of the lane's own word (mcur)
-        // and of the previous word (mprv) it covers; in_regs = false when it starts further back.
-        auto run_at = [&](uint32_t bit, uint64_t& b, uint64_t& mcur, uint64_t& mprv) -> bool {
-            uint64_t below = (1ull << bit) - 1ull;
-            uint64_t zeros = ~fw & below;
-            mprv = 0;
-            if (zeros) {
-                uint32_t zb = 64u - (uint32_t)__clzll((long long)zeros); // first flagged bit after the nearest 0
-                b = base + zb;
-                mcur = below & (~0ull << zb);
-                return true;
-            }
-            if (~pfw) {
-                uint32_t zb = 64u - (uint32_t)__clzll((long long)~pfw);   // 1..64
-                b = base - 64 + zb;
-                mcur = below;
-                mprv = zb < 64 ? ~0ull << zb : 0ull;
-                return true;
-            }
-            // run longer than the two words at hand: walk back through memory
-            mcur = 0;
-            uint64_t ww = w - 1;
-            b = 0;
-            while (ww > 0) {
-                --ww;
-                uint64_t g = ~flag_word(f, ww);
-                if (g) { b = (ww << 6) + (64u - (uint32_t)__clzll((long long)g)); break; }
-            }
-            return false;
-        };
-        // ---- pass 1a, bit-parallel: which closing runs contain a change of symbol at all.  A cluster whose rows all carry
-        // the same symbol (no variant, no read start: ~4 of 5) has at most one frequent letter and can never be kept
-        // (:961; two-sample modes need two distinct frequent letters to print anything, see below).  chg marks the
+        n_runs += (uint64_t)__popcll(ends);
+        if (p.dbg & 4u) continue;
+        // ---- bit-parallel: which closing runs contain a change of symbol at all.  A cluster whose rows all carry the
+        // same symbol (no variant, no read start: ~4 of 5) has at most one frequent letter and can never be kept
+        // (:961; two-sample modes need two distinct frequent letters to print anything, see analyse()).  chg marks the
         // positions i, i+1 of one run that differ; added to the run masks it carries out into exactly the closing
         // positions of the runs that hold such a pair (a run's mask plus any non-empty subset of it reaches the zero
         // that ends it and never passes it).
@@ -233,120 +382,91 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
             hot = (fw + chg + inj) & ends;
             if ((ends & 1ull) && prv_hot) hot |= 1ull;                       // a run that lies in the previous word and closes at bit 0
         }
-        // ---- pass 1b over all closing positions: run statistics only (CLUST_SIZES, counters)
-        n_runs += (uint64_t)__popcll(ends);
+        // ---- run statistics of every closing position (CLUST_SIZES, counters).  The flagged rows between two
+        // consecutive closing positions are exactly the run that closes at the second one, so a run's length is the
+        // difference of two prefix popcounts; the word is walked as two 32-bit halves (single-instruction bit ops, and a
+        // wave waits for the busiest lane of each half rather than of the whole word).
         {
-            const uint64_t pz = ~pfw;
-            const uint32_t plen = pz ? (uint32_t)__clzll((long long)pz) : 64u; // flagged rows at the top of the previous word
-            uint64_t rest = ends;
-            while (rest) {
-                uint32_t bit = (uint32_t)__ffsll((long long)rest) - 1u;
-                rest &= rest - 1;
-                uint64_t zeros = ~fw & ((1ull << bit) - 1ull);
-                uint64_t len;
-                if (zeros) len = bit - (64u - (uint32_t)__clzll((long long)zeros));
-                else if (pz) len = bit + plen;
-                else {
-                    uint64_t b0, m0, m1;
-                    run_at(bit, b0, m0, m1); // walks back through memory
-                    len = base + bit - b0;
+            uint64_t rest = ea;
+            int32_t cprev = 0; // prefix popcount at the previous closing position (negative: rows carried in from the previous word)
+            if (pfw >> 63) {
+                const uint64_t pz = ~pfw;
+                if (pz) cprev = -(int32_t)__clzll((long long)pz);
+                else if (rest) {
+                    // the first closing run reaches beyond the previous word: its length comes from memory
+                    uint32_t bit = (uint32_t)__ffsll((long long)rest) - 1u;
+                    rest &= rest - 1;
+                    if ((ends >> bit) & 1ull) {
+                        RunGeom g = run_geometry(f, w, fw, pfw, bit);
+                        uint64_t len = base + bit - g.b;
+                        n_bases += len;
+                        if (len <= 200 && !(p.dbg & 1u)) atomicAdd(&sh_hist[len], 1u);
+                        if (len >= p.min_len) ++n_clusters;
+                        else hot &= ~(1ull << bit);
+                    }
+                    cprev = (int32_t)bit; // all rows below `bit` are flagged
                 }
-                n_bases += len;
-                if (len <= 200 && !(p.dbg & 1u)) atomicAdd(&sh_hist[len], 1u);
-                if (len >= p.min_len) ++n_clusters;
-                else hot &= ~(1ull << bit);
             }
+            uint32_t nb32 = 0, nc32 = 0;
+            if (p.dbg & 16u) rest = 0;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const uint32_t h = (uint32_t)(fw >> (32 * half));
+                const int32_t cbase = half ? (int32_t)__popc((uint32_t)fw) : 0;
+                uint32_t eb = (uint32_t)(rest >> (32 * half));
+                const uint32_t er = (uint32_t)(ends >> (32 * half));
+                uint32_t short_bits = 0;
+                while (eb) {
+                    uint32_t bit = (uint32_t)__ffs((int)eb) - 1u;
+                    eb &= eb - 1;
+                    int32_t c = cbase + (int32_t)__popc(h & ((1u << bit) - 1u));
+                    uint32_t len = (uint32_t)(c - cprev);
+                    cprev = c;
+                    if ((er >> bit) & 1u) { // always, except in the words that hold the ends of the scanned range
+                        nb32 += len;
+                        if (len <= 200 && !(p.dbg & 1u)) atomicAdd(&sh_hist[len], 1u);
+                        if (len >= p.min_len) ++nc32;
+                        else short_bits |= 1u << bit;
+                    }
+                }
+                hot &= ~((uint64_t)short_bits << (32 * half));
+            }
+            n_bases += nb32;
+            n_clusters += nc32;
         }
-        // ---- pass 1c over the clusters that hold a change: two letters with >= mcov rows each need >= mcov rows that
-        // differ from the majority letter, and a row that differs does so in code plane x or y:
-        // (minority of x) + (minority of y) >= mcov is necessary.  Clusters with a stray TERM or two fall out here.
-        uint64_t todo = 0;
-        if (MODE == 2) todo = hot;
-        else
-            while (hot) {
-                uint32_t bit = (uint32_t)__ffsll((long long)hot) - 1u;
-                hot &= hot - 1;
-                uint64_t b, mcur, mprv;
-                bool in_regs = run_at(bit, b, mcur, mprv);
-                if (in_regs) {
-                    uint32_t l32 = (uint32_t)(base + bit - b);
-                    uint32_t ones_x = (uint32_t)__popcll(cur.x & mcur) + (uint32_t)__popcll(prv.x & mprv);
-                    uint32_t ones_y = (uint32_t)__popcll(cur.y & mcur) + (uint32_t)__popcll(prv.y & mprv);
-                    uint32_t dx = ones_x < l32 - ones_x ? ones_x : l32 - ones_x;
-                    uint32_t dy = ones_y < l32 - ones_y ? ones_y : l32 - ones_y;
-                    if (dx + dy < p.mcov) continue;
-                }
-                todo |= 1ull << bit;
-            }
-        if (p.dbg & 2u) todo = 0;
-        // ---- pass 2: histogram + frequent-symbol filter of the remaining clusters
-        while (todo) {
-            uint32_t bit = (uint32_t)__ffsll((long long)todo) - 1u;
-            todo &= todo - 1;
-            uint64_t b, mcur, mprv;
-            bool in_regs = run_at(bit, b, mcur, mprv);
-            uint64_t e = base + bit;
-            Survivor s;
-            s.b = b; s.e = e; s.b0 = s.e0 = s.b1 = s.e1 = 0; s.fmask0 = s.fmask1 = 0; s.pad = 0;
-            uint32_t c0[4], c1[4];
-            bool keep;
-            if constexpr (MODE == 2) {
-                // symbols live in the two BWTs' own coordinates: rank differences on both
-                s.b1 = da_rank(f, b); s.e1 = da_rank(f, e);
-                s.b0 = b - s.b1; s.e0 = e - s.e1;
-                hist_by_rank(x1, s.b0, s.e0, c0);
-                hist_by_rank(x2, s.b1, s.e1, c1);
-                s.fmask0 = frequent_mask(c0, p.mcov);
-                s.fmask1 = frequent_mask(c1, p.mcov);
-                int n0 = __popc(s.fmask0), n1 = __popc(s.fmask1);
-                keep = n0 > 0 && n1 > 0 && !(p.q > 0 && (n0 > p.q || n1 > p.q)); // :870-880
-                keep = keep && __popc(s.fmask0 | s.fmask1) > 1; // see can_emit_pairs() below
-            } else if (!in_regs) {
-                // run longer than the lane's two words: its histogram needs memory; k_long_runs does that later so
-                // that the streaming kernel carries no rank code (registers) for this rare case
-                s.fmask0 = EB_NEEDS_HIST;
-                keep = true;
-                atomicAdd(&cnt->n_long, 1ull);
-            } else if constexpr (MODE == 1) {
-                for (int c = 0; c < 4; ++c) c0[c] = (uint32_t)__popcll(cur.letter(c) & mcur) + (uint32_t)__popcll(prv.letter(c) & mprv);
-                s.fmask0 = frequent_mask(c0, p.mcov);
-                int nf = __popc(s.fmask0);
-                keep = nf >= 2 && !(p.q > 0 && nf > p.q); // ebwt2InDel.cpp:961-966
-            } else {
-                for (int c = 0; c < 4; ++c) {
-                    uint64_t lc = cur.letter(c) & mcur, lp = prv.letter(c) & mprv;
-                    c1[c] = (uint32_t)__popcll(lc & da_cur) + (uint32_t)__popcll(lp & da_prv);
-                    c0[c] = (uint32_t)__popcll(lc & ~da_cur) + (uint32_t)__popcll(lp & ~da_prv);
-                }
-                s.fmask0 = frequent_mask(c0, p.mcov);
-                s.fmask1 = frequent_mask(c1, p.mcov);
-                int n0 = __popc(s.fmask0), n1 = __popc(s.fmask1);
-                keep = n0 > 0 && n1 > 0 && !(p.q > 0 && (n0 > p.q || n1 > p.q)); // :1042-1052
-                // Pairs are emitted only for contexts whose last characters -- the frequent symbols themselves -- differ
-                // (:921, :1083), and an empty pair list leaves cluster_nr untouched (:1250): a cluster whose two sides
-                // share one single frequent letter can never reach the output, so its contexts are not computed.
-                keep = keep && __popc(s.fmask0 | s.fmask1) > 1;
-            }
-            if (keep) {
-                // LDS staging (no per-survivor global atomic); a full buffer spills straight to the list
-                uint32_t slot = atomicAdd(&s_count, 1u);
-                if (slot < (uint32_t)STAGE) {
-                    const uint4* src = reinterpret_cast<const uint4*>(&s);
-                    for (int k = 0; k < (int)(sizeof(Survivor) / 16); ++k) s_buf[slot * (sizeof(Survivor) / 16) + k] = src[k];
-                } else {
-                    unsigned long long g = atomicAdd(&cnt->nsurv, 1ull);
-                    if (g < surv_cap) surv[g] = s;
-                }
-            }
+        // ---- hand the clusters that may matter to the queues, one per lane and round
+        if (p.dbg & 8u) hot = 0;
+        for (;;) {
+            bool have = hot != 0;
+            if (!__ballot(have)) break;
+            uint32_t bit = have ? (uint32_t)__ffsll((long long)hot) - 1u : 0u;
+            if (have) hot &= hot - 1;
+            unsigned long long entry = (w << 6) | bit;
+            if (MODE == 2) todo_push(have, entry);
+            else hot_push(have, entry);
         }
         // Survivors are rare (~1 per 10^4 positions = ~2 per tile): empty the staging buffer every 16 tiles.  No
         // barrier in between (they would serialise the tiles of a workgroup); a buffer that fills up earlier sends
-        // the excess straight to the list (above), so the schedule never affects the result.
+        // the excess straight to the list (analyse), so the schedule never affects the result.
         if ((++trips & 15u) == 0) {
             __syncthreads();
             if (threadIdx.x == 0 && s_count > (uint32_t)STAGE) s_count = STAGE;
             stage.flush(surv, surv_cap, &cnt->nsurv);
         }
+    }
+    // what is left in the queues (fewer than 64 each)
+    if (hot_n) {
+        bool have = lane < hot_n;
+        unsigned long long e = have ? q_hot[wave][lane] : 0ull;
+        hot_n = 0;
+        __builtin_amdgcn_wave_barrier();
+        filter(have, e);
+    }
+    if (todo_n) {
+        bool have = lane < todo_n;
+        unsigned long long e = have ? q_todo[wave][lane] : 0ull;
+        todo_n = 0;
+        if (!(p.dbg & 2u)) analyse(have, e);
     }
     __syncthreads();
     if (threadIdx.x == 0 && s_count > (uint32_t)STAGE) s_count = STAGE;
