@@ -329,6 +329,18 @@ static oflags* flags_new(uint64_t n, int with_da) {
     return f;
 }
 uint64_t orc_flags_words(const oflags* f) { return (f->n + 63) / 64; }
+/* Test hook (no reference counterpart): flag vectors given as words, bit i of a vector = bit (i & 63) of word (i >> 6).
+ * Phase 4 only reads the vectors, so any pattern is a legal input to its loop (ebwt2InDel.cpp:1609-1655); the GPU scan
+ * is stressed with patterns the navigation would rarely produce. */
+oflags* orc_flags_import(uint64_t n, const uint64_t* thrK, const uint64_t* thrR, const uint64_t* minima, const uint64_t* da) {
+    oflags* f = flags_new(n, da != NULL);
+    uint64_t w = ((n + 63) / 64) * 8;
+    memcpy(f->thrK, thrK, w);
+    memcpy(f->thrR, thrR, w);
+    memcpy(f->minima, minima, w);
+    if (da) memcpy(f->da, da, w);
+    return f;
+}
 void orc_flags_export(const oflags* f, uint64_t* thrK, uint64_t* thrR, uint64_t* minima, uint64_t* da) {
     uint64_t w = orc_flags_words(f) * 8;
     if (thrK) memcpy(thrK, f->thrK, w);
@@ -913,6 +925,7 @@ void orc_free(void* p) { free(p); }
 /* Phase 4 only, on prebuilt index/flags, over clusters starting in [sb,se).
  * Writes .snp text (continuing *cluster_nr) and, when recs_out != NULL, the cluster records
  * in the product ABI's layout (used to test shard/gather/writer logic without a GPU). */
+static uint64_t g_last_hist[201];
 char* orc_scan(const oindex* x1, const oindex* x2, oflags* f, const eb_params* p, uint64_t sb, uint64_t se,
                uint64_t* cluster_nr, uint64_t* events, uint64_t* out_len,
                eb_cluster** recs_out, eb_chain** chains_out, uint64_t** left_out, uint64_t** right_out, uint64_t* nrecs, uint64_t* nchains,
@@ -929,8 +942,12 @@ char* orc_scan(const oindex* x1, const oindex* x2, oflags* f, const eb_params* p
     if (out_len) *out_len = r.out.len;
     if (recs_out) { *recs_out = r.recs; *chains_out = r.rec_chains; *left_out = r.rec_left; *right_out = r.rec_right; *nrecs = r.nrecs; *nchains = r.nchains; }
     if (stats5) { stats5[0] = r.runs_closed; stats5[1] = r.n_clusters; stats5[2] = r.clust_size; stats5[3] = r.nrecs; stats5[4] = r.chains; }
+    memcpy(g_last_hist, r.hist, sizeof g_last_hist);
     return r.out.p;
 }
+
+/* CLUST_SIZES of the most recent orc_scan (ebwt2InDel.cpp:1636: CLUST_SIZES[len] += len for len <= 200) */
+void orc_last_hist(uint64_t* out201) { memcpy(out201, g_last_hist, sizeof g_last_hist); }
 
 /* bounded rank micro-benchmark for bench.py's cpu_baseline leg: m pseudo-random queries, returns seconds */
 double orc_rank_bench(const oindex* x, uint64_t m, uint64_t seed, uint64_t* checksum) {

@@ -90,6 +90,8 @@ class Oracle:
         L.orc_navigate_two.restype = vp
         L.orc_navigate_two.argtypes = [vp, vp, C.c_int, C.c_int]
         L.orc_flags_set_da.argtypes = [vp, vp, u64]
+        L.orc_flags_import.restype = vp
+        L.orc_flags_import.argtypes = [u64, vp, vp, vp, vp]
         L.orc_flags_words.restype = u64
         L.orc_flags_words.argtypes = [vp]
         L.orc_flags_export.argtypes = [vp, vp, vp, vp, vp]
@@ -101,6 +103,7 @@ class Oracle:
         L.orc_scan.argtypes = [vp, vp, vp, C.POINTER(Params), u64, u64, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64),
                                C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(u64), C.POINTER(u64), vp]
         L.orc_free.argtypes = [vp]
+        L.orc_last_hist.argtypes = [vp]
         L.orc_rank_bench.restype = C.c_double
         L.orc_rank_bench.argtypes = [vp, u64, u64, C.POINTER(u64)]
 
@@ -193,10 +196,20 @@ class OracleIndex:
 class OracleFlags:
     """Phases 2-3 on the CPU oracle: bitvectors as uint64 word arrays."""
 
-    def __init__(self, orc, idx1, idx2=None, K=16, k_right=30, da=None):
+    def __init__(self, orc, idx1, idx2=None, K=16, k_right=30, da=None, vectors=None):
+        """vectors = (thrK, thrR, minima[, da words]) imports given flag words instead of navigating (scan stress tests)."""
         self.o = orc
         self.idx1, self.idx2 = idx1, idx2
         L = orc.lib
+        if vectors is not None:
+            v = [np.ascontiguousarray(a, dtype=np.uint64) if a is not None else None for a in vectors]
+            n = idx1.n + (idx2.n if idx2 is not None else 0)
+            assert all(a is None or len(a) >= (n + 63) // 64 for a in v)
+            self.h = L.orc_flags_import(n, v[0].ctypes.data, v[1].ctypes.data, v[2].ctypes.data,
+                                        v[3].ctypes.data if len(v) > 3 and v[3] is not None else None)
+            self.words = L.orc_flags_words(self.h)
+            self.has_da = len(v) > 3 and v[3] is not None
+            return
         self.h = L.orc_navigate_two(idx1.h, idx2.h, K, k_right) if idx2 is not None else L.orc_navigate_one(idx1.h, K, k_right)
         if da is not None:
             d = _u8(da)
@@ -238,6 +251,9 @@ class OracleFlags:
         L.orc_free(ptr)
         out = dict(text=text, cluster_nr=cn.value, events=ev.value,
                    stats=dict(zip(("runs_closed", "clusters", "bases_in_runs", "survivors", "chains"), (int(x) for x in st))))
+        hist = np.zeros(201, dtype=np.uint64)
+        L.orc_last_hist(hist.ctypes.data)
+        out["hist"] = hist
         if capture:
             k, m = nrec.value, nch.value
             lw, rw = (params.k_left + 31) // 32, (params.k_right + 31) // 32

@@ -419,3 +419,67 @@ def test_device_image_equals_host_blob(dip):
         assert got.tobytes() == want
         back = api.Calls.unpack(got.tobytes())
         assert back.format_snp(p, False)[0] == host.format_snp(p, False)[0]
+
+
+def _bits(rng, n, p_one):
+    return rng.random(n) < p_one
+
+
+def _pack_bits(bits):
+    pad = (-len(bits)) % 64
+    return np.packbits(np.concatenate([bits, np.zeros(pad, dtype=bool)]), bitorder="little").view(np.uint64).copy()
+
+
+_STRESS = {
+    # name: (n, P(symbol is TERM), flag pattern)
+    "dense_runs_of_20": (200_000, 0.02, lambda r, n: _bits(r, n, 0.95)),
+    "short_runs": (200_000, 0.02, lambda r, n: _bits(r, n, 0.6)),
+    "nine_clusters_per_word": (120_000, 0.02, lambda r, n: (np.arange(n) % 7) != 6),
+    "long_runs_150": (300_000, 0.02, lambda r, n: (np.arange(n) % 151) != 0),
+    "runs_across_many_words": (300_000, 0.0, lambda r, n: _bits(r, n, 0.9993)),
+    "one_giant_run": (150_000, 0.01, lambda r, n: (np.arange(n) != 70_001) & (np.arange(n) > 3)),
+    "word_aligned_runs": (130_000, 0.05, lambda r, n: (np.arange(n) % 64) != 63),
+    "two_word_runs": (130_000, 0.05, lambda r, n: (np.arange(n) % 128) != 0),
+}
+
+
+@pytest.mark.parametrize("mode", [1, 3])
+@pytest.mark.parametrize("name", sorted(_STRESS))
+def test_scan_on_adversarial_flag_patterns(oracle, name, mode):
+    """Phase 4 on inputs the navigation would never produce: a random symbol string (every cluster mixes letters, so all of
+    them reach the queues, the analysis and the survivor staging overflow) under flag patterns that pin the corner
+    cases of the run logic -- runs ending on word boundaries, spanning exactly two words, spanning hundreds, nine
+    clusters in one word.  The scan only reads these vectors (ebwt2InDel.cpp:1609-1655); records, counters and
+    CLUST_SIZES must equal the oracle's, whole range and cut at odd positions."""
+    n, p_term, pattern = _STRESS[name]
+    rng = _rng(sum(name.encode()) * 7 + mode)
+    sym = rng.choice(np.frombuffer(b"ACGT#", dtype=np.uint8), size=n, p=[(1 - p_term) / 4] * 4 + [p_term])
+    if p_term == 0.0:
+        sym[:8] = ord("#")                                       # F_A > 0: row 0 is a TERM row like in any eBWT
+    thrK = _pack_bits(pattern(rng, n))
+    thrR = thrK & _pack_bits(_bits(rng, n, 0.5))
+    minima = _pack_bits(_bits(rng, n, 0.01))
+    da_bits = _bits(rng, n, 0.5) if mode == 3 else None
+    da = _pack_bits(da_bits) if mode == 3 else None
+    args = ["-m", "2"] if name == "short_runs" else []
+    p, pp = _oracle.Params.from_args(args), api.make_params(args)
+    o1 = oracle.index(sym, p.term)
+    of = _oracle.OracleFlags(oracle, o1, vectors=(thrK, thrR, minima, da))
+    g1 = api.DnaBwt(sym, term=p.term)
+    gf = api.Flags.from_host(n, thrK, thrR, minima, da)
+    seen = []
+    for cuts in ([0, n], [0, 64 * 700 + 1, n // 2 + 17, n - 5, n]):
+        for b, e in zip(cuts[:-1], cuts[1:]):
+            want = of.scan(p, b, e, capture=True)
+            seen.append(want["count"])
+            calls = api.scan_clusters(g1, gf, pp, begin=b, end=e)
+            cl, chains, left, right = calls.arrays()
+            st = calls.stats
+            assert dict(runs_closed=st.runs_closed, clusters=st.clusters, bases_in_runs=st.bases_in_runs,
+                        survivors=st.survivors, chains=st.chains) == want["stats"]
+            assert np.array_equal(np.array(list(st.hist), dtype=np.uint64), want["hist"])
+            assert np.array_equal(cl, want["clusters"])
+            assert np.array_equal(chains, want["chains"])
+            assert np.array_equal(left, want["left"])
+            assert np.array_equal(right, want["right"])
+    assert seen[0] == sum(seen[1:]) and seen[0] > 0              # the cuts partition the clusters; the input is not trivial
