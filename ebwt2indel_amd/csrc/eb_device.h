@@ -37,6 +37,7 @@ struct eb_dev_flags {
     uint64_t* thrR;   // LCP[i] >= k_right
     uint64_t* minima; // local LCP minimum
     const uint64_t* flag; // thrK & ~minima, the only combination phase 4 reads (derived once, eb_flags_derive)
+    const uint4* mxy;     // two-BWT mode: scan planes of the merged sequence (k_merge_planes), else null
     uint64_t* da;     // document array (may be null)
     const uint64_t* da_rank; // ones before each group of 8 words (two-BWT mode), may be null
     uint64_t n;

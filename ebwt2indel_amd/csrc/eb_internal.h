@@ -63,6 +63,7 @@ struct eb_flags {
     uint64_t n = 0, words = 0;
     uint64_t *d_thrK = nullptr, *d_thrR = nullptr, *d_min = nullptr, *d_da = nullptr, *d_da_rank = nullptr;
     uint64_t* d_flag = nullptr; // thrK & ~minima
+    uint4* d_mxy = nullptr;     // two-BWT mode: merged scan planes, built by the first phase-4 call
     bool derived = false;       // d_flag / d_da_rank match the vectors (false between a sharded build and eb_flags_finalize)
     eb_dev_flags dev() const {
         eb_dev_flags f;
@@ -70,6 +71,7 @@ struct eb_flags {
         f.thrR = d_thrR;
         f.minima = d_min;
         f.flag = d_flag;
+        f.mxy = d_mxy;
         f.da = d_da;
         f.da_rank = d_da_rank;
         f.n = n;

@@ -816,6 +816,7 @@ extern "C" void eb_flags_destroy(eb_flags* f) {
     uint64_t* v[6] = {f->d_thrK, f->d_thrR, f->d_min, f->d_da, f->d_da_rank, f->d_flag};
     for (auto p : v)
         if (p) (void)hipFree(p);
+    if (f->d_mxy) (void)hipFree(f->d_mxy);
     if (f->stream) (void)hipStreamDestroy(f->stream);
     delete f;
 }

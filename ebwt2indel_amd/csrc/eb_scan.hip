@@ -101,8 +101,8 @@ struct Planes {
     }
 };
 
-__device__ __forceinline__ Planes load_planes(const eb_dev_index& x, uint64_t w) {
-    uint4 v = x.xy[w]; // scan planes: 16 bytes instead of the two 16-byte chunks (TERM plane and counters are not needed here)
+__device__ __forceinline__ Planes load_planes(const uint4* __restrict__ xy, uint64_t w) {
+    uint4 v = xy[w]; // scan planes: 16 bytes instead of the two 16-byte chunks (TERM plane and counters are not needed here)
     Planes p;
     p.x = (uint64_t)v.x | ((uint64_t)v.y << 32);
     p.y = (uint64_t)v.z | ((uint64_t)v.w << 32);
@@ -177,11 +177,13 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
     const uint64_t hi_pos = p.end < p.n ? p.end : p.n;
-    const uint64_t n_bwt_words = (x1.n_blocks << 1); // 64-symbol words backed by the packed BWT
+    // scan planes in the coordinates the flags live in: the index's own (modes 1, 3) or the two BWTs merged by the DA (mode 2)
+    const uint4* __restrict__ xy = MODE == 2 ? f.mxy : x1.xy;
+    const uint64_t n_bwt_words = MODE == 2 ? f.words : (x1.n_blocks << 1); // 64-symbol words backed by the planes
     uint64_t n_runs = 0, n_clusters = 0, n_bases = 0;
     uint32_t hot_n = 0, todo_n = 0;                   // queue fill, the same in every lane of the wave
     const uint64_t tiles = (w_count + 255) / 256;
-    constexpr bool local_syms = MODE != 2;
+    constexpr bool local_syms = true;
 
     // ---- a queued cluster: histogram + frequent-symbol filter -> survivor record
     auto analyse = [&](bool have, unsigned long long entry) {
@@ -194,18 +196,7 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
         s.b = g.b; s.e = (w << 6) + bit; s.b0 = s.e0 = s.b1 = s.e1 = 0; s.fmask0 = s.fmask1 = 0; s.pad = 0;
         uint32_t c0[4], c1[4];
         bool keep;
-        if constexpr (MODE == 2) {
-            // symbols live in the two BWTs' own coordinates: rank differences on both
-            s.b1 = da_rank(f, s.b); s.e1 = da_rank(f, s.e);
-            s.b0 = s.b - s.b1; s.e0 = s.e - s.e1;
-            hist_by_rank(x1, s.b0, s.e0, c0);
-            hist_by_rank(x2, s.b1, s.e1, c1);
-            s.fmask0 = frequent_mask(c0, p.mcov);
-            s.fmask1 = frequent_mask(c1, p.mcov);
-            int n0 = __popc(s.fmask0), n1 = __popc(s.fmask1);
-            keep = n0 > 0 && n1 > 0 && !(p.q > 0 && (n0 > p.q || n1 > p.q)); // :870-880
-            keep = keep && __popc(s.fmask0 | s.fmask1) > 1; // see can_emit_pairs() below
-        } else if (!g.in_regs) {
+        if (!g.in_regs) {
             // run longer than two words: its histogram needs memory; k_long_runs does that later so that the
             // streaming kernel carries no rank code (registers) for this rare case
             s.fmask0 = EB_NEEDS_HIST;
@@ -213,8 +204,8 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
             atomicAdd(&cnt->n_long, 1ull);
         } else {
             Planes cur = {0, 0}, prv = {0, 0};
-            if (w < n_bwt_words) cur = load_planes(x1, w);
-            if (g.mprv) prv = load_planes(x1, w - 1);
+            if (w < n_bwt_words) cur = load_planes(xy, w);
+            if (g.mprv) prv = load_planes(xy, w - 1);
             if constexpr (MODE == 1) {
                 for (int c = 0; c < 4; ++c) c0[c] = (uint32_t)__popcll(cur.letter(c) & g.mcur) + (uint32_t)__popcll(prv.letter(c) & g.mprv);
                 s.fmask0 = frequent_mask(c0, p.mcov);
@@ -235,6 +226,10 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
                 // (:921, :1083), and an empty pair list leaves cluster_nr untouched (:1250): a cluster whose two sides
                 // share one single frequent letter can never reach the output, so its contexts are not computed.
                 keep = keep && __popc(s.fmask0 | s.fmask1) > 1;
+                if (MODE == 2 && keep) { // the chains and the right context run in the two BWTs' own coordinates
+                    s.b1 = da_rank(f, s.b); s.e1 = da_rank(f, s.e);
+                    s.b0 = s.b - s.b1; s.e0 = s.e - s.e1;
+                }
             }
         }
         if (keep) {
@@ -294,8 +289,8 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
             }
             if (in_regs) {
                 Planes cur = {0, 0}, prv = {0, 0};
-                if (w < n_bwt_words) cur = load_planes(x1, w);
-                if (mprv) prv = load_planes(x1, w - 1);
+                if (w < n_bwt_words) cur = load_planes(xy, w);
+                if (mprv) prv = load_planes(xy, w - 1);
                 uint32_t ones_x = (uint32_t)__popcll(cur.x & mcur) + (uint32_t)__popcll(prv.x & mprv);
                 uint32_t ones_y = (uint32_t)__popcll(cur.y & mcur) + (uint32_t)__popcll(prv.y & mprv);
                 uint32_t dx = ones_x < len - ones_x ? ones_x : len - ones_x;
@@ -334,10 +329,10 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
         if (tile < tiles && t < w_count) {
             uint64_t w = w_lo + t;
             d.fw = flag_word(f, w);
-            if (local_syms && w < n_bwt_words) d.cur = load_planes(x1, w);
+            if (local_syms && w < n_bwt_words) d.cur = load_planes(xy, w);
             if (lane == 0 && w > 0) {
                 d.l0_pfw = flag_word(f, w - 1);
-                if (local_syms) d.l0_prv = load_planes(x1, w - 1);
+                if (local_syms) d.l0_prv = load_planes(xy, w - 1);
             }
         }
         return d;
@@ -370,7 +365,7 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
         // positions of the runs that hold such a pair (a run's mask plus any non-empty subset of it reaches the zero
         // that ends it and never passes it).
         uint64_t hot = ends;
-        if (MODE != 2) {
+        {
             uint64_t chg = ((cur.x ^ (cur.x >> 1)) | (cur.y ^ (cur.y >> 1))) & fw & (fw >> 1) & ~(1ull << 63);
             // the part of a run that lies in the previous word (its top run, bits zbp..63)
             uint64_t pz = ~pfw;
@@ -442,8 +437,7 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
             uint32_t bit = have ? (uint32_t)__ffsll((long long)hot) - 1u : 0u;
             if (have) hot &= hot - 1;
             unsigned long long entry = (w << 6) | bit;
-            if (MODE == 2) todo_push(have, entry);
-            else hot_push(have, entry);
+            hot_push(have, entry);
         }
         // Survivors are rare (~1 per 10^4 positions = ~2 per tile): empty the staging buffer every 16 tiles.  No
         // barrier in between (they would serialise the tiles of a workgroup); a buffer that fills up earlier sends
@@ -506,7 +500,7 @@ __global__ void __launch_bounds__(256) k_scan_reduce(const unsigned long long* _
 
 // Histogram + frequent-symbol filter of the clusters k_scan could not analyse from registers (runs longer than
 // 64..128 positions).  Dropped ones get begin = ~0, which the sort moves behind the real survivors.
-__global__ void __launch_bounds__(256) k_long_runs(eb_dev_index x1, eb_dev_flags f, ScanParams p, Survivor* __restrict__ surv, uint64_t n,
+__global__ void __launch_bounds__(256) k_long_runs(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, ScanParams p, Survivor* __restrict__ surv, uint64_t n,
                                                   unsigned long long* __restrict__ dropped) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -520,7 +514,15 @@ __global__ void __launch_bounds__(256) k_long_runs(eb_dev_index x1, eb_dev_flags
         int nf = __popc(s.fmask0);
         keep = nf >= 2 && !(p.q > 0 && nf > p.q);
     } else {
-        hist_by_da(x1, f, s.b, s.e, c0, c1);
+        if (p.mode == 2) {
+            // symbols live in the two BWTs' own coordinates: rank differences on both (ebwt2InDel.cpp:846-847)
+            s.b1 = da_rank(f, s.b); s.e1 = da_rank(f, s.e);
+            s.b0 = s.b - s.b1; s.e0 = s.e - s.e1;
+            hist_by_rank(x1, s.b0, s.e0, c0);
+            hist_by_rank(x2, s.b1, s.e1, c1);
+        } else {
+            hist_by_da(x1, f, s.b, s.e, c0, c1);
+        }
         s.fmask0 = frequent_mask(c0, p.mcov);
         s.fmask1 = frequent_mask(c1, p.mcov);
         int n0 = __popc(s.fmask0), n1 = __popc(s.fmask1);
@@ -679,6 +681,24 @@ __global__ void __launch_bounds__(256) k_right(eb_dev_index x1, eb_dev_index x2,
     recs[i] = r;
 }
 
+// Two-BWT mode: scan planes of the MERGED sequence (row i of the merge comes from bwt2 if DA[i] else bwt1, in order:
+// ebwt2InDel.cpp:1431-1432), so that the streaming scan reads symbols in the coordinates its flags live in, exactly
+// as with a merged BWT + DA.  Built once per flags object.  One lane per 64 merged rows.
+__global__ void __launch_bounds__(256) k_merge_planes(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, uint4* __restrict__ mxy) {
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < f.words; w += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t d = f.da[w];
+        uint64_t i1 = da_rank(f, w << 6), i0 = (w << 6) - i1;
+        uint64_t x = 0, y = 0;
+        const uint32_t rows = (uint32_t)((f.n - (w << 6)) < 64 ? (f.n - (w << 6)) : 64);
+        for (uint32_t k = 0; k < rows; ++k) {
+            uint32_t code = ((d >> k) & 1ull) ? eb_code(x2, i1++) : eb_code(x1, i0++);
+            x |= (uint64_t)(code & 1u) << k;          // TERM (code 4) has x = y = 0 and lands in 'A' (include.hpp:275-289)
+            y |= (uint64_t)((code >> 1) & 1u) << k;
+        }
+        mxy[w] = make_uint4((uint32_t)x, (uint32_t)(x >> 32), (uint32_t)y, (uint32_t)(y >> 32));
+    }
+}
+
 struct DevMem { // per-call temporary from the caching scratch allocator
     void* p = nullptr;
     size_t cap = 0;
@@ -768,6 +788,14 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
     if (!b2) { // modes 1 / 3 read symbols in the scan: 2-bit planes, derived from the index on first use
         int rcp = eb_index_scan_planes(b1);
         if (rcp != EB_OK) return rcp;
+    } else if (!f->d_mxy) { // mode 2: planes of the two BWTs merged by the document array, derived on first use
+        const size_t bytes = eb_bit_alloc_words(f->n) * sizeof(uint4);
+        hipError_t e = hipMalloc(&f->d_mxy, bytes);
+        if (e != hipSuccess) { eb_set_error("merged scan plane allocation failed (%zu bytes): %s", bytes, hipGetErrorString(e)); return EB_ERR_NOMEM; }
+        EB_HIP(hipMemsetAsync(f->d_mxy, 0, bytes, f->stream));
+        hipLaunchKernelGGL(k_merge_planes, dim3(4096), dim3(256), 0, f->stream, b1->dev(), b2->dev(), f->dev(), f->d_mxy);
+        EB_HIP(hipStreamSynchronize(f->stream));
+        EB_HIP(hipGetLastError());
     }
 
     ScanParams p;
@@ -907,7 +935,7 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
         if (x.ns_raw > 0x1FFFFFFFull) { eb_set_error("too many surviving clusters in one call; shard the range"); return EB_ERR_STATE; }
         EB_HIP(hipStreamWaitEvent(sP, x.e[E_SCAN_DONE], 0));
         if (hc.n_long) {
-            hipLaunchKernelGGL(k_long_runs, dim3(grid_of(x.ns_raw)), dim3(256), 0, sP, x1, df, p, x.surv.as<Survivor>(), x.ns_raw,
+            hipLaunchKernelGGL(k_long_runs, dim3(grid_of(x.ns_raw)), dim3(256), 0, sP, x1, x2, df, p, x.surv.as<Survivor>(), x.ns_raw,
                                &x.cnt.as<ScanCounters>()->dropped);
             EB_HIP(hipMemcpyAsync(x.h_cnt, x.cnt.p, sizeof(ScanCounters), hipMemcpyDeviceToHost, sP));
             EB_HIP(hipStreamSynchronize(sP));
