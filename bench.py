@@ -154,15 +154,21 @@ def main():
     def begin_step():
         return api.scan_clusters_begin(bwt, flags, p, begin=begin, end=end, device_only=device_gather)
 
-    def finish_step(job):
+    # collect(job) hands the job's records over and may leave the hand-over in flight; resolve() completes it.
+    def collect(job):
         if device_gather:
             job.wait()
             ptr, length = job.device_blob()
-            parts = ebd.gather_device(ptr, length, comm_dev)
-            return job.finish(), parts
+            return ebd.gather_device_async(ptr, length, comm_dev, keep=job)
         calls = job.finish()                                             # records now in page-locked host memory
         parts = ebd.gather_packed(calls.blob(), device=comm_dev) if use_dist else None
         return calls, parts
+
+    def resolve(pending):
+        if device_gather:
+            parts = pending.result()                                     # rank 0: records of all ranks in page-locked host memory
+            return pending.keep.finish(), parts                          # releases the job's device image
+        return pending
 
     def sync():
         if use_dist:
@@ -170,24 +176,31 @@ def main():
         torch.cuda.synchronize()
 
     def run_steps(k, record=None):
-        if args.no_pipeline:
-            last = None
-            for _ in range(k):
-                last = finish_step(begin_step())
-                if record is not None:
-                    record(last[0].stats)
-            return last
-        job = begin_step()
         last = None
-        for _ in range(k - 1):
-            nxt = begin_step()
-            last = finish_step(job)
+
+        def done(pending):
+            nonlocal last
+            last = resolve(pending)
             if record is not None:
                 record(last[0].stats)
-            job = nxt
-        last = finish_step(job)
-        if record is not None:
-            record(last[0].stats)
+
+        if args.no_pipeline:
+            for _ in range(k):
+                done(collect(begin_step()))
+            return last
+        # two stages in flight: the kernels of step i+1 run while the records of step i travel (PCIe download, or
+        # RCCL gather + rank 0's download), and that hand-over is waited for only after step i+1's has been started
+        job, pending = begin_step(), None
+        for _ in range(k - 1):
+            nxt = begin_step()
+            started = collect(job)
+            if pending is not None:
+                done(pending)
+            job, pending = nxt, started
+        started = collect(job)
+        if pending is not None:
+            done(pending)
+        done(started)
         return last
 
     if args.warmup > 0:

@@ -23,12 +23,12 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
 _bufs = {}
 
 
-def _buffers(world: int, cap: int, dev, root: bool):
+def _buffers(world: int, cap: int, dev, root: bool, slot: int = 0):
     """Staging tensors reused across steps: send buffer on `dev`; on the root a [world, cap] receive buffer on `dev`
-    and a page-locked host mirror."""
+    and a page-locked host mirror.  `slot` selects one of several independent sets (gathers in flight)."""
     import torch
 
-    key = (world, str(dev), root)
+    key = (world, str(dev), root, slot)
     cur = _bufs.get(key)
     if cur is None or cur["cap"] < cap:
         cur = {"cap": cap, "send": torch.empty(cap, dtype=torch.uint8, device=dev)}
@@ -46,15 +46,63 @@ class _DeviceBytes:
         self.__cuda_array_interface__ = {"shape": (length,), "typestr": "|u1", "data": (ptr, False), "version": 3, "strides": None}
 
 
-def gather_device(ptr: int, length: int, device, group=None, dst: int = 0) -> Optional[List[memoryview]]:
-    """gather_packed for a call set that is still in HBM (ScanJob.device_blob): the image goes GPU -> GPU over
-    xGMI without touching this rank's host memory; only the root downloads, once, into its reused page-locked buffer.
-    The caller must have waited for the job (ScanJob.wait) and keeps it alive until this returns."""
+class PendingGather:
+    """A gather in flight (gather_device_async): result() waits for it and returns what gather_packed returns."""
+
+    def __init__(self, event, views, keep):
+        self._event, self._views, self.keep = event, views, keep
+
+    def result(self):
+        if self._event is not None:
+            self._event.synchronize()
+            self._event = None
+        return self._views
+
+
+_slot = [0]
+
+
+def gather_device_async(ptr: int, length: int, device, group=None, dst: int = 0, keep=None) -> PendingGather:
+    """gather_packed for a call set that is still in HBM (ScanJob.device_blob), without blocking the host on the
+    payload: the image goes GPU -> GPU over xGMI without touching this rank's host memory; only the root downloads,
+    once, into a page-locked buffer.  Only the exchange of the sizes is synchronous; the payload gather and the root's
+    download are stream-ordered behind it, so a caller that pipelines its steps runs them under the next step's
+    kernels (two sets of staging buffers alternate).  `keep`: object that owns the device image (the ScanJob); it is
+    handed back as PendingGather.keep and must stay alive until result() returned."""
     import torch
+    import torch.distributed as dist
 
     dev = torch.device(device)
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
     src = torch.as_tensor(_DeviceBytes(ptr, length), device=dev) if length else torch.empty(0, dtype=torch.uint8, device=dev)
-    return gather_packed(src, group=group, device=dev, dst=dst)
+    sizes_t = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(sizes_t, torch.tensor([length], dtype=torch.int64, device=dev), group=group)
+    sizes = [int(x) for x in sizes_t.tolist()]
+    cap = (max(max(sizes), 1) + 0xFFFF) & ~0xFFFF          # same on every rank
+    _slot[0] ^= 1
+    buf = _buffers(world, cap + cap // 4, dev, rank == dst, slot=_slot[0])
+    send = buf["send"][:cap]
+    if length:
+        send[:length].copy_(src)
+    outs = [buf["recv"][r * cap:(r + 1) * cap] for r in range(world)] if rank == dst else None
+    work = dist.gather(send, outs, dst=dst, group=group, async_op=True)
+    work.wait()                                           # orders the current stream behind the collective, not the host
+    views = None
+    if rank == dst:
+        host = buf["host"]
+        for r in range(world):
+            host[r * cap: r * cap + sizes[r]].copy_(outs[r][: sizes[r]], non_blocking=True)
+        base = host.numpy()
+        views = [memoryview(base[r * cap: r * cap + sizes[r]]) for r in range(world)]
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    return PendingGather(ev, views, keep)
+
+
+def gather_device(ptr: int, length: int, device, group=None, dst: int = 0) -> Optional[List[memoryview]]:
+    """Blocking form of gather_device_async."""
+    return gather_device_async(ptr, length, device, group=group, dst=dst).result()
 
 
 def gather_packed(packed, group=None, device=None, dst: int = 0) -> Optional[List[memoryview]]:
