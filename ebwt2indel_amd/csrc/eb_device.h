@@ -169,56 +169,6 @@ __device__ __forceinline__ uint64_t eb_select(const eb_dev_index& x, uint64_t r,
     }
 }
 
-// eb_select for latency-bound callers (few walks in flight: a rank's slice of a multi-GPU job): after the directory entry
-// the guessed block AND its two neighbours are loaded at once, so a step of the walk is two dependent memory round
-// trips (~4-5 us each on a multi-GB index) instead of three or four; costs 3x the requests, which is why the
-// throughput-bound case keeps eb_select.
-__device__ __forceinline__ uint64_t eb_select_spec(const eb_dev_index& x, uint64_t r, int c) {
-    const uint32_t* dir = x.sel_dir + (c == 0 ? x.sel_off[0] : c == 1 ? x.sel_off[1] : c == 2 ? x.sel_off[2] : x.sel_off[3]);
-    uint64_t m = r >> EB_SEL_SHIFT;
-    uint64_t lo = dir[m], hi = dir[m + 1];
-    uint64_t g = lo + (((r - (m << EB_SEL_SHIFT)) * (hi - lo + 1)) >> EB_SEL_SHIFT);
-    if (g > hi) g = hi;
-    const uint64_t last = x.n_blocks - 1;
-    uint64_t g0 = g > 0 ? g - 1 : 0;
-    if (g0 + 2 > last) g0 = last >= 2 ? last - 2 : 0;
-    uint4 ch[3][4];
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-        uint64_t gb = g0 + b <= last ? g0 + b : last;
-        const uint4* p = x.chunks + (gb << 2);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) ch[b][q] = p[q];
-    }
-    const uint64_t sup = x.super[((g0 >> 25) << 2) + c]; // candidates straddling a superblock boundary fall through to eb_select
-    if (((g0 + 2) >> 25) == (g0 >> 25)) {
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            if (g0 + b > last) break;
-            uint32_t w = c == 0 ? ch[b][0].w : c == 1 ? ch[b][1].w : c == 2 ? ch[b][2].w : ch[b][3].w;
-            uint64_t before = sup + w;
-            uint32_t mk[4], k[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                mk[q] = ~ch[b][q].z & ((c & 2) ? ch[b][q].y : ~ch[b][q].y) & ((c & 1) ? ch[b][q].x : ~ch[b][q].x);
-                k[q] = (uint32_t)__popc(mk[q]);
-            }
-            uint32_t total = k[0] + k[1] + k[2] + k[3];
-            if (r >= before && r < before + total) {
-                uint32_t need = (uint32_t)(r - before);
-                uint32_t word, base;
-                if (need < k[0]) { word = mk[0]; base = 0; }
-                else if (need < k[0] + k[1]) { word = mk[1]; base = 32; need -= k[0]; }
-                else if (need < k[0] + k[1] + k[2]) { word = mk[2]; base = 64; need -= k[0] + k[1]; }
-                else { word = mk[3]; base = 96; need -= k[0] + k[1] + k[2]; }
-                for (uint32_t t = 0; t < need; ++t) word &= word - 1;
-                return ((g0 + b) << 7) + base + (uint32_t)__ffs((int)word) - 1u;
-            }
-        }
-    }
-    return eb_select(x, r, c); // not among the three candidates: the general search
-}
-
 // FL(i) (dna_bwt.hpp:115-133); i must not be a TERM row.
 __device__ __forceinline__ uint64_t eb_FL(const eb_dev_index& x, uint64_t i, int letter) {
     return eb_select(x, i - x.F[letter], letter);

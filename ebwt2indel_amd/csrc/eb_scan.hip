@@ -633,7 +633,6 @@ __global__ void __launch_bounds__(256) k_extend(eb_dev_index x1, eb_dev_index x2
 
 // One lane per cluster: record header + right context (extract_dna, ebwt2InDel.cpp:325-342) at the first
 // cluster position whose LCP >= k_right (:979-988; two BWTs :896-912); bases packed 2 bits each in text order.
-template <bool SPEC>
 __global__ void __launch_bounds__(256) k_right(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, ScanParams p,
                                               const Survivor* __restrict__ surv, const uint32_t* __restrict__ chain_off, uint32_t chain_base, uint64_t nsurv,
                                               eb_cluster* __restrict__ recs, uint64_t* __restrict__ right, uint32_t right_words) {
@@ -666,7 +665,7 @@ __global__ void __launch_bounds__(256) k_right(eb_dev_index x1, eb_dev_index x2,
             word |= (uint64_t)c << (2u * (len & 31u));
             ++len;
             if ((len & 31u) == 0) { out[(len >> 5) - 1] = word; word = 0; }
-            row = SPEC ? eb_select_spec(x, row - pick4(x.F, (uint32_t)c), c) : eb_FL(x, row, c);
+            row = eb_FL(x, row, c);
             c = eb_F_letter(x, row);
         }
         if (len & 31u) out[len >> 5] = word;
@@ -837,8 +836,6 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
     // Measured at 7.55 G positions (EB_SCAN_SUBSHARDS=1/2/4/8): 6.5 / 6.1 / 6.4 / 11.0 ms per call -- the streaming scan and
     // the random-access chains compete for the same memory request rate, so overlap buys little and slows each kernel.
     // Default: one shard (kernels run alone, cleanest timings); the knob stays for experiments.
-    uint64_t right_spec_max = 524288; // measured: 0.84 = 0.84, 1.37 < 1.60, 2.60 < 2.90, 5.36 > 4.47 ms per step at 98 k, 197 k, 395 k, 793 k clusters
-    if (const char* e = getenv("EB_RIGHT_SPEC_MAX")) right_spec_max = strtoull(e, nullptr, 10);
     int S = 1;
     if (const char* e = getenv("EB_SCAN_SUBSHARDS")) { int v = atoi(e); if (v >= 1 && v <= 16) S = v; }
     if ((uint64_t)S > w_total) S = w_total ? (int)w_total : 1;
@@ -1019,14 +1016,8 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
         EB_HIP(hipEventRecord(ctx->last_ext, sB));
         EB_HIP(hipStreamWaitEvent(sC, x.e[E_PREP_DONE], 0));
         EB_HIP(hipEventRecord(x.e[E_RIGHT0], sC));
-        // few walks (a rank's slice of a multi-GPU job) are latency-bound: speculative three-block probes; many are
-        // bound by the request rate: plain probes (measured; EB_RIGHT_SPEC_MAX overrides)
-        if (x.ns <= right_spec_max)
-            hipLaunchKernelGGL(k_right<true>, dim3(grid_of(x.ns)), dim3(256), 0, sC, x1, x2, df, p, x.sorted.as<Survivor>(), x.choff.as<uint32_t>(),
-                               (uint32_t)x.chain_base, x.ns, x.d_recs, x.d_right, rw);
-        else
-            hipLaunchKernelGGL(k_right<false>, dim3(grid_of(x.ns)), dim3(256), 0, sC, x1, x2, df, p, x.sorted.as<Survivor>(), x.choff.as<uint32_t>(),
-                               (uint32_t)x.chain_base, x.ns, x.d_recs, x.d_right, rw);
+        hipLaunchKernelGGL(k_right, dim3(grid_of(x.ns)), dim3(256), 0, sC, x1, x2, df, p, x.sorted.as<Survivor>(), x.choff.as<uint32_t>(), (uint32_t)x.chain_base,
+                           x.ns, x.d_recs, x.d_right, rw);
         EB_HIP(hipEventRecord(x.e[E_RIGHT_DONE], sC));
         EB_HIP(hipEventRecord(ctx->last_right, sC));
         EB_HIP(hipGetLastError());

@@ -198,13 +198,9 @@ def test_flags_import_export_round_trip(oracle):
 
 # ------------------------------------------------------------------ phase 4 and the whole path
 
-@pytest.mark.parametrize("right_spec_max", [None, "0"], ids=["right_spec", "right_plain"])
 @pytest.mark.parametrize("case", CASES, ids=CASE_IDS)
-def test_snp_byte_identical_to_reference(monkeypatch, case, right_spec_max):
-    """End to end on the GPU (index -> flags -> scan -> writer) against the reference-written golden .snp.
-    Both forms of the right-context walk: speculative three-block probes (small call sets) and plain probes."""
-    if right_spec_max is not None:
-        monkeypatch.setenv("EB_RIGHT_SPEC_MAX", right_spec_max)
+def test_snp_byte_identical_to_reference(case):
+    """End to end on the GPU (index -> flags -> scan -> writer) against the reference-written golden .snp."""
     p = api.make_params(case["args"])
     inp = case["inputs"]
     if case["mode"] == 1:
