@@ -152,13 +152,13 @@ def main():
     device_gather = use_dist and comm_dev.type == "cuda" and os.environ.get("EB_BENCH_HOST_GATHER", "0") != "1"
 
     def begin_step():
-        return api.scan_clusters_begin(bwt, flags, p, begin=begin, end=end, device_only=device_gather)
+        return api.scan_clusters_begin(bwt, flags, p, begin=begin, end=end, device_only=device_gather, wire=device_gather)
 
     # collect(job) hands the job's records over and may leave the hand-over in flight; resolve() completes it.
     def collect(job):
         if device_gather:
             job.wait()
-            ptr, length = job.device_blob()
+            ptr, length = job.device_wire()      # compact image: rank 0's PCIe link carries every record of the job
             return ebd.gather_device_async(ptr, length, comm_dev, keep=job)
         calls = job.finish()                                             # records now in page-locked host memory
         parts = ebd.gather_packed(calls.blob(), device=comm_dev) if use_dist else None

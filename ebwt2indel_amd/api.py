@@ -342,17 +342,27 @@ class ScanJob:
             pass
 
 
+    def device_wire(self):
+        """(device pointer, length) of the call set as the COMPACT wire image (eb_scan_job_device_wire): what ranks send
+        to rank 0.  Calls.unpack reads it.  Valid until finish()."""
+        ptr, ln = C.c_void_p(), C.c_uint64()
+        _check(lib().eb_scan_job_device_wire(self._h, C.byref(ptr), C.byref(ln)))
+        return int(ptr.value or 0), int(ln.value)
+
+
 SCAN_DEVICE_ONLY = 1
+SCAN_WIRE = 2
 
 
 def scan_clusters_begin(bwt1: DnaBwt, flags: Flags, params: Params, bwt2: Optional[DnaBwt] = None, begin: int = 0,
-                        end: Optional[int] = None, device_only: bool = False) -> ScanJob:
+                        end: Optional[int] = None, device_only: bool = False, wire: bool = False) -> ScanJob:
     """Enqueue phase 4 and return at once; the record download overlaps whatever the caller launches next.
-    device_only: keep the call set in HBM (ScanJob.device_blob) -- for ranks that forward it with RCCL."""
+    device_only: keep the call set in HBM (ScanJob.device_blob) -- for ranks that forward it with RCCL;
+    wire: the job also packs the compact wire image (ScanJob.device_wire) as its last step."""
     n = bwt1.n + (bwt2.n if bwt2 is not None else 0)
     h = C.c_void_p()
     _check(lib().eb_scan_clusters_begin_ex(bwt1._h, bwt2._h if bwt2 is not None else None, flags._h, begin, n if end is None else end,
-                                           C.byref(params), SCAN_DEVICE_ONLY if device_only else 0, C.byref(h)))
+                                           C.byref(params), (SCAN_DEVICE_ONLY if device_only else 0) | (SCAN_WIRE if wire else 0), C.byref(h)))
     return ScanJob(h)
 
 

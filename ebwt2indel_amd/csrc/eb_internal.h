@@ -26,6 +26,7 @@ struct eb_scan_ctx {
     std::vector<hipEvent_t> events;
     hipEvent_t last_ext = nullptr, last_right = nullptr; // end of the most recent job's context kernels
     void* h_pinned = nullptr;
+    std::vector<unsigned long long*> h_bad_pool; // pinned words recycled between jobs
 };
 void eb_scan_ctx_destroy(eb_scan_ctx* c);
 
@@ -86,6 +87,16 @@ struct eb_calls_header {
     uint64_t magic, count, n_chains, k_left, k_right, reserved[3];
 };
 static const uint64_t EB_CALLS_MAGIC = 0x32534C4C41434245ull; // "EBCALLS2"
+// compact wire image (eb_scan_job_device_wire): same header with this magic, then the two record arrays below, then the
+// context words exactly as in the blob
+static const uint64_t EB_WIRE_MAGIC = 0x33534C4C41434245ull;  // "EBCALLS3"
+struct eb_wire_cluster { uint64_t begin; uint32_t len; uint8_t n_slots, right_found; uint16_t right_len; };
+struct eb_wire_chain { uint8_t side, sym; uint16_t len; uint32_t support; };
+static_assert(sizeof(eb_wire_cluster) == 16 && sizeof(eb_wire_chain) == 8, "wire records");
+static inline uint64_t eb_wire_size(uint64_t count, uint64_t n_chains, int32_t k_left, int32_t k_right) {
+    return sizeof(eb_calls_header) + count * sizeof(eb_wire_cluster) + n_chains * sizeof(eb_wire_chain) +
+           n_chains * (((uint64_t)k_left + 31) / 32) * 8 + count * (((uint64_t)k_right + 31) / 32) * 8;
+}
 struct eb_calls {
     uint8_t* blob = nullptr;
     uint64_t size = 0;

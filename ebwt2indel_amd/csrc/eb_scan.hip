@@ -753,7 +753,38 @@ struct eb_scan_job {
     bool has_blob = false;      // sh[0].blob holds the contiguous device image
     uint64_t blob_bytes = 0;
     eb_calls_header header;     // first 64 bytes of the device image
+    DevMem wire;                // compact wire image (packed by the job with EB_SCAN_WIRE, else on demand)
+    unsigned long long* h_bad = nullptr; // pinned: records that do not fit the wire image
+    uint64_t wire_bytes = 0;
+    int32_t k_left = 0, k_right = 0;
 };
+
+// friendly records -> compact wire records (eb_scan_job_device_wire); *bad counts fields that do not fit
+__global__ void __launch_bounds__(256) k_pack_wire(const eb_cluster* __restrict__ recs, uint64_t count, const eb_chain* __restrict__ chains, uint64_t n_chains,
+                                                  eb_wire_cluster* __restrict__ wc, eb_wire_chain* __restrict__ wk, unsigned long long* __restrict__ bad) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) {
+        eb_cluster r = recs[i];
+        eb_wire_cluster w;
+        w.begin = r.begin;
+        w.len = (uint32_t)(r.end - r.begin);
+        w.n_slots = (uint8_t)r.n_slots;
+        w.right_found = (uint8_t)r.right_found;
+        w.right_len = (uint16_t)r.right_len;
+        if (r.end - r.begin > 0xFFFFFFFFull || r.right_len > 0xFFFFu || r.n_slots > 0xFFu) atomicAdd(bad, 1ull);
+        wc[i] = w;
+    }
+    if (i < n_chains) {
+        eb_chain k = chains[i];
+        eb_wire_chain w;
+        w.side = k.side;
+        w.sym = k.sym;
+        w.len = (uint16_t)k.len;
+        w.support = k.support;
+        if (k.len > 0xFFFFu) atomicAdd(bad, 1ull);
+        wk[i] = w;
+    }
+}
 
 // first 64 bytes of the device image of a call set
 __global__ void k_blob_header(eb_calls_header h, uint64_t* dst) {
@@ -769,8 +800,11 @@ void eb_scan_ctx_destroy(eb_scan_ctx* c) {
     if (c->last_ext) (void)hipEventDestroy(c->last_ext);
     if (c->last_right) (void)hipEventDestroy(c->last_right);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    for (unsigned long long* p : c->h_bad_pool) (void)hipHostFree(p);
     delete c;
 }
+
+static int wire_enqueue(eb_scan_job* job, hipStream_t st, unsigned long long* h_bad);
 
 extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f, uint64_t begin, uint64_t end, const eb_params* prm,
                                          uint32_t options, eb_scan_job** out_job) {
@@ -848,12 +882,24 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
             if (!*j) return;
             (void)hipDeviceSynchronize(); // nothing may still use the job's buffers
             for (hipEvent_t e : (*j)->events) ctx->events.push_back(e);
+            if ((*j)->h_bad) ctx->h_bad_pool.push_back((*j)->h_bad);
             if ((*j)->calls) eb_calls_free((*j)->calls);
             delete *j;
         }
     } job_guard{&job, ctx};
     job->b1 = b1;
     job->S = S;
+    if (ctx->h_bad_pool.empty()) {
+        void* hb = nullptr;
+        EB_HIP(hipHostMalloc(&hb, 64, hipHostMallocDefault));
+        job->h_bad = static_cast<unsigned long long*>(hb);
+    } else {
+        job->h_bad = ctx->h_bad_pool.back();
+        ctx->h_bad_pool.pop_back();
+    }
+    *job->h_bad = 0;
+    job->k_left = prm->k_left;
+    job->k_right = prm->k_right;
     job->options = options;
     job->begin = begin;
     job->end = end;
@@ -1065,6 +1111,9 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
             }
         }
     }
+    job->ns = ns;
+    job->n_chains = n_chains;
+    if ((options & EB_SCAN_WIRE) && job->has_blob && (rc = wire_enqueue(job, sD, job->h_bad)) != EB_OK) return rc;
     EB_HIP(hipEventRecord(ev_end, sD));
     job->calls = calls;
     calls = nullptr; // owned by the job from here on
@@ -1117,6 +1166,7 @@ extern "C" int eb_scan_clusters_end(eb_scan_job* job, eb_calls** out, eb_scan_st
         stats->scan_launches = (uint32_t)job->S;
     }
     for (hipEvent_t e : job->events) ctx->events.push_back(e);
+    if (job->h_bad) ctx->h_bad_pool.push_back(job->h_bad);
     eb_calls* calls = job->calls;
     delete job; // releases the device scratch to the cache
     if (werr != hipSuccess) {
@@ -1146,6 +1196,53 @@ extern "C" int eb_scan_job_device_blob(eb_scan_job* job, const void** d_data, ui
     if (!job->has_blob) { eb_set_error("the job was split into sub-shards: no contiguous device image"); return EB_ERR_STATE; }
     *d_data = job->sh[0].blob.p;
     *len = job->blob_bytes;
+    return EB_OK;
+}
+
+// enqueues the packing of the compact wire image on `st` (after the records are complete there); h_bad: pinned word
+static int wire_enqueue(eb_scan_job* job, hipStream_t st, unsigned long long* h_bad) {
+    const uint64_t count = job->ns, n_chains = job->n_chains;
+    const uint64_t lw = ((uint64_t)job->k_left + 31) / 32, rw = ((uint64_t)job->k_right + 31) / 32;
+    const uint64_t bytes = eb_wire_size(count, n_chains, job->k_left, job->k_right);
+    job->wire.device = job->b1->device;
+    int rc = job->wire.alloc(bytes + 16); // + the overflow counter
+    if (rc != EB_OK) return rc;
+    uint8_t* q = job->wire.as<uint8_t>();
+    unsigned long long* d_bad = reinterpret_cast<unsigned long long*>(q + ((bytes + 7) & ~7ull));
+    EB_HIP(hipMemsetAsync(d_bad, 0, 8, st));
+    eb_calls_header h = job->header;
+    h.magic = EB_WIRE_MAGIC;
+    hipLaunchKernelGGL(k_blob_header, dim3(1), dim3(64), 0, st, h, reinterpret_cast<uint64_t*>(q));
+    if (count) {
+        SubShard& x = job->sh[0];
+        eb_wire_cluster* wc = reinterpret_cast<eb_wire_cluster*>(q + sizeof(eb_calls_header));
+        eb_wire_chain* wk = reinterpret_cast<eb_wire_chain*>(q + sizeof(eb_calls_header) + count * sizeof(eb_wire_cluster));
+        uint8_t* ctx_words = reinterpret_cast<uint8_t*>(wk) + n_chains * sizeof(eb_wire_chain);
+        const uint64_t most = count > n_chains ? count : n_chains;
+        hipLaunchKernelGGL(k_pack_wire, dim3(grid_of(most)), dim3(256), 0, st, x.d_recs, count, x.d_crec, n_chains, wc, wk, d_bad);
+        EB_HIP(hipMemcpyAsync(ctx_words, x.d_left, n_chains * lw * 8, hipMemcpyDeviceToDevice, st));
+        EB_HIP(hipMemcpyAsync(ctx_words + n_chains * lw * 8, x.d_right, count * rw * 8, hipMemcpyDeviceToDevice, st));
+    }
+    EB_HIP(hipMemcpyAsync(h_bad, d_bad, 8, hipMemcpyDeviceToHost, st));
+    EB_HIP(hipGetLastError());
+    job->wire_bytes = bytes;
+    return EB_OK;
+}
+
+extern "C" int eb_scan_job_device_wire(eb_scan_job* job, const void** d_data, uint64_t* len) {
+    if (!job || !d_data || !len) { eb_set_error("null argument"); return EB_ERR_ARG; }
+    if (!job->has_blob) { eb_set_error("the job was split into sub-shards: no contiguous device image"); return EB_ERR_STATE; }
+    EB_HIP(hipSetDevice(job->b1->device));
+    EB_HIP(hipEventSynchronize(job->ev_end)); // the records (and, with EB_SCAN_WIRE, the packing) are complete
+    if (!job->wire.p) {                       // not asked for at _begin: pack now
+        hipStream_t st = job->b1->scan_ctx->copy;
+        int rc = wire_enqueue(job, st, job->h_bad);
+        if (rc != EB_OK) return rc;
+        EB_HIP(hipStreamSynchronize(st));
+    }
+    if (*job->h_bad) { eb_set_error("%llu records do not fit the compact wire image", *job->h_bad); return EB_ERR_STATE; }
+    *d_data = job->wire.p;
+    *len = job->wire_bytes;
     return EB_OK;
 }
 

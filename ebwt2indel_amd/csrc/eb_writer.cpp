@@ -324,16 +324,53 @@ extern "C" int eb_calls_unpack(const uint8_t* buf, uint64_t len, eb_calls** out)
     eb_calls_header h;
     if (len < sizeof h) { eb_set_error("truncated call set"); return EB_ERR_ARG; }
     memcpy(&h, buf, sizeof h);
-    if (h.magic != kMagic) { eb_set_error("not a packed call set"); return EB_ERR_ARG; }
+    if (h.magic != kMagic && h.magic != EB_WIRE_MAGIC) { eb_set_error("not a packed call set"); return EB_ERR_ARG; }
     if (h.k_left == 0 || h.k_left > (1u << 20) || h.k_right == 0 || h.k_right > (1u << 20) || h.count > (1ull << 40) || h.n_chains > h.count * EB_MAX_SLOTS) {
         eb_set_error("corrupt call set header");
         return EB_ERR_ARG;
     }
-    uint64_t need = eb_calls_blob_size(h.count, h.n_chains, (int32_t)h.k_left, (int32_t)h.k_right);
+    const bool wire = h.magic == EB_WIRE_MAGIC;
+    uint64_t need = wire ? eb_wire_size(h.count, h.n_chains, (int32_t)h.k_left, (int32_t)h.k_right)
+                         : eb_calls_blob_size(h.count, h.n_chains, (int32_t)h.k_left, (int32_t)h.k_right);
     if (len < need) { eb_set_error("truncated call set"); return EB_ERR_ARG; }
     eb_calls* c = eb_calls_alloc(h.count, h.n_chains, (int32_t)h.k_left, (int32_t)h.k_right, false);
     if (!c) return EB_ERR_NOMEM;
-    memcpy(c->blob, buf, need);
+    if (!wire) {
+        memcpy(c->blob, buf, need);
+    } else {
+        // compact image -> records (first_chain = running sum of n_slots)
+        const uint8_t* q = buf + sizeof h;
+        uint64_t chain = 0;
+        for (uint64_t i = 0; i < h.count; ++i) {
+            eb_wire_cluster w;
+            memcpy(&w, q + i * sizeof w, sizeof w);
+            eb_cluster& r = c->clusters[i];
+            r.begin = w.begin;
+            r.end = w.begin + w.len;
+            r.first_chain = (uint32_t)chain;
+            r.n_slots = w.n_slots;
+            r.right_found = w.right_found;
+            r.right_len = w.right_len;
+            r.reserved = 0;
+            chain += w.n_slots;
+        }
+        if (chain != h.n_chains) { eb_set_error("corrupt call set: chain counts do not add up"); eb_calls_free(c); return EB_ERR_ARG; }
+        q += h.count * sizeof(eb_wire_cluster);
+        for (uint64_t i = 0; i < h.n_chains; ++i) {
+            eb_wire_chain w;
+            memcpy(&w, q + i * sizeof w, sizeof w);
+            eb_chain& k = c->chains[i];
+            k.side = w.side;
+            k.sym = w.sym;
+            k.reserved = 0;
+            k.len = w.len;
+            k.support = w.support;
+        }
+        q += h.n_chains * sizeof(eb_wire_chain);
+        memcpy(c->left, q, h.n_chains * c->left_words() * 8);
+        q += h.n_chains * c->left_words() * 8;
+        memcpy(c->right, q, h.count * c->right_words() * 8);
+    }
     *out = c;
     return EB_OK;
 }

@@ -210,6 +210,9 @@ void eb_scan_clusters_cancel(eb_scan_job* job);
 /* Options for _begin_ex.  EB_SCAN_DEVICE_ONLY: leave the call set in device memory only (no copy to the host) -- for
  * ranks that forward it to rank 0 with RCCL; _end then returns *out = NULL. */
 #define EB_SCAN_DEVICE_ONLY 1u
+/* EB_SCAN_WIRE: the job also packs the compact wire image (eb_scan_job_device_wire) as its last step, so that asking
+ * for it later costs no extra launch or wait. */
+#define EB_SCAN_WIRE 2u
 int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f, uint64_t begin, uint64_t end, const eb_params* p,
                               uint32_t options, eb_scan_job** job);
 /* Blocks until the job's kernels and copies are complete; the job stays valid. */
@@ -217,6 +220,14 @@ int eb_scan_job_wait(eb_scan_job* job);
 /* The job's call set as one contiguous image in DEVICE memory (same format as eb_calls_blob), valid until _end.
  * EB_ERR_STATE when the job was split into sub-shards (EB_SCAN_SUBSHARDS > 1). */
 int eb_scan_job_device_blob(eb_scan_job* job, const void** d_data, uint64_t* len);
+/* The same call set as a COMPACT wire image in device memory (56 instead of 80 bytes per two-allele cluster), for the
+ * gather to rank 0 and its download -- the PCIe link of rank 0 carries every record of an N-GPU job:
+ *   [64-byte header, magic "EBCALLS3"][{u64 begin; u32 end-begin; u8 n_slots; u8 right_found; u16 right_len} x count]
+ *   [{u8 side; u8 sym; u16 len; u32 support} x n_chains][left words][right words]
+ * (first_chain is the running sum of n_slots).  eb_calls_unpack reads both images.  Packed on first call, valid until
+ * _end.  EB_ERR_STATE if a field does not fit (a cluster of 2^32 rows or more, contexts of 2^16 bases or more): use
+ * eb_scan_job_device_blob then. */
+int eb_scan_job_device_wire(eb_scan_job* job, const void** d_data, uint64_t* len);
 
 typedef struct {
     uint64_t count;                /* clusters */

@@ -408,15 +408,21 @@ def test_device_image_equals_host_blob(dip):
     for begin, end in [(0, n), (n // 3 // 64 * 64, n // 3 * 2 // 64 * 64), (64, 64)]:
         host = api.scan_clusters_begin(g, fl, p, begin=begin, end=end).finish()
         want = bytes(host.blob())
-        job = api.scan_clusters_begin(g, fl, p, begin=begin, end=end, device_only=True)
+        job = api.scan_clusters_begin(g, fl, p, begin=begin, end=end, device_only=True, wire=(begin == 0))   # packed by the job / on demand
         job.wait()
         ptr, length = job.device_blob()
         assert length == len(want)
         got = np.empty(length, dtype=np.uint8)
         sim._hip_copy_to_host(got, ptr, length)
+        wptr, wlen = job.device_wire()                           # compact wire image of the same call set
+        wire = np.empty(wlen, dtype=np.uint8)
+        sim._hip_copy_to_host(wire, wptr, wlen)
         done = job.finish()
         assert done._h is None and done.stats.survivors == len(host)
         assert got.tobytes() == want
+        assert wlen <= length and (len(host) == 0 or wlen < 0.75 * length)
+        from_wire = api.Calls.unpack(wire.tobytes())
+        assert bytes(from_wire.blob()) == want                   # unpacks to the very same records
         back = api.Calls.unpack(got.tobytes())
         assert back.format_snp(p, False)[0] == host.format_snp(p, False)[0]
 
