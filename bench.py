@@ -61,6 +61,8 @@ def main():
         raise SystemExit(f"{world} ranks but {ndev} GPU(s): one GPU per rank is required with nccl")
     local = local % ndev
     use_dist = world > 1 or os.environ.get("EB_BENCH_FORCE_DIST") == "1"   # the latter: exercise the collectives with one rank
+    if os.environ.get("EB_BENCH_FORCE_DIST") == "1":
+        os.environ["EB_FORCE_COLLECTIVES"] = "1"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
