@@ -164,14 +164,14 @@ template <int MODE>
 __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, ScanParams p, uint64_t w_lo,
                                              uint64_t w_count, Survivor* __restrict__ surv, uint64_t surv_cap,
                                              ScanCounters* __restrict__ cnt, unsigned long long* __restrict__ partial) {
-    __shared__ unsigned int sh_hist[201];
+    __shared__ unsigned int sh_hist[202]; // [201]: sink for runs that CLUST_SIZES does not count
     constexpr int STAGE = 128; // survivors are ~1 per 10^4 positions: a workgroup rarely fills this before its next flush
     __shared__ uint4 s_buf[STAGE * (sizeof(Survivor) / 16)];
     __shared__ uint32_t s_count;
     __shared__ unsigned long long s_base;
     __shared__ unsigned long long q_hot[4][128], q_todo[4][128]; // per wave; entry = word << 6 | bit
     Stager<Survivor, STAGE> stage{s_buf, &s_count, &s_base};
-    for (int k = threadIdx.x; k < 201; k += blockDim.x) sh_hist[k] = 0;
+    for (int k = threadIdx.x; k < 202; k += blockDim.x) sh_hist[k] = 0;
     if (threadIdx.x == 0) s_count = 0;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -358,24 +358,52 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
         if (base + 64 > hi_pos) ends &= (hi_pos <= base) ? 0ull : (~0ull >> (base + 64 - hi_pos));
         n_runs += (uint64_t)__popcll(ends);
         if (p.dbg & 4u) continue;
-        // ---- bit-parallel: which closing runs contain a change of symbol at all.  A cluster whose rows all carry the
-        // same symbol (no variant, no read start: ~4 of 5) has at most one frequent letter and can never be kept
-        // (:961; two-sample modes need two distinct frequent letters to print anything, see analyse()).  chg marks the
-        // positions i, i+1 of one run that differ; added to the run masks it carries out into exactly the closing
-        // positions of the runs that hold such a pair (a run's mask plus any non-empty subset of it reaches the zero
-        // that ends it and never passes it).
+        // ---- bit-parallel: which closing runs can hold two frequent letters at all.  Two letters with >= mcov rows each
+        // (:961; the two-sample modes need two distinct frequent letters to print anything, see analyse()) mean that at
+        // least mcov rows differ from any one row of the cluster -- take its first row inside this word.  All runs of the
+        // word at once:
+        //   fill   : adding the first-row bit of every run to the run masks flips exactly the runs whose first row has
+        //            a 1 (the carry stops at the zero that ends a run), which spreads that bit over the run;
+        //   differ : rows whose (x, y) differ from the spread first row;
+        //   >= mcov: the lowest differing row of every run is cleared mcov-1 times (a decrement that starts at each
+        //            run's first row and is stopped by the closing zero), what is left marks runs with >= mcov;
+        //   collect: the run masks plus a non-empty subset of them carry out into exactly their closing positions.
+        // ~19 of 20 clusters (one symbol, or a read start or two) end here.  Rows of a run that lie in the previous word
+        // are counted separately and lower the bar for that one run.
         uint64_t hot = ends;
         {
-            uint64_t chg = ((cur.x ^ (cur.x >> 1)) | (cur.y ^ (cur.y >> 1))) & fw & (fw >> 1) & ~(1ull << 63);
-            // the part of a run that lies in the previous word (its top run, bits zbp..63)
-            uint64_t pz = ~pfw;
-            uint32_t zbp = pz ? 64u - (uint32_t)__clzll((long long)pz) : 0u;
-            uint64_t pchg = ((prv.x ^ (prv.x >> 1)) | (prv.y ^ (prv.y >> 1))) & pfw & (pfw >> 1) & ~(1ull << 63);
-            bool prv_hot = !pz || (zbp < 64 && (pchg >> zbp) != 0);          // run reaches beyond the two words: decided later
-            bool joint = (((prv.x >> 63) ^ cur.x) | ((prv.y >> 63) ^ cur.y)) & 1ull; // rows 63 | 0 differ
-            uint64_t inj = ((fw & 1ull) && (pfw >> 63) && (prv_hot || joint)) ? 1ull : 0ull;
-            hot = (fw + chg + inj) & ends;
-            if ((ends & 1ull) && prv_hot) hot |= 1ull;                       // a run that lies in the previous word and closes at bit 0
+            const uint64_t carry = pfw >> 63;
+            const uint64_t first = (fw & ~((fw << 1) | carry)) | (fw & carry);   // first row of every run (part) in this word
+            uint64_t fx = fw & ~(fw + (cur.x & first)), fy = fw & ~(fw + (cur.y & first));
+            uint64_t d = ((cur.x ^ fx) | (cur.y ^ fy)) & fw;
+            // the run that comes in from the previous word: its rows there (bits zbp..63) against the same first row
+            uint32_t need0 = p.mcov;                 // differing rows still needed inside this word by that run
+            uint64_t inj = 0;
+            const uint64_t pz = ~pfw;
+            const uint32_t zbp = pz ? 64u - (uint32_t)__clzll((long long)pz) : 0u;
+            bool prv_hot = !pz;                      // the run reaches beyond the two words: decided later, from memory
+            if (carry) {
+                if (pz) {
+                    const uint64_t top = ~0ull << zbp; // zbp <= 63 here
+                    const uint64_t rx = (cur.x & 1ull) ? ~0ull : 0ull, ry = (cur.y & 1ull) ? ~0ull : 0ull;
+                    const uint32_t rp = (uint32_t)__popcll(((prv.x ^ rx) | (prv.y ^ ry)) & top);
+                    need0 = rp >= p.mcov ? 0u : p.mcov - rp;
+                    // a run that lies in the previous word only (closes at bit 0) has no first row here: any change keeps it
+                    const uint64_t pchg = ((prv.x ^ (prv.x >> 1)) | (prv.y ^ (prv.y >> 1))) & pfw & (pfw >> 1) & ~(1ull << 63);
+                    prv_hot = (pchg >> zbp) != 0;
+                } else {
+                    need0 = 0;
+                }
+                if ((fw & 1ull) && need0 == 0) inj = 1ull;
+            }
+            const uint32_t clears = p.mcov > 9u ? 8u : p.mcov - 1u;             // fewer clears only weaken the filter
+            const uint64_t first_in = first & ~1ull;                             // runs that begin in this word
+            for (uint32_t k = 1; k <= clears; ++k) {
+                uint64_t from = first_in | ((fw & carry & 1ull) && k < need0 ? 1ull : (first & 1ull & ~carry));
+                d &= (d | ea) - from;
+            }
+            hot = (fw + d + inj) & ends;
+            if ((ends & 1ull) && prv_hot) hot |= 1ull;
         }
         // ---- run statistics of every closing position (CLUST_SIZES, counters).  The flagged rows between two
         // consecutive closing positions are exactly the run that closes at the second one, so a run's length is the
@@ -402,8 +430,11 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
                     cprev = (int32_t)bit; // all rows below `bit` are flagged
                 }
             }
-            uint32_t nb32 = 0, nc32 = 0;
+            uint32_t nb32 = 0, n_short = 0;
             if (p.dbg & 16u) rest = 0;
+            // branch-free body: runs longer than 200 (and, in the two words that hold the ends of the scanned range, the
+            // closing positions outside it) add to a sink slot of the histogram instead of skipping the add
+            const bool edge = __ballot((rest & ~ends) != 0ull) != 0ull; // wave-uniform: some lane's word holds an end of the scanned range
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const uint32_t h = (uint32_t)(fw >> (32 * half));
@@ -411,23 +442,35 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
                 uint32_t eb = (uint32_t)(rest >> (32 * half));
                 const uint32_t er = (uint32_t)(ends >> (32 * half));
                 uint32_t short_bits = 0;
-                while (eb) {
-                    uint32_t bit = (uint32_t)__ffs((int)eb) - 1u;
-                    eb &= eb - 1;
-                    int32_t c = cbase + (int32_t)__popc(h & ((1u << bit) - 1u));
-                    uint32_t len = (uint32_t)(c - cprev);
-                    cprev = c;
-                    if ((er >> bit) & 1u) { // always, except in the words that hold the ends of the scanned range
+                if (!edge) {
+                    while (eb) {
+                        const uint32_t low = eb & (0u - eb);
+                        eb ^= low;
+                        int32_t c = cbase + (int32_t)__popc(h & (low - 1u));
+                        uint32_t len = (uint32_t)(c - cprev);
+                        cprev = c;
                         nb32 += len;
-                        if (len <= 200 && !(p.dbg & 1u)) atomicAdd(&sh_hist[len], 1u);
-                        if (len >= p.min_len) ++nc32;
-                        else short_bits |= 1u << bit;
+                        atomicAdd(&sh_hist[len < 201u ? len : 201u], 1u);
+                        short_bits |= len < p.min_len ? low : 0u;
+                    }
+                } else {
+                    while (eb) {
+                        const uint32_t low = eb & (0u - eb);
+                        eb ^= low;
+                        int32_t c = cbase + (int32_t)__popc(h & (low - 1u));
+                        uint32_t len = (uint32_t)(c - cprev);
+                        cprev = c;
+                        const bool counted = (er & low) != 0u;
+                        nb32 += counted ? len : 0u;
+                        atomicAdd(&sh_hist[counted && len < 201u ? len : 201u], 1u);
+                        short_bits |= counted && len < p.min_len ? low : 0u;
                     }
                 }
+                n_short += (uint32_t)__popc(short_bits);
                 hot &= ~((uint64_t)short_bits << (32 * half));
             }
             n_bases += nb32;
-            n_clusters += nc32;
+            n_clusters += (uint64_t)__popcll(ends & rest) - n_short; // closing positions walked here, minus the short runs
         }
         // ---- hand the clusters that may matter to the queues, one per lane and round
         if (p.dbg & 8u) hot = 0;
