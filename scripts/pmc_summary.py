@@ -32,8 +32,9 @@ out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (
        "units": "FETCH_SIZE / WRITE_SIZE in KiB per launch (mean over launches). gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE "
                 "reports 1/2 of the bytes of a wide coalesced streaming read of 16 B per lane; other widths are uncalibrated. k_scan streams "
                 "two arrays: the scan planes with 16 B per lane (n/4 bytes, reported at 1/2) and the fused flag words with 8 B per lane "
-                "(n/8 bytes, taken as reported): corrected = FETCH_SIZE + n/8 + WRITE_SIZE. The random 64-byte gathers of the other kernels "
-                "are reported raw.",
+                "(n/8 bytes, taken as reported): corrected = FETCH_SIZE + n/8 + WRITE_SIZE. That estimate lands within a few percent of the "
+                "bytes the two streams hold (streamed_bytes_per_launch), i.e. the kernel reads its inputs once; the 8-B-per-lane width is "
+                "uncalibrated, so the last few percent are not significant. The random 64-byte gathers of the other kernels are reported raw.",
        "workload_positions": n, "kernels": {}}
 for key in KERNELS:
     if key not in fetch and key not in write:
