@@ -449,7 +449,7 @@ _STRESS = {
 }
 
 
-@pytest.mark.parametrize("mode", [1, 3])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 @pytest.mark.parametrize("name", sorted(_STRESS))
 def test_scan_on_adversarial_flag_patterns(oracle, name, mode):
     """Phase 4 on inputs the navigation would never produce: a random symbol string (every cluster mixes letters, so all of
@@ -465,20 +465,29 @@ def test_scan_on_adversarial_flag_patterns(oracle, name, mode):
     thrK = _pack_bits(pattern(rng, n))
     thrR = thrK & _pack_bits(_bits(rng, n, 0.5))
     minima = _pack_bits(_bits(rng, n, 0.01))
-    da_bits = _bits(rng, n, 0.5) if mode == 3 else None
-    da = _pack_bits(da_bits) if mode == 3 else None
+    da_bits = _bits(rng, n, 0.5) if mode != 1 else None
+    da = _pack_bits(da_bits) if mode != 1 else None
     args = ["-m", "2"] if name == "short_runs" else []
     p, pp = _oracle.Params.from_args(args), api.make_params(args)
-    o1 = oracle.index(sym, p.term)
-    of = _oracle.OracleFlags(oracle, o1, vectors=(thrK, thrR, minima, da))
-    g1 = api.DnaBwt(sym, term=p.term)
+    o2 = g2 = None
+    if mode == 2:
+        # two symbol strings whose merge by the DA is `sym`: the scan must see the same rows as in mode 3
+        sym1, sym2 = sym[~da_bits].copy(), sym[da_bits].copy()
+        sym1[:4] = ord("#")
+        sym2[:4] = ord("#")
+        o1, o2 = oracle.index(sym1, p.term), oracle.index(sym2, p.term)
+        g1, g2 = api.DnaBwt(sym1, term=p.term), api.DnaBwt(sym2, term=p.term)
+    else:
+        o1 = oracle.index(sym, p.term)
+        g1 = api.DnaBwt(sym, term=p.term)
+    of = _oracle.OracleFlags(oracle, o1, o2, vectors=(thrK, thrR, minima, da))
     gf = api.Flags.from_host(n, thrK, thrR, minima, da)
     seen = []
     for cuts in ([0, n], [0, 64 * 700 + 1, n // 2 + 17, n - 5, n]):
         for b, e in zip(cuts[:-1], cuts[1:]):
             want = of.scan(p, b, e, capture=True)
             seen.append(want["count"])
-            calls = api.scan_clusters(g1, gf, pp, begin=b, end=e)
+            calls = api.scan_clusters(g1, gf, pp, bwt2=g2, begin=b, end=e)
             cl, chains, left, right = calls.arrays()
             st = calls.stats
             assert dict(runs_closed=st.runs_closed, clusters=st.clusters, bases_in_runs=st.bases_in_runs,
