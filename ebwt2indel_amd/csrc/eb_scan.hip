@@ -543,12 +543,16 @@ __global__ void __launch_bounds__(256) k_scan_reduce(const unsigned long long* _
 
 // Histogram + frequent-symbol filter of the clusters k_scan could not analyse from registers (runs longer than
 // 64..128 positions).  Dropped ones get begin = ~0, which the sort moves behind the real survivors.
+__device__ __forceinline__ uint32_t bucket_of(uint64_t b, uint64_t base);
 __global__ void __launch_bounds__(256) k_long_runs(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, ScanParams p, Survivor* __restrict__ surv, uint64_t n,
-                                                  unsigned long long* __restrict__ dropped) {
+                                                  unsigned long long* __restrict__ dropped, uint64_t bucket_base, uint32_t* __restrict__ bucket_cnt) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Survivor s = surv[i];
-    if (s.fmask0 != EB_NEEDS_HIST) return;
+    if (s.fmask0 != EB_NEEDS_HIST) { // the usual survivor: only counted into its position bucket (see k_bucket_place)
+        atomicAdd(&bucket_cnt[bucket_of(s.b, bucket_base)], 1u);
+        return;
+    }
     uint32_t c0[4], c1[4];
     bool keep;
     if (p.mode == 1) {
@@ -575,22 +579,56 @@ __global__ void __launch_bounds__(256) k_long_runs(eb_dev_index x1, eb_dev_index
         s.b = ~0ull;
         s.fmask0 = s.fmask1 = 0;
         atomicAdd(dropped, 1ull);
+    } else {
+        atomicAdd(&bucket_cnt[bucket_of(s.b, bucket_base)], 1u);
     }
     surv[i] = s;
 }
 
-__global__ void __launch_bounds__(256) k_surv_keys(const Survivor* __restrict__ s, uint64_t n, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+// ---- BWT order of the survivors.  They leave the scan in queue order; their begins are spread evenly over the range
+// (~1 per 10^4 positions), so instead of a general sort (rocprim falls back to a 10-pass merge sort below 1 M keys:
+// 0.2 ms) they are dealt into buckets of 2^EB_BUCKET_SHIFT positions -- count, exclusive scan, place -- and the few
+// buckets that receive more than one are put in order by one thread each.  Dropped long-run candidates (begin = ~0)
+// are left out here.
+#define EB_BUCKET_SHIFT 11
+__device__ __forceinline__ uint32_t bucket_of(uint64_t b, uint64_t base) { return b <= base ? 0u : (uint32_t)((b - base) >> EB_BUCKET_SHIFT); }
+
+__global__ void __launch_bounds__(256) k_bucket_place(const Survivor* __restrict__ s, uint64_t n, uint64_t base, const uint32_t* __restrict__ off,
+                                                     uint32_t* __restrict__ fill, Survivor* __restrict__ out) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { keys[i] = s[i].b; idx[i] = (uint32_t)i; }
+    if (i >= n) return;
+    Survivor v = s[i];
+    if (v.b == ~0ull) return;
+    uint32_t k = bucket_of(v.b, base);
+    out[off[k] + atomicAdd(&fill[k], 1u)] = v;
 }
-__global__ void __launch_bounds__(256) k_surv_gather(const Survivor* __restrict__ s, const uint32_t* __restrict__ idx, uint64_t n, Survivor* __restrict__ out,
+// one thread per bucket: insertion sort of the (rare) buckets with more than one survivor
+__global__ void __launch_bounds__(256) k_bucket_fix(const uint32_t* __restrict__ off, uint64_t n_buckets, Survivor* __restrict__ out) {
+    uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_buckets) return;
+    const uint32_t lo = off[k], hi = off[k + 1];
+    for (uint32_t i = lo + 1; i < hi; ++i) {
+        Survivor v = out[i];
+        uint32_t j = i;
+        while (j > lo && out[j - 1].b > v.b) { out[j] = out[j - 1]; --j; }
+        if (j != i) out[j] = v;
+    }
+}
+// chains per surviving cluster (slots beyond the survivors stay 0)
+__global__ void __launch_bounds__(256) k_surv_chains(const Survivor* __restrict__ sorted, const uint32_t* __restrict__ ns_ptr, uint64_t n_raw,
                                                     uint32_t* __restrict__ n_chains) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        Survivor v = s[idx[i]];
-        out[i] = v;
-        n_chains[i] = (uint32_t)(__popc(v.fmask0) + __popc(v.fmask1));
-    }
+    if (i >= n_raw) return;
+    uint32_t c = 0;
+    if (i < *ns_ptr) { Survivor v = sorted[i]; c = (uint32_t)(__popc(v.fmask0) + __popc(v.fmask1)); }
+    n_chains[i] = c;
+}
+// surviving clusters and their chains, for the host (one read-back for both)
+__global__ void k_prep_totals(const uint32_t* __restrict__ ns_ptr, const uint32_t* __restrict__ choff, const uint32_t* __restrict__ nch,
+                              uint32_t* __restrict__ out2) {
+    uint32_t ns = *ns_ptr;
+    out2[0] = ns;
+    out2[1] = ns ? choff[ns - 1] + nch[ns - 1] : 0u;
 }
 // dense work list for k_extend: one entry (cluster << 3 | side*4 + letter) per frequent symbol
 __global__ void __launch_bounds__(256) k_chain_list(const Survivor* __restrict__ s, const uint32_t* __restrict__ offset, uint64_t n, uint64_t* __restrict__ chains) {
@@ -770,7 +808,7 @@ unsigned scan_grid(uint64_t words) {
 namespace {
 struct SubShard {
     uint64_t begin = 0, end = 0, w_lo = 0, w_count = 0, cap = 0;
-    DevMem cnt, part, surv, sorted, keys, keys2, idx, idx2, tmp, nch, choff, chains, recs, crec, left, right, blob;
+    DevMem cnt, part, surv, sorted, bcnt, boff, tmp, nch, choff, chains, recs, crec, left, right, blob; // bcnt/boff: position buckets
     eb_cluster* d_recs = nullptr; // sections: inside `blob` (one shard) or the separate buffers above (sub-shards)
     eb_chain* d_crec = nullptr;
     uint64_t *d_left = nullptr, *d_right = nullptr;
@@ -988,7 +1026,7 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
     EB_HIP(hipEventRecord(ev_begin, sA));
     for (int k = 0; k < S; ++k) {
         SubShard& x = sh[(size_t)k];
-        for (DevMem* m : {&x.cnt, &x.part, &x.surv, &x.sorted, &x.keys, &x.keys2, &x.idx, &x.idx2, &x.tmp, &x.nch, &x.choff, &x.chains, &x.recs, &x.crec, &x.left, &x.right, &x.blob})
+        for (DevMem* m : {&x.cnt, &x.part, &x.surv, &x.sorted, &x.bcnt, &x.boff, &x.tmp, &x.nch, &x.choff, &x.chains, &x.recs, &x.crec, &x.left, &x.right, &x.blob})
             m->device = b1->device;
         for (int i = 0; i < 9; ++i) x.e[i] = job->events[2 + 9 * (size_t)k + (size_t)i];
         x.h_cnt = reinterpret_cast<ScanCounters*>(static_cast<uint8_t*>(ctx->h_pinned) + (size_t)k * (sizeof(ScanCounters) + 64));
@@ -1005,8 +1043,6 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
     }
 
     const uint32_t lw = (uint32_t)((prm->k_left + 31) / 32), rw = (uint32_t)((prm->k_right + 31) / 32);
-    int key_bits = 1;
-    while (key_bits < 64 && (n >> key_bits)) ++key_bits; // cluster begins are < n: fewer radix passes than 64 bits
     uint64_t rec_total = 0, chain_total = 0;
     ScanCounters c;
     memset(&c, 0, sizeof c);
@@ -1020,48 +1056,55 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
         }
         ScanCounters hc = *x.h_cnt;
         x.ns_raw = hc.nsurv;
-        x.ns = x.ns_raw;
         if (x.ns_raw > 0x1FFFFFFFull) { eb_set_error("too many surviving clusters in one call; shard the range"); return EB_ERR_STATE; }
         EB_HIP(hipStreamWaitEvent(sP, x.e[E_SCAN_DONE], 0));
-        if (hc.n_long) {
-            hipLaunchKernelGGL(k_long_runs, dim3(grid_of(x.ns_raw)), dim3(256), 0, sP, x1, x2, df, p, x.surv.as<Survivor>(), x.ns_raw,
-                               &x.cnt.as<ScanCounters>()->dropped);
-            EB_HIP(hipMemcpyAsync(x.h_cnt, x.cnt.p, sizeof(ScanCounters), hipMemcpyDeviceToHost, sP));
-            EB_HIP(hipStreamSynchronize(sP));
-            EB_HIP(hipGetLastError());
-            x.ns = x.ns_raw - x.h_cnt->dropped; // dropped candidates carry begin = ~0 and sort behind the survivors
-        }
         c.runs_closed += hc.runs_closed;
         c.clusters += hc.clusters;
         c.bases += hc.bases;
         for (int i = 0; i < 201; ++i) c.hist[i] += hc.hist[i];
         x.rec_base = rec_total;
         x.chain_base = chain_total;
-        if (x.ns == 0) continue;
-        // BWT order: sort survivors by begin
-        if ((rc = x.keys.alloc(x.ns_raw * 8)) != EB_OK || (rc = x.keys2.alloc(x.ns_raw * 8)) != EB_OK || (rc = x.idx.alloc(x.ns_raw * 4)) != EB_OK ||
-            (rc = x.idx2.alloc(x.ns_raw * 4)) != EB_OK || (rc = x.sorted.alloc(x.ns * sizeof(Survivor))) != EB_OK ||
-            (rc = x.nch.alloc(x.ns * 4)) != EB_OK || (rc = x.choff.alloc((x.ns + 1) * 4)) != EB_OK)
+        if (x.ns_raw == 0) { x.ns = 0; continue; }
+        // BWT order: deal the survivors into position buckets (x.ns, the count without the dropped candidates, comes back
+        // with the chain count)
+        const uint64_t bucket_base = x.begin & ~((1ull << EB_BUCKET_SHIFT) - 1ull);
+        const uint64_t range_end = x.end > n ? n : x.end;
+        const uint64_t n_buckets = ((range_end > bucket_base ? range_end - bucket_base : 0) >> EB_BUCKET_SHIFT) + 2;
+        if (n_buckets > 0x7FFFFFFEull) { eb_set_error("range too long for one call; shard it"); return EB_ERR_STATE; }
+        // bcnt = [count | fill] (zeroed), boff = offsets (n_buckets + 1)
+        if ((rc = x.bcnt.alloc((n_buckets + 1) * 8)) != EB_OK || (rc = x.boff.alloc((n_buckets + 2) * 4)) != EB_OK ||
+            (rc = x.sorted.alloc(x.ns_raw * sizeof(Survivor))) != EB_OK || (rc = x.nch.alloc(x.ns_raw * 4)) != EB_OK ||
+            (rc = x.choff.alloc((x.ns_raw + 3) * 4)) != EB_OK)
             return rc;
-        hipLaunchKernelGGL(k_surv_keys, dim3(grid_of(x.ns_raw)), dim3(256), 0, sP, x.surv.as<Survivor>(), x.ns_raw, x.keys.as<uint64_t>(), x.idx.as<uint32_t>());
+        uint32_t* d_bcnt = x.bcnt.as<uint32_t>();
+        uint32_t* d_bfill = d_bcnt + (n_buckets + 1);
+        uint32_t* d_boff = x.boff.as<uint32_t>();
         size_t tmp_bytes = 0, scan_bytes = 0;
-        const int end_bit = hc.n_long ? 64 : key_bits; // dropped long-run candidates carry begin = ~0 and must sort last
-        EB_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, x.keys.as<uint64_t>(), x.keys2.as<uint64_t>(), x.idx.as<uint32_t>(),
-                                                  x.idx2.as<uint32_t>(), (int)x.ns_raw, 0, end_bit, sP));
-        EB_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, x.nch.as<uint32_t>(), x.choff.as<uint32_t>(), (int)x.ns, sP));
+        EB_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_bcnt, d_boff, (int)(n_buckets + 1), sP));
+        EB_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, x.nch.as<uint32_t>(), x.choff.as<uint32_t>(), (int)x.ns_raw, sP));
         if (scan_bytes > tmp_bytes) tmp_bytes = scan_bytes;
         if ((rc = x.tmp.alloc(tmp_bytes)) != EB_OK) return rc;
-        EB_HIP(hipcub::DeviceRadixSort::SortPairs(x.tmp.p, tmp_bytes, x.keys.as<uint64_t>(), x.keys2.as<uint64_t>(), x.idx.as<uint32_t>(),
-                                                  x.idx2.as<uint32_t>(), (int)x.ns_raw, 0, end_bit, sP));
-        hipLaunchKernelGGL(k_surv_gather, dim3(grid_of(x.ns)), dim3(256), 0, sP, x.surv.as<Survivor>(), x.idx2.as<uint32_t>(), x.ns, x.sorted.as<Survivor>(),
-                           x.nch.as<uint32_t>());
+        EB_HIP(hipMemsetAsync(d_bcnt, 0, (n_buckets + 1) * 8, sP));
+        // candidates whose run is longer than the scan's two words get their histogram by rank differences (the ones
+        // that fail: begin = ~0); every survivor is counted into its bucket
+        hipLaunchKernelGGL(k_long_runs, dim3(grid_of(x.ns_raw)), dim3(256), 0, sP, x1, x2, df, p, x.surv.as<Survivor>(), x.ns_raw,
+                           &x.cnt.as<ScanCounters>()->dropped, bucket_base, d_bcnt);
+        EB_HIP(hipcub::DeviceScan::ExclusiveSum(x.tmp.p, tmp_bytes, d_bcnt, d_boff, (int)(n_buckets + 1), sP)); // d_boff[n_buckets] = survivors kept
+        hipLaunchKernelGGL(k_bucket_place, dim3(grid_of(x.ns_raw)), dim3(256), 0, sP, x.surv.as<Survivor>(), x.ns_raw, bucket_base, d_boff, d_bfill,
+                           x.sorted.as<Survivor>());
+        hipLaunchKernelGGL(k_bucket_fix, dim3(grid_of(n_buckets)), dim3(256), 0, sP, d_boff, n_buckets, x.sorted.as<Survivor>());
+        hipLaunchKernelGGL(k_surv_chains, dim3(grid_of(x.ns_raw)), dim3(256), 0, sP, x.sorted.as<Survivor>(), d_boff + n_buckets, x.ns_raw, x.nch.as<uint32_t>());
         // dense chain list: exclusive scan of the per-cluster chain counts
-        EB_HIP(hipcub::DeviceScan::ExclusiveSum(x.tmp.p, tmp_bytes, x.nch.as<uint32_t>(), x.choff.as<uint32_t>(), (int)x.ns, sP));
-        EB_HIP(hipMemcpyAsync(&x.h_last[0], x.choff.as<uint32_t>() + (x.ns - 1), 4, hipMemcpyDeviceToHost, sP));
-        EB_HIP(hipMemcpyAsync(&x.h_last[1], x.nch.as<uint32_t>() + (x.ns - 1), 4, hipMemcpyDeviceToHost, sP));
+        EB_HIP(hipcub::DeviceScan::ExclusiveSum(x.tmp.p, tmp_bytes, x.nch.as<uint32_t>(), x.choff.as<uint32_t>(), (int)x.ns_raw, sP));
+        uint32_t* d_tot = x.choff.as<uint32_t>() + x.ns_raw + 1;
+        hipLaunchKernelGGL(k_prep_totals, dim3(1), dim3(1), 0, sP, d_boff + n_buckets, x.choff.as<uint32_t>(), x.nch.as<uint32_t>(), d_tot);
+        EB_HIP(hipMemcpyAsync(&x.h_last[0], d_tot, 8, hipMemcpyDeviceToHost, sP));
         EB_HIP(hipEventRecord(x.e[E_PREP_CNT], sP));
         EB_HIP(hipEventSynchronize(x.e[E_PREP_CNT]));
-        x.n_chains = (uint64_t)x.h_last[0] + x.h_last[1];
+        EB_HIP(hipGetLastError());
+        x.ns = x.h_last[0];
+        x.n_chains = x.h_last[1];
+        if (x.ns == 0) continue;
         if (chain_total + x.n_chains > 0xFFFFFFFFull) { eb_set_error("too many chains in one call; shard the range"); return EB_ERR_STATE; }
         const size_t left_bytes = x.n_chains * (size_t)lw * 8, right_bytes = x.ns * (size_t)rw * 8;
         if ((rc = x.chains.alloc(x.n_chains * 8)) != EB_OK) return rc;
@@ -1191,6 +1234,14 @@ extern "C" int eb_scan_clusters_end(eb_scan_job* job, eb_calls** out, eb_scan_st
             (void)hipEventElapsedTime(&t, x.e[E_RIGHT0], x.e[E_RIGHT_DONE]);
             ms_right += t;
         }
+    }
+    if (werr == hipSuccess && getenv("EB_SCAN_TRACE") && job->S == 1) {
+        SubShard& x = job->sh[0];
+        auto at = [&](hipEvent_t e) { float t = 0; (void)hipEventElapsedTime(&t, job->ev_begin, e); return t; };
+        if (x.ns)
+            fprintf(stderr, "[scan] ms since begin: scan %.3f-%.3f  counters on host %.3f  sort+offsets %.3f  lists %.3f  extend %.3f-%.3f  right %.3f-%.3f  end %.3f\n",
+                    at(x.e[E_SCAN0]), at(x.e[E_SCAN1]), at(x.e[E_SCAN_DONE]), at(x.e[E_PREP_CNT]), at(x.e[E_PREP_DONE]), at(x.e[E_EXT0]), at(x.e[E_EXT_DONE]),
+                    at(x.e[E_RIGHT0]), at(x.e[E_RIGHT_DONE]), at(job->ev_end));
     }
     if (stats && werr == hipSuccess) {
         memset(stats, 0, sizeof *stats);
