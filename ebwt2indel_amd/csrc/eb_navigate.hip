@@ -23,8 +23,36 @@ namespace {
 // Records are padded to a multiple of 16 bytes so that lanes move them as uint4.
 struct alignas(16) Leaf1 { uint64_t l, r, depth, pad; };                              // sa_leaf (include.hpp:513-527)
 struct alignas(16) Node1 { uint64_t b[6]; uint64_t depth, pad; };                     // sa_node (include.hpp:394-413)
+// A one-BWT node travels through the stacks in 32 bytes: six 40-bit boundaries (n < 2^40) and a 16-bit depth that
+// saturates -- the depth is only ever compared with K and k_right (< 65535, checked by the host).  Half the record
+// traffic of the traversal, twice the records per arena.
+struct alignas(16) Node1P { uint64_t w[4]; };
+__host__ __device__ __forceinline__ Node1P pack_node(const Node1& n) {
+    const uint64_t m = (1ull << 40) - 1ull;
+    Node1P p;
+    p.w[0] = (n.b[0] & m) | (n.b[1] << 40);                          // b1: low 24 bits
+    p.w[1] = ((n.b[1] & m) >> 24) | ((n.b[2] & m) << 16) | (n.b[3] << 56); // b1 high 16, b2, b3 low 8
+    p.w[2] = ((n.b[3] & m) >> 8) | (n.b[4] << 32);                   // b3 high 32, b4 low 32
+    p.w[3] = ((n.b[4] & m) >> 32) | ((n.b[5] & m) << 8) | ((n.depth > 0xFFFFull ? 0xFFFFull : n.depth) << 48); // b4 high 8, b5, depth
+    return p;
+}
+__host__ __device__ __forceinline__ Node1 unpack_node(const Node1P& p) {
+    const uint64_t m = (1ull << 40) - 1ull;
+    Node1 n;
+    n.b[0] = p.w[0] & m;
+    n.b[1] = (p.w[0] >> 40) | ((p.w[1] & 0xFFFFull) << 24);
+    n.b[2] = (p.w[1] >> 16) & m;
+    n.b[3] = (p.w[1] >> 56) | ((p.w[2] & 0xFFFFFFFFull) << 8);
+    n.b[4] = (p.w[2] >> 32) | ((p.w[3] & 0xFFull) << 32);
+    n.b[5] = (p.w[3] >> 8) & m;
+    n.depth = p.w[3] >> 48;
+    n.pad = 0;
+    return n;
+}
 struct alignas(16) Leaf2 { uint64_t l1, r1, l2, r2, depth, pad[3]; };                 // pair<sa_leaf,sa_leaf>
 struct alignas(16) Node2 { uint64_t a[6]; uint64_t b[6]; uint64_t depth, pad[3]; };   // pair<sa_node,sa_node>
+__host__ __device__ __forceinline__ const Node2& pack_node(const Node2& n) { return n; }   // two-BWT nodes travel as they are
+__host__ __device__ __forceinline__ const Node2& unpack_node(const Node2& n) { return n; }
 
 struct NavCounters {
     unsigned long long pushed;     // children appended by the current launch
@@ -174,15 +202,16 @@ template <int NB>
 __global__ void __launch_bounds__(256) k_nodes(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, uint64_t* __restrict__ kr, NavParams p, const void* in_,
                                               uint64_t count, void* out_, uint64_t out_cap, NavCounters* cnt, unsigned long long* __restrict__ stat_rows) {
     using Node = typename std::conditional<NB == 1, Node1, Node2>::type;
-    constexpr int STAGE = NB == 1 ? 768 : 512;
-    __shared__ uint4 s_buf[STAGE * (sizeof(Node) / 16)];
+    using Rec = typename std::conditional<NB == 1, Node1P, Node2>::type; // the record as it lies in the stacks
+    constexpr int STAGE = NB == 1 ? 1536 : 512;
+    __shared__ uint4 s_buf[STAGE * (sizeof(Rec) / 16)];
     __shared__ uint32_t s_count;
     __shared__ unsigned long long s_base;
-    Stager<Node, STAGE> stage{s_buf, &s_count, &s_base};
+    Stager<Rec, STAGE> stage{s_buf, &s_count, &s_base};
     if (threadIdx.x == 0) s_count = 0;
     __syncthreads();
-    const Node* in = static_cast<const Node*>(in_);
-    Node* out = static_cast<Node*>(out_);
+    const Rec* in = static_cast<const Rec*>(in_);
+    Rec* out = static_cast<Rec*>(out_);
     const uint32_t j = threadIdx.x & 3u, q = threadIdx.x >> 2;
     uint64_t n_node = 0, n_lcp = 0, n_da = 0, n_rank = 0, n_min = 0;
     const uint64_t tiles = (count + 63) / 64;
@@ -192,7 +221,7 @@ __global__ void __launch_bounds__(256) k_nodes(eb_dev_index x1, eb_dev_index x2,
         bool active = i < count;
         Node N;
         memset(&N, 0, sizeof N);
-        if (active) N = in[i];
+        if (active) N = unpack_node(in[i]);
         uint64_t m[6]; // merged boundaries (merge_nodes, include.hpp:476-490)
         if constexpr (NB == 1) {
             for (int k = 0; k < 6; ++k) m[k] = N.b[k];
@@ -264,7 +293,7 @@ __global__ void __launch_bounds__(256) k_nodes(eb_dev_index x1, eb_dev_index x2,
                 for (int k = 1; k < 6; ++k) n_rank += (N.a[k] != N.a[k - 1]) + (N.b[k] != N.b[k - 1]);
             }
         }
-        stage.push(keep, child);
+        stage.push(keep, pack_node(child));
         // every tile adds at most 256 records: flushing every STAGE/256 tiles never overflows the buffer, and the
         // decision is the same in every thread without looking at shared state
         if (++trips % (STAGE / 256) == 0) stage.flush(out, out_cap, &cnt->pushed);
@@ -523,6 +552,8 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
                             eb_nav_stats* stats) {
     if (!b1 || !out) { eb_set_error("null argument"); return EB_ERR_ARG; }
     if (n_shards == 0 || shard >= n_shards) { eb_set_error("shard %u of %u", shard, n_shards); return EB_ERR_ARG; }
+    if (K < 0 || K > 65534 || k_right < 0 || k_right > 65534) { eb_set_error("K and k_right must be below 65535"); return EB_ERR_ARG; }
+    if (b1->n + (b2 ? b2->n : 0) >= (1ull << 40)) { eb_set_error("BWT of 2^40 symbols or more: node records hold 40-bit positions"); return EB_ERR_ARG; }
     if (b2 && b2->device != b1->device) { eb_set_error("both indexes must live on the same device"); return EB_ERR_ARG; }
     *out = nullptr;
     EB_HIP(hipSetDevice(b1->device));
@@ -559,7 +590,7 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
     hipStream_t st = f->stream;
     const uint64_t batch_max = env_u64("EB_NAV_BATCH", 16ull << 20);
     // one arena for both traversals: two stacks of EB_NAV_STACK_BATCHES / 2 batches of the largest record each
-    const uint64_t item_bytes = b2 ? sizeof(Node2) : sizeof(Node1);
+    const uint64_t item_bytes = b2 ? sizeof(Node2) : sizeof(Leaf1); // Leaf1 and the packed Node1P: 32 bytes
     uint64_t arena_batches = env_u64("EB_NAV_STACK_BATCHES", 12) + 1; // observed peak: 5 batches pending
     uint64_t eff_batch = batch_max < n / 2 + 64 ? batch_max : n / 2 + 64;
     uint64_t arena_records = arena_batches * eff_batch + (n < (1ull << 20) ? n + 4 * eff_batch + 64 : 0);
@@ -624,13 +655,13 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
         double t1 = now_s();
         s.seconds_leaves = t1 - t0;
         { // phase 3 (ebwt2InDel.cpp:622-673); root (dna_bwt.hpp:296-308)
-            Drain<Node1> d;
+            Drain<Node1P> d;
             d.device = b1->device; d.stream = st;
             d.shard = shard; d.n_shards = n_shards; d.split_min = split_min;
             if ((rc = d.init(d_arena, arena_bytes, n, batch_max)) != EB_OK) return rc;
             Node1 root{{0, b1->F[0], b1->F[1], b1->F[2], b1->F[3], b1->n}, 0, 0};
-            if ((rc = d.push_host(root)) != EB_OK) return rc;
-            rc = d.run<-1>(d_cnt, h_pushed, [&](Node1* in, uint64_t cnt, Node1* o, uint64_t ocap, int write) {
+            if ((rc = d.push_host(pack_node(root))) != EB_OK) return rc;
+            rc = d.run<-1>(d_cnt, h_pushed, [&](Node1P* in, uint64_t cnt, Node1P* o, uint64_t ocap, int write) {
                 NavParams q = p;
                 q.write = write;
                 hipLaunchKernelGGL(k_nodes<1>, dim3(nav_grid(cnt)), dim3(256), 0, st, x1, x2, df, d_kr, q, in, cnt, o, ocap, d_cnt, d_rows);
