@@ -23,36 +23,53 @@ namespace {
 // Records are padded to a multiple of 16 bytes so that lanes move them as uint4.
 struct alignas(16) Leaf1 { uint64_t l, r, depth, pad; };                              // sa_leaf (include.hpp:513-527)
 struct alignas(16) Node1 { uint64_t b[6]; uint64_t depth, pad; };                     // sa_node (include.hpp:394-413)
-// A one-BWT node travels through the stacks in 32 bytes: six 40-bit boundaries (n < 2^40) and a 16-bit depth that
-// saturates -- the depth is only ever compared with K and k_right (< 65535, checked by the host).  Half the record
-// traffic of the traversal, twice the records per arena.
-struct alignas(16) Node1P { uint64_t w[4]; };
-__host__ __device__ __forceinline__ Node1P pack_node(const Node1& n) {
-    const uint64_t m = (1ull << 40) - 1ull;
-    Node1P p;
-    p.w[0] = (n.b[0] & m) | (n.b[1] << 40);                          // b1: low 24 bits
-    p.w[1] = ((n.b[1] & m) >> 24) | ((n.b[2] & m) << 16) | (n.b[3] << 56); // b1 high 16, b2, b3 low 8
-    p.w[2] = ((n.b[3] & m) >> 8) | (n.b[4] << 32);                   // b3 high 32, b4 low 32
-    p.w[3] = ((n.b[4] & m) >> 32) | ((n.b[5] & m) << 8) | ((n.depth > 0xFFFFull ? 0xFFFFull : n.depth) << 48); // b4 high 8, b5, depth
-    return p;
-}
-__host__ __device__ __forceinline__ Node1 unpack_node(const Node1P& p) {
-    const uint64_t m = (1ull << 40) - 1ull;
-    Node1 n;
-    n.b[0] = p.w[0] & m;
-    n.b[1] = (p.w[0] >> 40) | ((p.w[1] & 0xFFFFull) << 24);
-    n.b[2] = (p.w[1] >> 16) & m;
-    n.b[3] = (p.w[1] >> 56) | ((p.w[2] & 0xFFFFFFFFull) << 8);
-    n.b[4] = (p.w[2] >> 32) | ((p.w[3] & 0xFFull) << 32);
-    n.b[5] = (p.w[3] >> 8) & m;
-    n.depth = p.w[3] >> 48;
-    n.pad = 0;
-    return n;
-}
 struct alignas(16) Leaf2 { uint64_t l1, r1, l2, r2, depth, pad[3]; };                 // pair<sa_leaf,sa_leaf>
 struct alignas(16) Node2 { uint64_t a[6]; uint64_t b[6]; uint64_t depth, pad[3]; };   // pair<sa_node,sa_node>
-__host__ __device__ __forceinline__ const Node2& pack_node(const Node2& n) { return n; }   // two-BWT nodes travel as they are
-__host__ __device__ __forceinline__ const Node2& unpack_node(const Node2& n) { return n; }
+
+// Records travel through the stacks packed: NF 40-bit positions (n < 2^40, checked by the host) and a 16-bit depth that
+// saturates -- the depth is only ever compared with K and k_right (< 65535, checked by the host).  A one-BWT node is
+// 32 bytes instead of 64, a two-BWT node 64 instead of 128, a two-BWT leaf 32 instead of 64: half the record traffic of
+// the traversal and twice the records per arena.
+template <int NF>
+struct alignas(16) Packed { uint64_t w[((NF * 40 + 16 + 127) / 128) * 2]; };
+template <int NF>
+__host__ __device__ __forceinline__ Packed<NF> pack_fields(const uint64_t* f, uint64_t depth) {
+    static_assert(((NF * 40) & 63) <= 48, "the depth must not straddle two words");
+    Packed<NF> p;
+    for (uint64_t& x : p.w) x = 0;
+#pragma unroll
+    for (int k = 0; k < NF; ++k) {
+        const int off = 40 * k, wd = off >> 6, sh = off & 63;
+        const uint64_t v = f[k] & ((1ull << 40) - 1ull);
+        p.w[wd] |= v << sh;
+        if (sh > 24) p.w[wd + 1] |= v >> (64 - sh);
+    }
+    p.w[(NF * 40) >> 6] |= (depth > 0xFFFFull ? 0xFFFFull : depth) << ((NF * 40) & 63);
+    return p;
+}
+template <int NF>
+__host__ __device__ __forceinline__ uint64_t unpack_fields(const Packed<NF>& p, uint64_t* f) {
+#pragma unroll
+    for (int k = 0; k < NF; ++k) {
+        const int off = 40 * k, wd = off >> 6, sh = off & 63;
+        uint64_t v = p.w[wd] >> sh;
+        if (sh > 24) v |= p.w[wd + 1] << (64 - sh);
+        f[k] = v & ((1ull << 40) - 1ull);
+    }
+    return (p.w[(NF * 40) >> 6] >> ((NF * 40) & 63)) & 0xFFFFull;
+}
+using Node1P = Packed<6>;
+using Node2P = Packed<12>;
+using Leaf2P = Packed<4>;
+static_assert(sizeof(Node1P) == 32 && sizeof(Node2P) == 64 && sizeof(Leaf2P) == 32, "packed record sizes");
+__host__ __device__ __forceinline__ Node1P pack_rec(const Node1& n) { return pack_fields<6>(n.b, n.depth); }
+__host__ __device__ __forceinline__ Node2P pack_rec(const Node2& n) { return pack_fields<12>(n.a, n.depth); }   // a[6] and b[6] are contiguous
+__host__ __device__ __forceinline__ Leaf2P pack_rec(const Leaf2& l) { return pack_fields<4>(&l.l1, l.depth); }
+__host__ __device__ __forceinline__ const Leaf1& pack_rec(const Leaf1& l) { return l; }                            // 32 bytes as it is
+__host__ __device__ __forceinline__ void unpack_rec(const Node1P& p, Node1& n) { n.depth = unpack_fields<6>(p, n.b); n.pad = 0; }
+__host__ __device__ __forceinline__ void unpack_rec(const Node2P& p, Node2& n) { n.depth = unpack_fields<12>(p, n.a); n.pad[0] = n.pad[1] = n.pad[2] = 0; }
+__host__ __device__ __forceinline__ void unpack_rec(const Leaf2P& p, Leaf2& l) { l.depth = unpack_fields<4>(p, &l.l1); l.pad[0] = l.pad[1] = l.pad[2] = 0; }
+__host__ __device__ __forceinline__ void unpack_rec(const Leaf1& p, Leaf1& l) { l = p; }
 
 struct NavCounters {
     unsigned long long pushed;     // children appended by the current launch
@@ -96,15 +113,16 @@ template <int NB>
 __global__ void __launch_bounds__(256) k_leaves(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, uint64_t* __restrict__ kr, NavParams p, const void* in_,
                                                uint64_t count, void* out_, uint64_t out_cap, NavCounters* cnt, unsigned long long* __restrict__ stat_rows) {
     using Leaf = typename std::conditional<NB == 1, Leaf1, Leaf2>::type;
+    using Rec = typename std::conditional<NB == 1, Leaf1, Leaf2P>::type; // the record as it lies in the stacks
     constexpr int STAGE = 1024;
-    __shared__ uint4 s_buf[STAGE * (sizeof(Leaf) / 16)];
+    __shared__ uint4 s_buf[STAGE * (sizeof(Rec) / 16)];
     __shared__ uint32_t s_count;
     __shared__ unsigned long long s_base;
-    Stager<Leaf, STAGE> stage{s_buf, &s_count, &s_base};
+    Stager<Rec, STAGE> stage{s_buf, &s_count, &s_base};
     if (threadIdx.x == 0) s_count = 0;
     __syncthreads();
-    const Leaf* in = static_cast<const Leaf*>(in_);
-    Leaf* out = static_cast<Leaf*>(out_);
+    const Rec* in = static_cast<const Rec*>(in_);
+    Rec* out = static_cast<Rec*>(out_);
     const uint32_t j = threadIdx.x & 3u, q = threadIdx.x >> 2;
     uint64_t n_leaf = 0, n_lcp = 0, n_da = 0, n_rank = 0;
     const uint64_t tiles = (count + 63) / 64;
@@ -114,7 +132,7 @@ __global__ void __launch_bounds__(256) k_leaves(eb_dev_index x1, eb_dev_index x2
         bool active = i < count;
         Leaf L;
         memset(&L, 0, sizeof L);
-        if (active) L = in[i];
+        if (active) unpack_rec(in[i], L);
         Leaf child;
         memset(&child, 0, sizeof child);
         bool keep = false;
@@ -183,7 +201,7 @@ __global__ void __launch_bounds__(256) k_leaves(eb_dev_index x1, eb_dev_index x2
                 }
             }
         }
-        stage.push(keep, child);
+        stage.push(keep, pack_rec(child));
         // every tile adds at most 256 records: flushing every STAGE/256 tiles never overflows the buffer, and the
         // decision is the same in every thread without looking at shared state
         if (++trips % (STAGE / 256) == 0) stage.flush(out, out_cap, &cnt->pushed);
@@ -202,8 +220,8 @@ template <int NB>
 __global__ void __launch_bounds__(256) k_nodes(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, uint64_t* __restrict__ kr, NavParams p, const void* in_,
                                               uint64_t count, void* out_, uint64_t out_cap, NavCounters* cnt, unsigned long long* __restrict__ stat_rows) {
     using Node = typename std::conditional<NB == 1, Node1, Node2>::type;
-    using Rec = typename std::conditional<NB == 1, Node1P, Node2>::type; // the record as it lies in the stacks
-    constexpr int STAGE = NB == 1 ? 1536 : 512;
+    using Rec = typename std::conditional<NB == 1, Node1P, Node2P>::type; // the record as it lies in the stacks
+    constexpr int STAGE = NB == 1 ? 1536 : 768;
     __shared__ uint4 s_buf[STAGE * (sizeof(Rec) / 16)];
     __shared__ uint32_t s_count;
     __shared__ unsigned long long s_base;
@@ -221,7 +239,7 @@ __global__ void __launch_bounds__(256) k_nodes(eb_dev_index x1, eb_dev_index x2,
         bool active = i < count;
         Node N;
         memset(&N, 0, sizeof N);
-        if (active) N = unpack_node(in[i]);
+        if (active) unpack_rec(in[i], N);
         uint64_t m[6]; // merged boundaries (merge_nodes, include.hpp:476-490)
         if constexpr (NB == 1) {
             for (int k = 0; k < 6; ++k) m[k] = N.b[k];
@@ -293,7 +311,7 @@ __global__ void __launch_bounds__(256) k_nodes(eb_dev_index x1, eb_dev_index x2,
                 for (int k = 1; k < 6; ++k) n_rank += (N.a[k] != N.a[k - 1]) + (N.b[k] != N.b[k - 1]);
             }
         }
-        stage.push(keep, pack_node(child));
+        stage.push(keep, pack_rec(child));
         // every tile adds at most 256 records: flushing every STAGE/256 tiles never overflows the buffer, and the
         // decision is the same in every thread without looking at shared state
         if (++trips % (STAGE / 256) == 0) stage.flush(out, out_cap, &cnt->pushed);
@@ -305,7 +323,7 @@ __global__ void __launch_bounds__(256) k_nodes(eb_dev_index x1, eb_dev_index x2,
 
 // Sharded traversal: at the first level wide enough, every shard keeps the records whose interval start
 // hashes to it -- content-addressed, so all shards agree whatever order their own launches left the level in.
-// W2 >= 0: second word added to the key (two-BWT records: the merged interval start).
+// W2 >= 0: a second word of the record is added to the key (packed two-BWT records: more of the two interval starts).
 template <typename Item, int W2>
 __global__ void __launch_bounds__(256) k_keep_shard(const Item* __restrict__ in, uint64_t count, Item* __restrict__ out, uint32_t shard, uint32_t n_shards,
                                                    NavCounters* cnt) {
@@ -590,7 +608,7 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
     hipStream_t st = f->stream;
     const uint64_t batch_max = env_u64("EB_NAV_BATCH", 16ull << 20);
     // one arena for both traversals: two stacks of EB_NAV_STACK_BATCHES / 2 batches of the largest record each
-    const uint64_t item_bytes = b2 ? sizeof(Node2) : sizeof(Leaf1); // Leaf1 and the packed Node1P: 32 bytes
+    const uint64_t item_bytes = b2 ? sizeof(Node2P) : sizeof(Node1P); // the largest record of the two traversals
     uint64_t arena_batches = env_u64("EB_NAV_STACK_BATCHES", 12) + 1; // observed peak: 5 batches pending
     uint64_t eff_batch = batch_max < n / 2 + 64 ? batch_max : n / 2 + 64;
     uint64_t arena_records = arena_batches * eff_batch + (n < (1ull << 20) ? n + 4 * eff_batch + 64 : 0);
@@ -660,7 +678,7 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
             d.shard = shard; d.n_shards = n_shards; d.split_min = split_min;
             if ((rc = d.init(d_arena, arena_bytes, n, batch_max)) != EB_OK) return rc;
             Node1 root{{0, b1->F[0], b1->F[1], b1->F[2], b1->F[3], b1->n}, 0, 0};
-            if ((rc = d.push_host(pack_node(root))) != EB_OK) return rc;
+            if ((rc = d.push_host(pack_rec(root))) != EB_OK) return rc;
             rc = d.run<-1>(d_cnt, h_pushed, [&](Node1P* in, uint64_t cnt, Node1P* o, uint64_t ocap, int write) {
                 NavParams q = p;
                 q.write = write;
@@ -672,12 +690,12 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
         s.seconds_nodes = now_s() - t1;
     } else {
         { // phase 2 (ebwt2InDel.cpp:708-756)
-            Drain<Leaf2> d;
+            Drain<Leaf2P> d;
             d.device = b1->device; d.stream = st;
             d.shard = shard; d.n_shards = n_shards; d.split_min = split_min;
             if ((rc = d.init(d_arena, arena_bytes, n, batch_max)) != EB_OK) return rc;
-            if ((rc = d.push_host(Leaf2{0, b1->F[0], 0, b2->F[0], 0, {0, 0, 0}})) != EB_OK) return rc;
-            rc = d.run<2>(d_cnt, h_pushed, [&](Leaf2* in, uint64_t cnt, Leaf2* o, uint64_t ocap, int write) {
+            if ((rc = d.push_host(pack_rec(Leaf2{0, b1->F[0], 0, b2->F[0], 0, {0, 0, 0}}))) != EB_OK) return rc;
+            rc = d.run<1>(d_cnt, h_pushed, [&](Leaf2P* in, uint64_t cnt, Leaf2P* o, uint64_t ocap, int write) {
                 NavParams q = p;
                 q.write = write;
                 hipLaunchKernelGGL(k_leaves<2>, dim3(nav_grid(cnt)), dim3(256), 0, st, x1, x2, df, d_kr, q, in, cnt, o, ocap, d_cnt, d_rows);
@@ -688,13 +706,13 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
         double t1 = now_s();
         s.seconds_leaves = t1 - t0;
         { // phase 3 (ebwt2InDel.cpp:764-823)
-            Drain<Node2> d;
+            Drain<Node2P> d;
             d.device = b1->device; d.stream = st;
             d.shard = shard; d.n_shards = n_shards; d.split_min = split_min;
             if ((rc = d.init(d_arena, arena_bytes, n, batch_max)) != EB_OK) return rc;
             Node2 root{{0, b1->F[0], b1->F[1], b1->F[2], b1->F[3], b1->n}, {0, b2->F[0], b2->F[1], b2->F[2], b2->F[3], b2->n}, 0, {0, 0, 0}};
-            if ((rc = d.push_host(root)) != EB_OK) return rc;
-            rc = d.run<6>(d_cnt, h_pushed, [&](Node2* in, uint64_t cnt, Node2* o, uint64_t ocap, int write) {
+            if ((rc = d.push_host(pack_rec(root))) != EB_OK) return rc;
+            rc = d.run<1>(d_cnt, h_pushed, [&](Node2P* in, uint64_t cnt, Node2P* o, uint64_t ocap, int write) {
                 NavParams q = p;
                 q.write = write;
                 hipLaunchKernelGGL(k_nodes<2>, dim3(nav_grid(cnt)), dim3(256), 0, st, x1, x2, df, d_kr, q, in, cnt, o, ocap, d_cnt, d_rows);
