@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -82,9 +83,19 @@ std::string event_label(const std::string& a, const std::string& b, int gap) {
     return out;
 }
 
-void header(std::string& o, uint64_t cluster_nr, uint64_t id_nr, size_t right_len, int cov, const std::string& type) {
+// Output of one contiguous piece of the call set.  The text lacks the cluster numbers: `marks` says where they go and
+// which number, counted from the piece's first cluster, so that pieces can be formatted in parallel and numbered
+// afterwards (cluster_nr runs over the whole file, ebwt2InDel.cpp:52).
+struct Piece {
+    std::string text;
+    std::vector<std::pair<size_t, uint64_t>> marks; // (offset into text, cluster_nr relative to the piece)
+    uint64_t clusters = 0, events = 0;               // cluster_nr increments / events of the piece
+};
+
+void header(Piece& out, uint64_t cluster_nr, uint64_t id_nr, size_t right_len, int cov, const std::string& type) {
+    std::string& o = out.text;
     o += ">cluster:";
-    o += std::to_string(cluster_nr);
+    out.marks.emplace_back(o.size(), cluster_nr);
     o += "_id:";
     o += std::to_string(id_nr);
     o += "_right:";
@@ -97,8 +108,10 @@ void header(std::string& o, uint64_t cluster_nr, uint64_t id_nr, size_t right_le
 }
 
 // one-sample writer (:1254-1330)
-void write_single(std::string& o, const std::vector<Ctx>& v, const std::string& right, const eb_params& p, uint64_t& cluster_nr,
-                  uint64_t& events) {
+void write_single(Piece& out, const std::vector<Ctx>& v, const std::string& right, const eb_params& p) {
+    std::string& o = out.text;
+    uint64_t& cluster_nr = out.clusters;
+    uint64_t& events = out.events;
     if (v.size() < 2) return; // :1256 -- cluster_nr untouched
     int max_dist = 0;
     std::vector<const Ctx*> good;
@@ -115,7 +128,7 @@ void write_single(std::string& o, const std::vector<Ctx>& v, const std::string& 
             // allele 0 is labelled against allele 1; allele i >= 1 carries distance(good[i-1], good[1]) (:1299-1307)
             const std::string& a = i == 0 ? good[0]->s : good[i - 1]->s;
             Align d = align_pair(a, good[1]->s, p.max_gap);
-            header(o, cluster_nr, id_nr++, right.size(), good[i]->support, event_label(a, good[1]->s, d.gap));
+            header(out, cluster_nr, id_nr++, right.size(), good[i]->support, event_label(a, good[1]->s, d.gap));
             o += good[i]->s;
             o += right;
             o += '\n';
@@ -126,8 +139,9 @@ void write_single(std::string& o, const std::vector<Ctx>& v, const std::string& 
 }
 
 // pair writer (:1149-1252)
-void write_pairs(std::string& o, const std::vector<Ctx>& c0, const std::vector<Ctx>& c1, const std::string& right, const eb_params& p,
-                 uint64_t& cluster_nr) {
+void write_pairs(Piece& out, const std::vector<Ctx>& c0, const std::vector<Ctx>& c1, const std::string& right, const eb_params& p) {
+    std::string& o = out.text;
+    uint64_t& cluster_nr = out.clusters;
     bool found = false;
     uint64_t id_nr = 1;
     for (const Ctx& a : c0)
@@ -138,11 +152,11 @@ void write_pairs(std::string& o, const std::vector<Ctx>& c0, const std::vector<C
             if (has_run(right, p.complexity) || d.mism > p.max_snvs || a.support < p.mcov_out || b.support < p.mcov_out) continue;
             found = true;
             std::string type = event_label(a.s, b.s, d.gap);
-            header(o, cluster_nr, id_nr, right.size(), a.support, type);
+            header(out, cluster_nr, id_nr, right.size(), a.support, type);
             o += d.gap < 0 ? a.s.substr((size_t)(-d.gap)) : a.s; // insertion in sample 1: sample 0 loses its first |gap| chars (:1197-1201)
             o += right;
             o += '\n';
-            header(o, cluster_nr, id_nr, right.size(), b.support, type);
+            header(out, cluster_nr, id_nr, right.size(), b.support, type);
             o += d.gap > 0 ? b.s.substr((size_t)d.gap) : b.s; // (:1231-1233)
             o += right;
             o += '\n';
@@ -160,19 +174,17 @@ std::string unpack_bases(const uint64_t* words, uint32_t len, bool reversed) {
     return s;
 }
 
-int format_calls(const eb_calls* c, const eb_params* p, int two_samples, uint64_t* cluster_nr, uint64_t* events, std::string& o) {
-    if (!c || !p || !cluster_nr) { eb_set_error("null argument"); return EB_ERR_ARG; }
-    if (c->k_left != p->k_left || c->k_right != p->k_right) { eb_set_error("call set was produced with other -L/-R values"); return EB_ERR_ARG; }
-    uint64_t ev = events ? *events : 0;
+// clusters [i0, i1) of the call set -> one piece
+int format_range(const eb_calls* c, const eb_params* p, int two_samples, uint64_t i0, uint64_t i1, Piece& out) {
     const uint64_t lw = c->left_words(), rw = c->right_words();
-    for (uint64_t i = 0; i < c->count; ++i) {
+    for (uint64_t i = i0; i < i1; ++i) {
         const eb_cluster& r = c->clusters[i];
         if (!r.right_found) continue; // no variants are collected without a right context (:985, :909, :1071)
         std::string right = unpack_bases(c->right + i * rw, r.right_len, false);
         std::vector<Ctx> side[2];
         for (uint32_t s = 0; s < r.n_slots; ++s) {
             uint64_t ch = (uint64_t)r.first_chain + s;
-            if (ch >= c->n_chains) { eb_set_error("corrupt call set: chain index out of range"); return EB_ERR_ARG; }
+            if (ch >= c->n_chains) return EB_ERR_ARG;
             const eb_chain& k = c->chains[ch];
             if (k.len != (uint32_t)c->k_left) continue; // shorter contexts are dropped (:317)
             Ctx x;
@@ -180,8 +192,53 @@ int format_calls(const eb_calls* c, const eb_params* p, int two_samples, uint64_
             x.support = (int)k.support;
             side[k.side ? 1 : 0].push_back(std::move(x));
         }
-        if (two_samples) write_pairs(o, side[0], side[1], right, *p, *cluster_nr);
-        else write_single(o, side[0], right, *p, *cluster_nr, ev);
+        if (two_samples) write_pairs(out, side[0], side[1], right, *p);
+        else write_single(out, side[0], right, *p);
+    }
+    return EB_OK;
+}
+
+// Event logic + text for the whole call set.  Large sets are cut into pieces formatted by host threads; the running
+// cluster number is filled in when the pieces are joined, so the text is the same whatever the number of threads.
+int format_calls(const eb_calls* c, const eb_params* p, int two_samples, uint64_t* cluster_nr, uint64_t* events, std::string& o) {
+    if (!c || !p || !cluster_nr) { eb_set_error("null argument"); return EB_ERR_ARG; }
+    if (c->k_left != p->k_left || c->k_right != p->k_right) { eb_set_error("call set was produced with other -L/-R values"); return EB_ERR_ARG; }
+    unsigned threads = 1;
+    if (const char* e = getenv("EB_WRITER_THREADS")) threads = (unsigned)atoi(e);                  // tests: any split
+    else if (c->count >= 50000) threads = std::min(std::thread::hardware_concurrency(), 32u);     // ~1 us per cluster: worth it from here
+    if (threads < 1) threads = 1;
+    if ((uint64_t)threads > c->count) threads = c->count ? (unsigned)c->count : 1u;
+    std::vector<Piece> pieces(threads);
+    std::vector<int> rcs(threads, EB_OK);
+    auto work = [&](unsigned t) {
+        uint64_t i0 = c->count * t / threads, i1 = c->count * (t + 1) / threads;
+        rcs[t] = format_range(c, p, two_samples, i0, i1, pieces[t]);
+    };
+    if (threads == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < threads; ++t) pool.emplace_back(work, t);
+        for (std::thread& th : pool) th.join();
+    }
+    for (int rc : rcs)
+        if (rc != EB_OK) { eb_set_error("corrupt call set: chain index out of range"); return rc; }
+    size_t total = 0;
+    for (const Piece& q : pieces) total += q.text.size() + 20 * q.marks.size();
+    o.reserve(o.size() + total);
+    uint64_t ev = events ? *events : 0;
+    char num[24];
+    for (const Piece& q : pieces) {
+        size_t from = 0;
+        for (const auto& mk : q.marks) {
+            o.append(q.text, from, mk.first - from);
+            int len = snprintf(num, sizeof num, "%llu", (unsigned long long)(*cluster_nr + mk.second));
+            o.append(num, (size_t)len);
+            from = mk.first;
+        }
+        o.append(q.text, from, std::string::npos);
+        *cluster_nr += q.clusters;
+        ev += q.events;
     }
     if (events) *events = ev;
     return EB_OK;

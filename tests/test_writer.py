@@ -36,6 +36,24 @@ def test_writer_reproduces_golden(oracle, case):
     assert api.Calls.unpack(calls.pack()).format_snp(pp, case["mode"] != 1)[0] == text   # pack/unpack round trip
 
 
+@pytest.mark.parametrize("threads", ["2", "7"])
+@pytest.mark.parametrize("case", [c for c in CASES if c["name"] in ("m1_default", "m1_edge_default", "m2_het_default", "m3_het_default")],
+                         ids=lambda c: c["name"])
+def test_writer_threads_do_not_change_the_text(oracle, monkeypatch, case, threads):
+    """Large call sets are formatted in pieces by host threads and numbered when the pieces are joined: same bytes,
+    same counters, also when the caller continues a running cluster_nr."""
+    p, fl, n = _setup(oracle, case)
+    rec = fl.scan(p, 0, n, capture=True)
+    pp = api.make_params(case["args"])
+    calls = api.Calls.unpack(_oracle.pack_calls(rec, p.k_left, p.k_right))
+    monkeypatch.setenv("EB_WRITER_THREADS", "1")
+    want = calls.format_snp(pp, case["mode"] != 1, 41, 7)
+    monkeypatch.setenv("EB_WRITER_THREADS", threads)
+    assert calls.format_snp(pp, case["mode"] != 1, 41, 7) == want
+    monkeypatch.delenv("EB_WRITER_THREADS")
+    assert calls.format_snp(pp, case["mode"] != 1)[0] == golden_bytes(case["snp"])
+
+
 @pytest.mark.parametrize("case", [c for c in CASES if c["name"] in ("m1_default", "m1_edge_default", "m2_het_default", "m3_hom_default")],
                          ids=lambda c: c["name"])
 @pytest.mark.parametrize("shards", [2, 5])
