@@ -57,6 +57,7 @@ extern "C" void eb_index_bad_symbol(uint8_t* symbol, uint64_t* position) {
 // ------------------------------------------------------------------ scratch cache
 
 #include <mutex>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -299,13 +300,14 @@ static int pack_piece(eb_index* h, const uint8_t* d_ascii, uint64_t piece_pos, u
 }
 
 // Counters, superblock table and F array from the packed planes.
-static int finish_index(eb_index* h, unsigned long long* d_bad, const uint8_t* d_text_or_null, const uint8_t* h_text_or_null) {
+static int finish_index(eb_index* h, unsigned long long* d_bad, const uint8_t* d_text_or_null, const uint8_t* h_text_or_null, int fd = -1) {
     unsigned long long bad = ~0ull;
     EB_HIP(hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, h->stream));
     EB_HIP(hipStreamSynchronize(h->stream));
     if (bad != ~0ull) {
         uint8_t sym = 0;
         if (h_text_or_null) sym = h_text_or_null[bad];
+        else if (fd >= 0) { if (pread(fd, &sym, 1, (off_t)bad) != 1) sym = 0; }
         else if (d_text_or_null) (void)hipMemcpy(&sym, d_text_or_null + bad, 1, hipMemcpyDeviceToHost);
         g_bad_sym = sym;
         g_bad_pos = bad;
@@ -371,47 +373,100 @@ extern "C" int eb_index_create_from_device(const void* d_ascii, uint64_t n, uint
     return EB_OK;
 }
 
-extern "C" int eb_index_create(const uint8_t* ascii, uint64_t n, uint8_t term, int device, eb_index** out) {
-    if (!out || (!ascii && n)) { eb_set_error("null argument"); return EB_ERR_ARG; }
+// ascii: the symbols in host memory, or NULL with fd >= 0: the symbols are the file's bytes (read with pread)
+static int index_create_from(const uint8_t* ascii, int fd, uint64_t n, uint8_t term, int device, eb_index** out) {
     *out = nullptr;
     eb_index* h = nullptr;
     int rc = index_alloc(n, term, device, &h);
     if (rc != EB_OK) return rc;
-    // Upload in pieces (multiple of 128 symbols) through two staging buffers so copies overlap packing.
-    const uint64_t PIECE = 256ull << 20;
-    uint8_t* d_stage[2] = {nullptr, nullptr};
-    hipEvent_t done[2];
+    // Upload in pieces (multiple of 128 symbols) through staging buffers so that copies overlap packing.  Large inputs
+    // (a memory-mapped file, or any pageable buffer) are first copied into page-locked pieces by a few host threads:
+    // the runtime's own staging of pageable memory runs at ~16 GB/s, PCIe at ~50.
+    uint64_t pinned_min = 256ull << 20, piece_pinned = 64ull << 20; // EB_INDEX_PINNED_MIN / _PIECE: tests exercise the path on small inputs
+    if (const char* ev = getenv("EB_INDEX_PINNED_MIN")) pinned_min = strtoull(ev, nullptr, 10);
+    if (const char* ev = getenv("EB_INDEX_PINNED_PIECE")) piece_pinned = strtoull(ev, nullptr, 10) & ~127ull;
+    if (piece_pinned < 128) piece_pinned = 128;
+    const bool pinned_path = n >= pinned_min || !ascii;
+    const uint64_t PIECE = pinned_path ? piece_pinned : (256ull << 20);
+    const int SLOTS = pinned_path ? 3 : 2;
+    uint8_t* d_stage[3] = {nullptr, nullptr, nullptr};
+    uint8_t* h_stage[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t done[3] = {nullptr, nullptr, nullptr};
     unsigned long long* d_bad = nullptr;
     unsigned long long init = ~0ull;
     uint64_t stage_bytes = n < PIECE ? (n ? n : 1) : PIECE;
     hipError_t e = hipMalloc(&d_bad, sizeof init);
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+    for (int i = 0; i < SLOTS && e == hipSuccess; ++i) {
         e = hipMalloc(&d_stage[i], stage_bytes);
+        if (e == hipSuccess && pinned_path) e = hipHostMalloc(reinterpret_cast<void**>(&h_stage[i]), stage_bytes, hipHostMallocDefault);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
     }
-    if (e != hipSuccess) { eb_set_error("staging allocation failed: %s", hipGetErrorString(e)); eb_index_destroy(h); return EB_ERR_NOMEM; }
-    EB_HIP(hipMemcpy(d_bad, &init, sizeof init, hipMemcpyHostToDevice));
+    auto release = [&]() {
+        for (int i = 0; i < 3; ++i) {
+            if (d_stage[i]) (void)hipFree(d_stage[i]);
+            if (h_stage[i]) (void)hipHostFree(h_stage[i]);
+            if (done[i]) (void)hipEventDestroy(done[i]);
+        }
+        if (d_bad) (void)hipFree(d_bad);
+    };
+    if (e != hipSuccess) { eb_set_error("staging allocation failed: %s", hipGetErrorString(e)); release(); eb_index_destroy(h); return EB_ERR_NOMEM; }
+    e = hipMemcpy(d_bad, &init, sizeof init, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { eb_set_error("hipMemcpy failed: %s", hipGetErrorString(e)); release(); eb_index_destroy(h); return EB_ERR_DEVICE; }
+    unsigned copy_threads = 4; // measured on the 7.55 GB file: 4 / 8 / 16 / 32 threads -> 36 / 29 / 30 / 24 GB/s
+    if (const char* ev = getenv("EB_INDEX_COPY_THREADS")) { int v = atoi(ev); if (v >= 1 && v <= 64) copy_threads = (unsigned)v; }
+    int io_error = 0;
     uint64_t pos = 0;
     int slot = 0;
-    bool first_use[2] = {true, true};
+    bool first_use[3] = {true, true, true};
     do {
         uint64_t len = n - pos < PIECE ? n - pos : PIECE;
         bool last = pos + len == n;
-        if (!first_use[slot]) EB_HIP(hipEventSynchronize(done[slot]));
+        if (!first_use[slot] && (e = hipEventSynchronize(done[slot])) != hipSuccess) break;
         first_use[slot] = false;
-        if (len) EB_HIP(hipMemcpyAsync(d_stage[slot], ascii + pos, len, hipMemcpyHostToDevice, h->stream));
+        const uint8_t* src = ascii ? ascii + pos : nullptr;
+        if (pinned_path && len) {
+            std::vector<std::thread> pool(copy_threads);
+            int* err = &io_error;
+            for (unsigned t = 0; t < copy_threads; ++t) {
+                uint64_t a0 = len * t / copy_threads, a1 = len * (t + 1) / copy_threads;
+                uint8_t* dst = h_stage[slot] + a0;
+                if (src) {
+                    pool[t] = std::thread([=]() { memcpy(dst, src + a0, a1 - a0); });
+                } else {
+                    pool[t] = std::thread([=]() { // page-cache -> page-locked piece, no page faults of a mapping in between
+                        uint64_t got = 0;
+                        while (got < a1 - a0) {
+                            ssize_t r = pread(fd, dst + got, a1 - a0 - got, (off_t)(pos + a0 + got));
+                            if (r <= 0) { *err = 1; return; }
+                            got += (uint64_t)r;
+                        }
+                    });
+                }
+            }
+            for (std::thread& th : pool) th.join();
+            if (io_error) { eb_set_error("read error in the input file"); rc = EB_ERR_IO; break; }
+            src = h_stage[slot];
+        }
+        if (len && (e = hipMemcpyAsync(d_stage[slot], src, len, hipMemcpyHostToDevice, h->stream)) != hipSuccess) break;
         rc = pack_piece(h, d_stage[slot], pos, len, last, d_bad);
         if (rc != EB_OK) break;
-        EB_HIP(hipEventRecord(done[slot], h->stream));
+        if ((e = hipEventRecord(done[slot], h->stream)) != hipSuccess) break;
         pos += len;
-        slot ^= 1;
+        slot = (slot + 1) % SLOTS;
     } while (pos < n);
-    if (rc == EB_OK) rc = finish_index(h, d_bad, nullptr, ascii);
-    for (int i = 0; i < 2; ++i) { (void)hipFree(d_stage[i]); (void)hipEventDestroy(done[i]); }
-    (void)hipFree(d_bad);
+    if (e != hipSuccess) { eb_set_error("upload failed: %s", hipGetErrorString(e)); rc = EB_ERR_DEVICE; }
+    if (rc != EB_OK) (void)hipStreamSynchronize(h->stream);
+    if (rc == EB_OK) rc = finish_index(h, d_bad, nullptr, ascii, fd);
+    release();
     if (rc != EB_OK) { eb_index_destroy(h); return rc; }
     *out = h;
     return EB_OK;
+}
+
+extern "C" int eb_index_create(const uint8_t* ascii, uint64_t n, uint8_t term, int device, eb_index** out) {
+    if (!out || (!ascii && n)) { eb_set_error("null argument"); return EB_ERR_ARG; }
+    static const uint8_t empty = 0;
+    return index_create_from(ascii ? ascii : &empty, -1, n, term, device, out);
 }
 
 extern "C" int eb_index_create_from_file(const char* path, uint8_t term, int device, eb_index** out) {
@@ -421,12 +476,7 @@ extern "C" int eb_index_create_from_file(const char* path, uint8_t term, int dev
     struct stat st;
     if (fstat(fd, &st) != 0) { close(fd); eb_set_error("cannot stat %s", path); return EB_ERR_IO; }
     uint64_t n = (uint64_t)st.st_size; // n = file size (dna_string.hpp:59)
-    void* map = n ? mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
-    if (n && map == MAP_FAILED) { close(fd); eb_set_error("cannot map %s", path); return EB_ERR_IO; }
-    if (n) madvise(map, n, MADV_SEQUENTIAL);
-    static const uint8_t empty = 0;
-    int rc = eb_index_create(n ? static_cast<const uint8_t*>(map) : &empty, n, term, device, out);
-    if (n) munmap(map, n);
+    int rc = index_create_from(nullptr, fd, n, term, device, out);
     close(fd);
     return rc;
 }

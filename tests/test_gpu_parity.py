@@ -58,6 +58,20 @@ def test_index_from_file_and_device_buffer(tmp_path, dip):
     assert np.array_equal(gd.parallel_rank(pos), o.rank4(pos))
 
 
+def test_threaded_pinned_upload_gives_the_same_index(monkeypatch, dip):
+    """Large inputs go to the GPU through page-locked pieces filled by host threads; forced here on a small one, with
+    pieces that do not divide it."""
+    e, g, _ = dip
+    monkeypatch.setenv("EB_INDEX_PINNED_MIN", "1")
+    monkeypatch.setenv("EB_INDEX_PINNED_PIECE", str(128 * 37))
+    g2 = api.DnaBwt(e)
+    assert g2.F_arr == g.F_arr and g2.n == g.n
+    pos = _positions(len(e), 20_000, 5)
+    assert np.array_equal(g2.parallel_rank(pos), g.parallel_rank(pos))
+    idx = _positions(len(e), 5_000, 6, upto_n=False)
+    assert np.array_equal(g2[idx], g[idx])
+
+
 def test_forbidden_character_is_reported():
     e = bytearray(golden_bytes("dip.ebwt"))
     e[70001] = ord("N")
