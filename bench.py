@@ -305,13 +305,32 @@ def main():
             shards = list(ex.map(lambda be: of.scan(po, be[0], be[1])["events"], cuts))
             t_scan_all = time.perf_counter() - t0
         assert sum(shards) == res["events"], "sharded CPU scan disagrees with the whole-range scan"
+        # the unmodified reference itself (oracle/_ref, built from the upstream sources in the build container) on the same
+        # file: end to end only -- it prints no phase timings -- and its .snp must equal the GPU's byte for byte
+        reference = None
+        ref_bin = os.path.join(ROOT, "oracle", "_ref", "ebwt2InDel_ref")
+        if os.path.exists(ref_bin):
+            import subprocess
+            import tempfile
+            with tempfile.TemporaryDirectory() as td:
+                pth, outp = os.path.join(td, "sample.ebwt"), os.path.join(td, "ref.snp")
+                se.tofile(pth)
+                t0 = time.perf_counter()
+                rr = subprocess.run([ref_bin, "-1", pth, "-o", outp], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+                t_ref = time.perf_counter() - t0
+                with open(outp, "rb") as fh:
+                    ref_snp = fh.read()
+            assert rr.returncode == 0 and ref_snp == got, "GPU .snp differs from the reference binary's on the baseline sample"
+            reference = {"binary": "oracle/_ref/ebwt2InDel_ref (g++ -Ofast build of the unmodified upstream sources)", "cores": 1,
+                         "e2e_seconds": round(t_ref, 2), "e2e_positions_per_s": round(n_s / t_ref, 1), "snp_identical_to_gpu": True}
         cpu = {"value": round(n_s / t_scan_cpu, 1), "unit": "positions/s", "cores": 1, "kind": "port",
                "sample": f"{s_reads} x {args.read_len} bp reads (n={n_s}), same generator; phase-4 scan only ({t_scan_cpu:.3f}s); "
                          f"phases 2-3 took {t_nav_cpu:.2f}s",
                "e2e_positions_per_s": round(n_s / (t_nav_cpu + t_scan_cpu), 1),
                "rank_queries_per_s": round(20_000_000 / rt, 1), "snp_identical_to_gpu": True,
                "all_cores": {"value": round(n_s / t_scan_all, 1), "unit": "positions/s", "cores": cores,
-                             "what": "the same phase-4 scan, range sharded over host threads"}}
+                             "what": "the same phase-4 scan, range sharded over host threads"},
+               "reference": reference}
 
     # HBM traffic of the dominant kernel from the PMC passes committed under profiles/ (FETCH_SIZE / WRITE_SIZE cannot be
     # collected from inside this process); used only when it was measured on the same launch size.
