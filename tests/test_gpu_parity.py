@@ -512,3 +512,32 @@ def test_scan_on_adversarial_flag_patterns(oracle, name, mode):
             assert np.array_equal(left, want["left"])
             assert np.array_equal(right, want["right"])
     assert seen[0] == sum(seen[1:]) and seen[0] > 0              # the cuts partition the clusters; the input is not trivial
+
+
+@pytest.mark.skipif(not os.path.exists(_oracle.REF_BIN), reason="reference binary did not travel with the tree")
+@pytest.mark.parametrize("seed,extra", [(301, []), (302, ["-m", "4", "-k", "18"]), (303, ["-L", "36", "-R", "28", "-g", "4", "-q", "2"])])
+def test_fresh_inputs_against_the_reference_binary(tmp_path, seed, extra):
+    """Not via fixtures and not via the oracle: the unmodified reference (oracle/_ref, built in the build container from
+    the upstream sources; git-ignored, travels with the tree) runs here on fresh seeded inputs in all three modes, and
+    the GPU path must write the same bytes."""
+    def ref(args):
+        out = tmp_path / "ref.snp"
+        rc = subprocess.run([_oracle.REF_BIN] + args + extra + ["-o", str(out)], stdout=subprocess.DEVNULL).returncode
+        assert rc == 0
+        return out.read_bytes()
+
+    p = api.make_params(extra)
+    reads, _, _ = sim.diploid_sample(30_000, 7_000, 100, seed=seed, snp_every=350, indel_every=900)
+    e = sim.build_ebwt(reads)
+    (tmp_path / "x.ebwt").write_bytes(e.tobytes())
+    want = ref(["-1", str(tmp_path / "x.ebwt")])
+    assert want.count(b">") > 20 and api.run_one_dataset(e, p) == want
+    r0, r1 = sim.two_samples(20_000, 4_500, 90, seed=seed + 50, het_second=True, snp_every=250, indel_every=700)
+    a, b = sim.build_ebwt(r0), sim.build_ebwt(r1)
+    m, da = sim.build_merged_ebwt(r0, r1)
+    for name, x in (("a", a), ("b", b), ("m", m), ("da", da)):
+        (tmp_path / name).write_bytes(x.tobytes())
+    want2 = ref(["-1", str(tmp_path / "a"), "-2", str(tmp_path / "b")])
+    want3 = ref(["-1", str(tmp_path / "m"), "-d", str(tmp_path / "da")])
+    assert want2.count(b">") > 20 and api.run_two_datasets(a, b, p) == want2
+    assert want3.count(b">") > 20 and api.run_two_datasets_da(m, da, p) == want3
