@@ -47,3 +47,19 @@ def test_bench_two_ranks_share_the_gpu_same_snp():
     d1 = _last_json(one.stdout)
     assert d["snp_sha256"] == d1["snp_sha256"] and d["snp_records"] == d1["snp_records"]
     assert d["clusters_emitted"] == d1["clusters_emitted"]
+
+
+def test_bench_nccl_collectives_with_one_rank_same_snp():
+    """The N > 1 code path of the driver's multi-GPU run -- RCCL process group, sharded traversal with its all-reduce,
+    device-only jobs, compact wire images gathered GPU to GPU and resolved one step later -- exercised with a single
+    rank (RCCL refuses two ranks on one device): same .snp as the plain N = 1 run."""
+    env = dict(os.environ, EB_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29519", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-sample-reads", "0", "--steps", "5"] + ARGS[:2] + ARGS[4:],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-sample-reads", "0"] + ARGS, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = _last_json(one.stdout)
+    assert d["snp_sha256"] == d1["snp_sha256"] and d["snp_records"] == d1["snp_records"]
+    assert d["phases23_gpu"]["nodes"] == d1["phases23_gpu"]["nodes"] and d["phases23_gpu"]["rank_queries"] == d1["phases23_gpu"]["rank_queries"]
