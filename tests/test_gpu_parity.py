@@ -515,7 +515,10 @@ def test_scan_on_adversarial_flag_patterns(oracle, name, mode):
 
 
 @pytest.mark.skipif(not os.path.exists(_oracle.REF_BIN), reason="reference binary did not travel with the tree")
-@pytest.mark.parametrize("seed,extra", [(301, []), (302, ["-m", "4", "-k", "18"]), (303, ["-L", "36", "-R", "28", "-g", "4", "-q", "2"])])
+@pytest.mark.parametrize("seed,extra", [(301, []), (302, ["-m", "4", "-k", "18"]), (303, ["-L", "36", "-R", "28", "-g", "4", "-q", "2"]),
+                                        (304, ["-L", "70", "-R", "66", "-k", "12"]),          # contexts of several words
+                                        (305, ["-m", "1", "-v", "1", "-k", "9"]),             # every run of two rows is a cluster
+                                        (306, ["-c", "6", "-q", "2", "-m", "2", "-g", "1"])])
 def test_fresh_inputs_against_the_reference_binary(tmp_path, seed, extra):
     """Not via fixtures and not via the oracle: the unmodified reference (oracle/_ref, built in the build container from
     the upstream sources; git-ignored, travels with the tree) runs here on fresh seeded inputs in all three modes, and
