@@ -15,6 +15,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
 
 
+def pytest_sessionstart(session):
+    """The suites need the in-tree builds (HIP library, tools, oracle); a checkout without them builds them first --
+    hipcc cross-compiles gfx950 without a GPU -- through the same entry point the driver uses."""
+    need = [os.path.join(ROOT, "ebwt2indel_amd", "_build", "libebwt2indel.so"), os.path.join(ROOT, "ebwt2indel_amd", "_build", "ebwt2InDel"),
+            os.path.join(ROOT, "oracle", "_build", "liboracle.so")]
+    if all(os.path.exists(p) for p in need):
+        return
+    try:
+        import __graft_entry__
+        __graft_entry__.build()
+    except Exception as e:  # the tests that need the missing piece will say what is missing
+        print(f"[conftest] build() failed: {e}", file=sys.stderr)
+
+
 def load_manifest():
     with open(os.path.join(GOLD, "manifest.json")) as f:
         return json.load(f)["cases"]
