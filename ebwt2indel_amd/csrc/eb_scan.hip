@@ -714,11 +714,14 @@ __global__ void __launch_bounds__(256) k_extend(eb_dev_index x1, eb_dev_index x2
 
 // One lane per cluster: record header + right context (extract_dna, ebwt2InDel.cpp:325-342) at the first
 // cluster position whose LCP >= k_right (:979-988; two BWTs :896-912); bases packed 2 bits each in text order.
+// It needs nothing but the survivors in BWT order, so it is launched as soon as they are -- before the host knows their
+// number (ns_ptr, device memory) and before the call set's image exists: records and contexts go to temporaries,
+// k_right_finish moves them into the image and adds the chain offsets.
 __global__ void __launch_bounds__(256) k_right(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, ScanParams p,
-                                              const Survivor* __restrict__ surv, const uint32_t* __restrict__ chain_off, uint32_t chain_base, uint64_t nsurv,
+                                              const Survivor* __restrict__ surv, const uint32_t* __restrict__ ns_ptr,
                                               eb_cluster* __restrict__ recs, uint64_t* __restrict__ right, uint32_t right_words) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nsurv) return;
+    const uint64_t ns = *ns_ptr;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += (uint64_t)gridDim.x * blockDim.x) {
     Survivor s = surv[i];
     // first position in [b,e) with thrR
     uint64_t pos = ~0ull;
@@ -754,12 +757,13 @@ __global__ void __launch_bounds__(256) k_right(eb_dev_index x1, eb_dev_index x2,
     eb_cluster r;
     r.begin = s.b;
     r.end = s.e;
-    r.first_chain = chain_off[i] + chain_base;
+    r.first_chain = 0; // k_right_finish
     r.n_slots = (uint16_t)(__popc(s.fmask0) + __popc(s.fmask1));
     r.right_found = pos != ~0ull ? 1 : 0;
     r.right_len = len;
     r.reserved = 0;
     recs[i] = r;
+    }
 }
 
 // Two-BWT mode: scan planes of the MERGED sequence (row i of the merge comes from bwt2 if DA[i] else bwt1, in order:
@@ -778,6 +782,16 @@ __global__ void __launch_bounds__(256) k_merge_planes(eb_dev_index x1, eb_dev_in
         }
         mxy[w] = make_uint4((uint32_t)x, (uint32_t)(x >> 32), (uint32_t)y, (uint32_t)(y >> 32));
     }
+}
+
+__global__ void __launch_bounds__(256) k_right_finish(const eb_cluster* __restrict__ tmp_recs, const uint64_t* __restrict__ tmp_right, const uint32_t* __restrict__ chain_off,
+                                                     uint32_t chain_base, uint64_t nsurv, uint32_t right_words, eb_cluster* __restrict__ recs, uint64_t* __restrict__ right) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nsurv) return;
+    eb_cluster r = tmp_recs[i];
+    r.first_chain = chain_off[i] + chain_base;
+    recs[i] = r;
+    for (uint32_t k = 0; k < right_words; ++k) right[i * (uint64_t)right_words + k] = tmp_right[i * (uint64_t)right_words + k];
 }
 
 struct DevMem { // per-call temporary from the caching scratch allocator
@@ -806,18 +820,18 @@ unsigned scan_grid(uint64_t words) {
 }  // namespace
 
 namespace {
+enum { E_SCAN0, E_SCAN1, E_SCAN_DONE, E_PREP_CNT, E_PREP_DONE, E_EXT0, E_EXT_DONE, E_RIGHT0, E_RIGHT_DONE, E_SORTED, E_PER_SHARD };
 struct SubShard {
     uint64_t begin = 0, end = 0, w_lo = 0, w_count = 0, cap = 0;
-    DevMem cnt, part, surv, sorted, bcnt, boff, tmp, nch, choff, chains, recs, crec, left, right, blob; // bcnt/boff: position buckets
+    DevMem cnt, part, surv, sorted, bcnt, boff, tmp, nch, choff, chains, recs, crec, left, right, blob, rt_rec, rt_right; // bcnt/boff: position buckets; rt_*: k_right's temporaries
     eb_cluster* d_recs = nullptr; // sections: inside `blob` (one shard) or the separate buffers above (sub-shards)
     eb_chain* d_crec = nullptr;
     uint64_t *d_left = nullptr, *d_right = nullptr;
     uint64_t ns_raw = 0, ns = 0, n_chains = 0, rec_base = 0, chain_base = 0;
-    hipEvent_t e[9]; // scan_t0, scan_t1, scan_done, prep_cnt, prep_done, ext_t0, ext_done, right_t0, right_done
+    hipEvent_t e[E_PER_SHARD]; // scan_t0, scan_t1, scan_done, prep_cnt, prep_done, ext_t0, ext_done, right_t0, right_done, sorted
     ScanCounters* h_cnt = nullptr;
     uint32_t* h_last = nullptr;
 };
-enum { E_SCAN0, E_SCAN1, E_SCAN_DONE, E_PREP_CNT, E_PREP_DONE, E_EXT0, E_EXT_DONE, E_RIGHT0, E_RIGHT_DONE };
 }  // namespace
 
 // A phase-4 call in flight: everything is enqueued, the record copies to host may still be running.
@@ -986,7 +1000,7 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
     job->end = end;
     job->sh.resize((size_t)S);
     std::vector<SubShard>& sh = job->sh;
-    const size_t n_events = 2 + 9 * (size_t)S;
+    const size_t n_events = 2 + (size_t)E_PER_SHARD * (size_t)S;
     for (size_t i = 0; i < n_events; ++i) { // events are recycled through the context's pool
         hipEvent_t e = nullptr;
         if (!ctx->events.empty()) { e = ctx->events.back(); ctx->events.pop_back(); }
@@ -1026,9 +1040,9 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
     EB_HIP(hipEventRecord(ev_begin, sA));
     for (int k = 0; k < S; ++k) {
         SubShard& x = sh[(size_t)k];
-        for (DevMem* m : {&x.cnt, &x.part, &x.surv, &x.sorted, &x.bcnt, &x.boff, &x.tmp, &x.nch, &x.choff, &x.chains, &x.recs, &x.crec, &x.left, &x.right, &x.blob})
+        for (DevMem* m : {&x.cnt, &x.part, &x.surv, &x.sorted, &x.bcnt, &x.boff, &x.tmp, &x.nch, &x.choff, &x.chains, &x.recs, &x.crec, &x.left, &x.right, &x.blob, &x.rt_rec, &x.rt_right})
             m->device = b1->device;
-        for (int i = 0; i < 9; ++i) x.e[i] = job->events[2 + 9 * (size_t)k + (size_t)i];
+        for (int i = 0; i < E_PER_SHARD; ++i) x.e[i] = job->events[2 + (size_t)E_PER_SHARD * (size_t)k + (size_t)i];
         x.h_cnt = reinterpret_cast<ScanCounters*>(static_cast<uint8_t*>(ctx->h_pinned) + (size_t)k * (sizeof(ScanCounters) + 64));
         x.h_last = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(x.h_cnt) + sizeof(ScanCounters));
         // cut on flag-word boundaries; clusters belong to the sub-shard that holds their closing position
@@ -1093,6 +1107,21 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
         hipLaunchKernelGGL(k_bucket_place, dim3(grid_of(x.ns_raw)), dim3(256), 0, sP, x.surv.as<Survivor>(), x.ns_raw, bucket_base, d_boff, d_bfill,
                            x.sorted.as<Survivor>());
         hipLaunchKernelGGL(k_bucket_fix, dim3(grid_of(n_buckets)), dim3(256), 0, sP, d_boff, n_buckets, x.sorted.as<Survivor>());
+        // The right-context walk needs nothing else.  For a small call set (a rank's slice of a multi-GPU job) it starts
+        // now, under the rest of the preparation and the host round trip (0.75 -> 0.66 ms per call at 98 k clusters); a
+        // large one saturates the memory system at once and the small kernels that follow here crawl (1.2 ms instead
+        // of 0.1 at 790 k clusters), so there it starts with k_extend as before.
+        const bool right_early = x.ns_raw <= 262144;
+        if ((rc = x.rt_rec.alloc(x.ns_raw * sizeof(eb_cluster))) != EB_OK || (rc = x.rt_right.alloc(x.ns_raw * (size_t)rw * 8)) != EB_OK) return rc;
+        const unsigned right_grid = grid_of(x.ns_raw);
+        if (right_early) {
+            EB_HIP(hipEventRecord(x.e[E_SORTED], sP));
+            EB_HIP(hipStreamWaitEvent(sC, x.e[E_SORTED], 0));
+            EB_HIP(hipEventRecord(x.e[E_RIGHT0], sC));
+            EB_HIP(hipMemsetAsync(x.rt_right.p, 0, x.ns_raw * (size_t)rw * 8, sC));
+            hipLaunchKernelGGL(k_right, dim3(right_grid), dim3(256), 0, sC, x1, x2, df, p, x.sorted.as<Survivor>(), d_boff + n_buckets,
+                               x.rt_rec.as<eb_cluster>(), x.rt_right.as<uint64_t>(), rw);
+        }
         hipLaunchKernelGGL(k_surv_chains, dim3(grid_of(x.ns_raw)), dim3(256), 0, sP, x.sorted.as<Survivor>(), d_boff + n_buckets, x.ns_raw, x.nch.as<uint32_t>());
         // dense chain list: exclusive scan of the per-cluster chain counts
         EB_HIP(hipcub::DeviceScan::ExclusiveSum(x.tmp.p, tmp_bytes, x.nch.as<uint32_t>(), x.choff.as<uint32_t>(), (int)x.ns_raw, sP));
@@ -1147,9 +1176,14 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
         EB_HIP(hipEventRecord(x.e[E_EXT_DONE], sB));
         EB_HIP(hipEventRecord(ctx->last_ext, sB));
         EB_HIP(hipStreamWaitEvent(sC, x.e[E_PREP_DONE], 0));
-        EB_HIP(hipEventRecord(x.e[E_RIGHT0], sC));
-        hipLaunchKernelGGL(k_right, dim3(grid_of(x.ns)), dim3(256), 0, sC, x1, x2, df, p, x.sorted.as<Survivor>(), x.choff.as<uint32_t>(), (uint32_t)x.chain_base,
-                           x.ns, x.d_recs, x.d_right, rw);
+        if (!right_early) {
+            EB_HIP(hipEventRecord(x.e[E_RIGHT0], sC));
+            EB_HIP(hipMemsetAsync(x.rt_right.p, 0, x.ns_raw * (size_t)rw * 8, sC));
+            hipLaunchKernelGGL(k_right, dim3(right_grid), dim3(256), 0, sC, x1, x2, df, p, x.sorted.as<Survivor>(), x.boff.as<uint32_t>() + n_buckets,
+                               x.rt_rec.as<eb_cluster>(), x.rt_right.as<uint64_t>(), rw);
+        }
+        hipLaunchKernelGGL(k_right_finish, dim3(grid_of(x.ns)), dim3(256), 0, sC, x.rt_rec.as<eb_cluster>(), x.rt_right.as<uint64_t>(), x.choff.as<uint32_t>(),
+                           (uint32_t)x.chain_base, x.ns, rw, x.d_recs, x.d_right);
         EB_HIP(hipEventRecord(x.e[E_RIGHT_DONE], sC));
         EB_HIP(hipEventRecord(ctx->last_right, sC));
         EB_HIP(hipGetLastError());
