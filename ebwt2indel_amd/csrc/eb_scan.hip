@@ -965,6 +965,8 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
     // Measured at 7.55 G positions (EB_SCAN_SUBSHARDS=1/2/4/8): 6.5 / 6.1 / 6.4 / 11.0 ms per call -- the streaming scan and
     // the random-access chains compete for the same memory request rate, so overlap buys little and slows each kernel.
     // Default: one shard (kernels run alone, cleanest timings); the knob stays for experiments.
+    uint64_t right_early_max = 524288; // see the launch of k_right below; EB_RIGHT_EARLY_MAX overrides (experiments)
+    if (const char* e = getenv("EB_RIGHT_EARLY_MAX")) right_early_max = strtoull(e, nullptr, 10);
     int S = 1;
     if (const char* e = getenv("EB_SCAN_SUBSHARDS")) { int v = atoi(e); if (v >= 1 && v <= 16) S = v; }
     if ((uint64_t)S > w_total) S = w_total ? (int)w_total : 1;
@@ -1108,10 +1110,11 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
                            x.sorted.as<Survivor>());
         hipLaunchKernelGGL(k_bucket_fix, dim3(grid_of(n_buckets)), dim3(256), 0, sP, d_boff, n_buckets, x.sorted.as<Survivor>());
         // The right-context walk needs nothing else.  For a small call set (a rank's slice of a multi-GPU job) it starts
-        // now, under the rest of the preparation and the host round trip (0.75 -> 0.66 ms per call at 98 k clusters); a
+        // now, under the rest of the preparation and the host round trip (per step: 0.78 -> 0.69 ms at 98 k clusters,
+        // 1.32 -> 1.24 at 197 k, 2.30 -> 2.16 at 395 k, no difference at 793 k); a
         // large one saturates the memory system at once and the small kernels that follow here crawl (1.2 ms instead
         // of 0.1 at 790 k clusters), so there it starts with k_extend as before.
-        const bool right_early = x.ns_raw <= 262144;
+        const bool right_early = x.ns_raw <= right_early_max;
         if ((rc = x.rt_rec.alloc(x.ns_raw * sizeof(eb_cluster))) != EB_OK || (rc = x.rt_right.alloc(x.ns_raw * (size_t)rw * 8)) != EB_OK) return rc;
         const unsigned right_grid = grid_of(x.ns_raw);
         if (right_early) {
