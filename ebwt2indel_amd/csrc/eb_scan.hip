@@ -719,9 +719,10 @@ __global__ void __launch_bounds__(256) k_extend(eb_dev_index x1, eb_dev_index x2
 // k_right_finish moves them into the image and adds the chain offsets.
 __global__ void __launch_bounds__(256) k_right(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, ScanParams p,
                                               const Survivor* __restrict__ surv, const uint32_t* __restrict__ ns_ptr,
+                                              const uint32_t* __restrict__ chain_off /* null: temporaries, k_right_finish adds it */, uint32_t chain_base,
                                               eb_cluster* __restrict__ recs, uint64_t* __restrict__ right, uint32_t right_words) {
-    const uint64_t ns = *ns_ptr;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *ns_ptr) return;
     Survivor s = surv[i];
     // first position in [b,e) with thrR
     uint64_t pos = ~0ull;
@@ -757,13 +758,12 @@ __global__ void __launch_bounds__(256) k_right(eb_dev_index x1, eb_dev_index x2,
     eb_cluster r;
     r.begin = s.b;
     r.end = s.e;
-    r.first_chain = 0; // k_right_finish
+    r.first_chain = chain_off ? chain_off[i] + chain_base : 0u;
     r.n_slots = (uint16_t)(__popc(s.fmask0) + __popc(s.fmask1));
     r.right_found = pos != ~0ull ? 1 : 0;
     r.right_len = len;
     r.reserved = 0;
     recs[i] = r;
-    }
 }
 
 // Two-BWT mode: scan planes of the MERGED sequence (row i of the merge comes from bwt2 if DA[i] else bwt1, in order:
@@ -1115,15 +1115,15 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
         // large one saturates the memory system at once and the small kernels that follow here crawl (1.2 ms instead
         // of 0.1 at 790 k clusters), so there it starts with k_extend as before.
         const bool right_early = x.ns_raw <= right_early_max;
-        if ((rc = x.rt_rec.alloc(x.ns_raw * sizeof(eb_cluster))) != EB_OK || (rc = x.rt_right.alloc(x.ns_raw * (size_t)rw * 8)) != EB_OK) return rc;
         const unsigned right_grid = grid_of(x.ns_raw);
         if (right_early) {
+            if ((rc = x.rt_rec.alloc(x.ns_raw * sizeof(eb_cluster))) != EB_OK || (rc = x.rt_right.alloc(x.ns_raw * (size_t)rw * 8)) != EB_OK) return rc;
             EB_HIP(hipEventRecord(x.e[E_SORTED], sP));
             EB_HIP(hipStreamWaitEvent(sC, x.e[E_SORTED], 0));
             EB_HIP(hipEventRecord(x.e[E_RIGHT0], sC));
             EB_HIP(hipMemsetAsync(x.rt_right.p, 0, x.ns_raw * (size_t)rw * 8, sC));
             hipLaunchKernelGGL(k_right, dim3(right_grid), dim3(256), 0, sC, x1, x2, df, p, x.sorted.as<Survivor>(), d_boff + n_buckets,
-                               x.rt_rec.as<eb_cluster>(), x.rt_right.as<uint64_t>(), rw);
+                               (const uint32_t*)nullptr, 0u, x.rt_rec.as<eb_cluster>(), x.rt_right.as<uint64_t>(), rw);
         }
         hipLaunchKernelGGL(k_surv_chains, dim3(grid_of(x.ns_raw)), dim3(256), 0, sP, x.sorted.as<Survivor>(), d_boff + n_buckets, x.ns_raw, x.nch.as<uint32_t>());
         // dense chain list: exclusive scan of the per-cluster chain counts
@@ -1179,13 +1179,12 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
         EB_HIP(hipEventRecord(x.e[E_EXT_DONE], sB));
         EB_HIP(hipEventRecord(ctx->last_ext, sB));
         EB_HIP(hipStreamWaitEvent(sC, x.e[E_PREP_DONE], 0));
-        if (!right_early) {
+        if (!right_early) { // straight into the image
             EB_HIP(hipEventRecord(x.e[E_RIGHT0], sC));
-            EB_HIP(hipMemsetAsync(x.rt_right.p, 0, x.ns_raw * (size_t)rw * 8, sC));
-            hipLaunchKernelGGL(k_right, dim3(right_grid), dim3(256), 0, sC, x1, x2, df, p, x.sorted.as<Survivor>(), x.boff.as<uint32_t>() + n_buckets,
-                               x.rt_rec.as<eb_cluster>(), x.rt_right.as<uint64_t>(), rw);
-        }
-        hipLaunchKernelGGL(k_right_finish, dim3(grid_of(x.ns)), dim3(256), 0, sC, x.rt_rec.as<eb_cluster>(), x.rt_right.as<uint64_t>(), x.choff.as<uint32_t>(),
+            hipLaunchKernelGGL(k_right, dim3(grid_of(x.ns)), dim3(256), 0, sC, x1, x2, df, p, x.sorted.as<Survivor>(), x.boff.as<uint32_t>() + n_buckets,
+                               x.choff.as<uint32_t>(), (uint32_t)x.chain_base, x.d_recs, x.d_right, rw);
+        } else
+            hipLaunchKernelGGL(k_right_finish, dim3(grid_of(x.ns)), dim3(256), 0, sC, x.rt_rec.as<eb_cluster>(), x.rt_right.as<uint64_t>(), x.choff.as<uint32_t>(),
                            (uint32_t)x.chain_base, x.ns, rw, x.d_recs, x.d_right);
         EB_HIP(hipEventRecord(x.e[E_RIGHT_DONE], sC));
         EB_HIP(hipEventRecord(ctx->last_right, sC));
