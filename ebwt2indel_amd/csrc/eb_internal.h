@@ -93,6 +93,16 @@ static const uint64_t EB_WIRE_MAGIC = 0x33534C4C41434245ull;  // "EBCALLS3"
 struct eb_wire_cluster { uint64_t begin; uint32_t len; uint8_t n_slots, right_found; uint16_t right_len; };
 struct eb_wire_chain { uint8_t side, sym; uint16_t len; uint32_t support; };
 static_assert(sizeof(eb_wire_cluster) == 16 && sizeof(eb_wire_chain) == 8, "wire records");
+// tighter still, when every field fits (begin < 2^40, cluster and contexts shorter than 2^16 rows / 8192 bases, supports
+// below 2^16 -- any real call set): 12-byte clusters, 4-byte chains
+static const uint64_t EB_WIRE4_MAGIC = 0x34534C4C41434245ull; // "EBCALLS4"
+struct eb_wire4_cluster { uint32_t begin_lo; uint8_t begin_hi, slots_found; uint16_t len; uint16_t right_len, pad; }; // slots_found: n_slots | right_found << 4
+struct eb_wire4_chain { uint16_t side_sym_len; uint16_t support; };                                                   // side | letter << 1 | len << 3
+static_assert(sizeof(eb_wire4_cluster) == 12 && sizeof(eb_wire4_chain) == 4, "wire records");
+static inline uint64_t eb_wire4_size(uint64_t count, uint64_t n_chains, int32_t k_left, int32_t k_right) {
+    uint64_t recs = (count * sizeof(eb_wire4_cluster) + n_chains * sizeof(eb_wire4_chain) + 7) & ~7ull;
+    return sizeof(eb_calls_header) + recs + n_chains * (((uint64_t)k_left + 31) / 32) * 8 + count * (((uint64_t)k_right + 31) / 32) * 8;
+}
 static inline uint64_t eb_wire_size(uint64_t count, uint64_t n_chains, int32_t k_left, int32_t k_right) {
     return sizeof(eb_calls_header) + count * sizeof(eb_wire_cluster) + n_chains * sizeof(eb_wire_chain) +
            n_chains * (((uint64_t)k_left + 31) / 32) * 8 + count * (((uint64_t)k_right + 31) / 32) * 8;

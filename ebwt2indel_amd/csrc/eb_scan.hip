@@ -852,6 +852,7 @@ struct eb_scan_job {
     unsigned long long* h_bad = nullptr; // pinned: records that do not fit the wire image
     uint64_t wire_bytes = 0;
     int32_t k_left = 0, k_right = 0;
+    bool wire_full_width = false; // the tight wire image overflowed: full-width records were packed instead
 };
 
 // friendly records -> compact wire records (eb_scan_job_device_wire); *bad counts fields that do not fit
@@ -881,6 +882,32 @@ __global__ void __launch_bounds__(256) k_pack_wire(const eb_cluster* __restrict_
     }
 }
 
+__global__ void __launch_bounds__(256) k_pack_wire4(const eb_cluster* __restrict__ recs, uint64_t count, const eb_chain* __restrict__ chains, uint64_t n_chains,
+                                                   eb_wire4_cluster* __restrict__ wc, eb_wire4_chain* __restrict__ wk, unsigned long long* __restrict__ bad) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) {
+        eb_cluster r = recs[i];
+        eb_wire4_cluster w;
+        w.begin_lo = (uint32_t)r.begin;
+        w.begin_hi = (uint8_t)(r.begin >> 32);
+        w.slots_found = (uint8_t)((r.n_slots & 15u) | ((r.right_found ? 1u : 0u) << 4));
+        w.len = (uint16_t)(r.end - r.begin);
+        w.right_len = (uint16_t)r.right_len;
+        w.pad = 0;
+        if ((r.begin >> 40) || r.end - r.begin > 0xFFFFull || r.right_len > 0xFFFFu || r.n_slots > 15u) atomicAdd(bad, 1ull);
+        wc[i] = w;
+    }
+    if (i < n_chains) {
+        eb_chain k = chains[i];
+        uint32_t letter = k.sym == 'A' ? 0u : k.sym == 'C' ? 1u : k.sym == 'G' ? 2u : 3u;
+        eb_wire4_chain w;
+        w.side_sym_len = (uint16_t)((k.side & 1u) | (letter << 1) | (k.len << 3));
+        w.support = (uint16_t)k.support;
+        if (k.len > 8191u || k.support > 0xFFFFu) atomicAdd(bad, 1ull);
+        wk[i] = w;
+    }
+}
+
 // first 64 bytes of the device image of a call set
 __global__ void k_blob_header(eb_calls_header h, uint64_t* dst) {
     const uint64_t v[8] = {h.magic, h.count, h.n_chains, h.k_left, h.k_right, 0, 0, 0};
@@ -899,7 +926,7 @@ void eb_scan_ctx_destroy(eb_scan_ctx* c) {
     delete c;
 }
 
-static int wire_enqueue(eb_scan_job* job, hipStream_t st, unsigned long long* h_bad);
+static int wire_enqueue(eb_scan_job* job, hipStream_t st, unsigned long long* h_bad, int version);
 
 extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f, uint64_t begin, uint64_t end, const eb_params* prm,
                                          uint32_t options, eb_scan_job** out_job) {
@@ -1235,7 +1262,7 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
     }
     job->ns = ns;
     job->n_chains = n_chains;
-    if ((options & EB_SCAN_WIRE) && job->has_blob && (rc = wire_enqueue(job, sD, job->h_bad)) != EB_OK) return rc;
+    if ((options & EB_SCAN_WIRE) && job->has_blob && (rc = wire_enqueue(job, sD, job->h_bad, 4)) != EB_OK) return rc;
     EB_HIP(hipEventRecord(ev_end, sD));
     job->calls = calls;
     calls = nullptr; // owned by the job from here on
@@ -1330,10 +1357,11 @@ extern "C" int eb_scan_job_device_blob(eb_scan_job* job, const void** d_data, ui
 }
 
 // enqueues the packing of the compact wire image on `st` (after the records are complete there); h_bad: pinned word
-static int wire_enqueue(eb_scan_job* job, hipStream_t st, unsigned long long* h_bad) {
+// version 4: the tightest image; version 3: the fallback with full-width fields
+static int wire_enqueue(eb_scan_job* job, hipStream_t st, unsigned long long* h_bad, int version) {
     const uint64_t count = job->ns, n_chains = job->n_chains;
     const uint64_t lw = ((uint64_t)job->k_left + 31) / 32, rw = ((uint64_t)job->k_right + 31) / 32;
-    const uint64_t bytes = eb_wire_size(count, n_chains, job->k_left, job->k_right);
+    const uint64_t bytes = version == 4 ? eb_wire4_size(count, n_chains, job->k_left, job->k_right) : eb_wire_size(count, n_chains, job->k_left, job->k_right);
     job->wire.device = job->b1->device;
     int rc = job->wire.alloc(bytes + 16); // + the overflow counter
     if (rc != EB_OK) return rc;
@@ -1341,15 +1369,25 @@ static int wire_enqueue(eb_scan_job* job, hipStream_t st, unsigned long long* h_
     unsigned long long* d_bad = reinterpret_cast<unsigned long long*>(q + ((bytes + 7) & ~7ull));
     EB_HIP(hipMemsetAsync(d_bad, 0, 8, st));
     eb_calls_header h = job->header;
-    h.magic = EB_WIRE_MAGIC;
+    h.magic = version == 4 ? EB_WIRE4_MAGIC : EB_WIRE_MAGIC;
     hipLaunchKernelGGL(k_blob_header, dim3(1), dim3(64), 0, st, h, reinterpret_cast<uint64_t*>(q));
     if (count) {
         SubShard& x = job->sh[0];
-        eb_wire_cluster* wc = reinterpret_cast<eb_wire_cluster*>(q + sizeof(eb_calls_header));
-        eb_wire_chain* wk = reinterpret_cast<eb_wire_chain*>(q + sizeof(eb_calls_header) + count * sizeof(eb_wire_cluster));
-        uint8_t* ctx_words = reinterpret_cast<uint8_t*>(wk) + n_chains * sizeof(eb_wire_chain);
         const uint64_t most = count > n_chains ? count : n_chains;
-        hipLaunchKernelGGL(k_pack_wire, dim3(grid_of(most)), dim3(256), 0, st, x.d_recs, count, x.d_crec, n_chains, wc, wk, d_bad);
+        uint8_t* ctx_words;
+        if (version == 4) {
+            eb_wire4_cluster* wc = reinterpret_cast<eb_wire4_cluster*>(q + sizeof(eb_calls_header));
+            eb_wire4_chain* wk = reinterpret_cast<eb_wire4_chain*>(q + sizeof(eb_calls_header) + count * sizeof(eb_wire4_cluster));
+            const uint64_t recs = (count * sizeof(eb_wire4_cluster) + n_chains * sizeof(eb_wire4_chain) + 7) & ~7ull;
+            ctx_words = q + sizeof(eb_calls_header) + recs;
+            if (recs >= 8) EB_HIP(hipMemsetAsync(ctx_words - 8, 0, 8, st)); // the padding behind the chains
+            hipLaunchKernelGGL(k_pack_wire4, dim3(grid_of(most)), dim3(256), 0, st, x.d_recs, count, x.d_crec, n_chains, wc, wk, d_bad);
+        } else {
+            eb_wire_cluster* wc = reinterpret_cast<eb_wire_cluster*>(q + sizeof(eb_calls_header));
+            eb_wire_chain* wk = reinterpret_cast<eb_wire_chain*>(q + sizeof(eb_calls_header) + count * sizeof(eb_wire_cluster));
+            ctx_words = reinterpret_cast<uint8_t*>(wk) + n_chains * sizeof(eb_wire_chain);
+            hipLaunchKernelGGL(k_pack_wire, dim3(grid_of(most)), dim3(256), 0, st, x.d_recs, count, x.d_crec, n_chains, wc, wk, d_bad);
+        }
         EB_HIP(hipMemcpyAsync(ctx_words, x.d_left, n_chains * lw * 8, hipMemcpyDeviceToDevice, st));
         EB_HIP(hipMemcpyAsync(ctx_words + n_chains * lw * 8, x.d_right, count * rw * 8, hipMemcpyDeviceToDevice, st));
     }
@@ -1364,9 +1402,15 @@ extern "C" int eb_scan_job_device_wire(eb_scan_job* job, const void** d_data, ui
     if (!job->has_blob) { eb_set_error("the job was split into sub-shards: no contiguous device image"); return EB_ERR_STATE; }
     EB_HIP(hipSetDevice(job->b1->device));
     EB_HIP(hipEventSynchronize(job->ev_end)); // the records (and, with EB_SCAN_WIRE, the packing) are complete
+    hipStream_t st = job->b1->scan_ctx->copy;
     if (!job->wire.p) {                       // not asked for at _begin: pack now
-        hipStream_t st = job->b1->scan_ctx->copy;
-        int rc = wire_enqueue(job, st, job->h_bad);
+        int rc = wire_enqueue(job, st, job->h_bad, 4);
+        if (rc != EB_OK) return rc;
+        EB_HIP(hipStreamSynchronize(st));
+    }
+    if (*job->h_bad && !job->wire_full_width) { // a field does not fit the tight image: full-width records
+        job->wire_full_width = true;
+        int rc = wire_enqueue(job, st, job->h_bad, 3);
         if (rc != EB_OK) return rc;
         EB_HIP(hipStreamSynchronize(st));
     }

@@ -381,18 +381,51 @@ extern "C" int eb_calls_unpack(const uint8_t* buf, uint64_t len, eb_calls** out)
     eb_calls_header h;
     if (len < sizeof h) { eb_set_error("truncated call set"); return EB_ERR_ARG; }
     memcpy(&h, buf, sizeof h);
-    if (h.magic != kMagic && h.magic != EB_WIRE_MAGIC) { eb_set_error("not a packed call set"); return EB_ERR_ARG; }
+    if (h.magic != kMagic && h.magic != EB_WIRE_MAGIC && h.magic != EB_WIRE4_MAGIC) { eb_set_error("not a packed call set"); return EB_ERR_ARG; }
     if (h.k_left == 0 || h.k_left > (1u << 20) || h.k_right == 0 || h.k_right > (1u << 20) || h.count > (1ull << 40) || h.n_chains > h.count * EB_MAX_SLOTS) {
         eb_set_error("corrupt call set header");
         return EB_ERR_ARG;
     }
-    const bool wire = h.magic == EB_WIRE_MAGIC;
-    uint64_t need = wire ? eb_wire_size(h.count, h.n_chains, (int32_t)h.k_left, (int32_t)h.k_right)
-                         : eb_calls_blob_size(h.count, h.n_chains, (int32_t)h.k_left, (int32_t)h.k_right);
+    const bool wire = h.magic == EB_WIRE_MAGIC, wire4 = h.magic == EB_WIRE4_MAGIC;
+    uint64_t need = wire4 ? eb_wire4_size(h.count, h.n_chains, (int32_t)h.k_left, (int32_t)h.k_right)
+                  : wire  ? eb_wire_size(h.count, h.n_chains, (int32_t)h.k_left, (int32_t)h.k_right)
+                          : eb_calls_blob_size(h.count, h.n_chains, (int32_t)h.k_left, (int32_t)h.k_right);
     if (len < need) { eb_set_error("truncated call set"); return EB_ERR_ARG; }
     eb_calls* c = eb_calls_alloc(h.count, h.n_chains, (int32_t)h.k_left, (int32_t)h.k_right, false);
     if (!c) return EB_ERR_NOMEM;
-    if (!wire) {
+    if (wire4) {
+        const uint8_t* q = buf + sizeof h;
+        uint64_t chain = 0;
+        for (uint64_t i = 0; i < h.count; ++i) {
+            eb_wire4_cluster w;
+            memcpy(&w, q + i * sizeof w, sizeof w);
+            eb_cluster& r = c->clusters[i];
+            r.begin = (uint64_t)w.begin_lo | ((uint64_t)w.begin_hi << 32);
+            r.end = r.begin + w.len;
+            r.first_chain = (uint32_t)chain;
+            r.n_slots = w.slots_found & 15u;
+            r.right_found = (w.slots_found >> 4) & 1u;
+            r.right_len = w.right_len;
+            r.reserved = 0;
+            chain += r.n_slots;
+        }
+        if (chain != h.n_chains) { eb_set_error("corrupt call set: chain counts do not add up"); eb_calls_free(c); return EB_ERR_ARG; }
+        q += h.count * sizeof(eb_wire4_cluster);
+        for (uint64_t i = 0; i < h.n_chains; ++i) {
+            eb_wire4_chain w;
+            memcpy(&w, q + i * sizeof w, sizeof w);
+            eb_chain& k = c->chains[i];
+            k.side = w.side_sym_len & 1u;
+            k.sym = (uint8_t)"ACGT"[(w.side_sym_len >> 1) & 3u];
+            k.reserved = 0;
+            k.len = w.side_sym_len >> 3;
+            k.support = w.support;
+        }
+        q = buf + sizeof h + ((h.count * sizeof(eb_wire4_cluster) + h.n_chains * sizeof(eb_wire4_chain) + 7) & ~7ull);
+        memcpy(c->left, q, h.n_chains * c->left_words() * 8);
+        q += h.n_chains * c->left_words() * 8;
+        memcpy(c->right, q, h.count * c->right_words() * 8);
+    } else if (!wire) {
         memcpy(c->blob, buf, need);
     } else {
         // compact image -> records (first_chain = running sum of n_slots)

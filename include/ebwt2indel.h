@@ -220,12 +220,16 @@ int eb_scan_job_wait(eb_scan_job* job);
 /* The job's call set as one contiguous image in DEVICE memory (same format as eb_calls_blob), valid until _end.
  * EB_ERR_STATE when the job was split into sub-shards (EB_SCAN_SUBSHARDS > 1). */
 int eb_scan_job_device_blob(eb_scan_job* job, const void** d_data, uint64_t* len);
-/* The same call set as a COMPACT wire image in device memory (56 instead of 80 bytes per two-allele cluster), for the
+/* The same call set as a COMPACT wire image in device memory (44 instead of 80 bytes per two-allele cluster), for the
  * gather to rank 0 and its download -- the PCIe link of rank 0 carries every record of an N-GPU job:
- *   [64-byte header, magic "EBCALLS3"][{u64 begin; u32 end-begin; u8 n_slots; u8 right_found; u16 right_len} x count]
- *   [{u8 side; u8 sym; u16 len; u32 support} x n_chains][left words][right words]
- * (first_chain is the running sum of n_slots).  eb_calls_unpack reads both images.  Packed on first call, valid until
- * _end.  EB_ERR_STATE if a field does not fit (a cluster of 2^32 rows or more, contexts of 2^16 bases or more): use
+ *   [64-byte header, magic "EBCALLS4"]
+ *   [{u32 begin_lo; u8 begin_hi; u8 n_slots | right_found << 4; u16 end-begin; u16 right_len; u16 0} x count]
+ *   [{u16 side | letter << 1 | len << 3; u16 support} x n_chains][pad to 8][left words][right words]
+ * (first_chain is the running sum of n_slots).  If a field does not fit (begin >= 2^40, a cluster of 2^16 rows or more,
+ * a context of 8192 bases or more, a support of 2^16 or more) the image has full-width records instead (magic
+ * "EBCALLS3": {u64 begin; u32 end-begin; u8 n_slots; u8 right_found; u16 right_len}, {u8 side; u8 sym; u16 len; u32
+ * support}; 56 bytes per two-allele cluster).  eb_calls_unpack reads all images.  Packed by the job with EB_SCAN_WIRE,
+ * else on first call; valid until _end.  EB_ERR_STATE if not even the full-width records fit: use
  * eb_scan_job_device_blob then. */
 int eb_scan_job_device_wire(eb_scan_job* job, const void** d_data, uint64_t* len);
 

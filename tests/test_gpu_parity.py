@@ -544,3 +544,46 @@ def test_fresh_inputs_against_the_reference_binary(tmp_path, seed, extra):
     want3 = ref(["-1", str(tmp_path / "m"), "-d", str(tmp_path / "da")])
     assert want2.count(b">") > 20 and api.run_two_datasets(a, b, p) == want2
     assert want3.count(b">") > 20 and api.run_two_datasets_da(m, da, p) == want3
+
+
+def test_wire_image_falls_back_to_full_width_records(oracle):
+    """A cluster of more than 65535 rows does not fit the tight wire image (16-bit length): the job then packs the
+    full-width one, and both unpack to the very records of the host blob."""
+    n = 150_000
+    rng = _rng(77)
+    sym = rng.choice(np.frombuffer(b"ACGT#", dtype=np.uint8), size=n, p=[0.2475] * 4 + [0.01])
+    bits = (np.arange(n) != 70_001) & (np.arange(n) > 3)          # two runs of ~70 k and ~80 k rows
+    thrK = _pack_bits(bits)
+    thrR = thrK & _pack_bits(_bits(rng, n, 0.5))
+    minima = _pack_bits(np.zeros(n, dtype=bool))
+    p = api.make_params()
+    g = api.DnaBwt(sym)
+    fl = api.Flags.from_host(n, thrK, thrR, minima)
+    host = api.scan_clusters_begin(g, fl, p).finish()
+    assert len(host) >= 1 and max(int(c.end - c.begin) for c in _clusters(host)) > 65535
+    for at_begin in (True, False):
+        job = api.scan_clusters_begin(g, fl, p, device_only=True, wire=at_begin)
+        job.wait()
+        ptr, length = job.device_wire()
+        wire = np.empty(length, dtype=np.uint8)
+        sim._hip_copy_to_host(wire, ptr, length)
+        job.finish()
+        assert wire[:8].tobytes() == b"EBCALLS3"
+        assert bytes(api.Calls.unpack(wire.tobytes()).blob()) == bytes(host.blob())
+    # and an ordinary call set takes the tight image
+    e = golden_bytes("dip.ebwt")
+    g2 = api.DnaBwt(e)
+    fl2 = api.navigate_one_bwt(g2, p)
+    job = api.scan_clusters_begin(g2, fl2, p, device_only=True, wire=True)
+    job.wait()
+    ptr, length = job.device_wire()
+    wire = np.empty(length, dtype=np.uint8)
+    sim._hip_copy_to_host(wire, ptr, length)
+    job.finish()
+    assert wire[:8].tobytes() == b"EBCALLS4"
+    assert bytes(api.Calls.unpack(wire.tobytes()).blob()) == bytes(api.scan_clusters(g2, fl2, p).blob())
+
+
+def _clusters(calls):
+    v = calls.view()
+    return [v.clusters[i] for i in range(v.count)]
