@@ -228,8 +228,12 @@ def test_snp_byte_identical_to_reference(case):
 
 @pytest.mark.parametrize("case", [c for c in CASES if c["name"] in ("m1_default", "m1_edge_m2", "m2_het_default", "m2_edge_default",
                                                                       "m3_het_default", "m3_edge_default")], ids=lambda c: c["name"])
-def test_cluster_records_match_oracle(oracle, case):
-    """Record-level parity of phase 4 (clusters, supports, contexts, counters), whole range and sharded."""
+@pytest.mark.parametrize("early_max", [None, "0"], ids=["walks_early", "walks_late"])
+def test_cluster_records_match_oracle(oracle, monkeypatch, case, early_max):
+    """Record-level parity of phase 4 (clusters, supports, contexts, counters), whole range and sharded -- with the
+    context walks launched early into temporaries (small call sets) and late, straight into the image (large ones)."""
+    if early_max is not None:
+        monkeypatch.setenv("EB_RIGHT_EARLY_MAX", early_max)
     p, e1, e2, da = _flag_case(oracle, case)
     pp = api.make_params(case["args"])
     o1 = oracle.index(e1, p.term)
