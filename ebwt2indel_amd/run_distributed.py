@@ -1,0 +1,100 @@
+"""ebwt2InDel over the GPUs of one node: one process per GPU, same flags as the executable.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \\
+        -m ebwt2indel_amd.run_distributed -1 reads.ebwt -o out.snp [-2 other.ebwt | -d reads.da] [-L -R -k -g -v -m -c -q -t]
+
+Every rank loads the eBWT(s) onto its GPU; phases 2-3 are split by Weiner-link subtrees and combined with one all-reduce
+per bit vector; phase 4 is split by closing position; the ranks' call sets travel as compact device images to rank 0
+(RCCL over xGMI), which runs the event logic and writes the .snp -- byte for byte the file of the single-GPU
+executable (tests/test_gpu_distributed.py).  Backend: nccl (= RCCL); EB_DIST_BACKEND=gloo stages through host memory
+(rehearsal with several ranks on one GPU).  The reference has no counterpart (one process, ebwt2InDel.cpp:1677-1823)."""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+
+
+def main(argv=None) -> int:
+    ap = argparse.ArgumentParser(prog="ebwt2indel_amd.run_distributed", add_help=True)
+    ap.add_argument("-1", dest="in1", required=True)
+    ap.add_argument("-2", dest="in2")
+    ap.add_argument("-d", dest="da")
+    ap.add_argument("-o", dest="out", required=True)
+    for flag in ("-L", "-R", "-k", "-g", "-v", "-m", "-c", "-q", "-t"):
+        ap.add_argument(flag, type=int, default=0)
+    a = ap.parse_args(argv)
+    if a.in2 and a.da:
+        print("Error: Document array (-d) can only be used with one input BWT file (-1)")   # ebwt2InDel.cpp:1760-1765
+        return 1
+
+    import torch
+    import torch.distributed as dist
+
+    from . import api
+    from . import distributed as ebd
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+    backend = os.environ.get("EB_DIST_BACKEND", "nccl")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    torch.cuda.set_device(local)
+    if backend == "nccl":
+        # RCCL prints a version banner on stdout while the group comes up: keep stdout clean for callers
+        keep = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+        finally:
+            os.dup2(keep, 1)
+            os.close(keep)
+        comm_dev = torch.device(f"cuda:{local}")
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+        comm_dev = torch.device("cpu")
+    try:
+        args = []
+        for flag in ("-L", "-R", "-k", "-g", "-v", "-m", "-c", "-q", "-t"):
+            v = getattr(a, flag[1:])
+            if v:
+                args += [flag, str(v)]
+        p = api.make_params(args)
+        two = bool(a.in2) or bool(a.da)
+        t0 = time.time()
+        b1 = api.DnaBwt(a.in1, term=p.term, device=local)
+        b2 = api.DnaBwt(a.in2, term=p.term, device=local) if a.in2 else None
+        t1 = time.time()
+        fl = ebd.navigate_sharded(b1, p, b2, device=comm_dev)
+        if a.da:
+            with open(a.da, "rb") as fh:
+                fl.set_da(fh.read())
+        t2 = time.time()
+        n = b1.n + (b2.n if b2 is not None else 0)
+        begin, end = ebd.shard_range(n, rank, world)
+        if comm_dev.type == "cuda":
+            job = api.scan_clusters_begin(b1, fl, p, bwt2=b2, begin=begin, end=end, device_only=True, wire=True)
+            job.wait()
+            ptr, length = job.device_wire()
+            parts = ebd.gather_device(ptr, length, comm_dev)
+            job.finish()
+        else:
+            calls = api.scan_clusters(b1, fl, p, bwt2=b2, begin=begin, end=end)
+            parts = ebd.gather_packed(calls.blob(), device=comm_dev)
+        t3 = time.time()
+        if rank == 0:
+            text, cluster_nr, events, total = ebd.write_gathered(parts, p, two)
+            with open(a.out, "wb") as fh:
+                fh.write(text)
+            st = fl.stats
+            print(f"ebwt2InDel on {world} GPU(s): n={n}, {st.nodes} suffix-tree nodes, {total} clusters -> {text.count(b'>')} records in {a.out}")
+            print(f"Timings (s): load+index {t1 - t0:.3f}, phases 2-3 {t2 - t1:.3f}, phase 4 + gather {t3 - t2:.3f}, write {time.time() - t3:.3f}")
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -107,3 +107,26 @@ def test_two_ranks_one_gpu_reproduce_golden(tmp_path, name):
     out = tmp_path / "out.snp"
     mp.spawn(_worker, args=(2, _free_port(), case, str(out)), nprocs=2, join=True)
     assert out.read_bytes() == golden_bytes(case["snp"])
+
+
+@pytest.mark.parametrize("name", ["m1_default", "m2_het_default", "m3_hom_default"])
+def test_multi_gpu_launcher_two_ranks(tmp_path, name):
+    """`python -m ebwt2indel_amd.run_distributed` (the executable's flags, one process per GPU) with two gloo ranks on
+    the one GPU: the file rank 0 writes is the reference's, byte for byte."""
+    import subprocess
+    import sys
+    case = _case(name)
+    inp = case["inputs"]
+    files = {}
+    for key, fname in inp.items():
+        pth = tmp_path / key
+        pth.write_bytes(golden_bytes(fname))
+        files[key] = str(pth)
+    out = tmp_path / "out.snp"
+    args = ["-1", files["bwt1"], "-o", str(out)] + (["-2", files["bwt2"]] if case["mode"] == 2 else []) + (["-d", files["da"]] if case["mode"] == 3 else [])
+    env = dict(os.environ, EB_DIST_BACKEND="gloo", EB_NAV_SPLIT_MIN="8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), "-m", "ebwt2indel_amd.run_distributed"] + args + list(case["args"])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert out.read_bytes() == golden_bytes(case["snp"])
