@@ -591,3 +591,18 @@ def test_wire_image_falls_back_to_full_width_records(oracle):
 def _clusters(calls):
     v = calls.view()
     return [v.clusters[i] for i in range(v.count)]
+
+
+@pytest.mark.skipif(not os.path.exists(_oracle.REF_BIN), reason="reference binary did not travel with the tree")
+@pytest.mark.parametrize("extra", [["-m", "12"], ["-m", "25"], ["-m", "40", "-k", "20"], ["-m", "33", "-q", "3"]], ids=lambda x: "".join(x))
+def test_large_min_coverage_against_the_reference_binary(tmp_path, extra):
+    """-m sets the shortest cluster analysed (2 x mcov rows): with 80 of them a cluster never fits one 64-row word of the
+    scan.  A 200x sample, against the reference binary."""
+    reads, _, _ = sim.diploid_sample(20_000, 40_000, 100, seed=11, snp_every=300, indel_every=800)
+    e = sim.build_ebwt(reads)
+    (tmp_path / "x.ebwt").write_bytes(e.tobytes())
+    out = tmp_path / "ref.snp"
+    rc = subprocess.run([_oracle.REF_BIN, "-1", str(tmp_path / "x.ebwt"), "-o", str(out)] + extra, stdout=subprocess.DEVNULL).returncode
+    want = out.read_bytes()
+    assert rc == 0 and want.count(b">") >= 2
+    assert api.run_one_dataset(e, api.make_params(extra)) == want
