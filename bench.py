@@ -32,6 +32,44 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def launch_ranks(n_gpus: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks (torch.distributed.run, one process per GPU, RCCL)
+    as CHILD processes with this command line, relay rank 0's JSON line and return the launcher's exit code.  Nothing
+    here initialises HIP (a process that did must not be replaced or forked into ranks)."""
+    import socket
+    import subprocess
+
+    backend = os.environ.get("EB_BENCH_BACKEND", "nccl")
+    import torch
+    ndev = torch.cuda.device_count()          # counts devices without creating a HIP context
+    if backend == "nccl" and ndev < n_gpus:
+        log(f"[bench] --gpus {n_gpus} needs {n_gpus} GPUs with RCCL, this node shows {ndev}; "
+            f"(EB_BENCH_BACKEND=gloo rehearses the N-rank path with ranks sharing devices)")
+        return 2
+    if ndev < 1:
+        log("[bench] no GPU visible: the hot path has no CPU fallback")
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n_gpus)))
+    log(f"[bench] launching {n_gpus} ranks ({backend}): {' '.join(cmd)}")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    for l in r.stdout.splitlines():
+        if not l.startswith("{"):
+            log(l)
+    if r.returncode != 0 or len(lines) != 1:
+        log(f"[bench] the {n_gpus}-rank run failed (exit {r.returncode}, {len(lines)} JSON lines)")
+        return r.returncode or 1
+    print(lines[0], flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -46,6 +84,20 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="finish every step before the next begins (profiling: under rocprofv3 the "
                     "overlapped record download runs as a blit kernel and slows the scan it overlaps)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if os.environ.get("EB_SCAN_DEBUG"):
+        # the shipped library has no work-skipping switches (they exist only in the -DEB_SCAN_EXPERIMENTS profiling build);
+        # a bench run must not even look as if it could have been hollowed out
+        raise SystemExit("EB_SCAN_DEBUG is set: refusing to benchmark (unset it; the switch belongs to the profiling build)")
+
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            # Started bare with --gpus N: this process becomes the launcher of N ranks (one per GPU) and never touches a
+            # GPU itself -- counting devices does not initialise HIP; the ranks are fresh child processes.
+            sys.exit(launch_ranks(args.gpus))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus and os.environ.get("EB_BENCH_FORCE_DIST") != "1":
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks: refusing to mislabel the run")
 
     import torch
     import torch.distributed as dist

@@ -185,6 +185,12 @@ class Flags:
         _check(lib().eb_flags_device_vectors(self._h, ptrs, C.byref(w)))
         return [int(p or 0) for p in ptrs], int(w.value)
 
+    def popcounts(self):
+        """Ones in thrK, thrR, minima, da (0 where absent), counted on the device."""
+        out = (C.c_uint64 * 4)()
+        _check(lib().eb_flags_popcounts(self._h, out))
+        return [int(v) for v in out]
+
     def finalize(self):
         _check(lib().eb_flags_finalize(self._h))
 

@@ -756,6 +756,26 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
     return EB_OK;
 }
 
+// Host-side round trip of the packed traversal records (the same __host__ __device__ code the kernels run): lets a
+// test without a GPU exercise 40-bit positions beyond 2^32 and the saturating depth.
+extern "C" int eb_selftest_pack_fields(int32_t n_fields, const uint64_t* fields, uint64_t depth, uint64_t* fields_out, uint64_t* depth_out,
+                                       uint64_t* words_out, uint32_t* n_words) {
+    if (!fields || !fields_out || !depth_out) { eb_set_error("null argument"); return EB_ERR_ARG; }
+    auto go = [&](auto packed, auto nf_tag) {
+        constexpr int NF = decltype(nf_tag)::value;
+        packed = pack_fields<NF>(fields, depth);
+        *depth_out = unpack_fields<NF>(packed, fields_out);
+        const uint32_t nw = (uint32_t)(sizeof(packed) / 8);
+        if (n_words) *n_words = nw;
+        if (words_out) memcpy(words_out, packed.w, sizeof(packed));
+    };
+    if (n_fields == 6) go(Node1P{}, std::integral_constant<int, 6>{});
+    else if (n_fields == 12) go(Node2P{}, std::integral_constant<int, 12>{});
+    else if (n_fields == 4) go(Leaf2P{}, std::integral_constant<int, 4>{});
+    else { eb_set_error("record kinds have 4, 6 or 12 position fields"); return EB_ERR_ARG; }
+    return EB_OK;
+}
+
 extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_right, eb_flags** out, eb_nav_stats* stats) {
     return flags_build_impl(b1, b2, K, k_right, 0, 1, out, stats);
 }
@@ -772,6 +792,39 @@ extern "C" int eb_flags_device_vectors(eb_flags* f, uint64_t* d_vectors[4], uint
     d_vectors[2] = f->d_min;
     d_vectors[3] = f->d_da;
     *words = f->words;
+    return EB_OK;
+}
+
+// ones in a bit vector: per-workgroup partial sums, added up by the host
+__global__ void __launch_bounds__(256) k_popcount_words(const uint64_t* __restrict__ v, uint64_t words, unsigned long long* __restrict__ partial) {
+    unsigned long long s = 0;
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < words; w += (uint64_t)gridDim.x * blockDim.x) s += (unsigned long long)__popcll(v[w]);
+    s = wave_sum(s);
+    __shared__ unsigned long long sh[4];
+    if ((threadIdx.x & 63u) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+extern "C" int eb_flags_popcounts(eb_flags* f, uint64_t ones[4]) {
+    if (!f || !ones) { eb_set_error("null argument"); return EB_ERR_ARG; }
+    EB_HIP(hipSetDevice(f->device));
+    const unsigned grid = 1024;
+    unsigned long long* d_part = nullptr;
+    EB_HIP(hipMalloc(&d_part, 4 * grid * sizeof(unsigned long long)));
+    struct G { void* p; ~G() { (void)hipFree(p); } } g{d_part};
+    const uint64_t* vec[4] = {f->d_thrK, f->d_thrR, f->d_min, f->d_da};
+    EB_HIP(hipMemsetAsync(d_part, 0, 4 * grid * sizeof(unsigned long long), f->stream));
+    for (int k = 0; k < 4; ++k)
+        if (vec[k]) hipLaunchKernelGGL(k_popcount_words, dim3(grid), dim3(256), 0, f->stream, vec[k], f->words, d_part + (size_t)k * grid);
+    std::vector<unsigned long long> h(4 * grid);
+    EB_HIP(hipMemcpyAsync(h.data(), d_part, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, f->stream));
+    EB_HIP(hipStreamSynchronize(f->stream));
+    EB_HIP(hipGetLastError());
+    for (int k = 0; k < 4; ++k) {
+        ones[k] = 0;
+        for (unsigned b = 0; b < grid; ++b) ones[k] += h[(size_t)k * grid + b];
+    }
     return EB_OK;
 }
 
@@ -801,14 +854,28 @@ __global__ void __launch_bounds__(256) k_pack_da(const uint8_t* __restrict__ asc
     da[first_word + t] = w;
 }
 
+// DA[from, n) = 1 (a document-array file that ends early on a '1', see eb_flags_set_da); bits at and beyond n stay 0
+__global__ void __launch_bounds__(256) k_fill_da_tail(uint64_t* __restrict__ da, uint64_t from, uint64_t n) {
+    const uint64_t w0 = from >> 6, w1 = (n - 1) >> 6;
+    for (uint64_t w = w0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w <= w1; w += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t m = ~0ull;
+        if (w == w0) m &= ~0ull << (from & 63u);
+        if (w == w1) m &= ~0ull >> (63u - ((n - 1) & 63u));
+        da[w] |= m; // one thread per word
+    }
+}
+
 extern "C" int eb_flags_set_da(eb_flags* f, const uint8_t* ascii01, uint64_t n) {
     if (!f || (!ascii01 && n)) { eb_set_error("null argument"); return EB_ERR_ARG; }
     EB_HIP(hipSetDevice(f->device));
-    // '1' -> 1, anything else (and anything past the end of the file) -> 0  (ebwt2InDel.cpp:1503-1508)
+    // '1' -> 1, anything else -> 0 (ebwt2InDel.cpp:1503-1508).  A file shorter than the BWT: the reference's read() fails
+    // and leaves its one-byte buffer untouched, so every remaining slot repeats the LAST byte of the file (k_fill_da_tail);
+    // with an empty file that buffer was never written (undefined upstream): zeros here.
     const size_t bytes = eb_bit_alloc_words(f->n) * 8;
     if (!f->d_da) EB_HIP(hipMalloc(&f->d_da, bytes));
     EB_HIP(hipMemsetAsync(f->d_da, 0, bytes, f->stream));
     const uint64_t lim = n < f->n ? n : f->n;
+    const bool sticky_one = lim > 0 && lim < f->n && ascii01[lim - 1] == '1';
     const uint64_t PIECE = 256ull << 20; // multiple of 64 positions
     uint8_t* d_stage = nullptr;
     EB_HIP(hipMalloc(&d_stage, lim < PIECE ? (lim ? lim : 1) : PIECE));
@@ -819,6 +886,10 @@ extern "C" int eb_flags_set_da(eb_flags* f, const uint8_t* ascii01, uint64_t n) 
         uint64_t n_words = (len + 63) / 64;
         hipLaunchKernelGGL(k_pack_da, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, f->stream, d_stage, len, pos / 64, n_words, f->d_da);
         EB_HIP(hipStreamSynchronize(f->stream)); // the staging buffer is reused
+    }
+    if (sticky_one) {
+        hipLaunchKernelGGL(k_fill_da_tail, dim3(2048), dim3(256), 0, f->stream, f->d_da, lim, f->n);
+        EB_HIP(hipStreamSynchronize(f->stream));
     }
     EB_HIP(hipGetLastError());
     return eb_flags_build_da_rank(f);

@@ -30,8 +30,18 @@ struct ScanParams {
     int k_left, k_right;
     uint64_t begin, end; // closing positions owned by this call
     uint64_t n;          // merged length
-    uint32_t dbg;        // EB_SCAN_DEBUG bits (profiling experiments only): 1 no length histogram, 2 no cluster analysis, 4 no run loop
+#ifdef EB_SCAN_EXPERIMENTS
+    uint32_t dbg;        // EB_SCAN_DEBUG bits: 1 no length histogram, 2 no cluster analysis, 4 no run loop, 8 no queues, 16 no statistics
+#endif
 };
+// Work-skipping switches for A/B timing of k_scan's parts exist only in the profiling build (make EXPERIMENTS=1, its own
+// output directory); in the shipped library EB_DBG() is the constant 0, the branches vanish and no environment variable
+// can hollow out the kernel.
+#ifdef EB_SCAN_EXPERIMENTS
+#define EB_DBG(p) ((p).dbg)
+#else
+#define EB_DBG(p) 0u
+#endif
 
 struct alignas(16) Survivor {
     uint64_t b, e;            // merged coordinates
@@ -256,7 +266,7 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
             todo_n -= 64u;
             unsigned long long e = q_todo[wave][todo_n + lane];
             __builtin_amdgcn_wave_barrier();
-            if (!(p.dbg & 2u)) analyse(true, e);
+            if (!(EB_DBG(p) & 2u)) analyse(true, e);
         }
     };
     // a queued cluster that holds a change of symbol: two letters with >= mcov rows each need >= mcov rows that differ
@@ -357,7 +367,7 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
         if (base < p.begin) ends &= (p.begin - base >= 64) ? 0ull : (~0ull << (p.begin - base));
         if (base + 64 > hi_pos) ends &= (hi_pos <= base) ? 0ull : (~0ull >> (base + 64 - hi_pos));
         n_runs += (uint64_t)__popcll(ends);
-        if (p.dbg & 4u) continue;
+        if (EB_DBG(p) & 4u) continue;
         // ---- bit-parallel: which closing runs can hold two frequent letters at all.  Two letters with >= mcov rows each
         // (:961; the two-sample modes need two distinct frequent letters to print anything, see analyse()) mean that at
         // least mcov rows differ from any one row of the cluster -- take its first row inside this word.  All runs of the
@@ -423,7 +433,7 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
                         RunGeom g = run_geometry(f, w, fw, pfw, bit);
                         uint64_t len = base + bit - g.b;
                         n_bases += len;
-                        if (len <= 200 && !(p.dbg & 1u)) atomicAdd(&sh_hist[len], 1u);
+                        if (len <= 200 && !(EB_DBG(p) & 1u)) atomicAdd(&sh_hist[len], 1u);
                         if (len >= p.min_len) ++n_clusters;
                         else hot &= ~(1ull << bit);
                     }
@@ -431,7 +441,7 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
                 }
             }
             uint32_t nb32 = 0, n_short = 0;
-            if (p.dbg & 16u) rest = 0;
+            if (EB_DBG(p) & 16u) rest = 0;
             // branch-free body: runs longer than 200 (and, in the two words that hold the ends of the scanned range, the
             // closing positions outside it) add to a sink slot of the histogram instead of skipping the add
             const bool edge = __ballot((rest & ~ends) != 0ull) != 0ull; // wave-uniform: some lane's word holds an end of the scanned range
@@ -473,7 +483,7 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
             n_clusters += (uint64_t)__popcll(ends & rest) - n_short; // closing positions walked here, minus the short runs
         }
         // ---- hand the clusters that may matter to the queues, one per lane and round
-        if (p.dbg & 8u) hot = 0;
+        if (EB_DBG(p) & 8u) hot = 0;
         for (;;) {
             bool have = hot != 0;
             if (!__ballot(have)) break;
@@ -503,7 +513,7 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
         bool have = lane < todo_n;
         unsigned long long e = have ? q_todo[wave][lane] : 0ull;
         todo_n = 0;
-        if (!(p.dbg & 2u)) analyse(have, e);
+        if (!(EB_DBG(p) & 2u)) analyse(have, e);
     }
     __syncthreads();
     if (threadIdx.x == 0 && s_count > (uint32_t)STAGE) s_count = STAGE;
@@ -964,7 +974,9 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
     p.begin = begin;
     p.end = end;
     p.n = n;
+#ifdef EB_SCAN_EXPERIMENTS
     p.dbg = getenv("EB_SCAN_DEBUG") ? (uint32_t)atoi(getenv("EB_SCAN_DEBUG")) : 0u;
+#endif
     eb_dev_index x1 = b1->dev(), x2 = b2 ? b2->dev() : b1->dev();
     eb_dev_flags df = f->dev();
 

@@ -171,13 +171,17 @@ def navigate_sharded(bwt1, params, bwt2=None, group=None, device=None):
         return fl
     st = fl.stats
     dev = torch.device("cpu") if device is None else torch.device(device)
+    # SUM stands in for OR only while every bit has ONE writer over all ranks; a doubly-set bit would carry into its
+    # neighbour and corrupt phase 4 silently.  popcount(a + b) = popcount(a) + popcount(b) - carries, so the ones of the
+    # reduced vectors must equal the sum of the ranks' ones -- checked on every run (four small device reductions).
+    ones = torch.tensor(fl.popcounts(), dtype=torch.int64, device=dev)
+    dist.all_reduce(ones, op=dist.ReduceOp.SUM, group=group)
     if dev.type == "cuda":
         ptrs, words = fl.device_vectors()
         for ptr in ptrs:
             if ptr:
                 dist.all_reduce(torch.as_tensor(_DeviceWords(ptr, words), device=dev), op=dist.ReduceOp.SUM, group=group)
         torch.cuda.current_stream(dev).synchronize()
-        fl.finalize()
     else:
         vecs = fl.export()
         for v in vecs:
@@ -187,6 +191,12 @@ def navigate_sharded(bwt1, params, bwt2=None, group=None, device=None):
         fl.close()
         fl = api.Flags.from_host(n, *vecs, device=bwt1.device)
         fl.stats = st
+    got = fl.popcounts()
+    if got != [int(v) for v in ones.tolist()]:
+        raise RuntimeError(f"sharded traversal: a bit of the flag vectors was set by more than one rank (ones after the reduction {got}, "
+                           f"sum of the ranks' ones {ones.tolist()}; order thrK, thrR, minima, da)")
+    if dev.type == "cuda":
+        fl.finalize()
     cnt = torch.tensor([int(getattr(st, k)) for k in _NAV_COUNTERS], dtype=torch.int64, device=dev)
     sec = torch.tensor([st.seconds_leaves, st.seconds_nodes], dtype=torch.float64, device=dev)
     dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)

@@ -36,8 +36,16 @@ def main(argv=None) -> int:
     from . import distributed as ebd
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+    ndev = torch.cuda.device_count()
     backend = os.environ.get("EB_DIST_BACKEND", "nccl")
+    if ndev < 1:
+        print("Error: no GPU visible (the hot path has no CPU fallback)")
+        return 1
+    if backend == "nccl" and world > ndev:
+        # RCCL needs one GPU per rank; wrapping LOCAL_RANK would put two ranks on one device
+        print(f"Error: {world} ranks but {ndev} GPU(s): one GPU per rank is required with nccl (EB_DIST_BACKEND=gloo lets ranks share devices)")
+        return 1
+    local = int(os.environ.get("LOCAL_RANK", "0")) % ndev
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     torch.cuda.set_device(local)

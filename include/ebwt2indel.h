@@ -139,9 +139,14 @@ int eb_flags_build_shard(eb_index* b1, eb_index* b2, int32_t K, int32_t k_right,
                          eb_nav_stats* stats);
 /* Device pointers of thrK, thrR, minima, da (NULL in one-BWT mode), eb_flags_words() words each, for the reduction. */
 int eb_flags_device_vectors(eb_flags* f, uint64_t* d_vectors[4], uint64_t* words);
+/* Ones in thrK, thrR, minima, da (0 where absent).  The SUM reduction of a sharded build is an OR only while every bit
+ * has a single writer; a doubly-set bit would carry into its neighbour.  Since popcount(a + b) = popcount(a) +
+ * popcount(b) - carries, the ranks check  popcount(reduced) == sum of the ranks' popcounts  (distributed.py does). */
+int eb_flags_popcounts(eb_flags* f, uint64_t ones[4]);
 /* After the vectors of a sharded build were combined: rebuilds what is derived from them (the DA rank directory). */
 int eb_flags_finalize(eb_flags* f);
-/* Mode 3: ASCII '0'/'1' document array, '1' -> 1, anything else -> 0 (ebwt2InDel.cpp:1503-1508). */
+/* Mode 3: ASCII '0'/'1' document array, '1' -> 1, anything else -> 0 (ebwt2InDel.cpp:1503-1508).  n < BWT length:
+ * the remaining slots repeat the file's last byte, as the reference's failed read() leaves its buffer unchanged. */
 int eb_flags_set_da(eb_flags* f, const uint8_t* ascii01, uint64_t n);
 /* Bit i of each vector is bit (i & 63) of word (i >> 6).  Any pointer may be NULL.
  * export: device -> host (tests, broadcast to other ranks); import: host -> device. */
@@ -263,6 +268,13 @@ int eb_write_snp(const eb_calls* c, const eb_params* p, int two_samples, const c
 int eb_format_snp(const eb_calls* c, const eb_params* p, int two_samples, uint64_t* cluster_nr, uint64_t* events,
                   char** text, uint64_t* len);
 void eb_free(void* p);
+
+/* ------------------------------------------------------------------ self-test hooks (host only, no GPU needed)
+ * Round trip of the traversal's packed stack records (eb_navigate.hip: 40-bit positions + saturating 16-bit depth;
+ * n_fields = 6 one-BWT node, 12 two-BWT node, 4 two-BWT leaf) through the same code the kernels run.  fields_out gets
+ * n_fields values, words_out (may be NULL) the packed words, *n_words their number. */
+int eb_selftest_pack_fields(int32_t n_fields, const uint64_t* fields, uint64_t depth, uint64_t* fields_out, uint64_t* depth_out,
+                            uint64_t* words_out, uint32_t* n_words);
 
 #ifdef __cplusplus
 }

@@ -538,12 +538,17 @@ oflags* orc_navigate_two(const oindex* x1, const oindex* x2, int K, int k_right)
     return f;
 }
 
-/* mode 3 DA reader: ebwt2InDel.cpp:1503-1508 ('1' -> 1, anything else -> 0) */
+/* mode 3 DA reader: ebwt2InDel.cpp:1503-1508 ('1' -> 1, anything else -> 0).  Past the end of a short file the
+ * reference's read() fails and leaves its one-byte buffer as it was: the remaining slots repeat the last byte read
+ * (an empty file leaves that buffer uninitialised upstream; zeros here). */
 void orc_flags_set_da(oflags* f, const uint8_t* ascii01, uint64_t n) {
     if (!f->da) f->da = (uint64_t*)calloc(f->words, 8);
     else memset(f->da, 0, f->words * 8);
-    for (uint64_t i = 0; i < n && i < f->n; ++i)
-        if (ascii01[i] == '1') bit_set(f->da, i);
+    uint8_t x = 0;
+    for (uint64_t i = 0; i < f->n; ++i) {
+        if (i < n) x = ascii01[i];
+        if (x == '1') bit_set(f->da, i);
+    }
 }
 
 /* ------------------------------------------------------------------ per-cluster analysis */

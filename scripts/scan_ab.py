@@ -1,5 +1,9 @@
 """A/B timing of the phase-4 kernels on a generated workload under EB_SCAN_DEBUG variants."""
 import sys, time, os
+# the work-skipping switches exist only in the profiling build: make -C ebwt2indel_amd/csrc EXPERIMENTS=1
+_exp = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ebwt2indel_amd", "_build_exp", "libebwt2indel.so")
+assert os.path.exists(_exp), "build the profiling library first: make -C ebwt2indel_amd/csrc EXPERIMENTS=1"
+os.environ["EB_LIB_PATH"] = _exp
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from ebwt2indel_amd import sim, api
