@@ -289,3 +289,32 @@ def build_ebwt_gpu(text: np.ndarray, starts: np.ndarray, read_len: int, term: in
     if rc != 0:
         raise RuntimeError(f"ebgen_build failed ({rc}): {g.ebgen_last_error().decode()}")
     return DeviceEbwt(d_bwt.value, d_da.value if want_da else None, n.value, list(tm))
+
+
+def replicated_ebwt_gpu(n_reads: int, read_len: int, coverage: float, copies: int, seed: int, device: int = 0):
+    """eBWT of the collection in which every read of a diploid sample occurs `copies` times in a row (reads j*copies ..
+    j*copies + copies - 1 are copies of base read j), as a torch uint8 tensor on `device`.
+
+    Equal suffixes are ordered by read index, so the `copies` instances of a suffix are adjacent and preceded by the
+    same symbol: the eBWT is the base collection's with every symbol repeated `copies` times (checked against the
+    suffix-sorting builder in tests/test_sim.py).  The suffix tree has the base collection's right-maximal nodes, so the
+    CPU reference gets through it in minutes although the text is `copies` times longer -- which is what makes inputs
+    past 2^32 positions checkable against the reference binary itself (scripts/ref_past_2p32.py)."""
+    import torch
+
+    genome_len = int(n_reads * read_len / coverage)
+    g = random_genome(genome_len, seed)
+    h2 = mutate_haplotype(g, seed)
+    text, offs = haplotype_text([g, h2])
+    starts = sample_read_starts([g, h2], offs, n_reads, read_len, seed)
+    dev = build_ebwt_gpu(text, starts, read_len, device=device)
+
+    class _Bytes:
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (ptr, False), "version": 3, "strides": None}
+    base = torch.as_tensor(_Bytes(dev.ptr, dev.n), device=f"cuda:{device}")
+    out = base[:, None].expand(-1, copies).reshape(-1) if copies > 1 else base.clone()   # one contiguous copy
+    torch.cuda.synchronize()
+    del base
+    dev.free()
+    return out

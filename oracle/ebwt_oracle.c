@@ -145,6 +145,84 @@ oindex* orc_index_from_buffer(const uint8_t* ascii, uint64_t n, uint8_t term) {
     return x;
 }
 
+/* The same index built by several host threads (checker for full-size inputs; see orc_navigate_one_mt): chunks of
+ * 2^20 blocks are packed independently with counters relative to the chunk, then shifted by the totals of the chunks
+ * before them inside the same 2^25-block superblock.  Bit-identical to orc_index_from_buffer's. */
+oindex* orc_index_from_buffer_mt(const uint8_t* ascii, uint64_t n, uint8_t term, int threads) {
+    if (threads <= 1) return orc_index_from_buffer(ascii, n, term);
+    oindex* x = (oindex*)calloc(1, sizeof *x);
+    x->n = n;
+    x->term = term;
+    x->nblocks = (n + 1 + 127) / 128;
+    x->nsuper = (n + 1 + 0xFFFFFFFFull) >> 32;
+    x->blk = (oblock*)aligned_alloc(64, x->nblocks * sizeof(oblock));
+    x->super = (rank4_t*)calloc(x->nsuper, sizeof(rank4_t));
+    const uint64_t CH = 1ull << 20, nch = (x->nblocks + CH - 1) / CH;
+    uint64_t* tot = (uint64_t*)calloc(nch * 5, 8); /* A,C,G,T,TERM per chunk */
+    uint64_t bad_pos = UINT64_MAX;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+    for (long long c = 0; c < (long long)nch; ++c) {
+        uint32_t rel[4] = {0, 0, 0, 0};
+        uint64_t nterm = 0, b1 = ((uint64_t)c + 1) * CH < x->nblocks ? ((uint64_t)c + 1) * CH : x->nblocks;
+        for (uint64_t b = (uint64_t)c * CH; b < b1; ++b) {
+            oblock* k = &x->blk[b];
+            memset(k, 0, sizeof *k);
+            for (int q = 0; q < 4; ++q) k->cnt[q] = rel[q];
+            uint64_t base = b * 128;
+            for (uint64_t j = 0; j < 128 && base + j < n; ++j) {
+                int code = sym_code(ascii[base + j], term);
+                if (code < 0) {
+                    uint64_t seen = __atomic_load_n(&bad_pos, __ATOMIC_RELAXED);
+                    while (base + j < seen && !__atomic_compare_exchange_n(&bad_pos, &seen, base + j, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+                    continue;
+                }
+                uint64_t m = 1ull << (j & 63);
+                if (code & 1) k->b0[j >> 6] |= m;
+                if (code & 2) k->b1[j >> 6] |= m;
+                if (code & 4) k->b2[j >> 6] |= m;
+                if (code < 4) rel[code]++; else nterm++;
+            }
+        }
+        for (int q = 0; q < 4; ++q) tot[5 * c + q] = rel[q];
+        tot[5 * c + 4] = nterm;
+    }
+    if (bad_pos != UINT64_MAX) {
+        x->bad_sym = ascii[bad_pos];
+        x->bad_pos = bad_pos;
+        x->n = UINT64_MAX;
+        free(tot);
+        return x;
+    }
+    uint64_t abs4[4] = {0, 0, 0, 0}, nterm = 0;
+    uint64_t* off = (uint64_t*)calloc(nch * 4, 8); /* counts before the chunk inside its superblock */
+    uint64_t rel4[4] = {0, 0, 0, 0};
+    for (uint64_t c = 0; c < nch; ++c) {
+        if (((c * CH) & ((1ull << 25) - 1)) == 0) {
+            for (int q = 0; q < 4; ++q) { x->super[(c * CH) >> 25].v[q] = abs4[q]; rel4[q] = 0; }
+        }
+        for (int q = 0; q < 4; ++q) { off[4 * c + q] = rel4[q]; rel4[q] += tot[5 * c + q]; abs4[q] += tot[5 * c + q]; }
+        nterm += tot[5 * c + 4];
+    }
+#pragma omp parallel for schedule(static) num_threads(threads)
+    for (long long c = 0; c < (long long)nch; ++c) {
+        uint64_t b1 = ((uint64_t)c + 1) * CH < x->nblocks ? ((uint64_t)c + 1) * CH : x->nblocks;
+        if (!(off[4 * c] | off[4 * c + 1] | off[4 * c + 2] | off[4 * c + 3])) continue;
+        for (uint64_t b = (uint64_t)c * CH; b < b1; ++b)
+            for (int q = 0; q < 4; ++q) x->blk[b].cnt[q] += (uint32_t)off[4 * c + q];
+    }
+    free(tot); free(off);
+    x->F[0] = nterm;
+    x->F[1] = x->F[0] + abs4[0];
+    x->F[2] = x->F[1] + abs4[1];
+    x->F[3] = x->F[2] + abs4[2];
+    return x;
+}
+/* whole-index comparison for the test of the threaded builder */
+int orc_index_equal(const oindex* a, const oindex* b) {
+    return a->n == b->n && a->nblocks == b->nblocks && a->nsuper == b->nsuper && !memcmp(a->F, b->F, sizeof a->F) &&
+           !memcmp(a->super, b->super, a->nsuper * sizeof(rank4_t)) && !memcmp(a->blk, b->blk, a->nblocks * sizeof(oblock));
+}
+
 oindex* orc_index_from_file(const char* path, uint8_t term) {
     FILE* f = fopen(path, "rb");
     if (!f) return NULL;
@@ -449,6 +527,106 @@ oflags* orc_navigate_one(const oindex* x, int K, int k_right) {
         f->max_stack = mx;
         free(S.a);
     }
+    return f;
+}
+
+/* ---- the same two traversals on several host threads, for checking the GPU at sizes where one thread would take
+ * the better part of an hour (BASELINE configs[1]: 7.55 G positions).  Not the timed baseline (that is the serial
+ * orc_navigate_one above, the reference's own order) -- a checker.  Legal because every LCP / minimum slot has exactly
+ * one writer (lcp_values reaches n, ebwt2InDel.cpp:617,670), so the visiting order is free: the top of the tree is
+ * expanded breadth-first by one thread until the frontier is wide enough, then the frontier's subtrees are walked
+ * depth-first by the threads (dynamic schedule), each with the serial code's expansion rule.  Bits are set with atomic
+ * ORs (threads share words); counters are per thread and added up.  max_stack is not meaningful here (0). */
+static inline void bit_set_atomic(uint64_t* b, uint64_t i) { __atomic_fetch_or(&b[i >> 6], 1ull << (i & 63), __ATOMIC_RELAXED); }
+static inline void bits_fill_atomic(uint64_t* b, uint64_t lo, uint64_t hi) { /* [lo,hi) */
+    if (hi <= lo) return;
+    uint64_t w0 = lo >> 6, w1 = (hi - 1) >> 6;
+    for (uint64_t w = w0; w <= w1; ++w) {
+        uint64_t m = ~0ull;
+        if (w == w0) m &= ~0ull << (lo & 63);
+        if (w == w1) m &= ~0ull >> (63 - ((hi - 1) & 63));
+        __atomic_fetch_or(&b[w], m, __ATOMIC_RELAXED);
+    }
+}
+typedef struct { uint64_t leaves, nodes, lcp, n_min; } nav_tally;
+
+static void leaf_visit_mt(const oindex* x, oflags* f, int K, int k_right, const oleaf* L, nav_tally* t, leaf_stack* S) {
+    t->leaves++;
+    if (L->rn.r > L->rn.l + 1) { /* update_LCP_leaf :344-355 */
+        if ((int64_t)L->depth >= K) bits_fill_atomic(f->thrK, L->rn.l + 1, L->rn.r);
+        if ((int64_t)L->depth >= k_right) bits_fill_atomic(f->thrR, L->rn.l + 1, L->rn.r);
+        t->lcp += L->rn.r - L->rn.l - 1;
+    }
+    prange_t e = LF_range(x, L->rn); /* next_leaves dna_bwt.hpp:358-379 (order is free here) */
+    for (int c = 0; c < 4; ++c)
+        if (e.c[c].r - e.c[c].l >= 2) { oleaf ch = {e.c[c], L->depth + 1}; leaf_stack_push(S, ch); }
+}
+static void node_visit_mt(const oindex* x, oflags* f, int K, int k_right, const onode* N, nav_tally* t, node_stack* S) {
+    t->nodes++;
+    for (int j = 0; j < 4; ++j) /* update_lcp_threshold include.hpp:826-860 */
+        if (N->b[j + 1] > N->b[j] && N->b[j + 1] != N->b[5]) {
+            if ((int64_t)N->depth >= K) bit_set_atomic(f->thrK, N->b[j + 1]);
+            if ((int64_t)N->depth >= k_right) bit_set_atomic(f->thrR, N->b[j + 1]);
+            t->lcp++;
+        }
+    for (int j = 1; j <= 3; ++j) /* update_lcp_minima ebwt2InDel.cpp:357-391 */
+        if (N->b[j + 1] - N->b[j] >= 2 && N->b[j + 1] < N->b[5] - 1) { bit_set_atomic(f->minima, N->b[j + 1]); t->n_min++; }
+    onode ch[4];
+    LF_node(x, N, ch); /* next_nodes dna_bwt.hpp:381-404 */
+    for (int c = 0; c < 4; ++c)
+        if (node_children(&ch[c]) >= 2) node_stack_push(S, ch[c]);
+}
+
+oflags* orc_navigate_one_mt(const oindex* x, int K, int k_right, int threads) {
+    if (threads < 1) threads = 1;
+    oflags* f = flags_new(x->n, 0);
+    const size_t want = (size_t)threads * 512;
+    nav_tally tot = {0, 0, 0, 0};
+    { /* phase 2 */
+        leaf_stack cur = {0}, nxt = {0};
+        oleaf first = {{0, x->F[0]}, 0};
+        leaf_stack_push(&cur, first);
+        while (cur.n && cur.n < want) { /* breadth-first top */
+            nxt.n = 0;
+            for (size_t i = 0; i < cur.n; ++i) leaf_visit_mt(x, f, K, k_right, &cur.a[i], &tot, &nxt);
+            leaf_stack sw = cur; cur = nxt; nxt = sw;
+        }
+        uint64_t a_leaves = 0, a_lcp = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(+ : a_leaves, a_lcp)
+        for (long long i = 0; i < (long long)cur.n; ++i) {
+            leaf_stack S = {0};
+            nav_tally t = {0, 0, 0, 0};
+            leaf_stack_push(&S, cur.a[i]);
+            while (S.n) { oleaf L = S.a[--S.n]; leaf_visit_mt(x, f, K, k_right, &L, &t, &S); }
+            free(S.a);
+            a_leaves += t.leaves; a_lcp += t.lcp;
+        }
+        tot.leaves += a_leaves; tot.lcp += a_lcp;
+        free(cur.a); free(nxt.a);
+    }
+    { /* phase 3 */
+        node_stack cur = {0}, nxt = {0};
+        onode root = {{0, x->F[0], x->F[1], x->F[2], x->F[3], x->n}, 0};
+        node_stack_push(&cur, root);
+        while (cur.n && cur.n < want) {
+            nxt.n = 0;
+            for (size_t i = 0; i < cur.n; ++i) node_visit_mt(x, f, K, k_right, &cur.a[i], &tot, &nxt);
+            node_stack sw = cur; cur = nxt; nxt = sw;
+        }
+        uint64_t a_nodes = 0, a_lcp = 0, a_min = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(+ : a_nodes, a_lcp, a_min)
+        for (long long i = 0; i < (long long)cur.n; ++i) {
+            node_stack S = {0};
+            nav_tally t = {0, 0, 0, 0};
+            node_stack_push(&S, cur.a[i]);
+            while (S.n) { onode N = S.a[--S.n]; node_visit_mt(x, f, K, k_right, &N, &t, &S); }
+            free(S.a);
+            a_nodes += t.nodes; a_lcp += t.lcp; a_min += t.n_min;
+        }
+        tot.nodes += a_nodes; tot.lcp += a_lcp; tot.n_min += a_min;
+        free(cur.a); free(nxt.a);
+    }
+    f->leaves = tot.leaves; f->nodes = tot.nodes; f->lcp_values += tot.lcp; f->n_min = tot.n_min; f->max_stack = 0;
     return f;
 }
 

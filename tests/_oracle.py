@@ -87,6 +87,11 @@ class Oracle:
         L.orc_lf_range_sym_batch.argtypes = [vp, vp, vp, u64, vp]
         L.orc_navigate_one.restype = vp
         L.orc_navigate_one.argtypes = [vp, C.c_int, C.c_int]
+        L.orc_navigate_one_mt.restype = vp
+        L.orc_navigate_one_mt.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+        L.orc_index_from_buffer_mt.restype = vp
+        L.orc_index_from_buffer_mt.argtypes = [vp, u64, u8, C.c_int]
+        L.orc_index_equal.argtypes = [vp, vp]
         L.orc_navigate_two.restype = vp
         L.orc_navigate_two.argtypes = [vp, vp, C.c_int, C.c_int]
         L.orc_flags_set_da.argtypes = [vp, vp, u64]
@@ -126,15 +131,19 @@ class Oracle:
         return out, st
 
     # ---- index + primitives
-    def index(self, ascii_bwt, term=35):
-        return OracleIndex(self, ascii_bwt, term)
+    def index(self, ascii_bwt, term=35, threads=1):
+        """threads > 1: the threaded builder (bit-identical index), for full-size checks."""
+        return OracleIndex(self, ascii_bwt, term, threads)
 
 
 class OracleIndex:
-    def __init__(self, orc, ascii_bwt, term=35):
+    def __init__(self, orc, ascii_bwt, term=35, threads=1):
         self.o = orc
         self.buf = _u8(ascii_bwt)
-        self.h = orc.lib.orc_index_from_buffer(self.buf.ctypes.data, len(self.buf), term)
+        if threads > 1:
+            self.h = orc.lib.orc_index_from_buffer_mt(self.buf.ctypes.data, len(self.buf), term, threads)
+        else:
+            self.h = orc.lib.orc_index_from_buffer(self.buf.ctypes.data, len(self.buf), term)
         self.ok = bool(orc.lib.orc_index_ok(self.h))
         self.n = len(self.buf)
         self.term = term
@@ -196,8 +205,9 @@ class OracleIndex:
 class OracleFlags:
     """Phases 2-3 on the CPU oracle: bitvectors as uint64 word arrays."""
 
-    def __init__(self, orc, idx1, idx2=None, K=16, k_right=30, da=None, vectors=None):
-        """vectors = (thrK, thrR, minima[, da words]) imports given flag words instead of navigating (scan stress tests)."""
+    def __init__(self, orc, idx1, idx2=None, K=16, k_right=30, da=None, vectors=None, threads=1):
+        """vectors = (thrK, thrR, minima[, da words]) imports given flag words instead of navigating (scan stress tests).
+        threads > 1 (one BWT only): the threaded traversal -- same vectors and counters, for full-size checks."""
         self.o = orc
         self.idx1, self.idx2 = idx1, idx2
         L = orc.lib
@@ -210,7 +220,12 @@ class OracleFlags:
             self.words = L.orc_flags_words(self.h)
             self.has_da = len(v) > 3 and v[3] is not None
             return
-        self.h = L.orc_navigate_two(idx1.h, idx2.h, K, k_right) if idx2 is not None else L.orc_navigate_one(idx1.h, K, k_right)
+        if idx2 is not None:
+            self.h = L.orc_navigate_two(idx1.h, idx2.h, K, k_right)
+        elif threads > 1:
+            self.h = L.orc_navigate_one_mt(idx1.h, K, k_right, threads)
+        else:
+            self.h = L.orc_navigate_one(idx1.h, K, k_right)
         if da is not None:
             d = _u8(da)
             L.orc_flags_set_da(self.h, d.ctypes.data, len(d))

@@ -63,3 +63,38 @@ def test_bench_nccl_collectives_with_one_rank_same_snp():
     d1 = _last_json(one.stdout)
     assert d["snp_sha256"] == d1["snp_sha256"] and d["snp_records"] == d1["snp_records"]
     assert d["phases23_gpu"]["nodes"] == d1["phases23_gpu"]["nodes"] and d["phases23_gpu"]["rank_queries"] == d1["phases23_gpu"]["rank_queries"]
+
+
+def test_bench_gpus_2_without_two_gpus_fails_loudly():
+    """`python bench.py --gpus 2` started bare on a box with one GPU must not quietly run (and label) a 1-GPU job."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has two GPUs")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + ARGS, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "needs 2 GPUs" in r.stderr
+
+
+def test_bench_gpus_2_launches_its_own_ranks():
+    """Bare `python bench.py --gpus 2` (no torchrun around it): the process starts the two ranks itself (gloo rehearsal:
+    the ranks share the one GPU) and relays exactly one JSON line with n_gpus = 2 and the N = 1 .snp."""
+    env = dict(os.environ, EB_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cpu-sample-reads", "0"] + ARGS,
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-sample-reads", "0"] + ARGS, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    assert d["snp_sha256"] == _last_json(one.stdout)["snp_sha256"]
+
+
+def test_bench_refuses_mismatched_world_and_debug_switch():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"] + ARGS, capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "refusing to mislabel" in r.stderr
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + ARGS, capture_output=True, text=True, timeout=120, env=dict(os.environ, EB_SCAN_DEBUG="4"))
+    assert r.returncode != 0 and "EB_SCAN_DEBUG" in r.stderr

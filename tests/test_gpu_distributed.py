@@ -22,8 +22,9 @@ def _case(name):
 
 
 @pytest.mark.parametrize("name", ["m1_default", "m2_het_default"])
-@pytest.mark.parametrize("n_shards,split_min", [(2, 1), (3, 4), (8, 16), (2, 1 << 40)])
-def test_shards_partition_the_flag_vectors(monkeypatch, name, n_shards, split_min):
+@pytest.mark.parametrize("n_shards,split_min,nav_bytes", [(2, 1, "1"), (3, 4, "1"), (8, 16, "1"), (2, 1 << 40, "1"), (3, 4, "0")])
+def test_shards_partition_the_flag_vectors(monkeypatch, name, n_shards, split_min, nav_bytes):
+    monkeypatch.setenv("EB_NAV_BYTES", nav_bytes)               # "0": the memory-short traversal (atomicOr on bit words)
     case = _case(name)
     inp = case["inputs"]
     p = api.make_params(case["args"])
@@ -45,6 +46,8 @@ def test_shards_partition_the_flag_vectors(monkeypatch, name, n_shards, split_mi
         for k in _COUNTERS:
             totals[k] += int(getattr(part.stats, k))
         busy += int(part.stats.nodes > 0)
+        ones = part.popcounts()                                   # the invariant navigate_sharded checks behind its SUM all-reduce
+        assert ones == [int(np.unpackbits(v.view(np.uint8)).sum()) if v is not None else 0 for v in vecs]
     for a, w in zip(acc, want):
         if w is not None:
             assert np.array_equal(a, w)

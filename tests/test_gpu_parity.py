@@ -164,8 +164,13 @@ FLAG_CASES = [c for c in CASES if c["name"] in ("m1_default", "m1_k20", "m1_L40_
                                                 "m3_het_default", "m1_tiny_nocluster")]
 
 
+@pytest.mark.parametrize("nav_bytes", ["1", "0"], ids=["lcp_bytes", "atomic_words"])
 @pytest.mark.parametrize("case", FLAG_CASES, ids=lambda c: c["name"])
-def test_flag_vectors_bit_exact(oracle, case):
+def test_flag_vectors_bit_exact(oracle, monkeypatch, case, nav_bytes):
+    """Both ways the traversal collects the LCP thresholds: one byte per position with plain stores (needs n spare bytes of
+    HBM), and -- EB_NAV_BYTES=0, the path a BWT too large for that takes (configs[4]: 151 GB of bytes do not fit) --
+    interleaved K/R bit words set with atomicOr."""
+    monkeypatch.setenv("EB_NAV_BYTES", nav_bytes)
     p, e1, e2, da = _flag_case(oracle, case)
     o1 = oracle.index(e1, p.term)
     o2 = oracle.index(e2, p.term) if e2 is not None else None
@@ -193,11 +198,30 @@ def test_flags_batch_size_does_not_change_result(oracle, monkeypatch):
     e = golden_bytes("dip.ebwt")
     g = api.DnaBwt(e)
     ref = api.Flags.build(g, None, 16, 30).export()
-    for batch in ("64", "1000"):                               # tiny batches: many launches, depth-first order
+    for batch, nav_bytes in (("64", "1"), ("1000", "1"), ("777", "0")):   # tiny batches: many launches, depth-first order
         monkeypatch.setenv("EB_NAV_BATCH", batch)
+        monkeypatch.setenv("EB_NAV_BYTES", nav_bytes)
         got = api.Flags.build(g, None, 16, 30).export()
         for a, b in zip(got[:3], ref[:3]):
             assert np.array_equal(a, b)
+
+
+def test_short_document_array_repeats_its_last_byte(oracle):
+    """A -d file shorter than the BWT: the reference's failed read() leaves its one-byte buffer unchanged, so the rest of
+    the DA repeats the last byte read (ebwt2InDel.cpp:1503-1508; oracle pinned on this against the reference binary in
+    tests/test_oracle_vs_ref.py)."""
+    m, da = golden_bytes("het_m.ebwt"), golden_bytes("het_m.da")
+    for cut, last in ((len(da) * 2 // 3, b"1"), (len(da) * 2 // 3 + 5, b"0"), (len(da) // 2 + 64, b"1"), (1, b"1")):
+        d = bytearray(da[:cut])
+        d[-1] = last[0]
+        want, _ = oracle.run(m, da=bytes(d))
+        assert api.run_two_datasets_da(m, bytes(d)) == want
+        g = api.DnaBwt(m)
+        fl = api.Flags.build(g, None, 16, 30)
+        fl.set_da(bytes(d))
+        bits = np.unpackbits(fl.export()[3].view(np.uint8), bitorder="little")[: len(m)]
+        assert bits[cut:].all() == (last == b"1") and bits[cut:].any() == (last == b"1")
+        assert np.array_equal(bits[:cut], (np.frombuffer(bytes(d), dtype=np.uint8) == ord("1")).astype(np.uint8))
 
 
 def test_flags_import_export_round_trip(oracle):

@@ -1,0 +1,48 @@
+"""The oracle's threaded index builder and traversal (checkers for full-size inputs, scripts/fullsize_check.py) against
+its serial, reference-ordered code: same index bit for bit, same flag vectors, same counters."""
+import numpy as np
+import pytest
+
+from ebwt2indel_amd import sim
+from tests import _oracle
+from tests.conftest import golden_bytes
+
+
+@pytest.mark.parametrize("name,term", [("dip.ebwt", 35), ("edge.ebwt", 35), ("n128_t36.ebwt", 36), ("tiny.ebwt", 35), ("het_m.ebwt", 35)])
+@pytest.mark.parametrize("threads", [2, 5])
+def test_threaded_oracle_equals_serial(oracle, name, term, threads):
+    e = golden_bytes(name)
+    a, b = oracle.index(e, term), oracle.index(e, term, threads=threads)
+    assert oracle.lib.orc_index_equal(a.h, b.h)
+    fa = _oracle.OracleFlags(oracle, a, None, 16, 30)
+    fb = _oracle.OracleFlags(oracle, b, None, 16, 30, threads=threads)
+    for va, vb in zip(fa.export()[:3], fb.export()[:3]):
+        assert np.array_equal(va, vb)
+    ca, cb = fa.counters(), fb.counters()
+    for k in ("leaves", "nodes", "lcp_values", "minima"):
+        assert ca[k] == cb[k], k
+
+
+def test_threaded_index_spans_several_chunks_and_reports_the_first_bad_symbol(oracle):
+    # > 2^20 blocks = several builder chunks (2^27 symbols each); random symbols are enough for the index
+    rng = np.random.Generator(np.random.PCG64(11))
+    e = np.frombuffer(b"ACGT#", dtype=np.uint8)[rng.integers(0, 5, size=(1 << 28) + 12345)]
+    a, b = oracle.index(e), oracle.index(e, threads=4)
+    assert oracle.lib.orc_index_equal(a.h, b.h)
+    del a, b
+    e = e.copy()
+    e[200_000_000] = ord("N")
+    e[150_000_001] = ord("x")
+    bad = oracle.index(e, threads=4)
+    assert not bad.ok and bad.bad() == (ord("x"), 150_000_001)
+
+
+def test_threaded_oracle_on_fresh_reads(oracle):
+    reads, _, _ = sim.diploid_sample(60_000, 12_000, 100, seed=21)
+    e = sim.build_ebwt(reads)
+    a = oracle.index(e)
+    fa = _oracle.OracleFlags(oracle, a, None, 16, 30)
+    fb = _oracle.OracleFlags(oracle, a, None, 16, 30, threads=8)
+    for va, vb in zip(fa.export()[:3], fb.export()[:3]):
+        assert np.array_equal(va, vb)
+    assert fa.counters()["nodes"] == fb.counters()["nodes"] and fa.counters()["minima"] == fb.counters()["minima"]

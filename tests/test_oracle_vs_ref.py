@@ -69,3 +69,29 @@ def test_degenerate_inputs_against_reference(oracle, tmp_path, reads):
     assert rc in (0, -8)
     got, _ = oracle.run(e)
     assert got == want
+
+
+def test_short_document_array_against_reference(oracle, tmp_path):
+    """A -d file shorter than the BWT: the reference's read() fails and its one-byte buffer keeps the last byte read, so the
+    rest of the DA repeats it (ebwt2InDel.cpp:1503-1508).  Cuts inside printed clusters, so that what fills the tail
+    decides which side those clusters' last rows count for: ending on '1' and on '0' must differ somewhere."""
+    r0, r1 = sim.two_samples(15000, 3500, 80, seed=211, het_second=True, snp_every=250, indel_every=700)
+    m, da = sim.build_merged_ebwt(r0, r1)
+    (tmp_path / "m").write_bytes(m.tobytes())
+    p = _oracle.Params.from_args([])
+    full = _oracle.OracleFlags(oracle, oracle.index(m), None, p.K, p.k_right, da).scan(p, 0, len(m), capture=True)
+    cl = np.frombuffer(full["clusters"].tobytes(), dtype=np.uint64).reshape(-1, 4)
+    cuts = [int(b + (e - b) // 2) for b, e in cl[len(cl) // 3: len(cl) // 3 + 6, :2]] + [len(da) // 3 + 7]
+    differ = 0
+    for cut in cuts:
+        outs = []
+        for last in (b"1", b"0"):
+            d = bytearray(da.tobytes()[:cut])
+            d[-1] = last[0]
+            (tmp_path / "da").write_bytes(bytes(d))
+            want, rc = _ref(tmp_path, ["-1", str(tmp_path / "m"), "-d", str(tmp_path / "da")])
+            got, _ = oracle.run(m, da=bytes(d))
+            assert rc == 0 and got == want
+            outs.append(want)
+        differ += outs[0] != outs[1]
+    assert differ > 0

@@ -22,3 +22,16 @@ def test_simulator_is_deterministic():
     r2, g2, h2 = sim.diploid_sample(5000, 300, 50, seed=9)
     assert np.array_equal(r1, r2) and np.array_equal(g1, g2) and np.array_equal(h1, h2)
     assert not np.array_equal(g1[:len(h1)], h1[:len(g1)])
+
+
+def test_replicating_every_read_repeats_every_bwt_symbol():
+    """The identity behind sim.replicated_ebwt_gpu (inputs past 2^32 positions that the reference binary can still get
+    through): with every read `c` times in a row, the eBWT is the base one with each symbol repeated c times."""
+    reads, _, _ = sim.diploid_sample(3000, 400, 40, seed=4)
+    base = sim.build_ebwt(reads)
+    for c in (2, 3, 8):
+        rep = np.repeat(reads, c, axis=0)
+        assert np.array_equal(sim.build_ebwt(rep), np.repeat(base, c))
+    ragged = [b"ACGT", b"ACG", b"ACGT", b"A", b"TTGACA", b"GACA"]     # shared suffixes, prefixes, duplicates in the base itself
+    rep = [r for r in ragged for _ in range(3)]
+    assert sim.build_ebwt(rep).tobytes() == np.repeat(np.frombuffer(sim.build_ebwt_naive(ragged), dtype=np.uint8), 3).tobytes()
