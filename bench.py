@@ -259,7 +259,7 @@ def main():
 
     if args.warmup > 0:
         run_steps(args.warmup)
-    scan_ms, ext_ms, right_ms, tot_ms = [], [], [], []
+    scan_ms, ext_ms, right_ms, tot_ms, ctx_ms, req_ext, req_right = [], [], [], [], [], [], []
     scan_launches = 1
 
     def record(st):
@@ -269,6 +269,9 @@ def main():
         ext_ms.append(st.ms_extend)
         right_ms.append(st.ms_right)
         tot_ms.append(st.ms_total)
+        ctx_ms.append(st.ms_context)
+        req_ext.append(int(st.requests_extend))
+        req_right.append(int(st.requests_right))
 
     sync()
     t0 = time.perf_counter()
@@ -418,10 +421,27 @@ def main():
                          "frac": round(scan_gbs / 8000.0, 5), "traffic": traffic, "kernel": "k_scan",
                          "avg_launch_ms": round(scan_avg_ms, 4), "launches_per_step": scan_launches, "positions_per_launch": int(positions_per_launch),
                          "algorithmic_bytes_per_position": 0.75},
+            # the whole step against the scan's roofline (SURVEY.md 8(d) metric 1: 0.75 B x positions / step time): what `value` is worth
+            "step_roofline": {"bound": "hbm", "achieved": round(0.75 * n / (ms_per_step * 1e-3) / 1e9, 2), "peak": 8000.0 * world, "unit": "GB/s",
+                              "frac": round(0.75 * n / (ms_per_step * 1e-3) / 1e9 / (8000.0 * world), 5),
+                              "what": "0.75 algorithmic bytes x all positions / ms_per_step, against the HBM peak of the GPUs used: scan + "
+                                      "survivor ordering + both context kernels + hand-over of the records"},
+            # the kernels that dominate the step: k_extend || k_right (side by side on two streams), dependent random reads.  Requests
+            # are counted on the device where they are issued (eb_scan_stats.requests_*), 64 bytes each, over first start .. last end.
+            "context_roofline": {"bound": "hbm", "achieved": round((np.mean(req_ext) + np.mean(req_right)) * 64 / (max(np.mean(ctx_ms), 1e-9) * 1e-3) / 1e9, 2),
+                                 "peak": 8000.0, "unit": "GB/s",
+                                 "frac": round((np.mean(req_ext) + np.mean(req_right)) * 64 / (max(np.mean(ctx_ms), 1e-9) * 1e-3) / 1e9 / 8000.0, 5),
+                                 "traffic": None, "kernel": "k_extend || k_right", "ms": round(float(np.mean(ctx_ms)), 4),
+                                 "requests_extend": int(np.mean(req_ext)), "requests_right": int(np.mean(req_right)),
+                                 "bytes_per_request": 64, "requests_per_s": round((np.mean(req_ext) + np.mean(req_right)) / (max(np.mean(ctx_ms), 1e-9) * 1e-3), 1),
+                                 "what": "rank 0's shard; k_extend: one request per 64-byte block of a rank pair (1-2 per LF step); k_right: one per "
+                                         "select-directory read + one per block probed; ceiling for independent random 64-byte reads on this chip: "
+                                         "profiles/r02_rank_probe.txt"},
             "rank_roofline": rank_info,
             "cpu_baseline": cpu,
             "phase4_device_ms": {"scan": round(scan_sum_ms, 4), "extend": round(float(np.mean(ext_ms)), 4),
-                                 "right": round(float(np.mean(right_ms)), 4), "total": round(float(np.mean(tot_ms)), 4)},
+                                 "right": round(float(np.mean(right_ms)), 4), "context_span": round(float(np.mean(ctx_ms)), 4),
+                                 "total": round(float(np.mean(tot_ms)), 4)},
             "phases23_gpu": {"seconds": round(t_nav, 4), "traversal_shards": world if use_dist else 1, "traversal_seconds": round(float(ns.seconds_leaves + ns.seconds_nodes), 4),
                              "rank_gq_per_s": round(ns.rank_queries / max(ns.seconds_leaves + ns.seconds_nodes, 1e-9) / 1e9, 2), "nodes": int(ns.nodes), "leaves": int(ns.leaves), "rank_queries": int(ns.rank_queries),
                              "launches": int(ns.batches), "e2e_positions_per_s": round(n / (t_nav + ms_per_step * 1e-3), 1)},

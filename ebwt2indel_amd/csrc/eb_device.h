@@ -133,13 +133,17 @@ __device__ __forceinline__ uint64_t eb_block_count(const eb_dev_index& x, uint64
 // counter says how many c precede it, its planes how many it holds, so the block that contains the answer is
 // recognised without probing its neighbour, and the in-block select needs no further memory access.
 // Same unique answer as the reference's bisection in ~2.3 dependent 64-byte reads.
-__device__ __forceinline__ uint64_t eb_select(const eb_dev_index& x, uint64_t r, int c) {
+// `probes` counts the memory requests issued: 1 for the directory pair + 1 per 64-byte block probed (bench.py's
+// context_roofline is built from these counts).
+__device__ __forceinline__ uint64_t eb_select(const eb_dev_index& x, uint64_t r, int c, uint32_t& probes) {
     const uint32_t* dir = x.sel_dir + (c == 0 ? x.sel_off[0] : c == 1 ? x.sel_off[1] : c == 2 ? x.sel_off[2] : x.sel_off[3]);
     uint64_t m = r >> EB_SEL_SHIFT;
     uint64_t lo = dir[m], hi = dir[m + 1]; // the answer lies in a block of [lo, hi]
     uint64_t g = lo + (((r - (m << EB_SEL_SHIFT)) * (hi - lo + 1)) >> EB_SEL_SHIFT);
     if (g > hi) g = hi;
+    ++probes;
     for (;;) {
+        ++probes;
         const uint4* b = x.chunks + (g << 2);
         uint4 ch0 = b[0], ch1 = b[1], ch2 = b[2], ch3 = b[3];
         uint32_t w = c == 0 ? ch0.w : c == 1 ? ch1.w : c == 2 ? ch2.w : ch3.w;
@@ -169,9 +173,17 @@ __device__ __forceinline__ uint64_t eb_select(const eb_dev_index& x, uint64_t r,
     }
 }
 
+__device__ __forceinline__ uint64_t eb_select(const eb_dev_index& x, uint64_t r, int c) {
+    uint32_t probes = 0;
+    return eb_select(x, r, c, probes);
+}
+
 // FL(i) (dna_bwt.hpp:115-133); i must not be a TERM row.
 __device__ __forceinline__ uint64_t eb_FL(const eb_dev_index& x, uint64_t i, int letter) {
     return eb_select(x, i - x.F[letter], letter);
+}
+__device__ __forceinline__ uint64_t eb_FL(const eb_dev_index& x, uint64_t i, int letter, uint32_t& probes) {
+    return eb_select(x, i - x.F[letter], letter, probes);
 }
 
 __device__ __forceinline__ bool eb_bit(const uint64_t* b, uint64_t i) { return (b[i >> 6] >> (i & 63u)) & 1ull; }

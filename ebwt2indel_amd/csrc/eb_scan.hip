@@ -53,9 +53,12 @@ struct alignas(16) Survivor {
 #define EB_NEEDS_HIST 0x80000000u
 #define EB_SCAN_PARTIAL 204 /* runs, clusters, bases, hist[201] */
 
+#define EB_REQ_SLOTS 64
 struct ScanCounters {
     unsigned long long nsurv, runs_closed, clusters, bases, n_long, dropped;
     unsigned long long hist[201];
+    unsigned long long req_ext[EB_REQ_SLOTS], req_right[EB_REQ_SLOTS]; // memory requests counted by k_extend / k_right (count_requests)
+    unsigned long long req_sum[2];                                     // their sums (k_req_sum), copied to the job's pinned words
 };
 
 __device__ __forceinline__ uint64_t flag_word(const eb_dev_flags& f, uint64_t w) { return f.flag[w]; }
@@ -654,16 +657,25 @@ __global__ void __launch_bounds__(256) k_chain_list(const Survivor* __restrict__
 
 __device__ __forceinline__ uint64_t pick4(const uint64_t* F, uint32_t c) { return c == 0 ? F[0] : c == 1 ? F[1] : c == 2 ? F[2] : F[3]; }
 
+// Memory requests issued by the context kernels, counted where they are issued (eb_scan_stats.requests_*): every lane
+// of the wave calls this once at the end; one non-returning atomic per wave, spread over EB_REQ_SLOTS words.
+__device__ __forceinline__ void count_requests(unsigned long long* __restrict__ slots, uint32_t mine) {
+    uint32_t v = mine;
+    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
+    if ((threadIdx.x & 63u) == 0 && v) atomicAdd(&slots[(blockIdx.x * 4u + (threadIdx.x >> 6)) & (EB_REQ_SLOTS - 1)], (unsigned long long)v);
+}
+
 // Four lanes per chain.  extract_consensus(bwt,range,c,...) ebwt2InDel.cpp:303-319 -> LF(range,c), then
 // up to k_left-1 x { LF(range) ; consensus_letter } (:243-282).  Output: eb_chain + bases packed 2 bits each in
 // extension order (the writer reverses them, :315).
 __global__ void __launch_bounds__(256) k_extend(eb_dev_index x1, eb_dev_index x2, ScanParams p, const Survivor* __restrict__ surv,
                                                const uint64_t* __restrict__ chains, uint64_t n_chains, eb_chain* __restrict__ crec,
-                                               uint64_t* __restrict__ left, uint32_t left_words) {
+                                               uint64_t* __restrict__ left, uint32_t left_words, unsigned long long* __restrict__ req_slots) {
     const uint32_t j = threadIdx.x & 3u;
     const uint32_t qbase = (threadIdx.x & 63u) & ~3u; // first lane of this quad inside the wave
     uint64_t ch = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
-    if (ch >= n_chains) return; // uniform inside a quad
+    uint32_t n_req = 0; // 64-byte block requests issued by this quad (counted by its lane 0)
+    if (ch < n_chains) { // uniform inside a quad
     uint64_t item = chains[ch];
     uint64_t i = item >> 3;
     uint32_t sidx = (uint32_t)(item & 7u);
@@ -677,6 +689,7 @@ __global__ void __launch_bounds__(256) k_extend(eb_dev_index x1, eb_dev_index x2
     // LF(range, c)
     uint64_t a, bq;
     eb_rank4_quad_pair(x, L, R, j, a, bq);
+    n_req += 1u + ((R >> 7) != (L >> 7));
     uint64_t Fc = pick4(x.F, c);
     L = Fc + __shfl((unsigned long long)a, qbase + c);
     R = Fc + __shfl((unsigned long long)bq, qbase + c);
@@ -685,6 +698,7 @@ __global__ void __launch_bounds__(256) k_extend(eb_dev_index x1, eb_dev_index x2
     uint64_t word = c; // base 0 = the frequent symbol itself
     while (have < (uint32_t)p.k_left) {
         eb_rank4_quad_pair(x, L, R, j, a, bq);
+        n_req += 1u + ((R >> 7) != (L >> 7));
         uint64_t len = bq - a;
         // arg-max over the quad, ties to the smaller letter (stable descending sort, ebwt2InDel.cpp:252-255)
         uint64_t bl = len;
@@ -720,6 +734,8 @@ __global__ void __launch_bounds__(256) k_extend(eb_dev_index x1, eb_dev_index x2
         k.support = support;
         crec[ch] = k;
     }
+    }
+    count_requests(req_slots, j == 0 ? n_req : 0u);
 }
 
 // One lane per cluster: record header + right context (extract_dna, ebwt2InDel.cpp:325-342) at the first
@@ -730,10 +746,31 @@ __global__ void __launch_bounds__(256) k_extend(eb_dev_index x1, eb_dev_index x2
 __global__ void __launch_bounds__(256) k_right(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, ScanParams p,
                                               const Survivor* __restrict__ surv, const uint32_t* __restrict__ ns_ptr,
                                               const uint32_t* __restrict__ chain_off /* null: temporaries, k_right_finish adds it */, uint32_t chain_base,
-                                              eb_cluster* __restrict__ recs, uint64_t* __restrict__ right, uint32_t right_words) {
+                                              eb_cluster* __restrict__ recs, uint64_t* __restrict__ right, uint32_t right_words,
+                                              unsigned long long* __restrict__ req_slots, const eb_chain* __restrict__ gate_chains) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= *ns_ptr) return;
+    uint32_t n_req = 0; // directory reads + 64-byte blocks probed by this lane's FL steps
+    if (i < *ns_ptr) {
     Survivor s = surv[i];
+    // Gate (large call sets, launched behind k_extend): the writer touches a cluster's right context only when it prints,
+    // and it cannot print unless two contexts reached their full length (one sample: v.size() < 2 returns before anything
+    // else, ebwt2InDel.cpp:1256; two samples: a pair needs a full context on each side whose last characters differ,
+    // :1161-1163 / :921,1083 -- shorter contexts were dropped at :317).  About one surviving cluster in five sits next to
+    // a read start and fails this; its 30 FL steps (~75 memory requests) are skipped and the record says so.
+    bool walk = true;
+    if (gate_chains) {
+        const uint32_t n_slots = (uint32_t)(__popc(s.fmask0) + __popc(s.fmask1));
+        const eb_chain* k = gate_chains + chain_off[i];
+        uint32_t full0 = 0, full1 = 0; // letters (bit = A,C,G,T) with a full-length context, per side
+        for (uint32_t t = 0; t < n_slots; ++t) {
+            eb_chain c = k[t];
+            if (c.len != (uint32_t)p.k_left) continue;
+            uint32_t bit = c.sym == 'A' ? 1u : c.sym == 'C' ? 2u : c.sym == 'G' ? 4u : 8u;
+            if (c.side) full1 |= bit; else full0 |= bit;
+        }
+        if (p.mode == 1) walk = __popc(full0) >= 2;
+        else walk = full0 && full1 && (__popc(full0 | full1) >= 2); // some a in side 0, b in side 1 with different letters
+    }
     // first position in [b,e) with thrR
     uint64_t pos = ~0ull;
     for (uint64_t w = s.b >> 6; w <= (s.e - 1) >> 6; ++w) {
@@ -744,7 +781,7 @@ __global__ void __launch_bounds__(256) k_right(eb_dev_index x1, eb_dev_index x2,
         if (m) { pos = lo + (uint32_t)__ffsll((long long)m) - 1u; break; }
     }
     uint32_t len = 0;
-    if (pos != ~0ull) {
+    if (pos != ~0ull && walk) {
         bool second = false;
         uint64_t row = pos;
         if (p.mode == 2) {
@@ -760,7 +797,7 @@ __global__ void __launch_bounds__(256) k_right(eb_dev_index x1, eb_dev_index x2,
             word |= (uint64_t)c << (2u * (len & 31u));
             ++len;
             if ((len & 31u) == 0) { out[(len >> 5) - 1] = word; word = 0; }
-            row = eb_FL(x, row, c);
+            row = eb_FL(x, row, c, n_req);
             c = eb_F_letter(x, row);
         }
         if (len & 31u) out[len >> 5] = word;
@@ -772,8 +809,16 @@ __global__ void __launch_bounds__(256) k_right(eb_dev_index x1, eb_dev_index x2,
     r.n_slots = (uint16_t)(__popc(s.fmask0) + __popc(s.fmask1));
     r.right_found = pos != ~0ull ? 1 : 0;
     r.right_len = len;
-    r.reserved = 0;
+    r.reserved = walk ? 0u : EB_RIGHT_SKIPPED;
     recs[i] = r;
+    }
+    count_requests(req_slots, n_req);
+}
+
+__global__ void k_req_sum(ScanCounters* __restrict__ c) {
+    unsigned long long a = c->req_ext[threadIdx.x], b = c->req_right[threadIdx.x];
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+    if (threadIdx.x == 0) { c->req_sum[0] = a; c->req_sum[1] = b; }
 }
 
 // Two-BWT mode: scan planes of the MERGED sequence (row i of the merge comes from bwt2 if DA[i] else bwt1, in order:
@@ -875,7 +920,7 @@ __global__ void __launch_bounds__(256) k_pack_wire(const eb_cluster* __restrict_
         w.begin = r.begin;
         w.len = (uint32_t)(r.end - r.begin);
         w.n_slots = (uint8_t)r.n_slots;
-        w.right_found = (uint8_t)r.right_found;
+        w.right_found = (uint8_t)((r.right_found ? 1u : 0u) | ((r.reserved & EB_RIGHT_SKIPPED) ? 2u : 0u));
         w.right_len = (uint16_t)r.right_len;
         if (r.end - r.begin > 0xFFFFFFFFull || r.right_len > 0xFFFFu || r.n_slots > 0xFFu) atomicAdd(bad, 1ull);
         wc[i] = w;
@@ -900,7 +945,7 @@ __global__ void __launch_bounds__(256) k_pack_wire4(const eb_cluster* __restrict
         eb_wire4_cluster w;
         w.begin_lo = (uint32_t)r.begin;
         w.begin_hi = (uint8_t)(r.begin >> 32);
-        w.slots_found = (uint8_t)((r.n_slots & 15u) | ((r.right_found ? 1u : 0u) << 4));
+        w.slots_found = (uint8_t)((r.n_slots & 15u) | ((r.right_found ? 1u : 0u) << 4) | (((r.reserved & EB_RIGHT_SKIPPED) ? 1u : 0u) << 5));
         w.len = (uint16_t)(r.end - r.begin);
         w.right_len = (uint16_t)r.right_len;
         w.pad = 0;
@@ -1027,13 +1072,13 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
     job->S = S;
     if (ctx->h_bad_pool.empty()) {
         void* hb = nullptr;
-        EB_HIP(hipHostMalloc(&hb, 64, hipHostMallocDefault));
+        EB_HIP(hipHostMalloc(&hb, 512, hipHostMallocDefault)); // [0] wire overflow count, [1 + 2k, 2 + 2k] request counts of sub-shard k (<= 16)
         job->h_bad = static_cast<unsigned long long*>(hb);
     } else {
         job->h_bad = ctx->h_bad_pool.back();
         ctx->h_bad_pool.pop_back();
     }
-    *job->h_bad = 0;
+    memset(job->h_bad, 0, 512);
     job->k_left = prm->k_left;
     job->k_right = prm->k_right;
     job->options = options;
@@ -1162,7 +1207,8 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
             EB_HIP(hipEventRecord(x.e[E_RIGHT0], sC));
             EB_HIP(hipMemsetAsync(x.rt_right.p, 0, x.ns_raw * (size_t)rw * 8, sC));
             hipLaunchKernelGGL(k_right, dim3(right_grid), dim3(256), 0, sC, x1, x2, df, p, x.sorted.as<Survivor>(), d_boff + n_buckets,
-                               (const uint32_t*)nullptr, 0u, x.rt_rec.as<eb_cluster>(), x.rt_right.as<uint64_t>(), rw);
+                               (const uint32_t*)nullptr, 0u, x.rt_rec.as<eb_cluster>(), x.rt_right.as<uint64_t>(), rw, x.cnt.as<ScanCounters>()->req_right,
+                               (const eb_chain*)nullptr);
         }
         hipLaunchKernelGGL(k_surv_chains, dim3(grid_of(x.ns_raw)), dim3(256), 0, sP, x.sorted.as<Survivor>(), d_boff + n_buckets, x.ns_raw, x.nch.as<uint32_t>());
         // dense chain list: exclusive scan of the per-cluster chain counts
@@ -1214,14 +1260,19 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
         EB_HIP(hipEventRecord(x.e[E_EXT0], sB));
         if (x.n_chains)
             hipLaunchKernelGGL(k_extend, dim3(grid_of(x.n_chains * 4)), dim3(256), 0, sB, x1, x2, p, x.sorted.as<Survivor>(), x.chains.as<uint64_t>(), x.n_chains,
-                               x.d_crec, x.d_left, lw);
+                               x.d_crec, x.d_left, lw, x.cnt.as<ScanCounters>()->req_ext);
         EB_HIP(hipEventRecord(x.e[E_EXT_DONE], sB));
         EB_HIP(hipEventRecord(ctx->last_ext, sB));
         EB_HIP(hipStreamWaitEvent(sC, x.e[E_PREP_DONE], 0));
-        if (!right_early) { // straight into the image
+        if (!right_early) {
+            // A large call set keeps the memory system busy with either kernel alone, so nothing is lost by running the
+            // right-context walk BEHIND the left-context extension -- and it can then skip the clusters whose chains came
+            // out too short to ever print (see the gate in k_right): straight into the image, one request in nine saved.
+            EB_HIP(hipStreamWaitEvent(sC, x.e[E_EXT_DONE], 0));
             EB_HIP(hipEventRecord(x.e[E_RIGHT0], sC));
             hipLaunchKernelGGL(k_right, dim3(grid_of(x.ns)), dim3(256), 0, sC, x1, x2, df, p, x.sorted.as<Survivor>(), x.boff.as<uint32_t>() + n_buckets,
-                               x.choff.as<uint32_t>(), (uint32_t)x.chain_base, x.d_recs, x.d_right, rw);
+                               x.choff.as<uint32_t>(), (uint32_t)x.chain_base, x.d_recs, x.d_right, rw, x.cnt.as<ScanCounters>()->req_right,
+                               (const eb_chain*)x.d_crec);
         } else
             hipLaunchKernelGGL(k_right_finish, dim3(grid_of(x.ns)), dim3(256), 0, sC, x.rt_rec.as<eb_cluster>(), x.rt_right.as<uint64_t>(), x.choff.as<uint32_t>(),
                            (uint32_t)x.chain_base, x.ns, rw, x.d_recs, x.d_right);
@@ -1253,6 +1304,12 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
         if (x.ns == 0) continue;
         EB_HIP(hipStreamWaitEvent(sD, x.e[E_EXT_DONE], 0));
         EB_HIP(hipStreamWaitEvent(sD, x.e[E_RIGHT_DONE], 0));
+    }
+    for (int k = 0; k < S; ++k) { // request counts of the context kernels -> the job's pinned words [1 + 2k, 2 + 2k]
+        SubShard& x = sh[(size_t)k];
+        if (x.ns == 0) continue;
+        hipLaunchKernelGGL(k_req_sum, dim3(1), dim3(EB_REQ_SLOTS), 0, sD, x.cnt.as<ScanCounters>());
+        EB_HIP(hipMemcpyAsync(job->h_bad + 1 + 2 * k, x.cnt.as<ScanCounters>()->req_sum, 16, hipMemcpyDeviceToHost, sD));
     }
     if (!device_only) {
         calls = eb_calls_alloc(ns, n_chains, prm->k_left, prm->k_right, ns != 0);
@@ -1295,7 +1352,8 @@ extern "C" int eb_scan_clusters_end(eb_scan_job* job, eb_calls** out, eb_scan_st
     hipError_t werr = hipEventSynchronize(job->ev_end);
     if (werr == hipSuccess) werr = hipStreamSynchronize(ctx->ext);
     if (werr == hipSuccess) werr = hipStreamSynchronize(ctx->right);
-    float ms_scan = 0, ms_ext = 0, ms_right = 0, ms_total = 0;
+    float ms_scan = 0, ms_ext = 0, ms_right = 0, ms_total = 0, ms_context = 0;
+    uint64_t req_ext = 0, req_right = 0;
     if (werr == hipSuccess) {
         (void)hipEventElapsedTime(&ms_total, job->ev_begin, job->ev_end);
         for (int k = 0; k < job->S; ++k) {
@@ -1308,6 +1366,16 @@ extern "C" int eb_scan_clusters_end(eb_scan_job* job, eb_calls** out, eb_scan_st
             ms_ext += t;
             (void)hipEventElapsedTime(&t, x.e[E_RIGHT0], x.e[E_RIGHT_DONE]);
             ms_right += t;
+            // the two kernels run side by side on two streams: first start .. last end
+            float span = 0;
+            for (int a : {E_EXT0, E_RIGHT0})
+                for (int b : {E_EXT_DONE, E_RIGHT_DONE}) {
+                    (void)hipEventElapsedTime(&t, x.e[a], x.e[b]);
+                    if (t > span) span = t;
+                }
+            ms_context += span;
+            req_ext += job->h_bad[1 + 2 * k];
+            req_right += job->h_bad[2 + 2 * k];
         }
     }
     if (werr == hipSuccess && getenv("EB_SCAN_TRACE") && job->S == 1) {
@@ -1333,6 +1401,9 @@ extern "C" int eb_scan_clusters_end(eb_scan_job* job, eb_calls** out, eb_scan_st
         stats->ms_right = ms_right;
         stats->ms_total = ms_total;
         stats->scan_launches = (uint32_t)job->S;
+        stats->ms_context = ms_context;
+        stats->requests_extend = req_ext;
+        stats->requests_right = req_right;
     }
     for (hipEvent_t e : job->events) ctx->events.push_back(e);
     if (job->h_bad) ctx->h_bad_pool.push_back(job->h_bad);

@@ -192,8 +192,10 @@ int format_range(const eb_calls* c, const eb_params* p, int two_samples, uint64_
             x.support = (int)k.support;
             side[k.side ? 1 : 0].push_back(std::move(x));
         }
+        const size_t before = out.text.size();
         if (two_samples) write_pairs(out, side[0], side[1], right, *p);
         else write_single(out, side[0], right, *p);
+        if ((r.reserved & EB_RIGHT_SKIPPED) && out.text.size() != before) return EB_ERR_STATE; // a skipped right context was needed
     }
     return EB_OK;
 }
@@ -222,7 +224,10 @@ int format_calls(const eb_calls* c, const eb_params* p, int two_samples, uint64_
         for (std::thread& th : pool) th.join();
     }
     for (int rc : rcs)
-        if (rc != EB_OK) { eb_set_error("corrupt call set: chain index out of range"); return rc; }
+        if (rc != EB_OK) {
+            eb_set_error(rc == EB_ERR_STATE ? "corrupt call set: a cluster marked EB_RIGHT_SKIPPED would print" : "corrupt call set: chain index out of range");
+            return rc;
+        }
     size_t total = 0;
     for (const Piece& q : pieces) total += q.text.size() + 20 * q.marks.size();
     o.reserve(o.size() + total);
@@ -406,7 +411,7 @@ extern "C" int eb_calls_unpack(const uint8_t* buf, uint64_t len, eb_calls** out)
             r.n_slots = w.slots_found & 15u;
             r.right_found = (w.slots_found >> 4) & 1u;
             r.right_len = w.right_len;
-            r.reserved = 0;
+            r.reserved = ((w.slots_found >> 5) & 1u) ? EB_RIGHT_SKIPPED : 0u;
             chain += r.n_slots;
         }
         if (chain != h.n_chains) { eb_set_error("corrupt call set: chain counts do not add up"); eb_calls_free(c); return EB_ERR_ARG; }
@@ -439,9 +444,9 @@ extern "C" int eb_calls_unpack(const uint8_t* buf, uint64_t len, eb_calls** out)
             r.end = w.begin + w.len;
             r.first_chain = (uint32_t)chain;
             r.n_slots = w.n_slots;
-            r.right_found = w.right_found;
+            r.right_found = w.right_found & 1u;
             r.right_len = w.right_len;
-            r.reserved = 0;
+            r.reserved = (w.right_found & 2u) ? EB_RIGHT_SKIPPED : 0u;
             chain += w.n_slots;
         }
         if (chain != h.n_chains) { eb_set_error("corrupt call set: chain counts do not add up"); eb_calls_free(c); return EB_ERR_ARG; }

@@ -171,8 +171,13 @@ typedef struct {
     uint16_t n_slots;              /* chains of this cluster (<= EB_MAX_SLOTS) */
     uint16_t right_found;          /* 1 iff some cluster position has LCP >= k_right (:982-985) */
     uint32_t right_len;            /* bases of right context extracted there (k_right unless TERM was met) */
-    uint32_t reserved;
+    uint32_t reserved;             /* EB_RIGHT_SKIPPED or 0 */
 } eb_cluster;
+/* eb_cluster.reserved: the right context was not extracted (right_len = 0, words zero) because the cluster can never
+ * reach the output: fewer than two of its left contexts have full length (to_file returns at ebwt2InDel.cpp:1256
+ * before it touches cluster_nr; pair mode: no pair of full contexts with different last characters, :1161-1163 with
+ * :317).  Set by large call sets, whose right-context walk runs behind the left-context extension. */
+#define EB_RIGHT_SKIPPED 1u
 
 typedef struct {
     uint8_t  side;                 /* 0/1 (always 0 in one-sample mode) */
@@ -193,7 +198,10 @@ typedef struct {
     float    ms_scan, ms_extend, ms_right; /* HIP-event kernel times summed over the sub-shard launches */
     float    ms_total;                     /* first scan launch .. last record byte in host memory */
     uint32_t scan_launches;                /* k_scan launches (sub-shards) behind ms_scan */
-    uint32_t reserved;
+    float    ms_context;                   /* first start .. last end of the two context kernels (they run side by side) */
+    /* memory requests the context kernels issued, counted on the device where they are issued: k_extend one per
+     * 64-byte block of a rank pair (1 or 2 per LF step), k_right one per select-directory read + one per block probed */
+    uint64_t requests_extend, requests_right;
 } eb_scan_stats;
 
 /* Replaces the phase-4 loops run_one_dataset (:1609-1655), run_two_datasets (:1395-1445)
@@ -228,11 +236,11 @@ int eb_scan_job_device_blob(eb_scan_job* job, const void** d_data, uint64_t* len
 /* The same call set as a COMPACT wire image in device memory (44 instead of 80 bytes per two-allele cluster), for the
  * gather to rank 0 and its download -- the PCIe link of rank 0 carries every record of an N-GPU job:
  *   [64-byte header, magic "EBCALLS4"]
- *   [{u32 begin_lo; u8 begin_hi; u8 n_slots | right_found << 4; u16 end-begin; u16 right_len; u16 0} x count]
+ *   [{u32 begin_lo; u8 begin_hi; u8 n_slots | right_found << 4 | right_skipped << 5; u16 end-begin; u16 right_len; u16 0} x count]
  *   [{u16 side | letter << 1 | len << 3; u16 support} x n_chains][pad to 8][left words][right words]
  * (first_chain is the running sum of n_slots).  If a field does not fit (begin >= 2^40, a cluster of 2^16 rows or more,
  * a context of 8192 bases or more, a support of 2^16 or more) the image has full-width records instead (magic
- * "EBCALLS3": {u64 begin; u32 end-begin; u8 n_slots; u8 right_found; u16 right_len}, {u8 side; u8 sym; u16 len; u32
+ * "EBCALLS3": {u64 begin; u32 end-begin; u8 n_slots; u8 right_found | right_skipped << 1; u16 right_len}, {u8 side; u8 sym; u16 len; u32
  * support}; 56 bytes per two-allele cluster).  eb_calls_unpack reads all images.  Packed by the job with EB_SCAN_WIRE,
  * else on first call; valid until _end.  EB_ERR_STATE if not even the full-width records fit: use
  * eb_scan_job_device_blob then. */

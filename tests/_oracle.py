@@ -293,3 +293,29 @@ def pack_calls(rec: dict, k_left: int, k_right: int) -> bytes:
     chains = rec["chains"].tobytes()
     chains += b"\0" * ((-len(chains)) % 8)
     return hdr + rec["clusters"].tobytes() + chains + rec["left"].tobytes() + rec["right"].tobytes()
+
+
+def apply_right_gate(rec: dict, k_left: int, k_right: int, mode: int) -> dict:
+    """The record capture as a LARGE call set leaves the product (include/ebwt2indel.h, EB_RIGHT_SKIPPED): clusters that can
+    never print -- one sample: fewer than two full-length left contexts (ebwt2InDel.cpp:1256 with :317); two samples: no
+    full context on each side with different letters (:1161-1163) -- carry no right context (right_len 0, words zero,
+    reserved = 1).  The oracle itself always extracts it, like the reference; this applies the definition to its capture."""
+    out = dict(rec)
+    cl = np.frombuffer(rec["clusters"].tobytes(), dtype=[("b", "<u8"), ("e", "<u8"), ("fc", "<u4"), ("ns", "<u2"), ("rf", "<u2"), ("rl", "<u4"), ("res", "<u4")]).copy()
+    ch = np.frombuffer(rec["chains"].tobytes(), dtype=[("side", "u1"), ("sym", "u1"), ("r", "<u2"), ("len", "<u4"), ("sup", "<u4")])
+    rw = (k_right + 31) // 32
+    right = np.frombuffer(rec["right"].tobytes(), dtype=np.uint64).reshape(-1, rw).copy() if len(cl) else np.zeros((0, rw), np.uint64)
+    skipped = 0
+    for i, c in enumerate(cl):
+        k = ch[c["fc"]: c["fc"] + c["ns"]]
+        full = k[k["len"] == k_left]
+        s0, s1 = set(full["sym"][full["side"] == 0].tolist()), set(full["sym"][full["side"] == 1].tolist())
+        walk = len(s0) >= 2 if mode == 1 else bool(s0) and bool(s1) and len(s0 | s1) >= 2
+        if not walk:
+            cl[i]["rl"], cl[i]["res"] = 0, 1
+            right[i] = 0
+            skipped += 1
+    out["clusters"] = np.frombuffer(cl.tobytes(), dtype=np.uint8).copy()
+    out["right"] = np.frombuffer(right.tobytes(), dtype=np.uint8).copy()
+    out["skipped"] = skipped
+    return out
