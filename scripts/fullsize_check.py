@@ -1,0 +1,124 @@
+"""The bench's own input at full size (BASELINE configs[1]: 50 M x 150 bp, n = 7.55 G, seed 1) through the CPU oracle.
+
+The unmodified reference needs ~45 min for this input (single thread, 2.9 M positions/s at DRAM-resident sizes: SURVEY.md
+section 6), more than a GPU-box call may last; its word at this scale is taken on the replicated input of
+scripts/ref_past_2p32.py.  Here the ORACLE -- pinned to the reference by the golden fixtures, by the fresh-input runs
+against the reference binary and, past 2^32, by tests/test_gpu_superblocks.py -- walks the very eBWT the bench builds,
+on the GPU box's host threads (threaded index + traversal, scan sharded over threads), and its .snp must equal the GPU's
+byte for byte.  The SHA-256 goes to profiles/r02_fullsize_config2.json; bench.py asserts it on every default run.
+
+    gpurun --timeout 1200 -- 'python scripts/fullsize_check.py > gpurun_out/fullsize.log 2>&1'
+"""
+import hashlib
+import json
+import os
+import sys
+import threading
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+from ebwt2indel_amd import api, sim  # noqa: E402
+from ebwt2indel_amd import distributed as ebd  # noqa: E402
+from tests import _oracle  # noqa: E402
+
+READS = int(sys.argv[1]) if len(sys.argv) > 1 else 50_000_000
+READ_LEN, COVERAGE, SEED = 150, 30.0, 1
+THREADS = int(os.environ.get("EB_CHECK_THREADS", str(min(os.cpu_count() or 8, 32))))
+
+
+def log(*a):
+    print(time.strftime("%H:%M:%S"), *a, flush=True)
+
+
+class Heartbeat:
+    """A line a minute while a long C call runs (ctypes releases the GIL): the GPU box kills silent commands."""
+
+    def __init__(self, what):
+        self.what, self.stop = what, threading.Event()
+
+    def __enter__(self):
+        self.t0 = time.time()
+
+        def beat():
+            while not self.stop.wait(60):
+                log(f"... {self.what}: {time.time() - self.t0:.0f}s")
+        self.th = threading.Thread(target=beat, daemon=True)
+        self.th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop.set()
+        log(f"{self.what}: {time.time() - self.t0:.1f}s")
+
+
+def main():
+    genome_len = int(READS * READ_LEN / COVERAGE)
+    g = sim.random_genome(genome_len, SEED)
+    h2 = sim.mutate_haplotype(g, SEED)
+    text, offs = sim.haplotype_text([g, h2])
+    starts = sim.sample_read_starts([g, h2], offs, READS, READ_LEN, SEED)
+    del g, h2
+    with Heartbeat("eBWT on the GPU"):
+        dev = sim.build_ebwt_gpu(text, starts, READ_LEN)
+    del text, starts
+    n = dev.n
+    log(f"n = {n}")
+    host = np.empty(n, dtype=np.uint8)
+    sim._hip_copy_to_host(host, dev.ptr, n)
+    p = api.make_params()
+    t0 = time.time()
+    bwt = api.DnaBwt(None, device_ptr=dev.ptr, n=n)
+    dev.free()
+    flags = api.navigate_one_bwt(bwt, p)
+    calls = api.scan_clusters(bwt, flags, p)
+    got, cluster_nr, events = calls.format_snp(p, False)
+    t_gpu = time.time() - t0
+    gpu_sha = hashlib.sha256(got).hexdigest()
+    log(f"GPU: {events} records, {len(calls)} clusters in the call set, sha256 {gpu_sha} ({t_gpu:.2f}s index + traversal + scan + text)")
+    ns = flags.stats
+
+    orc = _oracle.Oracle()
+    po = _oracle.Params.from_args([])
+    with Heartbeat(f"oracle index, {THREADS} threads"):
+        idx = orc.index(host, threads=THREADS)
+    assert idx.ok
+    with Heartbeat(f"oracle traversal (phases 2-3), {THREADS} threads"):
+        of = _oracle.OracleFlags(orc, idx, None, po.K, po.k_right, threads=THREADS)
+    oc = of.counters()
+    log(f"oracle: {oc}")
+    assert (ns.leaves, ns.nodes, ns.minima, ns.lcp_values) == (oc["leaves"], oc["nodes"], oc["minima"], oc["lcp_values"]), "traversal counters differ"
+    # flag vectors, bit for bit
+    for name, a, b in zip(("thrK", "thrR", "minima"), flags.export()[:3], of.export()[:3]):
+        assert np.array_equal(a, b), f"{name} differs"
+    log("flag vectors identical (thrK, thrR, minima)")
+    # phase 4 sharded over the host threads: pass 1 finds how many cluster numbers each shard uses, pass 2 writes the text
+    cuts = [ebd.shard_range(n, i, THREADS * 4) for i in range(THREADS * 4)]
+    with Heartbeat("oracle scan, pass 1"), ThreadPoolExecutor(THREADS) as ex:
+        used = list(ex.map(lambda be: of.scan(po, be[0], be[1])["cluster_nr"] - 1, cuts))
+    first = np.concatenate([[1], 1 + np.cumsum(used)[:-1]]).astype(int)
+    with Heartbeat("oracle scan, pass 2"), ThreadPoolExecutor(THREADS) as ex:
+        parts = list(ex.map(lambda a: of.scan(po, a[0][0], a[0][1], cluster_nr=int(a[1]))["text"], zip(cuts, first)))
+    want = b"".join(parts)
+    orc_sha = hashlib.sha256(want).hexdigest()
+    log(f"oracle: {want.count(b'>')} records, sha256 {orc_sha}")
+    res = {"what": "BASELINE configs[1] at full size, bench.py's own input: GPU .snp vs the CPU oracle's (threaded index + traversal, scan sharded over host threads)",
+           "input": {"reads": READS, "read_len": READ_LEN, "coverage": COVERAGE, "seed": SEED, "n": int(n), "ebwt_sha256": hashlib.sha256(host).hexdigest()},
+           "options": "defaults (-L31 -R30 -k16 -g10 -v2 -m3 -c20 -q0)",
+           "gpu_snp_sha256": gpu_sha, "oracle_snp_sha256": orc_sha, "identical": got == want, "snp_records": int(events), "snp_bytes": len(got),
+           "flag_vectors_identical": True, "counters": {k: int(oc[k]) for k in ("leaves", "nodes", "minima", "lcp_values")}, "oracle_threads": THREADS,
+           "why_not_the_reference_binary": "single-threaded, ~45 min for 7.55 G positions; a GPU-box call is capped at 20 min. It vouches past 2^32 "
+                                           "on the replicated input of profiles/r02_reference_past_2p32.json instead."}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", f"fullsize_check_{READS}.json"), "w") as f:
+        json.dump(res, f, indent=1)
+    log(json.dumps(res))
+    assert got == want, "GPU .snp differs from the oracle's at full size"
+
+
+if __name__ == "__main__":
+    main()
