@@ -337,6 +337,21 @@ def main():
         out["snp_sha256"] = hashlib.sha256(text).hexdigest()
         out["snp_records"] = text.count(b">")
         out["clusters_emitted"] = total_recs
+        # The default workload's .snp is known: scripts/fullsize_check.py walked this very eBWT (7.55 G positions) through the
+        # CPU oracle on the GPU box's host threads -- flag vectors and .snp identical to the GPU's -- and left the SHA-256
+        # under profiles/.  Every default run is held to it (any number of GPUs: the shards' call sets concatenate to the same text).
+        out["snp_verified"] = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r02_fullsize_config2.json")) as fh:
+                known = json.load(fh)
+        except OSError:
+            known = None
+        if known is not None and known["input"] == {"reads": args.reads, "read_len": args.read_len, "coverage": args.coverage, "seed": args.seed,
+                                                    "n": int(n), "ebwt_sha256": known["input"]["ebwt_sha256"]}:
+            if out["snp_sha256"] != known["oracle_snp_sha256"] or out["snp_records"] != known["snp_records"]:
+                raise SystemExit(f"[bench] .snp of the timed path differs from the full-size CPU oracle run (profiles/r02_fullsize_config2.json): "
+                                 f"{out['snp_sha256']} vs {known['oracle_snp_sha256']}")
+            out["snp_verified"] = "sha256 equals the CPU oracle's .snp of this very input at full size (profiles/r02_fullsize_config2.json)"
 
     # ---------------- CPU baseline on a bounded sample of the same workload family (rank 0, N=1 only)
     cpu = None
