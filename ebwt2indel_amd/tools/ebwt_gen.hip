@@ -10,8 +10,10 @@
 //  equal strings -> read index, as in the eBWT definition used by ebwt2indel_amd/tools/ebwt_build.cpp.)
 // Steps: (1) SA of T on its first 256 symbols by prefix doubling with radix sorts; (2) LCP of adjacent rows,
 // capped at 255; (3) for each suffix length len = 0..L: lo_len[j] = max{ j' <= j : LCP[j'] < len } by a
-// prefix-max scan, then one 64-bit key per read; (4) bucket the keys into slabs by lo, radix-sort each slab;
-// (5) emit the symbol preceding each suffix (TERM for whole reads).
+// prefix-max scan, then one 64-bit key per read; (4) the keys go straight into slabs by lo (a counting pass sizes the
+// slabs, a second pass places the keys: no n-key staging buffer, so 15 G keys fit one GPU) and keep only lo's offset
+// INSIDE the slab -- (lo mod slab, |W|, read index) fits 64 bits whatever the text and collection sizes; each slab is
+// radix-sorted on its own; (5) emit the symbol preceding each suffix (TERM for whole reads).
 // tests/test_gpu_generator.py checks the result against the suffix-sorting host builder.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
@@ -105,17 +107,19 @@ __global__ void __launch_bounds__(256) k_lo_seed(const uint8_t* __restrict__ lcp
 
 struct KeyLayout {
     uint32_t rbits;      // read index bits
-    uint32_t slab_shift; // slab = lo >> slab_shift
+    uint32_t slab_shift; // slab = lo >> slab_shift; the key holds lo's low slab_shift bits
 };
 
-__device__ __forceinline__ uint64_t make_key(uint32_t lo, uint32_t len, uint64_t r, uint32_t rbits) {
-    return ((uint64_t)lo << (8 + rbits)) | ((uint64_t)len << rbits) | r;
+__device__ __forceinline__ uint64_t make_key(uint32_t lo_in_slab, uint32_t len, uint64_t r, uint32_t rbits) {
+    return ((uint64_t)lo_in_slab << (8 + rbits)) | ((uint64_t)len << rbits) | r;
 }
 
-// one key per read for suffix length `len` (offset i = L - len inside the read)
+// One key per read for suffix length `len` (offset i = L - len inside the read).  Pass 1 (keys == nullptr): count the
+// keys of every slab; pass 2: place them, slab by slab, at the cursors the counts gave (order inside a slab is free:
+// each slab is sorted afterwards).
 __global__ void __launch_bounds__(256) k_make_keys(const uint64_t* __restrict__ starts, uint64_t n_reads, uint32_t L, uint32_t len,
                                                    const uint32_t* __restrict__ inv, const uint32_t* __restrict__ lo_len, KeyLayout kl,
-                                                   uint64_t* __restrict__ keys, unsigned long long* __restrict__ slab_count) {
+                                                   uint64_t* __restrict__ keys, unsigned long long* __restrict__ slab_cursor) {
     uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
     uint32_t lo = 0;
@@ -123,19 +127,8 @@ __global__ void __launch_bounds__(256) k_make_keys(const uint64_t* __restrict__ 
         uint64_t q = starts[r] + (L - len);
         lo = lo_len[inv[q]];
     }
-    keys[(uint64_t)len * n_reads + r] = make_key(lo, len, r, kl.rbits);
-    atomicAdd(&slab_count[lo >> kl.slab_shift], 1ull);
-}
-
-__global__ void __launch_bounds__(256) k_scatter_slabs(const uint64_t* __restrict__ keys, uint64_t n, KeyLayout kl, unsigned long long* __restrict__ cursor,
-                                                       uint64_t* __restrict__ out) {
-    // grid-stride: a dispatch holds fewer than 2^32 work-items, n can be larger
-    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
-        uint64_t key = keys[k];
-        uint32_t lo = (uint32_t)(key >> (8 + kl.rbits));
-        unsigned long long pos = atomicAdd(&cursor[lo >> kl.slab_shift], 1ull);
-        out[pos] = key;
-    }
+    unsigned long long pos = atomicAdd(&slab_cursor[lo >> kl.slab_shift], 1ull);
+    if (keys) keys[pos] = make_key(lo & ((1u << kl.slab_shift) - 1u), len, r, kl.rbits);
 }
 
 __global__ void __launch_bounds__(256) k_emit(const uint64_t* __restrict__ keys, uint64_t n, KeyLayout kl, const uint8_t* __restrict__ t,
@@ -190,13 +183,16 @@ int ebgen_build(const uint8_t* text, uint64_t text_len, const uint64_t* starts, 
     KeyLayout kl;
     kl.rbits = 1;
     while ((1ull << kl.rbits) < n_reads) ++kl.rbits;
-    uint32_t lobits = 1;
-    while ((1ull << lobits) < (uint64_t)m) ++lobits;
-    if (lobits + 8 + kl.rbits > 64) { snprintf(g_err, sizeof g_err, "key does not fit 64 bits (text %u bits, reads %u bits)", lobits, kl.rbits); return -1; }
-    uint32_t n_slabs_target = n > (1ull << 30) ? 256 : (n > (1ull << 24) ? 16 : 1);
+    if (const char* e = getenv("EBGEN_RBITS")) { uint32_t v = (uint32_t)atoi(e); if (v > kl.rbits && v <= 48) kl.rbits = v; } // tests: a wide read-index field
+    // slabs: few enough that each is a decent sort, many enough that (lo inside the slab, 8-bit length, read index) fits
+    // 64 bits and that the largest slab's sort buffer stays small next to the n keys
+    uint32_t n_slabs_target = n > (1ull << 32) ? 4096 : (n > (1ull << 30) ? 256 : (n > (1ull << 24) ? 16 : 1));
     if (const char* e = getenv("EBGEN_SLABS")) n_slabs_target = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : n_slabs_target; // tests
     kl.slab_shift = 0;
     while (((uint64_t)m >> kl.slab_shift) + 1 > n_slabs_target) ++kl.slab_shift;
+    while (kl.slab_shift > 1 && kl.slab_shift + 8 + kl.rbits > 64) --kl.slab_shift; // more slabs until the key fits
+    if (kl.slab_shift + 8 + kl.rbits > 64) { snprintf(g_err, sizeof g_err, "key does not fit 64 bits (%u read-index bits)", kl.rbits); return -1; }
+    if (kl.slab_shift > 31) kl.slab_shift = 31;
     const uint32_t n_slabs = (uint32_t)(((uint64_t)m >> kl.slab_shift) + 1);
 
     double t0 = now_s();
@@ -251,66 +247,54 @@ int ebgen_build(const uint8_t* text, uint64_t text_len, const uint64_t* starts, 
     d_idx2.release();
     double t2 = now_s();
 
-    // ---- (3) keys, one suffix length at a time
-    Buf d_all, d_slab_count, d_lo;
-    GEN_HIP(d_all.alloc(n * 8));
+    // ---- (3) + (4) keys, one suffix length at a time: first only counted per slab, then placed into their slabs
+    Buf d_slab_count, d_lo, d_slabbed, d_alt;
     GEN_HIP(d_slab_count.alloc((size_t)n_slabs * 8));
     GEN_HIP(hipMemset(d_slab_count.p, 0, (size_t)n_slabs * 8));
     GEN_HIP(d_lo.alloc((size_t)m * 4));
-    for (uint32_t len = 0; len <= L; ++len) {
-        if (len > 0) {
-            hipLaunchKernelGGL(k_lo_seed, dim3(grid_of(m)), dim3(256), 0, st, d_lcp.as<uint8_t>(), m, len, d_u32.as<uint32_t>());
-            GEN_HIP(hipcub::DeviceScan::InclusiveScan(d_tmp.p, tmp_bytes, d_u32.as<uint32_t>(), d_lo.as<uint32_t>(), hipcub::Max(), (size_t)m, st));
+    std::vector<unsigned long long> cnt(n_slabs), off(n_slabs + 1, 0);
+    uint64_t max_slab = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (uint32_t len = 0; len <= L; ++len) {
+            if (len > 0) {
+                hipLaunchKernelGGL(k_lo_seed, dim3(grid_of(m)), dim3(256), 0, st, d_lcp.as<uint8_t>(), m, len, d_u32.as<uint32_t>());
+                GEN_HIP(hipcub::DeviceScan::InclusiveScan(d_tmp.p, tmp_bytes, d_u32.as<uint32_t>(), d_lo.as<uint32_t>(), hipcub::Max(), (size_t)m, st));
+            }
+            hipLaunchKernelGGL(k_make_keys, dim3(grid_of(n_reads)), dim3(256), 0, st, d_starts.as<uint64_t>(), n_reads, L, len, d_inv.as<uint32_t>(),
+                               d_lo.as<uint32_t>(), kl, pass ? d_slabbed.as<uint64_t>() : (uint64_t*)nullptr, d_slab_count.as<unsigned long long>());
         }
-        hipLaunchKernelGGL(k_make_keys, dim3(grid_of(n_reads)), dim3(256), 0, st, d_starts.as<uint64_t>(), n_reads, L, len, d_inv.as<uint32_t>(),
-                           d_lo.as<uint32_t>(), kl, d_all.as<uint64_t>(), d_slab_count.as<unsigned long long>());
+        GEN_HIP(hipDeviceSynchronize());
+        GEN_HIP(hipGetLastError());
+        if (pass == 0) {
+            GEN_HIP(hipMemcpy(cnt.data(), d_slab_count.p, (size_t)n_slabs * 8, hipMemcpyDeviceToHost));
+            for (uint32_t s = 0; s < n_slabs; ++s) { off[s + 1] = off[s] + cnt[s]; if (cnt[s] > max_slab) max_slab = cnt[s]; }
+            if (off[n_slabs] != n) { snprintf(g_err, sizeof g_err, "internal: slab counts do not add up"); return -6; }
+            GEN_HIP(hipMemcpy(d_slab_count.p, off.data(), (size_t)n_slabs * 8, hipMemcpyHostToDevice)); // cursors of pass 2
+            GEN_HIP(d_slabbed.alloc(n * 8));
+        }
     }
-    GEN_HIP(hipDeviceSynchronize());
-    GEN_HIP(hipGetLastError());
     d_lo.release();
     d_u32.release();
     d_lcp.release();
     d_inv.release();
     double t3 = now_s();
 
-    // ---- (4) slabs by lo, each sorted on its own
-    std::vector<unsigned long long> cnt(n_slabs), off(n_slabs + 1, 0);
-    GEN_HIP(hipMemcpy(cnt.data(), d_slab_count.p, (size_t)n_slabs * 8, hipMemcpyDeviceToHost));
-    uint64_t max_slab = 0;
-    for (uint32_t s = 0; s < n_slabs; ++s) { off[s + 1] = off[s] + cnt[s]; if (cnt[s] > max_slab) max_slab = cnt[s]; }
-    if (off[n_slabs] != n) { snprintf(g_err, sizeof g_err, "internal: slab counts do not add up"); return -6; }
-    Buf d_slabbed, d_alt;
-    uint64_t* sorted = nullptr;
-    if (n_slabs == 1) {
-        GEN_HIP(d_alt.alloc(n * 8));
-        size_t tb = 0;
-        GEN_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, d_all.as<uint64_t>(), d_alt.as<uint64_t>(), (size_t)n, 0, 64, st));
-        if (tb > tmp_bytes) { GEN_HIP(d_tmp.alloc(tb)); tmp_bytes = tb; }
-        GEN_HIP(hipcub::DeviceRadixSort::SortKeys(d_tmp.p, tmp_bytes, d_all.as<uint64_t>(), d_alt.as<uint64_t>(), (size_t)n, 0, 64, st));
-        GEN_HIP(hipDeviceSynchronize());
-        d_all.release();
-        sorted = d_alt.as<uint64_t>();
-    } else {
-        GEN_HIP(d_slabbed.alloc(n * 8));
-        GEN_HIP(hipMemcpy(d_slab_count.p, off.data(), (size_t)n_slabs * 8, hipMemcpyHostToDevice)); // cursors
-        hipLaunchKernelGGL(k_scatter_slabs, dim3(grid_capped(n)), dim3(256), 0, st, d_all.as<uint64_t>(), n, kl, d_slab_count.as<unsigned long long>(),
-                           d_slabbed.as<uint64_t>());
-        GEN_HIP(hipDeviceSynchronize());
-        d_all.release();
+    {
         GEN_HIP(d_alt.alloc(max_slab * 8));
         size_t tb = 0;
         GEN_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, d_slabbed.as<uint64_t>(), d_alt.as<uint64_t>(), (size_t)max_slab, 0, 64, st));
         if (tb > tmp_bytes) { GEN_HIP(d_tmp.alloc(tb)); tmp_bytes = tb; }
+        const int key_bits = (int)(kl.slab_shift + 8 + kl.rbits);
         for (uint32_t s = 0; s < n_slabs; ++s) {
             if (cnt[s] == 0) continue;
             uint64_t* seg = d_slabbed.as<uint64_t>() + off[s];
-            GEN_HIP(hipcub::DeviceRadixSort::SortKeys(d_tmp.p, tmp_bytes, seg, d_alt.as<uint64_t>(), (size_t)cnt[s], 0, 64, st));
+            GEN_HIP(hipcub::DeviceRadixSort::SortKeys(d_tmp.p, tmp_bytes, seg, d_alt.as<uint64_t>(), (size_t)cnt[s], 0, key_bits, st));
             GEN_HIP(hipMemcpyAsync(seg, d_alt.p, cnt[s] * 8, hipMemcpyDeviceToDevice, st));
         }
         GEN_HIP(hipDeviceSynchronize());
         d_alt.release();
-        sorted = d_slabbed.as<uint64_t>();
     }
+    uint64_t* sorted = d_slabbed.as<uint64_t>();
 
     // ---- (5) emit
     void* out_bwt = nullptr;

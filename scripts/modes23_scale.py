@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from ebwt2indel_amd import sim, api
 n_each = int(sys.argv[1]); L = 150
-glen = int(2 * n_each * L / 30)
+glen = int(2 * n_each * L / 30)            # each sample covers its haplotype 15x: 30x of the diploid genome
 g = sim.random_genome(glen, 5); h2 = sim.mutate_haplotype(g, 5)
 text, offs = sim.haplotype_text([g, h2])
 rng = np.random.Generator(np.random.PCG64(99))

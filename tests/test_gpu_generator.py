@@ -55,3 +55,21 @@ def test_gpu_generator_slabbed_sort(monkeypatch):
     got, _ = dev.to_host()
     dev.free()
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("slabs,rbits", [("64", None), ("1000", "40"), ("3", "47")])
+def test_gpu_generator_slab_relative_keys(monkeypatch, slabs, rbits):
+    """The key layout of the large configurations forced on a small input: many slabs with only lo's offset inside the slab
+    in the key, and a read-index field as wide as 100 M / 1 G reads need (EBGEN_RBITS; with 47 bits the generator must
+    itself raise the number of slabs until (lo in slab, length, read index) fits 64 bits)."""
+    monkeypatch.setenv("EBGEN_SLABS", slabs)
+    if rbits:
+        monkeypatch.setenv("EBGEN_RBITS", rbits)
+    text, starts = _case(80_000, 30_000, 110, 8, snp_every=300, indel_every=900)
+    reads = sim.reads_from_starts(text, starts, 110)
+    want, want_da = sim.build_merged_ebwt(reads[:13_000], reads[13_000:])
+    dev = sim.build_ebwt_gpu(text, starts, 110, n_first=13_000, want_da=True)
+    got, da = dev.to_host()
+    dev.free()
+    assert np.array_equal(got, want)
+    assert np.array_equal(da, want_da)
