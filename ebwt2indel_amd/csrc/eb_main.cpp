@@ -1,6 +1,15 @@
 // eb_main.cpp -- the `ebwt2InDel` command line, same flags / defaults / messages as the reference
 // (ebwt2InDel.cpp:76-103 help, :1677-1823 main), driving the GPU hot path through the C ABI only.
-// Extra flag (not in the reference): -D <device> selects the GPU (default 0).
+// Extra flags (not in the reference): -D <device> selects the GPU (default 0); -G <n> runs on n GPUs of the node:
+// ONE process, one host thread per GPU, RCCL communicators from ncclCommInitAll -- the input files are read once and
+// uploaded to every GPU (BWT replicated), phases 2-3 are split by Weiner-link subtrees and combined by an in-place
+// ncclAllReduce (SUM == OR: one writer per bit, checked by popcounts), phase 4 is split by closing position and the
+// ranks' compact call-set images travel GPU -> GPU (ncclSend / ncclRecv over xGMI) to GPU 0, whose thread downloads
+// them and writes the .snp -- the same bytes as -G 1 and as the reference.  (EB_MULTI_BACKEND=host replaces the two
+// collectives by exchanges through host memory and lets ranks share devices: rehearsal on a box with fewer GPUs.)
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
 #include <getopt.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -8,8 +17,12 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <array>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ebwt2indel.h"
@@ -34,7 +47,8 @@ static void help() {
            "            run of <arg> equal characters. Default: length of right context (-R), minus 10.\n"
            "-q          Maximum number of allowed variants per genomic position in each sample. If 0, there is no limit. Default: 0.\n"
            "-t <arg>    ASCII value of terminator character. Default: 35 (#).\n"
-           "-D <arg>    GPU to run on. Default: 0.\n\n"
+           "-D <arg>    GPU to run on. Default: 0.\n"
+           "-G <arg>    Number of GPUs of this node to run on (one host thread per GPU, RCCL). Default: 1.\n\n"
            "\nTo run ebwt2InDel, you must first build the extended Burrows-Wheeler Transform of the input sequences.\n\n"
            "Output format: A fasta file with DNA fragments containing the variations.\n");
     exit(0);
@@ -65,6 +79,350 @@ static int read_file(const std::string& path, std::vector<uint8_t>& out) {
     return r == out.size() ? 0 : -1;
 }
 
+// ------------------------------------------------------------------------------------------------ -G n: n GPUs, one process
+namespace {
+
+struct Barrier {
+    std::mutex mu;
+    std::condition_variable cv;
+    int n, waiting = 0;
+    uint64_t gen = 0;
+    explicit Barrier(int n_) : n(n_) {}
+    void wait() {
+        std::unique_lock<std::mutex> lk(mu);
+        uint64_t g = gen;
+        if (++waiting == n) { waiting = 0; ++gen; cv.notify_all(); }
+        else cv.wait(lk, [&] { return gen != g; });
+    }
+};
+
+// contiguous slice of closing positions for `rank`; cuts fall on 64-position flag words (ebwt2indel_amd/distributed.py: shard_range)
+void shard_range(uint64_t n, int rank, int world, uint64_t* b, uint64_t* e) {
+    auto cut = [&](int i) -> uint64_t {
+        if (i <= 0) return 0;
+        if (i >= world) return n;
+        uint64_t c = (uint64_t)((unsigned __int128)n * (unsigned)i / (unsigned)world);
+        c = (c + 63) / 64 * 64;
+        return c < n ? c : n;
+    };
+    *b = cut(rank);
+    *e = cut(rank + 1);
+}
+
+struct MultiJob {
+    int world = 1;
+    bool host_backend = false;
+    std::vector<int> dev;
+    std::vector<ncclComm_t> comm;
+    const std::vector<uint8_t>*text1 = nullptr, *text2 = nullptr, *da = nullptr;
+    eb_params p;
+    Barrier* bar = nullptr;
+    // per rank
+    std::vector<int> rc;
+    std::vector<std::string> err;
+    std::vector<eb_nav_stats> ns;
+    std::vector<eb_scan_stats> ss;
+    std::vector<std::array<uint64_t, 4>> ones;
+    std::vector<const void*> wire_ptr;
+    std::vector<uint64_t> wire_len;
+    std::vector<std::vector<uint8_t>> image; // rank 0's host copies of all ranks' call-set images, in rank order
+    // host backend: OR of the shards' vectors
+    std::mutex mu;
+    std::vector<uint64_t> acc[4];
+    uint8_t bad_sym = 0;
+    uint64_t bad_pos = 0;
+    double t_index = 0, t_nav = 0, t_scan = 0;
+};
+
+bool any_failed(MultiJob& J) {
+    for (int r : J.rc) if (r != EB_OK) return true;
+    return false;
+}
+
+#define MJ_FAIL(code, ...)                                 \
+    do {                                                   \
+        char b_[512];                                      \
+        snprintf(b_, sizeof b_, __VA_ARGS__);              \
+        J.rc[(size_t)r] = (code);                          \
+        J.err[(size_t)r] = b_;                             \
+    } while (0)
+#define MJ_HIP(call)                                                                                      \
+    do {                                                                                                  \
+        hipError_t e_ = (call);                                                                           \
+        if (e_ != hipSuccess && J.rc[(size_t)r] == EB_OK) MJ_FAIL(EB_ERR_DEVICE, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+#define MJ_NCCL(call)                                                                                     \
+    do {                                                                                                  \
+        ncclResult_t e_ = (call);                                                                         \
+        if (e_ != ncclSuccess && J.rc[(size_t)r] == EB_OK) MJ_FAIL(EB_ERR_DEVICE, "%s: %s", #call, ncclGetErrorString(e_)); \
+    } while (0)
+
+// One rank = one host thread bound to one GPU.  Every step that can fail is followed by a barrier and a common check, so
+// that no rank enters a collective its peers will not join.
+void rank_main(MultiJob& J, int r) {
+    const int device = J.dev[(size_t)r];
+    const bool two = J.text2 != nullptr;
+    eb_index *b1 = nullptr, *b2 = nullptr;
+    eb_flags* fl = nullptr;
+    eb_scan_job* job = nullptr;
+    eb_calls* calls = nullptr;
+    hipStream_t st = nullptr;
+    std::vector<void*> recv; // rank 0: device buffers of the other ranks' images
+    auto cleanup = [&] {
+        if (job) eb_scan_clusters_cancel(job);
+        if (calls) eb_calls_free(calls);
+        for (void* q : recv) if (q) (void)hipFree(q);
+        if (fl) eb_flags_destroy(fl);
+        eb_index_destroy(b1);
+        eb_index_destroy(b2);
+        if (st) (void)hipStreamDestroy(st);
+    };
+    auto sync_ok = [&]() -> bool { J.bar->wait(); return !any_failed(J); };
+
+    // ---- phase 1: the text is in host memory once; every rank uploads and packs it on its own GPU (PCIe links in parallel)
+    double t0 = now_s();
+    (void)hipSetDevice(device);
+    MJ_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    int rc = eb_index_create(J.text1->data(), J.text1->size(), (uint8_t)J.p.term, device, &b1);
+    if (rc == EB_OK && two) rc = eb_index_create(J.text2->data(), J.text2->size(), (uint8_t)J.p.term, device, &b2);
+    if (rc != EB_OK) {
+        if (rc == EB_ERR_ALPHABET) eb_index_bad_symbol(&J.bad_sym, &J.bad_pos); // same symbol on every rank
+        MJ_FAIL(rc, "%s", eb_last_error());
+    }
+    if (!sync_ok()) return cleanup();
+    if (r == 0) J.t_index = now_s() - t0;
+
+    // ---- phases 2-3: this rank's Weiner-link subtrees, then the vectors are combined
+    t0 = now_s();
+    rc = eb_flags_build_shard(b1, b2, J.p.K, J.p.k_right, (uint32_t)r, (uint32_t)J.world, &fl, &J.ns[(size_t)r]);
+    if (rc == EB_OK) rc = eb_flags_popcounts(fl, J.ones[(size_t)r].data());
+    if (rc != EB_OK) MJ_FAIL(rc, "%s", eb_last_error());
+    if (!sync_ok()) return cleanup();
+    const uint64_t n = J.ns[(size_t)r].n;
+    uint64_t* v[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint64_t words = 0;
+    (void)eb_flags_device_vectors(fl, v, &words);
+    if (!J.host_backend) {
+        // every bit has ONE writer over all ranks: integer SUM == OR (RCCL has no bitwise OR); in place, in HBM, over xGMI
+        for (int k = 0; k < 4; ++k)
+            if (v[k]) MJ_NCCL(ncclAllReduce(v[k], v[k], words, ncclUint64, ncclSum, J.comm[(size_t)r], st));
+        MJ_HIP(hipStreamSynchronize(st));
+    } else {
+        std::vector<uint64_t> h[4];
+        for (int k = 0; k < 4; ++k) if (v[k]) h[k].resize(words);
+        rc = eb_flags_export(fl, h[0].data(), h[1].data(), h[2].data(), v[3] ? h[3].data() : nullptr);
+        if (rc != EB_OK) MJ_FAIL(rc, "%s", eb_last_error());
+        {
+            std::lock_guard<std::mutex> lk(J.mu);
+            for (int k = 0; k < 4; ++k) {
+                if (!v[k]) continue;
+                if (J.acc[k].empty()) J.acc[k].assign(words, 0);
+                for (uint64_t w = 0; w < words; ++w) J.acc[k][w] += h[k][w]; // the same SUM the all-reduce computes
+            }
+        }
+        J.bar->wait();
+        eb_flags_destroy(fl);
+        fl = nullptr;
+        if (J.rc[(size_t)r] == EB_OK) {
+            rc = eb_flags_import(n, device, J.acc[0].data(), J.acc[1].data(), J.acc[2].data(), J.acc[3].empty() ? nullptr : J.acc[3].data(), &fl);
+            if (rc != EB_OK) MJ_FAIL(rc, "%s", eb_last_error());
+        }
+    }
+    if (J.rc[(size_t)r] == EB_OK) {
+        // SUM stood in for OR: popcount(a + b) = popcount(a) + popcount(b) - carries, so the ones must add up exactly
+        uint64_t got[4], want[4] = {0, 0, 0, 0};
+        rc = eb_flags_popcounts(fl, got);
+        for (int q = 0; q < J.world; ++q) for (int k = 0; k < 4; ++k) want[k] += J.ones[(size_t)q][(size_t)k];
+        if (rc != EB_OK) MJ_FAIL(rc, "%s", eb_last_error());
+        else if (memcmp(got, want, sizeof got) != 0) MJ_FAIL(EB_ERR_STATE, "sharded traversal: a bit of the flag vectors was set by more than one rank");
+        else if (!J.host_backend && (rc = eb_flags_finalize(fl)) != EB_OK) MJ_FAIL(rc, "%s", eb_last_error());
+    }
+    if (J.rc[(size_t)r] == EB_OK && J.da) {
+        rc = eb_flags_set_da(fl, J.da->data(), J.da->size());
+        if (rc != EB_OK) MJ_FAIL(rc, "%s", eb_last_error());
+    }
+    if (!sync_ok()) return cleanup();
+    if (r == 0) J.t_nav = now_s() - t0;
+
+    // ---- phase 4: this rank's slice of closing positions; the call sets meet on GPU 0
+    t0 = now_s();
+    uint64_t begin = 0, end = 0;
+    shard_range(n, r, J.world, &begin, &end);
+    if (!J.host_backend) {
+        rc = eb_scan_clusters_begin_ex(b1, b2, fl, begin, end, &J.p, EB_SCAN_DEVICE_ONLY | EB_SCAN_WIRE, &job);
+        if (rc == EB_OK) rc = eb_scan_job_wait(job);
+        if (rc == EB_OK) rc = eb_scan_job_device_wire(job, &J.wire_ptr[(size_t)r], &J.wire_len[(size_t)r]);
+        if (rc != EB_OK) MJ_FAIL(rc, "%s", eb_last_error());
+        if (!sync_ok()) return cleanup();
+        // variable-length gather to rank 0: the lengths are known to everyone (one process), the payloads go GPU -> GPU
+        if (r == 0) {
+            recv.assign((size_t)J.world, nullptr);
+            for (int q = 1; q < J.world; ++q) MJ_HIP(hipMalloc(&recv[(size_t)q], J.wire_len[(size_t)q]));
+        }
+        if (!sync_ok()) return cleanup();
+        if (r == 0) {
+            MJ_NCCL(ncclGroupStart());
+            for (int q = 1; q < J.world; ++q) MJ_NCCL(ncclRecv(recv[(size_t)q], J.wire_len[(size_t)q], ncclUint8, q, J.comm[0], st));
+            MJ_NCCL(ncclGroupEnd());
+        } else {
+            MJ_NCCL(ncclSend(J.wire_ptr[(size_t)r], J.wire_len[(size_t)r], ncclUint8, 0, J.comm[(size_t)r], st));
+        }
+        MJ_HIP(hipStreamSynchronize(st));
+        if (r == 0) {
+            for (int q = 0; q < J.world; ++q) {
+                J.image[(size_t)q].resize(J.wire_len[(size_t)q]);
+                MJ_HIP(hipMemcpy(J.image[(size_t)q].data(), q == 0 ? J.wire_ptr[0] : recv[(size_t)q], J.wire_len[(size_t)q], hipMemcpyDeviceToHost));
+            }
+        }
+        J.bar->wait(); // the senders' images may be released now
+        rc = eb_scan_clusters_end(job, nullptr, &J.ss[(size_t)r]);
+        job = nullptr;
+        if (rc != EB_OK) MJ_FAIL(rc, "%s", eb_last_error());
+    } else {
+        rc = eb_scan_clusters(b1, b2, fl, begin, end, &J.p, &calls, &J.ss[(size_t)r]);
+        if (rc == EB_OK) {
+            const uint8_t* blob = nullptr;
+            uint64_t len = 0;
+            rc = eb_calls_blob(calls, &blob, &len);
+            if (rc == EB_OK) J.image[(size_t)r].assign(blob, blob + len);
+        }
+        if (rc != EB_OK) MJ_FAIL(rc, "%s", eb_last_error());
+    }
+    J.bar->wait();
+    if (r == 0) J.t_scan = now_s() - t0;
+    cleanup();
+}
+
+}  // namespace
+
+static void print_report(const eb_nav_stats& ns, const eb_scan_stats& ss, bool two_bwts, bool with_da, uint64_t events, uint64_t cluster_nr) {
+    printf("\nDone.\nAnalyzed %llu clusters.\n", (unsigned long long)ss.clusters);
+    printf("Average cluster length: %g.\n\n", ss.clusters ? (double)ss.bases_in_runs / (double)ss.clusters : 0.0);
+    if (!two_bwts && !with_da) printf("Stored to file %llu events clustered in %llu clusters.\n\n", (unsigned long long)events, (unsigned long long)(cluster_nr - 1));
+    printf("Distribution of bases inside clusters (cluster length / number of bases inside clusters of that length): \n\n");
+    uint64_t scale = 0;
+    for (int i = 0; i <= 200; ++i) scale = ss.hist[i] > scale ? ss.hist[i] : scale;
+    // the reference divides by `scale` unguarded and dies with SIGFPE when no cluster closed (:1664-1669); we print an empty histogram
+    for (int i = 0; i <= 200; ++i) {
+        printf("%d%s", i, i < 10 ? "   " : (i < 100 ? "  " : " "));
+        uint64_t bar = scale ? (100 * ss.hist[i]) / scale : 0;
+        for (uint64_t j = 0; j < bar; ++j) putchar('-');
+        printf(" %llu\n", (unsigned long long)ss.hist[i]);
+    }
+    if (with_da) printf("\nStored to file %llu sequences clustered in %llu clusters.\n", (unsigned long long)events, (unsigned long long)(cluster_nr - 1));
+    (void)ns;
+}
+
+// -G n: the whole tool on n GPUs of this node (see the head of this file)
+static int run_multi(int world, const std::string& input1, const std::string& input2, const std::string& input_da, const std::string& output,
+                     const eb_params& p) {
+    const bool two_bwts = !input2.empty(), with_da = !input_da.empty();
+    const char* be = getenv("EB_MULTI_BACKEND");
+    const bool host_backend = be && !strcmp(be, "host");
+    const int ndev = eb_device_count();
+    if (world < 1 || world > 64) { printf("Error: -G %d: between 1 and 64 GPUs\n", world); return 1; }
+    if (!host_backend && world > ndev) {
+        printf("Error: -G %d but this node shows %d GPU(s): RCCL needs one GPU per rank (EB_MULTI_BACKEND=host lets ranks share devices)\n", world, ndev);
+        return 1;
+    }
+    MultiJob J;
+    J.world = world;
+    J.host_backend = host_backend;
+    J.p = p;
+    for (int r = 0; r < world; ++r) J.dev.push_back(r % ndev);
+    printf(two_bwts ? "Phase 1/4: loading and indexing eBWTs on %d GPU(s) ... " : "Phase 1/4: loading and indexing eBWT on %d GPU(s) ... ", world);
+    fflush(stdout);
+    double t0 = now_s();
+    std::vector<uint8_t> text1, text2, da; // read ONCE; every rank uploads from here
+    if (read_file(input1, text1) != 0) { printf("Error: could not read file %s\n", input1.c_str()); return 1; }
+    if (two_bwts && read_file(input2, text2) != 0) { printf("Error: could not read file %s\n", input2.c_str()); return 1; }
+    if (with_da && read_file(input_da, da) != 0) { printf("Error: could not read file %s\n", input_da.c_str()); return 1; }
+    const double t_read = now_s() - t0;
+    J.text1 = &text1;
+    J.text2 = two_bwts ? &text2 : nullptr;
+    J.da = with_da ? &da : nullptr;
+    if (!host_backend) {
+        J.comm.resize((size_t)world);
+        ncclResult_t e = ncclCommInitAll(J.comm.data(), world, J.dev.data());
+        if (e != ncclSuccess) { printf("Error: ncclCommInitAll failed: %s\n", ncclGetErrorString(e)); return 1; }
+    }
+    Barrier bar(world);
+    J.bar = &bar;
+    J.rc.assign((size_t)world, EB_OK);
+    J.err.resize((size_t)world);
+    J.ns.resize((size_t)world);
+    J.ss.resize((size_t)world);
+    J.ones.resize((size_t)world);
+    J.wire_ptr.assign((size_t)world, nullptr);
+    J.wire_len.assign((size_t)world, 0);
+    J.image.resize((size_t)world);
+    for (auto& s : J.ns) memset(&s, 0, sizeof s);
+    for (auto& s : J.ss) memset(&s, 0, sizeof s);
+    std::vector<std::thread> th;
+    for (int r = 1; r < world; ++r) th.emplace_back(rank_main, std::ref(J), r);
+    rank_main(J, 0);
+    for (std::thread& t : th) t.join();
+    if (!host_backend) for (ncclComm_t c : J.comm) (void)ncclCommDestroy(c);
+    for (int r = 0; r < world; ++r)
+        if (J.rc[(size_t)r] != EB_OK) {
+            if (J.rc[(size_t)r] == EB_ERR_ALPHABET) {
+                printf("\nError while reading file: read forbidden character '%c' (ASCII code %d).\n"
+                       "Only A,C,G,T, and %c are admitted in the input BWT!\n"
+                       "If the unknown character is the terminator, you can solve the problem by adding option \"-t %d\".\n",
+                       J.bad_sym, (int)(char)J.bad_sym, (char)p.term, (int)(char)J.bad_sym);
+            } else {
+                printf("\nError on GPU rank %d: %s\n", r, J.err[(size_t)r].c_str());
+            }
+            return 1;
+        }
+    printf("done.\n");
+    // totals over the ranks: every counter has one writer per suffix-tree record / closing position
+    eb_nav_stats ns;
+    memset(&ns, 0, sizeof ns);
+    eb_scan_stats ss;
+    memset(&ss, 0, sizeof ss);
+    for (int r = 0; r < world; ++r) {
+        const eb_nav_stats& a = J.ns[(size_t)r];
+        ns.n = a.n;
+        ns.leaves += a.leaves; ns.nodes += a.nodes; ns.lcp_values += a.lcp_values; ns.da_values += a.da_values; ns.minima += a.minima;
+        ns.rank_queries += a.rank_queries; ns.batches += a.batches;
+        if (a.seconds_leaves > ns.seconds_leaves) ns.seconds_leaves = a.seconds_leaves;
+        if (a.seconds_nodes > ns.seconds_nodes) ns.seconds_nodes = a.seconds_nodes;
+        const eb_scan_stats& b = J.ss[(size_t)r];
+        ss.runs_closed += b.runs_closed; ss.clusters += b.clusters; ss.bases_in_runs += b.bases_in_runs; ss.survivors += b.survivors; ss.chains += b.chains;
+        for (int i = 0; i <= 200; ++i) ss.hist[i] += b.hist[i];
+        if (b.ms_scan > ss.ms_scan) ss.ms_scan = b.ms_scan;
+        if (b.ms_extend > ss.ms_extend) ss.ms_extend = b.ms_extend;
+        if (b.ms_right > ss.ms_right) ss.ms_right = b.ms_right;
+    }
+    printf(two_bwts ? "\nPhase 2/4: merging eBWTs.\n" : "\nPhase 2/4: navigating suffix tree leaves.\n");
+    if (two_bwts) printf("Computed %llu/%llu DA values.\n", (unsigned long long)ns.da_values, (unsigned long long)ns.n);
+    printf("Processed %llu suffix-tree leaves.\n\n", (unsigned long long)ns.leaves);
+    printf("Phase 3/4: computing LCP minima.\n");
+    printf("Computed %llu/%llu LCP values.\n", (unsigned long long)ns.lcp_values, (unsigned long long)ns.n);
+    printf("Found %llu LCP minima.\n", (unsigned long long)ns.minima);
+    printf("Processed %llu suffix-tree nodes.\n\n", (unsigned long long)ns.nodes);
+    printf("Phase 4/4: detecting SNPs and indels.\n");
+    printf("Output events will be stored in %s\n", output.c_str());
+    // rank 0's host: the ranks' call sets in rank order = BWT order; cluster_nr runs through (ebwt2InDel.cpp:52)
+    double t4 = now_s();
+    uint64_t cluster_nr = 1, events = 0;
+    for (int r = 0; r < world; ++r) {
+        eb_calls* calls = nullptr;
+        int rc = eb_calls_unpack(J.image[(size_t)r].data(), J.image[(size_t)r].size(), &calls);
+        if (rc == EB_OK) rc = eb_write_snp(calls, &p, two_bwts || with_da, output.c_str(), r > 0, &cluster_nr, &events);
+        if (calls) eb_calls_free(calls);
+        if (rc != EB_OK) return fail("Error while writing the output");
+    }
+    double t5 = now_s();
+    print_report(ns, ss, two_bwts, with_da, events, cluster_nr);
+    printf("\nTimings (s) on %d GPU(s)%s: read %.3f, upload+index %.3f, phases 2-3 %.3f (%llu rank queries, %llu launches over all ranks), "
+           "phase 4 + gather %.3f (slowest rank: scan %.3f ms, extend %.3f ms, right %.3f ms), write %.3f\n",
+           world, host_backend ? " [host-memory exchange]" : " [RCCL]", t_read, J.t_index, J.t_nav, (unsigned long long)ns.rank_queries,
+           (unsigned long long)ns.batches, J.t_scan, ss.ms_scan, ss.ms_extend, ss.ms_right, t5 - t4);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     setenv("GPU_MAX_HW_QUEUES", "16", 0); // the phase-4 driver overlaps five streams; the HIP default of 4 queues serialises them
     if (argc < 3) help();
@@ -72,9 +430,9 @@ int main(int argc, char** argv) {
     memset(&p, 0, sizeof p);
     p.term = '#';
     std::string input1, input2, input_da, output;
-    int device = 0;
+    int device = 0, gpus = 0;
     int opt;
-    while ((opt = getopt(argc, argv, "h1:2:v:L:R:m:g:k:t:o:d:c:q:D:")) != -1) {
+    while ((opt = getopt(argc, argv, "h1:2:v:L:R:m:g:k:t:o:d:c:q:D:G:")) != -1) {
         switch (opt) {
             case 'h': help(); break;
             case '1': input1 = optarg; break;
@@ -91,6 +449,7 @@ int main(int argc, char** argv) {
             case 'c': p.complexity = atoi(optarg); break;
             case 'q': p.max_variants_per_position = atoi(optarg); break;
             case 'D': device = atoi(optarg); break;
+            case 'G': gpus = atoi(optarg); break;
             default: help(); return -1;
         }
     }
@@ -119,6 +478,7 @@ int main(int argc, char** argv) {
 
     const bool two_bwts = !input2.empty();
     const bool with_da = !input_da.empty();
+    if (gpus != 0) return run_multi(gpus, input1, input2, input_da, output, p);
     double t0 = now_s();
     printf(two_bwts ? "Phase 1/4: loading and indexing eBWTs ... " : "Phase 1/4: loading and indexing eBWT ... ");
     fflush(stdout);
@@ -171,20 +531,7 @@ int main(int argc, char** argv) {
     if (rc != EB_OK) return fail("Error while writing the output");
     double t4 = now_s();
 
-    printf("\nDone.\nAnalyzed %llu clusters.\n", (unsigned long long)ss.clusters);
-    printf("Average cluster length: %g.\n\n", ss.clusters ? (double)ss.bases_in_runs / (double)ss.clusters : 0.0);
-    if (!two_bwts && !with_da) printf("Stored to file %llu events clustered in %llu clusters.\n\n", (unsigned long long)events, (unsigned long long)(cluster_nr - 1));
-    printf("Distribution of bases inside clusters (cluster length / number of bases inside clusters of that length): \n\n");
-    uint64_t scale = 0;
-    for (int i = 0; i <= 200; ++i) scale = ss.hist[i] > scale ? ss.hist[i] : scale;
-    // the reference divides by `scale` unguarded and dies with SIGFPE when no cluster closed (:1664-1669); we print an empty histogram
-    for (int i = 0; i <= 200; ++i) {
-        printf("%d%s", i, i < 10 ? "   " : (i < 100 ? "  " : " "));
-        uint64_t bar = scale ? (100 * ss.hist[i]) / scale : 0;
-        for (uint64_t j = 0; j < bar; ++j) putchar('-');
-        printf(" %llu\n", (unsigned long long)ss.hist[i]);
-    }
-    if (with_da) printf("\nStored to file %llu sequences clustered in %llu clusters.\n", (unsigned long long)events, (unsigned long long)(cluster_nr - 1));
+    print_report(ns, ss, two_bwts, with_da, events, cluster_nr);
     printf("\nTimings (s): load+index %.3f, phases 2-3 %.3f (leaves %.3f, nodes %.3f, %llu rank queries, %llu launches), "
            "phase 4 device %.3f (scan %.3f ms, extend %.3f ms, right %.3f ms), write %.3f\n",
            t1 - t0, t2 - t1, ns.seconds_leaves, ns.seconds_nodes, (unsigned long long)ns.rank_queries, (unsigned long long)ns.batches,
