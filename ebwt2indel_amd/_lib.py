@@ -61,7 +61,7 @@ ABI_SYMBOLS = [
     "eb_index_create", "eb_index_create_from_file", "eb_index_create_from_device", "eb_index_destroy", "eb_index_bad_symbol",
     "eb_index_info", "eb_rank4_batch", "eb_access_batch", "eb_lf_range_batch", "eb_lf_range_sym_batch", "eb_fl_batch",
     "eb_lf_node_batch", "eb_rank4_batch_device", "eb_flags_build", "eb_flags_build_shard", "eb_flags_device_vectors", "eb_flags_popcounts", "eb_flags_finalize", "eb_flags_set_da", "eb_flags_words", "eb_flags_has_da",
-    "eb_flags_export", "eb_flags_import", "eb_flags_destroy", "eb_scan_clusters", "eb_scan_clusters_begin", "eb_scan_clusters_end",
+    "eb_flags_export", "eb_flags_import", "eb_flags_import_shard_sum", "eb_flags_destroy", "eb_scan_clusters", "eb_scan_clusters_begin", "eb_scan_clusters_end",
     "eb_scan_clusters_cancel", "eb_scan_clusters_begin_ex", "eb_scan_job_wait", "eb_scan_job_device_blob", "eb_scan_job_device_wire", "eb_calls_get", "eb_calls_free",
     "eb_calls_packed_size", "eb_calls_pack", "eb_calls_unpack", "eb_calls_blob", "eb_write_snp", "eb_format_snp", "eb_free",
     "eb_selftest_pack_fields",
@@ -120,6 +120,7 @@ def load():
     L.eb_flags_has_da.argtypes = [vp]
     L.eb_flags_export.argtypes = [vp, vp, vp, vp, vp]
     L.eb_flags_import.argtypes = [u64, C.c_int, vp, vp, vp, vp, P(vp)]
+    L.eb_flags_import_shard_sum.argtypes = [u64, C.c_int, vp, vp, vp, vp, P(vp)]
     L.eb_flags_destroy.argtypes = [vp]
     L.eb_flags_destroy.restype = None
     L.eb_scan_clusters.argtypes = [vp, vp, vp, u64, u64, P(Params), P(vp), P(ScanStats)]

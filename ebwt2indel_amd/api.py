@@ -201,6 +201,14 @@ class Flags:
         _check(lib().eb_flags_import(n, device, *[a.ctypes.data if a is not None else None for a in arrs], C.byref(h)))
         return cls(h)
 
+    @classmethod
+    def from_shard_sum(cls, n: int, thrK_below, thrR_below, minima, da=None, device: int = 0) -> "Flags":
+        """The SUM of the shards' exported vectors (shard form: thrK / thrR complemented) -> finalised flags."""
+        h = C.c_void_p()
+        arrs = [np.ascontiguousarray(a, dtype=np.uint64) if a is not None else None for a in (thrK_below, thrR_below, minima, da)]
+        _check(lib().eb_flags_import_shard_sum(n, device, *[a.ctypes.data if a is not None else None for a in arrs], C.byref(h)))
+        return cls(h)
+
     def set_da(self, ascii01):
         d = _u8(ascii01)
         _check(lib().eb_flags_set_da(self._h, d.ctypes.data, len(d)))

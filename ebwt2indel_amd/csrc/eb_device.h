@@ -88,6 +88,15 @@ __device__ __forceinline__ uint64_t eb_rank4_quad(const eb_dev_index& x, uint64_
     return x.super[((i >> EB_SUPER_SHIFT) << 2) + j] + c.w + ((p >> (8u * j)) & 0xFFu);
 }
 
+// The same in two steps, so that a kernel can put the loads of many queries in flight before it needs the first result.
+__device__ __forceinline__ uint4 eb_rank4_quad_load(const eb_dev_index& x, uint64_t i, uint32_t j) { return x.chunks[((i >> 7) << 2) + j]; }
+__device__ __forceinline__ uint64_t eb_rank4_quad_finish(const eb_dev_index& x, uint4 c, uint64_t i, uint32_t j) {
+    uint32_t p = eb_chunk_counts(c, eb_prefix_mask32((uint32_t)(i & 127u), j));
+    p += (uint32_t)__shfl_xor((int)p, 1);
+    p += (uint32_t)__shfl_xor((int)p, 2);
+    return x.super[((i >> EB_SUPER_SHIFT) << 2) + j] + c.w + ((p >> (8u * j)) & 0xFFu);
+}
+
 // Ranks at both ends of an interval [lo, hi] by one quad: a narrow interval (the usual case when following a
 // cluster's left context, width ~ coverage) lies in ONE block, which is then loaded once.
 __device__ __forceinline__ void eb_rank4_quad_pair(const eb_dev_index& x, uint64_t lo, uint64_t hi, uint32_t j, uint64_t& a, uint64_t& b) {

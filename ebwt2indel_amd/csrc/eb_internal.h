@@ -66,6 +66,7 @@ struct eb_flags {
     uint64_t* d_flag = nullptr; // thrK & ~minima
     uint4* d_mxy = nullptr;     // two-BWT mode: merged scan planes, built by the first phase-4 call
     bool derived = false;       // d_flag / d_da_rank match the vectors (false between a sharded build and eb_flags_finalize)
+    bool complemented = false;  // d_thrK / d_thrR hold the complement (bit = LCP BELOW the threshold) until eb_flags_derive inverts them
     eb_dev_flags dev() const {
         eb_dev_flags f;
         f.thrK = d_thrK;

@@ -224,14 +224,15 @@ void rank_main(MultiJob& J, int r) {
         eb_flags_destroy(fl);
         fl = nullptr;
         if (J.rc[(size_t)r] == EB_OK) {
-            rc = eb_flags_import(n, device, J.acc[0].data(), J.acc[1].data(), J.acc[2].data(), J.acc[3].empty() ? nullptr : J.acc[3].data(), &fl);
+            rc = eb_flags_import_shard_sum(n, device, J.acc[0].data(), J.acc[1].data(), J.acc[2].data(), J.acc[3].empty() ? nullptr : J.acc[3].data(), &fl);
             if (rc != EB_OK) MJ_FAIL(rc, "%s", eb_last_error());
         }
     }
     if (J.rc[(size_t)r] == EB_OK) {
         // SUM stood in for OR: popcount(a + b) = popcount(a) + popcount(b) - carries, so the ones must add up exactly
-        uint64_t got[4], want[4] = {0, 0, 0, 0};
-        rc = eb_flags_popcounts(fl, got);
+        uint64_t got[4] = {0, 0, 0, 0}, want[4] = {0, 0, 0, 0};
+        if (!J.host_backend) rc = eb_flags_popcounts(fl, got); // the reduced vectors, still in shard form
+        else for (int k = 0; k < 4; ++k) for (uint64_t w : J.acc[k]) got[k] += (uint64_t)__builtin_popcountll(w);
         for (int q = 0; q < J.world; ++q) for (int k = 0; k < 4; ++k) want[k] += J.ones[(size_t)q][(size_t)k];
         if (rc != EB_OK) MJ_FAIL(rc, "%s", eb_last_error());
         else if (memcmp(got, want, sizeof got) != 0) MJ_FAIL(EB_ERR_STATE, "sharded traversal: a bit of the flag vectors was set by more than one rank");
@@ -394,6 +395,12 @@ static int run_multi(int world, const std::string& input1, const std::string& in
         if (b.ms_scan > ss.ms_scan) ss.ms_scan = b.ms_scan;
         if (b.ms_extend > ss.ms_extend) ss.ms_extend = b.ms_extend;
         if (b.ms_right > ss.ms_right) ss.ms_right = b.ms_right;
+    }
+    if (ns.n > 0 && ns.lcp_values != ns.n) {
+        // the shards collect the complement of the LCP thresholds, exact only when every position has one writer
+        printf("\nError: the traversal wrote %llu of %llu LCP slots: the input is not the eBWT of a read collection; run without -G "
+               "(the single-GPU path handles such inputs the reference's way)\n", (unsigned long long)ns.lcp_values, (unsigned long long)ns.n);
+        return 1;
     }
     printf(two_bwts ? "\nPhase 2/4: merging eBWTs.\n" : "\nPhase 2/4: navigating suffix tree leaves.\n");
     if (two_bwts) printf("Computed %llu/%llu DA values.\n", (unsigned long long)ns.da_values, (unsigned long long)ns.n);

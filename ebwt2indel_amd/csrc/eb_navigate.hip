@@ -14,6 +14,8 @@
 #include <string.h>
 
 #include <chrono>
+#include <string>
+#include <thread>
 #include <type_traits>
 
 #include "eb_internal.h"
@@ -71,6 +73,10 @@ __host__ __device__ __forceinline__ void unpack_rec(const Node2P& p, Node2& n) {
 __host__ __device__ __forceinline__ void unpack_rec(const Leaf2P& p, Leaf2& l) { l.depth = unpack_fields<4>(p, &l.l1); l.pad[0] = l.pad[1] = l.pad[2] = 0; }
 __host__ __device__ __forceinline__ void unpack_rec(const Leaf1& p, Leaf1& l) { l = p; }
 
+#ifndef EB_NODES_PER_QUAD
+#define EB_NODES_PER_QUAD 2 /* one-BWT nodes per quad and trip in k_nodes (1, 2, 3 or 6: must divide 1536 / 256) */
+#endif
+
 struct NavCounters {
     unsigned long long pushed;     // children appended by the current launch
     unsigned long long pad0[7];    // keep the hot word on its own 64-byte line
@@ -81,7 +87,21 @@ struct NavParams {
     int K, k_right;
     int write;     // 0: expand only (the shared top of the tree on shards other than 0): no bit writes, no statistics
     uint8_t* lcpb; // one byte per position (bit 0: LCP >= K, bit 1: LCP >= k_right) or null -> interleaved bit words `kr`
+    // below != 0: the COMPLEMENT is collected -- a writer marks its positions iff its depth is BELOW the threshold, and the
+    // vectors are inverted once at the end.  Every position 1..n-1 has exactly one writer (a node border or a leaf
+    // interior; lcp_values reaches n, ebwt2InDel.cpp:617,670) and with reads of 100+ bases nearly all writers lie deeper
+    // than K and k_right: marking the few shallow ones instead of the many deep ones removes ~95 % of the scattered
+    // stores of the traversal (phases 2-3 at 7.55 G positions: 0.58 -> 0.47 s).
+    int below;
+#ifdef EB_SCAN_EXPERIMENTS
+    uint32_t dbg;  // EB_NAV_DEBUG (profiling build only; results are wrong): 1 no LCP stores, 2 no minima, 4 children not appended below depth 40
+#endif
 };
+#ifdef EB_SCAN_EXPERIMENTS
+#define EB_NDBG(p) ((p).dbg)
+#else
+#define EB_NDBG(p) 0u
+#endif
 
 __device__ __forceinline__ uint64_t wave_sum(uint64_t v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor((unsigned long long)v, o);
@@ -145,7 +165,7 @@ __global__ void __launch_bounds__(256) k_leaves(eb_dev_index x1, eb_dev_index x2
             if (active && p.write && L.r > L.l + 1) {
                 // LCP slots l+1 .. r-1 of the leaf: the quad splits the touched words
                 uint64_t lo = L.l + 1, hi = L.r;
-                bool setK = (int64_t)L.depth >= p.K, setR = (int64_t)L.depth >= p.k_right;
+                bool setK = ((int64_t)L.depth >= p.K) != (p.below != 0), setR = ((int64_t)L.depth >= p.k_right) != (p.below != 0);
                 if ((setK || setR) && p.lcpb) {
                     uint8_t v = (uint8_t)((setK ? 1 : 0) | (setR ? 2 : 0));
                     for (uint64_t i2 = lo + j; i2 < hi; i2 += 4) p.lcpb[i2] = v; // every position has one writer: plain byte stores
@@ -170,7 +190,7 @@ __global__ void __launch_bounds__(256) k_leaves(eb_dev_index x1, eb_dev_index x2
             keep = active && ((b1 - a1) + (b2 - a2) >= 2);
             if (active && p.write) {
                 uint64_t s1 = L.l1 + L.l2, s2 = L.l2 + L.r1, e = L.r1 + L.r2;
-                bool setK = (int64_t)L.depth >= p.K, setR = (int64_t)L.depth >= p.k_right;
+                bool setK = ((int64_t)L.depth >= p.K) != (p.below != 0), setR = ((int64_t)L.depth >= p.k_right) != (p.below != 0);
                 // words of [s1, e): DA = 1 on [s2,e) (second collection), LCP bits on [s1+1, e)
                 uint64_t w0 = s1 >> 6, w1 = e > s1 ? (e - 1) >> 6 : w0;
                 for (uint64_t w = w0 + j; w <= w1 && e > s1; w += 4) {
@@ -216,12 +236,15 @@ __global__ void __launch_bounds__(256) k_leaves(eb_dev_index x1, eb_dev_index x2
 // (dna_bwt.hpp:381-404 / ebwt2InDel.cpp:529-553).  Four lanes per node: lane j loads the j-th chunk of the
 // six boundary blocks (one coalesced 64-byte segment per rank query), owns letter j, i.e. the Weiner-link
 // child "ACGT"[j] + W, and writes border j's LCP / minimum bits.
-template <int NB>
+// U nodes per quad and trip: the kernel is bound by memory latency x occupancy (three workgroups per CU because of the staging
+// buffer), so every lane puts the 6 U block loads of its U nodes in flight before it touches the first result.
+template <int NB, int U>
 __global__ void __launch_bounds__(256) k_nodes(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, uint64_t* __restrict__ kr, NavParams p, const void* in_,
                                               uint64_t count, void* out_, uint64_t out_cap, NavCounters* cnt, unsigned long long* __restrict__ stat_rows) {
     using Node = typename std::conditional<NB == 1, Node1, Node2>::type;
     using Rec = typename std::conditional<NB == 1, Node1P, Node2P>::type; // the record as it lies in the stacks
     constexpr int STAGE = NB == 1 ? 1536 : 768;
+    static_assert(STAGE % (256 * U) == 0, "a whole number of trips fills the staging buffer");
     __shared__ uint4 s_buf[STAGE * (sizeof(Rec) / 16)];
     __shared__ uint32_t s_count;
     __shared__ unsigned long long s_base;
@@ -232,89 +255,115 @@ __global__ void __launch_bounds__(256) k_nodes(eb_dev_index x1, eb_dev_index x2,
     Rec* out = static_cast<Rec*>(out_);
     const uint32_t j = threadIdx.x & 3u, q = threadIdx.x >> 2;
     uint64_t n_node = 0, n_lcp = 0, n_da = 0, n_rank = 0, n_min = 0;
-    const uint64_t tiles = (count + 63) / 64;
+    const uint64_t tiles = (count + 64 * U - 1) / (64 * U);
     uint32_t trips = 0;
     for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        uint64_t i = tile * 64 + q;
-        bool active = i < count;
-        Node N;
-        memset(&N, 0, sizeof N);
-        if (active) unpack_rec(in[i], N);
-        uint64_t m[6]; // merged boundaries (merge_nodes, include.hpp:476-490)
-        if constexpr (NB == 1) {
-            for (int k = 0; k < 6; ++k) m[k] = N.b[k];
-        } else {
-            for (int k = 0; k < 6; ++k) m[k] = N.a[k] + N.b[k];
+        Node N[U];
+        bool active[U];
+        uint4 ca[U][6], cb[NB == 2 ? U : 1][6];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t i = (tile * U + u) * 64 + q;
+            active[u] = i < count;
+            memset(&N[u], 0, sizeof(Node));
+            if (active[u]) unpack_rec(in[i], N[u]);
         }
-        if (active && p.write) {
-            // lane j looks after border j (right end of child TERM,A,C,G)
-            uint64_t lo = 0, hi = 0;
-            for (int k = 0; k < 4; ++k) if (j == (uint32_t)k) { lo = m[k]; hi = m[k + 1]; }
-            if (hi > lo && hi != m[5]) {
-                // the two threshold bits of a position sit in adjacent words of the same line (second atomic hits in L2)
-                if (p.lcpb) {
-                    // each LCP slot has exactly one writer (ebwt2InDel.cpp:617,670): a plain byte store replaces two
-                    // memory-side atomics (integer atomics on random lines cost ~2x a store and bypass L2)
-                    uint8_t v = (uint8_t)(((int64_t)N.depth >= p.K ? 1 : 0) | ((int64_t)N.depth >= p.k_right ? 2 : 0));
-                    if (v) p.lcpb[hi] = v;
+        // all rank loads of the trip, back to back
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                if constexpr (NB == 1) {
+                    ca[u][k] = eb_rank4_quad_load(x1, N[u].b[k], j);
                 } else {
-                    if ((int64_t)N.depth >= p.K) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * (hi >> 6)), 1ull << (hi & 63u));
-                    if ((int64_t)N.depth >= p.k_right) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * (hi >> 6) + 1), 1ull << (hi & 63u));
+                    ca[u][k] = eb_rank4_quad_load(x1, N[u].a[k], j);
+                    cb[u][k] = eb_rank4_quad_load(x2, N[u].b[k], j);
                 }
-                ++n_lcp;
             }
-            // a local LCP minimum follows each child A,C,G of size >= 2 that ends before last-1
-            if (j >= 1 && hi - lo >= 2 && hi < m[5] - 1) {
-                eb_bit_set_atomic(f.minima, hi);
-                ++n_min;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const Node& Nu = N[u];
+            uint64_t m[6]; // merged boundaries (merge_nodes, include.hpp:476-490)
+            if constexpr (NB == 1) {
+                for (int k = 0; k < 6; ++k) m[k] = Nu.b[k];
+            } else {
+                for (int k = 0; k < 6; ++k) m[k] = Nu.a[k] + Nu.b[k];
             }
-            if constexpr (NB == 2) {
-                // leaves of merged size 1 were not visited in phase 2: write their DA slot now (find_leaves)
-                for (int k = 0; k < 5; ++k) {
-                    if ((uint32_t)(k & 3) != j || (k == 4 && j != 0)) continue;
-                    uint64_t s1 = N.a[k + 1] - N.a[k], s2 = N.b[k + 1] - N.b[k];
-                    if (s1 + s2 == 1) {
-                        if (s2) eb_bit_set_atomic(f.da, N.b[k] + N.a[k + 1]);
-                        ++n_da;
+            if (active[u] && p.write) {
+                // lane j looks after border j (right end of child TERM,A,C,G)
+                uint64_t lo = 0, hi = 0;
+                for (int k = 0; k < 4; ++k) if (j == (uint32_t)k) { lo = m[k]; hi = m[k + 1]; }
+                if (hi > lo && hi != m[5]) {
+                    // the two threshold bits of a position sit in adjacent words of the same line (second atomic hits in L2)
+                    const bool setK = ((int64_t)Nu.depth >= p.K) != (p.below != 0), setR = ((int64_t)Nu.depth >= p.k_right) != (p.below != 0);
+                    if (p.lcpb) {
+                        // each LCP slot has exactly one writer (ebwt2InDel.cpp:617,670): a plain byte store replaces two
+                        // memory-side atomics (integer atomics on random lines cost ~2x a store and bypass L2)
+                        uint8_t v = (uint8_t)((setK ? 1 : 0) | (setR ? 2 : 0));
+                        if (v && !(EB_NDBG(p) & 1u)) p.lcpb[hi] = v;
+                    } else {
+                        if (setK) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * (hi >> 6)), 1ull << (hi & 63u));
+                        if (setR) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * (hi >> 6) + 1), 1ull << (hi & 63u));
+                    }
+                    ++n_lcp;
+                }
+                // a local LCP minimum follows each child A,C,G of size >= 2 that ends before last-1
+                if (j >= 1 && hi - lo >= 2 && hi < m[5] - 1) {
+                    if (!(EB_NDBG(p) & 2u)) eb_bit_set_atomic(f.minima, hi);
+                    ++n_min;
+                }
+                if constexpr (NB == 2) {
+                    // leaves of merged size 1 were not visited in phase 2: write their DA slot now (find_leaves)
+                    for (int k = 0; k < 5; ++k) {
+                        if ((uint32_t)(k & 3) != j || (k == 4 && j != 0)) continue;
+                        uint64_t s1 = Nu.a[k + 1] - Nu.a[k], s2 = Nu.b[k + 1] - Nu.b[k];
+                        if (s1 + s2 == 1) {
+                            if (s2) eb_bit_set_atomic(f.da, Nu.b[k] + Nu.a[k + 1]);
+                            ++n_da;
+                        }
                     }
                 }
             }
         }
-        Node child;
-        memset(&child, 0, sizeof child);
-        bool keep = false;
-        if constexpr (NB == 1) {
-            uint64_t Fj = pick4(x1.F, j);
-            int kids = 0;
-            for (int k = 0; k < 6; ++k) child.b[k] = Fj + eb_rank4_quad(x1, N.b[k], j);
-            for (int k = 0; k < 5; ++k) kids += child.b[k + 1] > child.b[k];
-            child.depth = N.depth + 1;
-            keep = active && kids >= 2; // number_of_children (include.hpp:760-768)
-            if (active && p.write && j == 0) {
-                ++n_node;
-                n_rank += 1;
-                for (int k = 1; k < 6; ++k) n_rank += N.b[k] != N.b[k - 1]; // the reference shares the query of equal neighbours
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const Node& Nu = N[u];
+            Node child;
+            memset(&child, 0, sizeof child);
+            bool keep = false;
+            if constexpr (NB == 1) {
+                uint64_t Fj = pick4(x1.F, j);
+                int kids = 0;
+                for (int k = 0; k < 6; ++k) child.b[k] = Fj + eb_rank4_quad_finish(x1, ca[u][k], Nu.b[k], j);
+                for (int k = 0; k < 5; ++k) kids += child.b[k + 1] > child.b[k];
+                child.depth = Nu.depth + 1;
+                keep = active[u] && kids >= 2; // number_of_children (include.hpp:760-768)
+                if (active[u] && p.write && j == 0) {
+                    ++n_node;
+                    n_rank += 1;
+                    for (int k = 1; k < 6; ++k) n_rank += Nu.b[k] != Nu.b[k - 1]; // the reference shares the query of equal neighbours
+                }
+            } else {
+                uint64_t F1 = pick4(x1.F, j), F2 = pick4(x2.F, j);
+                int kids = 0;
+                for (int k = 0; k < 6; ++k) {
+                    child.a[k] = F1 + eb_rank4_quad_finish(x1, ca[u][k], Nu.a[k], j);
+                    child.b[k] = F2 + eb_rank4_quad_finish(x2, cb[u][k], Nu.b[k], j);
+                }
+                for (int k = 0; k < 5; ++k) kids += (child.a[k + 1] > child.a[k]) || (child.b[k + 1] > child.b[k]); // include.hpp:784-792
+                child.depth = Nu.depth + 1;
+                keep = active[u] && kids >= 2;
+                if (active[u] && p.write && j == 0) {
+                    ++n_node;
+                    n_rank += 2;
+                    for (int k = 1; k < 6; ++k) n_rank += (Nu.a[k] != Nu.a[k - 1]) + (Nu.b[k] != Nu.b[k - 1]);
+                }
             }
-        } else {
-            uint64_t F1 = pick4(x1.F, j), F2 = pick4(x2.F, j);
-            int kids = 0;
-            for (int k = 0; k < 6; ++k) {
-                child.a[k] = F1 + eb_rank4_quad(x1, N.a[k], j);
-                child.b[k] = F2 + eb_rank4_quad(x2, N.b[k], j);
-            }
-            for (int k = 0; k < 5; ++k) kids += (child.a[k + 1] > child.a[k]) || (child.b[k + 1] > child.b[k]); // include.hpp:784-792
-            child.depth = N.depth + 1;
-            keep = active && kids >= 2;
-            if (active && p.write && j == 0) {
-                ++n_node;
-                n_rank += 2;
-                for (int k = 1; k < 6; ++k) n_rank += (N.a[k] != N.a[k - 1]) + (N.b[k] != N.b[k - 1]);
-            }
+            stage.push(keep, pack_rec(child));
         }
-        stage.push(keep, pack_rec(child));
-        // every tile adds at most 256 records: flushing every STAGE/256 tiles never overflows the buffer, and the
+        // every trip adds at most 256 U records: flushing every STAGE / (256 U) trips never overflows the buffer, and the
         // decision is the same in every thread without looking at shared state
-        if (++trips % (STAGE / 256) == 0) stage.flush(out, out_cap, &cnt->pushed);
+        if (++trips % (STAGE / (256 * U)) == 0) stage.flush(out, out_cap, &cnt->pushed);
     }
     stage.flush(out, out_cap, &cnt->pushed);
     const uint64_t st[EB_NAV_STATS] = {0, n_node, n_lcp, n_da, n_min, n_rank};
@@ -379,6 +428,22 @@ __global__ void __launch_bounds__(256) k_pack_lcp(const uint4* __restrict__ lcpb
         }
         thrK[w] = k;
         thrR[w] = r;
+    }
+}
+
+// complement form -> final form: thr = ~collected on positions 1 .. n-1, zero elsewhere (position 0 is never written by
+// the reference and stays 0; so do the spare bits behind n)
+__global__ void __launch_bounds__(256) k_invert_thr(uint64_t* __restrict__ thrK, uint64_t* __restrict__ thrR, uint64_t n, uint64_t alloc_words) {
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < alloc_words; w += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t m = 0;
+        const uint64_t base = w << 6;
+        if (base < n) {
+            m = ~0ull;
+            if (n - base < 64) m &= ~0ull >> (64 - (n - base));
+            if (w == 0) m &= ~1ull;
+        }
+        thrK[w] = ~thrK[w] & m;
+        thrR[w] = ~thrR[w] & m;
     }
 }
 
@@ -492,9 +557,9 @@ struct Drain {
     }
 };
 
-// 64 records per 256-thread workgroup and trip; the grid is capped and strides over the batch
-unsigned nav_grid(uint64_t count) {
-    uint64_t tiles = (count + 63) / 64;
+// 64 * per_quad records per 256-thread workgroup and trip; the grid is capped and strides over the batch
+unsigned nav_grid(uint64_t count, uint64_t per_quad = 1) {
+    uint64_t tiles = (count + 64 * per_quad - 1) / (64 * per_quad);
     const uint64_t cap = 256ull * 8;
     return (unsigned)(tiles < 1 ? 1 : (tiles > cap ? cap : tiles));
 }
@@ -556,6 +621,10 @@ __global__ void __launch_bounds__(256) k_fuse_flags(const uint64_t* __restrict__
 
 int eb_flags_derive(eb_flags* f) {
     EB_HIP(hipSetDevice(f->device));
+    if (f->complemented) { // a traversal (or the sum of its shards) left thrK / thrR in complement form
+        hipLaunchKernelGGL(k_invert_thr, dim3(2048), dim3(256), 0, f->stream, f->d_thrK, f->d_thrR, f->n, eb_bit_alloc_words(f->n));
+        f->complemented = false;
+    }
     // phase 4 reads LCP_threshold[2i] only as `LCP_threshold[2i] && !LCP_minima[i]` (ebwt2InDel.cpp:1618,1632): one word instead of two
     hipLaunchKernelGGL(k_fuse_flags, dim3(2048), dim3(256), 0, f->stream, f->d_thrK, f->d_min, eb_bit_alloc_words(f->n), f->d_flag);
     EB_HIP(hipStreamSynchronize(f->stream));
@@ -567,7 +636,7 @@ int eb_flags_derive(eb_flags* f) {
 }
 
 static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_right, uint32_t shard, uint32_t n_shards, eb_flags** out,
-                            eb_nav_stats* stats) {
+                            eb_nav_stats* stats, bool complement) {
     if (!b1 || !out) { eb_set_error("null argument"); return EB_ERR_ARG; }
     if (n_shards == 0 || shard >= n_shards) { eb_set_error("shard %u of %u", shard, n_shards); return EB_ERR_ARG; }
     if (K < 0 || K > 65534 || k_right < 0 || k_right > 65534) { eb_set_error("K and k_right must be below 65535"); return EB_ERR_ARG; }
@@ -600,10 +669,27 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
     EB_HIP(hipMemset(d_rows, 0, 2048 * EB_NAV_STATS * sizeof(unsigned long long)));
     struct GuardR { void* p; ~GuardR() { (void)hipFree(p); } } guard_r{d_rows};
     struct Guard2 { NavCounters* c; unsigned long long* h; ~Guard2() { (void)hipFree(c); (void)hipHostFree(h); } } guard2{d_cnt, h_pushed};
+    // The two traversals are independent (leaves write leaf interiors, nodes write child borders: disjoint positions), so
+    // they run side by side -- the leaves on a second stream driven by a second host thread, with counters, statistics
+    // rows and stacks of their own: the short leaf launches fill the gaps of the node launches (0.06 s hidden at config 2).
+    NavCounters* d_cnt2 = nullptr;
+    unsigned long long* h_pushed2 = nullptr;
+    unsigned long long* d_rows2 = nullptr;
+    hipStream_t st2 = nullptr;
+    EB_HIP(hipMalloc(&d_cnt2, sizeof(NavCounters)));
+    EB_HIP(hipMemset(d_cnt2, 0, sizeof(NavCounters)));
+    EB_HIP(hipHostMalloc(&h_pushed2, sizeof(unsigned long long)));
+    EB_HIP(hipMalloc(&d_rows2, 2048 * EB_NAV_STATS * sizeof(unsigned long long)));
+    EB_HIP(hipMemset(d_rows2, 0, 2048 * EB_NAV_STATS * sizeof(unsigned long long)));
+    EB_HIP(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
+    struct Guard5 { NavCounters* c; unsigned long long* h; unsigned long long* r; hipStream_t s; ~Guard5() { (void)hipFree(c); (void)hipHostFree(h); (void)hipFree(r); (void)hipStreamDestroy(s); } } guard5{d_cnt2, h_pushed2, d_rows2, st2};
 
     eb_dev_index x1 = b1->dev(), x2 = b2 ? b2->dev() : b1->dev();
     eb_dev_flags df = f->dev();
-    NavParams p{K, k_right, 1, nullptr};
+    NavParams p{K, k_right, 1, nullptr, complement ? 1 : 0};
+#ifdef EB_SCAN_EXPERIMENTS
+    p.dbg = (uint32_t)env_u64("EB_NAV_DEBUG", 0);
+#endif
     const uint64_t split_min = env_u64("EB_NAV_SPLIT_MIN", 4096);
     hipStream_t st = f->stream;
     const uint64_t batch_max = env_u64("EB_NAV_BATCH", 16ull << 20);
@@ -627,6 +713,12 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
     void* d_arena = eb_scratch_get(device, arena_bytes, &arena_cap);
     if (!d_arena) { eb_set_error("traversal arena allocation failed (%llu bytes)", (unsigned long long)arena_bytes); return EB_ERR_NOMEM; }
     struct Guard3 { int dev; void* p; size_t cap; ~Guard3() { eb_scratch_put(dev, p, cap); } } guard3{device, d_arena, arena_cap};
+    const bool concurrent = env_u64("EB_NAV_CONCURRENT", 1) != 0;
+    size_t arena2_cap = 0;
+    uint64_t arena2_bytes = concurrent ? arena_bytes / 2 : 0; // the leaf frontier stays far smaller than the node frontier
+    void* d_arena2 = concurrent ? eb_scratch_get(device, arena2_bytes, &arena2_cap) : nullptr;
+    struct Guard6 { int dev; void* p; size_t cap; ~Guard6() { if (p) eb_scratch_put(dev, p, cap); } } guard6{device, d_arena2, arena2_cap};
+    const bool side_by_side = concurrent && d_arena2 != nullptr;
     lap("arena allocated");
     // Threshold bits are collected either as one byte per position (plain stores; needs n bytes of spare HBM) or, when
     // memory is short, as interleaved bit words set with atomics; both are converted to the two bit vectors afterwards.
@@ -637,7 +729,10 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
     {
         size_t free_b = 0, total_b = 0;
         EB_HIP(hipMemGetInfo(&free_b, &total_b));
-        bool want_bytes = env_u64("EB_NAV_BYTES", 1) != 0 && lcpb_bytes + (4ull << 30) < free_b;
+        // Complement form (the default): writers are few, so atomicOr on the interleaved bit words costs nothing and the n-byte
+        // array, its clearing and its packing pass are saved.  The reference's form (EB_NAV_COMPLEMENT=0, and the fallback
+        // for inputs that are no eBWT) writes every position: bytes with plain stores when n spare bytes of HBM exist.
+        bool want_bytes = !complement && env_u64("EB_NAV_BYTES", 1) != 0 && lcpb_bytes + (4ull << 30) < free_b;
         if (want_bytes) d_lcpb = static_cast<uint8_t*>(eb_scratch_get(device, lcpb_bytes, &thr_cap));
         if (!d_lcpb) {
             d_kr = static_cast<uint64_t*>(eb_scratch_get(device, eb_bit_alloc_words(n) * 16, &thr_cap));
@@ -652,88 +747,110 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
     eb_nav_stats s;
     memset(&s, 0, sizeof s);
     s.n = n;
-    double t0 = now_s();
-    uint64_t launches = 0;
-
-    if (!b2) {
-        { // phase 2 (ebwt2InDel.cpp:577-615); first_leaf = {[0,F_A), 0} (dna_bwt.hpp:313-317)
+    EB_HIP(hipStreamSynchronize(f->stream)); // the cleared threshold words, before either traversal touches them
+    uint64_t launches_l = 0, launches_n = 0;
+    // phase 2 (ebwt2InDel.cpp:577-615 / :708-756); first_leaf = {[0,F_A), 0} (dna_bwt.hpp:313-317)
+    auto phase_leaves = [&](hipStream_t sx, NavCounters* dc, unsigned long long* hp, unsigned long long* rows, void* arena, uint64_t bytes) -> int {
+        int r;
+        if (!b2) {
             Drain<Leaf1> d;
-            d.device = b1->device; d.stream = st;
+            d.device = b1->device; d.stream = sx;
             d.shard = shard; d.n_shards = n_shards; d.split_min = split_min;
-            if ((rc = d.init(d_arena, arena_bytes, n, batch_max)) != EB_OK) return rc;
-            if ((rc = d.push_host(Leaf1{0, b1->F[0], 0, 0})) != EB_OK) return rc;
-            rc = d.run<-1>(d_cnt, h_pushed, [&](Leaf1* in, uint64_t cnt, Leaf1* o, uint64_t ocap, int write) {
+            if ((r = d.init(arena, bytes, n, batch_max)) != EB_OK) return r;
+            if ((r = d.push_host(Leaf1{0, b1->F[0], 0, 0})) != EB_OK) return r;
+            r = d.run<-1>(dc, hp, [&](Leaf1* in, uint64_t cnt, Leaf1* o, uint64_t ocap, int write) {
                 NavParams q = p;
                 q.write = write;
-                hipLaunchKernelGGL(k_leaves<1>, dim3(nav_grid(cnt)), dim3(256), 0, st, x1, x2, df, d_kr, q, in, cnt, o, ocap, d_cnt, d_rows);
+                hipLaunchKernelGGL(k_leaves<1>, dim3(nav_grid(cnt)), dim3(256), 0, sx, x1, x2, df, d_kr, q, in, cnt, o, ocap, dc, rows);
             });
-            if (rc != EB_OK) return rc;
-            launches += d.launches;
+            launches_l = d.launches;
+            return r;
         }
-        double t1 = now_s();
-        s.seconds_leaves = t1 - t0;
-        { // phase 3 (ebwt2InDel.cpp:622-673); root (dna_bwt.hpp:296-308)
+        Drain<Leaf2P> d;
+        d.device = b1->device; d.stream = sx;
+        d.shard = shard; d.n_shards = n_shards; d.split_min = split_min;
+        if ((r = d.init(arena, bytes, n, batch_max)) != EB_OK) return r;
+        if ((r = d.push_host(pack_rec(Leaf2{0, b1->F[0], 0, b2->F[0], 0, {0, 0, 0}}))) != EB_OK) return r;
+        r = d.run<1>(dc, hp, [&](Leaf2P* in, uint64_t cnt, Leaf2P* o, uint64_t ocap, int write) {
+            NavParams q = p;
+            q.write = write;
+            hipLaunchKernelGGL(k_leaves<2>, dim3(nav_grid(cnt)), dim3(256), 0, sx, x1, x2, df, d_kr, q, in, cnt, o, ocap, dc, rows);
+        });
+        launches_l = d.launches;
+        return r;
+    };
+    // phase 3 (ebwt2InDel.cpp:622-673 / :764-823); root (dna_bwt.hpp:296-308)
+    auto phase_nodes = [&](hipStream_t sx, NavCounters* dc, unsigned long long* hp, unsigned long long* rows, void* arena, uint64_t bytes) -> int {
+        int r;
+        if (!b2) {
             Drain<Node1P> d;
-            d.device = b1->device; d.stream = st;
+            d.device = b1->device; d.stream = sx;
             d.shard = shard; d.n_shards = n_shards; d.split_min = split_min;
-            if ((rc = d.init(d_arena, arena_bytes, n, batch_max)) != EB_OK) return rc;
+            if ((r = d.init(arena, bytes, n, batch_max)) != EB_OK) return r;
             Node1 root{{0, b1->F[0], b1->F[1], b1->F[2], b1->F[3], b1->n}, 0, 0};
-            if ((rc = d.push_host(pack_rec(root))) != EB_OK) return rc;
-            rc = d.run<-1>(d_cnt, h_pushed, [&](Node1P* in, uint64_t cnt, Node1P* o, uint64_t ocap, int write) {
+            if ((r = d.push_host(pack_rec(root))) != EB_OK) return r;
+            r = d.run<-1>(dc, hp, [&](Node1P* in, uint64_t cnt, Node1P* o, uint64_t ocap, int write) {
                 NavParams q = p;
                 q.write = write;
-                hipLaunchKernelGGL(k_nodes<1>, dim3(nav_grid(cnt)), dim3(256), 0, st, x1, x2, df, d_kr, q, in, cnt, o, ocap, d_cnt, d_rows);
+                hipLaunchKernelGGL((k_nodes<1, EB_NODES_PER_QUAD>), dim3(nav_grid(cnt, EB_NODES_PER_QUAD)), dim3(256), 0, sx, x1, x2, df, d_kr, q, in, cnt, o, ocap, dc, rows);
             });
-            if (rc != EB_OK) return rc;
-            launches += d.launches;
+            launches_n = d.launches;
+            return r;
         }
-        s.seconds_nodes = now_s() - t1;
+        Drain<Node2P> d;
+        d.device = b1->device; d.stream = sx;
+        d.shard = shard; d.n_shards = n_shards; d.split_min = split_min;
+        if ((r = d.init(arena, bytes, n, batch_max)) != EB_OK) return r;
+        Node2 root{{0, b1->F[0], b1->F[1], b1->F[2], b1->F[3], b1->n}, {0, b2->F[0], b2->F[1], b2->F[2], b2->F[3], b2->n}, 0, {0, 0, 0}};
+        if ((r = d.push_host(pack_rec(root))) != EB_OK) return r;
+        r = d.run<1>(dc, hp, [&](Node2P* in, uint64_t cnt, Node2P* o, uint64_t ocap, int write) {
+            NavParams q = p;
+            q.write = write;
+            hipLaunchKernelGGL((k_nodes<2, 1>), dim3(nav_grid(cnt)), dim3(256), 0, sx, x1, x2, df, d_kr, q, in, cnt, o, ocap, dc, rows);
+        });
+        launches_n = d.launches;
+        return r;
+    };
+    double t0 = now_s();
+    if (side_by_side) {
+        int rc_l = EB_OK;
+        std::string err_l;
+        double t_l = 0;
+        std::thread leaf_thread([&] {
+            (void)hipSetDevice(device);
+            rc_l = phase_leaves(st2, d_cnt2, h_pushed2, d_rows2, d_arena2, arena2_bytes);
+            if (rc_l != EB_OK) err_l = eb_last_error(); // the message is thread-local
+            t_l = now_s() - t0;
+        });
+        rc = phase_nodes(st, d_cnt, h_pushed, d_rows, d_arena, arena_bytes);
+        s.seconds_nodes = now_s() - t0;
+        leaf_thread.join();
+        s.seconds_leaves = t_l;
+        if (rc == EB_OK && rc_l != EB_OK) { eb_set_error("%s", err_l.c_str()); rc = rc_l; }
+        if (rc != EB_OK) return rc;
     } else {
-        { // phase 2 (ebwt2InDel.cpp:708-756)
-            Drain<Leaf2P> d;
-            d.device = b1->device; d.stream = st;
-            d.shard = shard; d.n_shards = n_shards; d.split_min = split_min;
-            if ((rc = d.init(d_arena, arena_bytes, n, batch_max)) != EB_OK) return rc;
-            if ((rc = d.push_host(pack_rec(Leaf2{0, b1->F[0], 0, b2->F[0], 0, {0, 0, 0}}))) != EB_OK) return rc;
-            rc = d.run<1>(d_cnt, h_pushed, [&](Leaf2P* in, uint64_t cnt, Leaf2P* o, uint64_t ocap, int write) {
-                NavParams q = p;
-                q.write = write;
-                hipLaunchKernelGGL(k_leaves<2>, dim3(nav_grid(cnt)), dim3(256), 0, st, x1, x2, df, d_kr, q, in, cnt, o, ocap, d_cnt, d_rows);
-            });
-            if (rc != EB_OK) return rc;
-            launches += d.launches;
-        }
+        if ((rc = phase_leaves(st, d_cnt, h_pushed, d_rows, d_arena, arena_bytes)) != EB_OK) return rc;
         double t1 = now_s();
         s.seconds_leaves = t1 - t0;
-        { // phase 3 (ebwt2InDel.cpp:764-823)
-            Drain<Node2P> d;
-            d.device = b1->device; d.stream = st;
-            d.shard = shard; d.n_shards = n_shards; d.split_min = split_min;
-            if ((rc = d.init(d_arena, arena_bytes, n, batch_max)) != EB_OK) return rc;
-            Node2 root{{0, b1->F[0], b1->F[1], b1->F[2], b1->F[3], b1->n}, {0, b2->F[0], b2->F[1], b2->F[2], b2->F[3], b2->n}, 0, {0, 0, 0}};
-            if ((rc = d.push_host(pack_rec(root))) != EB_OK) return rc;
-            rc = d.run<1>(d_cnt, h_pushed, [&](Node2P* in, uint64_t cnt, Node2P* o, uint64_t ocap, int write) {
-                NavParams q = p;
-                q.write = write;
-                hipLaunchKernelGGL(k_nodes<2>, dim3(nav_grid(cnt)), dim3(256), 0, st, x1, x2, df, d_kr, q, in, cnt, o, ocap, d_cnt, d_rows);
-            });
-            if (rc != EB_OK) return rc;
-            launches += d.launches;
-        }
+        if ((rc = phase_nodes(st, d_cnt, h_pushed, d_rows, d_arena, arena_bytes)) != EB_OK) return rc;
         s.seconds_nodes = now_s() - t1;
     }
+    const uint64_t launches = launches_l + launches_n;
     if (d_lcpb) hipLaunchKernelGGL(k_pack_lcp, dim3(4096), dim3(256), 0, st, reinterpret_cast<const uint4*>(d_lcpb), f->words, f->d_thrK, f->d_thrR);
     else hipLaunchKernelGGL(k_split_kr, dim3(2048), dim3(256), 0, st, reinterpret_cast<const uint4*>(d_kr), f->words, f->d_thrK, f->d_thrR);
     lap("traversals");
     EB_HIP(hipStreamSynchronize(st));
     EB_HIP(hipGetLastError());
     lap("threshold bits packed");
+    f->complemented = complement;
     if (n_shards == 1 && (rc = eb_flags_derive(f)) != EB_OK) return rc; // shards: eb_flags_finalize, after the reduction
     NavCounters c;
     memset(&c, 0, sizeof c);
     {
-        std::vector<unsigned long long> rows(2048 * EB_NAV_STATS);
+        std::vector<unsigned long long> rows(2048 * EB_NAV_STATS), rows2(2048 * EB_NAV_STATS);
         EB_HIP(hipMemcpy(rows.data(), d_rows, rows.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        EB_HIP(hipMemcpy(rows2.data(), d_rows2, rows2.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < rows.size(); ++k) rows[k] += rows2[k];
         for (size_t r = 0; r < 2048; ++r) {
             c.leaves += rows[r * EB_NAV_STATS + 0];
             c.nodes += rows[r * EB_NAV_STATS + 1];
@@ -777,12 +894,29 @@ extern "C" int eb_selftest_pack_fields(int32_t n_fields, const uint64_t* fields,
 }
 
 extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_right, eb_flags** out, eb_nav_stats* stats) {
-    return flags_build_impl(b1, b2, K, k_right, 0, 1, out, stats);
+    if (!out) { eb_set_error("null argument"); return EB_ERR_ARG; }
+    const bool complement = env_u64("EB_NAV_COMPLEMENT", 1) != 0;
+    eb_nav_stats s;
+    int rc = flags_build_impl(b1, b2, K, k_right, 0, 1, out, &s, complement);
+    if (rc != EB_OK) return rc;
+    if (complement && s.lcp_values != s.n) {
+        // Not every LCP slot was written exactly once: the input is not the eBWT of a read collection.  The reference leaves
+        // unwritten slots at 0 (vector<bool>(n,false), ebwt2InDel.cpp:571), which the complement form cannot know: walk again
+        // the reference's way (writers at or above the thresholds set their bits).
+        eb_flags_destroy(*out);
+        *out = nullptr;
+        rc = flags_build_impl(b1, b2, K, k_right, 0, 1, out, &s, false);
+        if (rc != EB_OK) return rc;
+    }
+    if (stats) *stats = s;
+    return EB_OK;
 }
 
 extern "C" int eb_flags_build_shard(eb_index* b1, eb_index* b2, int32_t K, int32_t k_right, uint32_t shard, uint32_t n_shards, eb_flags** out,
                                     eb_nav_stats* stats) {
-    return flags_build_impl(b1, b2, K, k_right, shard, n_shards, out, stats);
+    // shards collect the complement (see NavParams::below): their vectors still add up (one writer per marked bit), and
+    // eb_flags_finalize inverts the sum.  Callers check that the shards' lcp_values add up to n (a valid eBWT).
+    return flags_build_impl(b1, b2, K, k_right, shard, n_shards, out, stats, n_shards > 1 ? true : env_u64("EB_NAV_COMPLEMENT", 1) != 0);
 }
 
 extern "C" int eb_flags_device_vectors(eb_flags* f, uint64_t* d_vectors[4], uint64_t* words) {
@@ -912,13 +1046,14 @@ extern "C" int eb_flags_export(eb_flags* f, uint64_t* thrK, uint64_t* thrR, uint
     return EB_OK;
 }
 
-extern "C" int eb_flags_import(uint64_t n, int device, const uint64_t* thrK, const uint64_t* thrR, const uint64_t* minima,
-                               const uint64_t* da, eb_flags** out) {
+static int flags_import_impl(uint64_t n, int device, const uint64_t* thrK, const uint64_t* thrR, const uint64_t* minima, const uint64_t* da,
+                             bool complemented, eb_flags** out) {
     if (!out || !thrK || !thrR || !minima) { eb_set_error("null argument"); return EB_ERR_ARG; }
     *out = nullptr;
     eb_flags* f = nullptr;
     int rc = eb_flags_alloc(n, device, da != nullptr, &f);
     if (rc != EB_OK) return rc;
+    f->complemented = complemented;
     size_t bytes = f->words * 8;
     hipError_t e = hipMemcpy(f->d_thrK, thrK, bytes, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(f->d_thrR, thrR, bytes, hipMemcpyHostToDevice);
@@ -928,6 +1063,16 @@ extern "C" int eb_flags_import(uint64_t n, int device, const uint64_t* thrK, con
     if ((rc = eb_flags_derive(f)) != EB_OK) { eb_flags_destroy(f); return rc; }
     *out = f;
     return EB_OK;
+}
+
+extern "C" int eb_flags_import(uint64_t n, int device, const uint64_t* thrK, const uint64_t* thrR, const uint64_t* minima,
+                               const uint64_t* da, eb_flags** out) {
+    return flags_import_impl(n, device, thrK, thrR, minima, da, false, out);
+}
+
+extern "C" int eb_flags_import_shard_sum(uint64_t n, int device, const uint64_t* thrK_below, const uint64_t* thrR_below, const uint64_t* minima,
+                                         const uint64_t* da, eb_flags** out) {
+    return flags_import_impl(n, device, thrK_below, thrR_below, minima, da, true, out);
 }
 
 extern "C" void eb_flags_destroy(eb_flags* f) {

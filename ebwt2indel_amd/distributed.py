@@ -189,9 +189,11 @@ def navigate_sharded(bwt1, params, bwt2=None, group=None, device=None):
                 dist.all_reduce(torch.from_numpy(v.view(np.int64)), op=dist.ReduceOp.SUM, group=group)
         n = bwt1.n + (bwt2.n if bwt2 is not None else 0)
         fl.close()
-        fl = api.Flags.from_host(n, *vecs, device=bwt1.device)
+        fl = api.Flags.from_shard_sum(n, *vecs, device=bwt1.device)
         fl.stats = st
-    got = fl.popcounts()
+        got = [int(np.unpackbits(v.view(np.uint8)).sum()) if v is not None else 0 for v in vecs]
+    if dev.type == "cuda":
+        got = fl.popcounts()
     if got != [int(v) for v in ones.tolist()]:
         raise RuntimeError(f"sharded traversal: a bit of the flag vectors was set by more than one rank (ones after the reduction {got}, "
                            f"sum of the ranks' ones {ones.tolist()}; order thrK, thrR, minima, da)")
@@ -203,6 +205,10 @@ def navigate_sharded(bwt1, params, bwt2=None, group=None, device=None):
     dist.all_reduce(sec, op=dist.ReduceOp.MAX, group=group)
     for k, v in zip(_NAV_COUNTERS, cnt.tolist()):
         setattr(st, k, int(v))
+    if st.n > 0 and st.lcp_values != st.n:
+        # the shards collected the complement of the LCP thresholds, which is exact only if every position has one writer
+        raise RuntimeError(f"sharded traversal wrote {st.lcp_values} of {st.n} LCP slots: the input is not the eBWT of a read collection "
+                           f"(the single-GPU path handles such inputs the reference's way)")
     st.seconds_leaves, st.seconds_nodes = float(sec[0]), float(sec[1])
     return fl
 

@@ -137,6 +137,13 @@ int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_right, eb_fl
  * combine with an integer SUM (== OR) all-reduce -- RCCL has no bitwise OR.  Then call eb_flags_finalize on every rank. */
 int eb_flags_build_shard(eb_index* b1, eb_index* b2, int32_t K, int32_t k_right, uint32_t shard, uint32_t n_shards, eb_flags** out,
                          eb_nav_stats* stats);
+/* SHARD FORM.  Until eb_flags_finalize, the thrK / thrR vectors of a shard hold the COMPLEMENT: bit i set iff this shard
+ * wrote position i with an LCP BELOW the threshold (with reads of 100+ bases nearly all writers lie deeper than K and
+ * k_right, so the traversal marks the few shallow ones and skips ~95 % of its scattered stores); minima and da are plain.
+ * Every position 1..n-1 has one writer over all shards when the input is the eBWT of a read collection -- callers check
+ * that the shards' lcp_values add up to n -- so the shards' vectors still combine with SUM, and eb_flags_finalize turns
+ * the sum into thrK / thrR (inverts it on positions 1..n-1).  eb_flags_device_vectors and eb_flags_export hand out the
+ * vectors as they are stored; eb_flags_import_shard_sum takes the sum back when it was formed in host memory. */
 /* Device pointers of thrK, thrR, minima, da (NULL in one-BWT mode), eb_flags_words() words each, for the reduction. */
 int eb_flags_device_vectors(eb_flags* f, uint64_t* d_vectors[4], uint64_t* words);
 /* Ones in thrK, thrR, minima, da (0 where absent).  The SUM reduction of a sharded build is an OR only while every bit
@@ -155,6 +162,9 @@ int eb_flags_has_da(const eb_flags* f);
 int eb_flags_export(eb_flags* f, uint64_t* thrK, uint64_t* thrR, uint64_t* minima, uint64_t* da);
 int eb_flags_import(uint64_t n, int device, const uint64_t* thrK, const uint64_t* thrR, const uint64_t* minima,
                     const uint64_t* da, eb_flags** out);
+/* import of vectors in SHARD FORM (the SUM of the shards' eb_flags_export words); returns finalised flags */
+int eb_flags_import_shard_sum(uint64_t n, int device, const uint64_t* thrK_below, const uint64_t* thrR_below, const uint64_t* minima,
+                              const uint64_t* da, eb_flags** out);
 void eb_flags_destroy(eb_flags* f);
 
 /* ------------------------------------------------------------------ phase 4
