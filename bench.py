@@ -197,10 +197,10 @@ def main():
     begin, end = ebd.shard_range(n, rank, world)
 
     # One step = one phase-4 pass over the whole BWT + hand-over of the cluster records to rank 0's host memory.
-    # Steps are software-pipelined one deep, as a production caller with a queue of samples would run them: the
-    # next pass is enqueued (eb_scan_clusters_begin) before the previous one's records are waited for / gathered, so
-    # the PCIe download and the RCCL gather of step i overlap the kernels of step i+1.  Exactly `steps` passes start
-    # and finish between the two barriers.
+    # Steps are software-pipelined, as a caller with a queue of work would run them (run_steps below): passes are begun
+    # (eb_scan_clusters_begin) ahead of the one whose records are waited for / gathered, so the PCIe download and the
+    # RCCL gather of step i overlap the kernels of the steps behind it.  Exactly `steps` passes start and finish between
+    # the two barriers.
     # With RCCL the call set never visits a non-root host: each rank's device image goes GPU -> GPU over xGMI and rank 0
     # downloads once.  (gloo rehearsal / single GPU: records are downloaded by the library into page-locked memory.)
     device_gather = use_dist and comm_dev.type == "cuda" and os.environ.get("EB_BENCH_HOST_GATHER", "0") != "1"
@@ -242,19 +242,27 @@ def main():
             for _ in range(k):
                 done(collect(begin_step()))
             return last
-        # two stages in flight: the kernels of step i+1 run while the records of step i travel (PCIe download, or
-        # RCCL gather + rank 0's download), and that hand-over is waited for only after step i+1's has been started
-        job, pending = begin_step(), None
-        for _ in range(k - 1):
-            nxt = begin_step()
-            started = collect(job)
+        # A caller with a queue of work keeps TWO passes begun ahead of the one it collects: begin(i+1) puts its scan on the
+        # GPU and, behind that scan, the context kernels pass i was holding back (eb_scan.hip: launch_contexts) -- so the small
+        # kernels and the host round trip between a scan and its own context kernels lie under the previous pass's context
+        # kernels -- and begin(i+2) is issued before pass i's records are waited for, so that their download (PCIe) or their
+        # RCCL gather runs under pass i+1's kernels.  The hand-over of pass i is resolved one collect later.
+        from collections import deque
+        begun, pending = deque(), None
+        for _ in range(k):
+            begun.append(begin_step())
+            if len(begun) > 2:
+                started = collect(begun.popleft())
+                if pending is not None:
+                    done(pending)
+                pending = started
+        while begun:
+            started = collect(begun.popleft())
             if pending is not None:
                 done(pending)
-            job, pending = nxt, started
-        started = collect(job)
+            pending = started
         if pending is not None:
             done(pending)
-        done(started)
         return last
 
     if args.warmup > 0:
@@ -431,7 +439,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": workload, "mode": 1, "options": "-L31 -R30 -k16 -g10 -v2 -m3 -c20 -q0",
-                       "parallelism": f"scan range split over {world} GPU(s), BWT+flags replicated, gather of cluster records to rank 0; " + ("steps back to back" if args.no_pipeline else "steps pipelined one deep")},
+                       "parallelism": f"scan range split over {world} GPU(s), BWT+flags replicated, gather of cluster records to rank 0; " + ("steps back to back" if args.no_pipeline else "steps pipelined (two begun ahead of the one collected)")},
             "roofline": {"bound": "hbm", "achieved": round(scan_gbs, 2), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(scan_gbs / 8000.0, 5), "traffic": traffic, "kernel": "k_scan",
                          "avg_launch_ms": round(scan_avg_ms, 4), "launches_per_step": scan_launches, "positions_per_launch": int(positions_per_launch),

@@ -187,12 +187,17 @@ __device__ __forceinline__ uint64_t eb_select(const eb_dev_index& x, uint64_t r,
     return eb_select(x, r, c, probes);
 }
 
+// F[letter] by selects: a dynamic index into a kernel-argument array would send the whole struct to scratch memory
+__device__ __forceinline__ uint64_t eb_F_of(const eb_dev_index& x, int letter) {
+    return letter == 0 ? x.F[0] : letter == 1 ? x.F[1] : letter == 2 ? x.F[2] : x.F[3];
+}
+
 // FL(i) (dna_bwt.hpp:115-133); i must not be a TERM row.
 __device__ __forceinline__ uint64_t eb_FL(const eb_dev_index& x, uint64_t i, int letter) {
-    return eb_select(x, i - x.F[letter], letter);
+    return eb_select(x, i - eb_F_of(x, letter), letter);
 }
 __device__ __forceinline__ uint64_t eb_FL(const eb_dev_index& x, uint64_t i, int letter, uint32_t& probes) {
-    return eb_select(x, i - x.F[letter], letter, probes);
+    return eb_select(x, i - eb_F_of(x, letter), letter, probes);
 }
 
 __device__ __forceinline__ bool eb_bit(const uint64_t* b, uint64_t i) { return (b[i >> 6] >> (i & 63u)) & 1ull; }

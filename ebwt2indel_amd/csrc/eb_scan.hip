@@ -615,16 +615,42 @@ __global__ void __launch_bounds__(256) k_bucket_place(const Survivor* __restrict
     uint32_t k = bucket_of(v.b, base);
     out[off[k] + atomicAdd(&fill[k], 1u)] = v;
 }
-// one thread per bucket: insertion sort of the (rare) buckets with more than one survivor
+// one thread per bucket puts the buckets with more than one survivor in order: insertion sort for the usual handful,
+// an in-place heapsort when a bucket is crowded (a repeat-rich stretch of the BWT, or the adversarial test patterns), so
+// that no input turns this into a quadratic crawl
 __global__ void __launch_bounds__(256) k_bucket_fix(const uint32_t* __restrict__ off, uint64_t n_buckets, Survivor* __restrict__ out) {
     uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_buckets) return;
     const uint32_t lo = off[k], hi = off[k + 1];
-    for (uint32_t i = lo + 1; i < hi; ++i) {
-        Survivor v = out[i];
-        uint32_t j = i;
-        while (j > lo && out[j - 1].b > v.b) { out[j] = out[j - 1]; --j; }
-        if (j != i) out[j] = v;
+    const uint32_t m = hi - lo;
+    if (m <= 24) {
+        for (uint32_t i = lo + 1; i < hi; ++i) {
+            Survivor v = out[i];
+            uint32_t j = i;
+            while (j > lo && out[j - 1].b > v.b) { out[j] = out[j - 1]; --j; }
+            if (j != i) out[j] = v;
+        }
+        return;
+    }
+    Survivor* a = out + lo;
+    auto sift = [&](uint32_t root, uint32_t end) { // max-heap on .b over a[0, end)
+        Survivor v = a[root];
+        for (;;) {
+            uint32_t child = 2 * root + 1;
+            if (child >= end) break;
+            if (child + 1 < end && a[child + 1].b > a[child].b) ++child;
+            if (a[child].b <= v.b) break;
+            a[root] = a[child];
+            root = child;
+        }
+        a[root] = v;
+    };
+    for (uint32_t i = m / 2; i-- > 0;) sift(i, m);
+    for (uint32_t end = m - 1; end > 0; --end) {
+        Survivor t = a[0];
+        a[0] = a[end];
+        a[end] = t;
+        sift(0, end);
     }
 }
 // chains per surviving cluster (slots beyond the survivors stay 0)
@@ -668,6 +694,7 @@ __device__ __forceinline__ void count_requests(unsigned long long* __restrict__ 
 // Four lanes per chain.  extract_consensus(bwt,range,c,...) ebwt2InDel.cpp:303-319 -> LF(range,c), then
 // up to k_left-1 x { LF(range) ; consensus_letter } (:243-282).  Output: eb_chain + bases packed 2 bits each in
 // extension order (the writer reverses them, :315).
+template <bool TWO> // TWO: two-BWT mode (the only one in which a chain may run in the second index)
 __global__ void __launch_bounds__(256) k_extend(eb_dev_index x1, eb_dev_index x2, ScanParams p, const Survivor* __restrict__ surv,
                                                const uint64_t* __restrict__ chains, uint64_t n_chains, eb_chain* __restrict__ crec,
                                                uint64_t* __restrict__ left, uint32_t left_words, unsigned long long* __restrict__ req_slots) {
@@ -681,10 +708,12 @@ __global__ void __launch_bounds__(256) k_extend(eb_dev_index x1, eb_dev_index x2
     uint32_t sidx = (uint32_t)(item & 7u);
     Survivor s = surv[i];
     uint32_t side = sidx >> 2, c = sidx & 3u;
-    const bool second = p.mode == 2 && side == 1;
-    const eb_dev_index& x = second ? x2 : x1;
+    // the index of this chain: a by-value pick of the few fields used (a reference chosen at run time between two kernel
+    // arguments would put both structs into scratch memory, on the path of every dependent step)
+    eb_dev_index x = x1;
+    if (TWO && side == 1) { x.chunks = x2.chunks; x.super = x2.super; for (int k = 0; k < 4; ++k) x.F[k] = x2.F[k]; }
     uint64_t L, R;
-    if (p.mode == 2) { L = side ? s.b1 : s.b0; R = side ? s.e1 : s.e0; } else { L = s.b; R = s.e; }
+    if (TWO) { L = side ? s.b1 : s.b0; R = side ? s.e1 : s.e0; } else { L = s.b; R = s.e; }
     uint64_t* out = left + ch * (uint64_t)left_words;
     // LF(range, c)
     uint64_t a, bq;
@@ -743,6 +772,7 @@ __global__ void __launch_bounds__(256) k_extend(eb_dev_index x1, eb_dev_index x2
 // It needs nothing but the survivors in BWT order, so it is launched as soon as they are -- before the host knows their
 // number (ns_ptr, device memory) and before the call set's image exists: records and contexts go to temporaries,
 // k_right_finish moves them into the image and adds the chain offsets.
+template <bool TWO>
 __global__ void __launch_bounds__(256) k_right(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, ScanParams p,
                                               const Survivor* __restrict__ surv, const uint32_t* __restrict__ ns_ptr,
                                               const uint32_t* __restrict__ chain_off /* null: temporaries, k_right_finish adds it */, uint32_t chain_base,
@@ -782,14 +812,17 @@ __global__ void __launch_bounds__(256) k_right(eb_dev_index x1, eb_dev_index x2,
     }
     uint32_t len = 0;
     if (pos != ~0ull && walk) {
-        bool second = false;
         uint64_t row = pos;
-        if (p.mode == 2) {
-            second = eb_bit(f.da, pos);
+        eb_dev_index x = x1; // by value, see k_extend
+        if (TWO) {
+            const bool second = eb_bit(f.da, pos);
             uint64_t i1 = da_rank(f, pos);
             row = second ? i1 : pos - i1;
+            if (second) {
+                x.chunks = x2.chunks; x.super = x2.super; x.sel_dir = x2.sel_dir;
+                for (int k = 0; k < 4; ++k) { x.F[k] = x2.F[k]; x.sel_off[k] = x2.sel_off[k]; }
+            }
         }
-        const eb_dev_index& x = second ? x2 : x1;
         uint64_t* out = right + i * (uint64_t)right_words;
         uint64_t word = 0;
         int c = eb_F_letter(x, row);
@@ -883,6 +916,8 @@ struct SubShard {
     eb_chain* d_crec = nullptr;
     uint64_t *d_left = nullptr, *d_right = nullptr;
     uint64_t ns_raw = 0, ns = 0, n_chains = 0, rec_base = 0, chain_base = 0;
+    bool right_early = false;        // k_right was launched with the preparation (small call set); only its finishing kernel is left
+    const uint32_t* d_ns = nullptr;  // survivors kept, in device memory (k_right's bound)
     hipEvent_t e[E_PER_SHARD]; // scan_t0, scan_t1, scan_done, prep_cnt, prep_done, ext_t0, ext_done, right_t0, right_done, sorted
     ScanCounters* h_cnt = nullptr;
     uint32_t* h_last = nullptr;
@@ -908,6 +943,11 @@ struct eb_scan_job {
     uint64_t wire_bytes = 0;
     int32_t k_left = 0, k_right = 0;
     bool wire_full_width = false; // the tight wire image overflowed: full-width records were packed instead
+    // what launch_contexts (part two of _begin) needs
+    eb_dev_index x1, x2;
+    eb_dev_flags df;
+    ScanParams p;
+    uint32_t lw = 0, rw = 0;
 };
 
 // friendly records -> compact wire records (eb_scan_job_device_wire); *bad counts fields that do not fit
@@ -983,6 +1023,116 @@ void eb_scan_ctx_destroy(eb_scan_ctx* c) {
 
 static int wire_enqueue(eb_scan_job* job, hipStream_t st, unsigned long long* h_bad, int version);
 
+// Part two of a phase-4 job: the context kernels, the hand-over of the call set (host blob or device image, wire image)
+// and the end event.  (Round 2 tried holding this part back until the NEXT job on the index had enqueued its scan, so that
+// the small kernels and the host round trip between a scan and its own context kernels would lie under the previous job's
+// context kernels: 3.80 ms per step against 3.61 -- the preparation kernels and the context kernels slow each other down
+// by more than the gap they hide.)
+static int launch_contexts(eb_scan_job* job) {
+    eb_index* b1 = job->b1;
+    eb_scan_ctx* ctx = b1->scan_ctx;
+    EB_HIP(hipSetDevice(b1->device));
+    const hipStream_t sB = ctx->ext, sC = ctx->right, sD = ctx->copy;
+    const eb_dev_index& x1 = job->x1;
+    const eb_dev_index& x2 = job->x2;
+    const eb_dev_flags& df = job->df;
+    const ScanParams& p = job->p;
+    const uint32_t lw = job->lw, rw = job->rw;
+    const int S = job->S;
+    const uint32_t options = job->options;
+    std::vector<SubShard>& sh = job->sh;
+    auto kern_extend = p.mode == 2 ? k_extend<true> : k_extend<false>;
+    auto kern_right = p.mode == 2 ? k_right<true> : k_right<false>;
+    int rc;
+    for (int k = 0; k < S; ++k) {
+        SubShard& x = sh[(size_t)k];
+        if (x.ns == 0) continue;
+        const bool right_early = x.right_early;
+        // the two context kernels are independent dependent-load chains: one stream each
+        EB_HIP(hipStreamWaitEvent(sB, x.e[E_PREP_DONE], 0));
+        EB_HIP(hipEventRecord(x.e[E_EXT0], sB));
+        if (x.n_chains)
+            hipLaunchKernelGGL(kern_extend, dim3(grid_of(x.n_chains * 4)), dim3(256), 0, sB, x1, x2, p, x.sorted.as<Survivor>(), x.chains.as<uint64_t>(), x.n_chains,
+                               x.d_crec, x.d_left, lw, x.cnt.as<ScanCounters>()->req_ext);
+        EB_HIP(hipEventRecord(x.e[E_EXT_DONE], sB));
+        EB_HIP(hipEventRecord(ctx->last_ext, sB));
+        EB_HIP(hipStreamWaitEvent(sC, x.e[E_PREP_DONE], 0));
+        if (!right_early) {
+            // A large call set keeps the memory system busy with either kernel alone, so nothing is lost by running the
+            // right-context walk BEHIND the left-context extension -- and it can then skip the clusters whose chains came
+            // out too short to ever print (see the gate in k_right): straight into the image, one request in nine saved.
+            EB_HIP(hipStreamWaitEvent(sC, x.e[E_EXT_DONE], 0));
+            EB_HIP(hipEventRecord(x.e[E_RIGHT0], sC));
+            hipLaunchKernelGGL(kern_right, dim3(grid_of(x.ns)), dim3(256), 0, sC, x1, x2, df, p, x.sorted.as<Survivor>(), x.d_ns,
+                               x.choff.as<uint32_t>(), (uint32_t)x.chain_base, x.d_recs, x.d_right, rw, x.cnt.as<ScanCounters>()->req_right,
+                               (const eb_chain*)x.d_crec);
+        } else
+            hipLaunchKernelGGL(k_right_finish, dim3(grid_of(x.ns)), dim3(256), 0, sC, x.rt_rec.as<eb_cluster>(), x.rt_right.as<uint64_t>(), x.choff.as<uint32_t>(),
+                           (uint32_t)x.chain_base, x.ns, rw, x.d_recs, x.d_right);
+        EB_HIP(hipEventRecord(x.e[E_RIGHT_DONE], sC));
+        EB_HIP(hipEventRecord(ctx->last_right, sC));
+        EB_HIP(hipGetLastError());
+    }
+    const uint64_t ns = job->ns, n_chains = job->n_chains;
+    struct { int32_t k_left, k_right; } prm_{job->k_left, job->k_right};
+    auto* prm = &prm_;
+    hipEvent_t ev_end = job->ev_end;
+    // ---- the call set in host memory (unless the caller keeps it on the device): one page-locked blob; with one shard
+    // the device image is copied in one piece, with sub-shards each shard's sections as soon as its kernels are done
+    const bool device_only = (options & EB_SCAN_DEVICE_ONLY) != 0;
+    if (ns == 0 && S == 1 && !job->has_blob) {
+        // nothing survived: the device image is just a header
+        SubShard& x = sh[0];
+        if ((rc = x.blob.alloc(sizeof(eb_calls_header))) != EB_OK) return rc;
+        job->has_blob = true;
+        job->blob_bytes = sizeof(eb_calls_header);
+        job->header = eb_calls_header{EB_CALLS_MAGIC, 0, 0, (uint64_t)(uint32_t)prm->k_left, (uint64_t)(uint32_t)prm->k_right, {0, 0, 0}};
+        hipLaunchKernelGGL(k_blob_header, dim3(1), dim3(64), 0, sD, job->header, x.blob.as<uint64_t>());
+    }
+    eb_calls* calls = nullptr;
+    struct CallGuard { eb_calls** c; ~CallGuard() { if (*c) eb_calls_free(*c); } } cg{&calls};
+    EB_HIP(hipStreamWaitEvent(sD, sh[(size_t)S - 1].e[E_SCAN_DONE], 0));
+    for (int k = 0; k < S; ++k) {
+        SubShard& x = sh[(size_t)k];
+        if (x.ns == 0) continue;
+        EB_HIP(hipStreamWaitEvent(sD, x.e[E_EXT_DONE], 0));
+        EB_HIP(hipStreamWaitEvent(sD, x.e[E_RIGHT_DONE], 0));
+    }
+    for (int k = 0; k < S; ++k) { // request counts of the context kernels -> the job's pinned words [1 + 2k, 2 + 2k]
+        SubShard& x = sh[(size_t)k];
+        if (x.ns == 0) continue;
+        hipLaunchKernelGGL(k_req_sum, dim3(1), dim3(EB_REQ_SLOTS), 0, sD, x.cnt.as<ScanCounters>());
+        EB_HIP(hipMemcpyAsync(job->h_bad + 1 + 2 * k, x.cnt.as<ScanCounters>()->req_sum, 16, hipMemcpyDeviceToHost, sD));
+    }
+    if (!device_only) {
+        calls = eb_calls_alloc(ns, n_chains, prm->k_left, prm->k_right, ns != 0);
+        if (!calls) return EB_ERR_NOMEM;
+        if (job->has_blob && ns) {
+            EB_HIP(hipMemcpyAsync(calls->blob, sh[0].blob.p, job->blob_bytes, hipMemcpyDeviceToHost, sD));
+        } else {
+            for (int k = 0; k < S; ++k) {
+                SubShard& x = sh[(size_t)k];
+                if (x.ns == 0) continue;
+                EB_HIP(hipMemcpyAsync(calls->clusters + x.rec_base, x.d_recs, x.ns * sizeof(eb_cluster), hipMemcpyDeviceToHost, sD));
+                EB_HIP(hipMemcpyAsync(calls->right + x.rec_base * rw, x.d_right, x.ns * (size_t)rw * 8, hipMemcpyDeviceToHost, sD));
+                if (x.n_chains) {
+                    EB_HIP(hipMemcpyAsync(calls->chains + x.chain_base, x.d_crec, x.n_chains * sizeof(eb_chain), hipMemcpyDeviceToHost, sD));
+                    EB_HIP(hipMemcpyAsync(calls->left + x.chain_base * lw, x.d_left, x.n_chains * (size_t)lw * 8, hipMemcpyDeviceToHost, sD));
+                }
+            }
+        }
+    }
+    job->ns = ns;
+    job->n_chains = n_chains;
+    if ((options & EB_SCAN_WIRE) && job->has_blob && (rc = wire_enqueue(job, sD, job->h_bad, 4)) != EB_OK) return rc;
+    EB_HIP(hipEventRecord(ev_end, sD));
+    job->calls = calls;
+    calls = nullptr; // owned by the job from here on
+    job->ns = ns;
+    job->n_chains = n_chains;
+    return EB_OK;
+}
+
 extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f, uint64_t begin, uint64_t end, const eb_params* prm,
                                          uint32_t options, eb_scan_job** out_job) {
     if (!b1 || !f || !prm || !out_job) { eb_set_error("null argument"); return EB_ERR_ARG; }
@@ -1043,7 +1193,7 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
         EB_HIP(hipEventRecord(ctx->last_ext, ctx->ext));
         EB_HIP(hipEventRecord(ctx->last_right, ctx->right));
     }
-    const hipStream_t sA = b1->stream, sP = ctx->prep, sB = ctx->ext, sC = ctx->right, sD = ctx->copy;
+    const hipStream_t sA = b1->stream, sP = ctx->prep, sC = ctx->right;
     uint64_t w_lo = begin >> 6, w_hi = (end + 63) >> 6;
     uint64_t w_total = w_hi > w_lo ? w_hi - w_lo : 0;
     // Measured at 7.55 G positions (EB_SCAN_SUBSHARDS=1/2/4/8): 6.5 / 6.1 / 6.4 / 11.0 ms per call -- the streaming scan and
@@ -1098,6 +1248,7 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
     job->ev_end = ev_end;
     int rc;
     auto kern = p.mode == 1 ? k_scan<1> : (p.mode == 2 ? k_scan<2> : k_scan<3>);
+    auto kern_right = p.mode == 2 ? k_right<true> : k_right<false>;
     auto launch_scan = [&](SubShard& x) -> int {
         ScanParams q = p;
         q.begin = x.begin;
@@ -1208,7 +1359,7 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
             EB_HIP(hipStreamWaitEvent(sC, x.e[E_SORTED], 0));
             EB_HIP(hipEventRecord(x.e[E_RIGHT0], sC));
             EB_HIP(hipMemsetAsync(x.rt_right.p, 0, x.ns_raw * (size_t)rw * 8, sC));
-            hipLaunchKernelGGL(k_right, dim3(right_grid), dim3(256), 0, sC, x1, x2, df, p, x.sorted.as<Survivor>(), d_boff + n_buckets,
+            hipLaunchKernelGGL(kern_right, dim3(right_grid), dim3(256), 0, sC, x1, x2, df, p, x.sorted.as<Survivor>(), d_boff + n_buckets,
                                (const uint32_t*)nullptr, 0u, x.rt_rec.as<eb_cluster>(), x.rt_right.as<uint64_t>(), rw, x.cnt.as<ScanCounters>()->req_right,
                                (const eb_chain*)nullptr);
         }
@@ -1257,89 +1408,21 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
         }
         hipLaunchKernelGGL(k_chain_list, dim3(grid_of(x.ns)), dim3(256), 0, sP, x.sorted.as<Survivor>(), x.choff.as<uint32_t>(), x.ns, x.chains.as<uint64_t>());
         EB_HIP(hipEventRecord(x.e[E_PREP_DONE], sP));
-        // the two context kernels are independent dependent-load chains: one stream each
-        EB_HIP(hipStreamWaitEvent(sB, x.e[E_PREP_DONE], 0));
-        EB_HIP(hipEventRecord(x.e[E_EXT0], sB));
-        if (x.n_chains)
-            hipLaunchKernelGGL(k_extend, dim3(grid_of(x.n_chains * 4)), dim3(256), 0, sB, x1, x2, p, x.sorted.as<Survivor>(), x.chains.as<uint64_t>(), x.n_chains,
-                               x.d_crec, x.d_left, lw, x.cnt.as<ScanCounters>()->req_ext);
-        EB_HIP(hipEventRecord(x.e[E_EXT_DONE], sB));
-        EB_HIP(hipEventRecord(ctx->last_ext, sB));
-        EB_HIP(hipStreamWaitEvent(sC, x.e[E_PREP_DONE], 0));
-        if (!right_early) {
-            // A large call set keeps the memory system busy with either kernel alone, so nothing is lost by running the
-            // right-context walk BEHIND the left-context extension -- and it can then skip the clusters whose chains came
-            // out too short to ever print (see the gate in k_right): straight into the image, one request in nine saved.
-            EB_HIP(hipStreamWaitEvent(sC, x.e[E_EXT_DONE], 0));
-            EB_HIP(hipEventRecord(x.e[E_RIGHT0], sC));
-            hipLaunchKernelGGL(k_right, dim3(grid_of(x.ns)), dim3(256), 0, sC, x1, x2, df, p, x.sorted.as<Survivor>(), x.boff.as<uint32_t>() + n_buckets,
-                               x.choff.as<uint32_t>(), (uint32_t)x.chain_base, x.d_recs, x.d_right, rw, x.cnt.as<ScanCounters>()->req_right,
-                               (const eb_chain*)x.d_crec);
-        } else
-            hipLaunchKernelGGL(k_right_finish, dim3(grid_of(x.ns)), dim3(256), 0, sC, x.rt_rec.as<eb_cluster>(), x.rt_right.as<uint64_t>(), x.choff.as<uint32_t>(),
-                           (uint32_t)x.chain_base, x.ns, rw, x.d_recs, x.d_right);
-        EB_HIP(hipEventRecord(x.e[E_RIGHT_DONE], sC));
-        EB_HIP(hipEventRecord(ctx->last_right, sC));
-        EB_HIP(hipGetLastError());
+        x.right_early = right_early;
+        x.d_ns = x.boff.as<uint32_t>() + n_buckets;
         rec_total += x.ns;
         chain_total += x.n_chains;
     }
-    const uint64_t ns = rec_total, n_chains = chain_total;
-
-    // ---- the call set in host memory (unless the caller keeps it on the device): one page-locked blob; with one shard
-    // the device image is copied in one piece, with sub-shards each shard's sections as soon as its kernels are done
-    const bool device_only = (options & EB_SCAN_DEVICE_ONLY) != 0;
-    if (ns == 0 && S == 1 && !job->has_blob) {
-        // nothing survived: the device image is just a header
-        SubShard& x = sh[0];
-        if ((rc = x.blob.alloc(sizeof(eb_calls_header))) != EB_OK) return rc;
-        job->has_blob = true;
-        job->blob_bytes = sizeof(eb_calls_header);
-        job->header = eb_calls_header{EB_CALLS_MAGIC, 0, 0, (uint64_t)(uint32_t)prm->k_left, (uint64_t)(uint32_t)prm->k_right, {0, 0, 0}};
-        hipLaunchKernelGGL(k_blob_header, dim3(1), dim3(64), 0, sD, job->header, x.blob.as<uint64_t>());
-    }
-    eb_calls* calls = nullptr;
-    struct CallGuard { eb_calls** c; ~CallGuard() { if (*c) eb_calls_free(*c); } } cg{&calls};
-    EB_HIP(hipStreamWaitEvent(sD, sh[(size_t)S - 1].e[E_SCAN_DONE], 0));
-    for (int k = 0; k < S; ++k) {
-        SubShard& x = sh[(size_t)k];
-        if (x.ns == 0) continue;
-        EB_HIP(hipStreamWaitEvent(sD, x.e[E_EXT_DONE], 0));
-        EB_HIP(hipStreamWaitEvent(sD, x.e[E_RIGHT_DONE], 0));
-    }
-    for (int k = 0; k < S; ++k) { // request counts of the context kernels -> the job's pinned words [1 + 2k, 2 + 2k]
-        SubShard& x = sh[(size_t)k];
-        if (x.ns == 0) continue;
-        hipLaunchKernelGGL(k_req_sum, dim3(1), dim3(EB_REQ_SLOTS), 0, sD, x.cnt.as<ScanCounters>());
-        EB_HIP(hipMemcpyAsync(job->h_bad + 1 + 2 * k, x.cnt.as<ScanCounters>()->req_sum, 16, hipMemcpyDeviceToHost, sD));
-    }
-    if (!device_only) {
-        calls = eb_calls_alloc(ns, n_chains, prm->k_left, prm->k_right, ns != 0);
-        if (!calls) return EB_ERR_NOMEM;
-        if (job->has_blob && ns) {
-            EB_HIP(hipMemcpyAsync(calls->blob, sh[0].blob.p, job->blob_bytes, hipMemcpyDeviceToHost, sD));
-        } else {
-            for (int k = 0; k < S; ++k) {
-                SubShard& x = sh[(size_t)k];
-                if (x.ns == 0) continue;
-                EB_HIP(hipMemcpyAsync(calls->clusters + x.rec_base, x.d_recs, x.ns * sizeof(eb_cluster), hipMemcpyDeviceToHost, sD));
-                EB_HIP(hipMemcpyAsync(calls->right + x.rec_base * rw, x.d_right, x.ns * (size_t)rw * 8, hipMemcpyDeviceToHost, sD));
-                if (x.n_chains) {
-                    EB_HIP(hipMemcpyAsync(calls->chains + x.chain_base, x.d_crec, x.n_chains * sizeof(eb_chain), hipMemcpyDeviceToHost, sD));
-                    EB_HIP(hipMemcpyAsync(calls->left + x.chain_base * lw, x.d_left, x.n_chains * (size_t)lw * 8, hipMemcpyDeviceToHost, sD));
-                }
-            }
-        }
-    }
-    job->ns = ns;
-    job->n_chains = n_chains;
-    if ((options & EB_SCAN_WIRE) && job->has_blob && (rc = wire_enqueue(job, sD, job->h_bad, 4)) != EB_OK) return rc;
-    EB_HIP(hipEventRecord(ev_end, sD));
-    job->calls = calls;
-    calls = nullptr; // owned by the job from here on
+    job->ns = rec_total;
+    job->n_chains = chain_total;
     job->c = c;
-    job->ns = ns;
-    job->n_chains = n_chains;
+    job->x1 = x1;
+    job->x2 = x2;
+    job->df = df;
+    job->p = p;
+    job->lw = lw;
+    job->rw = rw;
+    if ((rc = launch_contexts(job)) != EB_OK) return rc;
     *out_job = job;
     job = nullptr;
     return EB_OK;

@@ -222,8 +222,15 @@ typedef struct {
 int eb_scan_clusters(eb_index* b1, eb_index* b2, eb_flags* f, uint64_t begin, uint64_t end, const eb_params* p,
                      eb_calls** out, eb_scan_stats* stats);
 
-/* Split form for callers that pipeline calls (the record download of one call overlaps the kernels of the next):
- * _begin returns once everything is enqueued on the handles' streams; _end waits and hands over the results.
+/* Split form for callers that pipeline calls (the record download of one call overlaps the kernels of the next).
+ * _begin enqueues the scan, waits for it on the host (the number of surviving clusters sizes the next buffers; a list
+ * that overflowed is scanned again with room), enqueues the ordering of the survivors, waits a second time (survivor
+ * and chain counts size the call set's image), enqueues the context kernels, the copy to page-locked host memory and,
+ * if asked for, the wire image -- and returns.  So _begin blocks for about the time of the scan (plus ~0.25 ms); what
+ * is still in flight when it returns are the context kernels and the hand-over of the records, i.e. most of the job.
+ * _end waits for those and hands over the results.  (Making _begin enqueue-only was tried twice in round 2 -- sizing
+ * everything by the survivor list's capacity with device-resident counts, and holding the context kernels back for the
+ * next job's scan -- and measured slower both times: DESIGN.md section 3.)
  * Several jobs may be in flight on the same handles; each must be ended (or cancelled) exactly once, in any order. */
 typedef struct eb_scan_job eb_scan_job;
 int eb_scan_clusters_begin(eb_index* b1, eb_index* b2, eb_flags* f, uint64_t begin, uint64_t end, const eb_params* p,

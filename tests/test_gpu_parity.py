@@ -164,13 +164,24 @@ FLAG_CASES = [c for c in CASES if c["name"] in ("m1_default", "m1_k20", "m1_L40_
                                                 "m3_het_default", "m1_tiny_nocluster")]
 
 
-@pytest.mark.parametrize("nav_bytes", ["1", "0"], ids=["lcp_bytes", "atomic_words"])
+NAV_MODES = {
+    # default: writers BELOW the thresholds mark their positions in interleaved bit words (atomicOr), inverted at the end;
+    # leaves and nodes side by side on two streams
+    "complement": {},
+    "complement_one_stream": {"EB_NAV_CONCURRENT": "0"},
+    # the reference's form (also the fallback for inputs that are no eBWT): writers at or above the thresholds set their bits --
+    # one byte per position with plain stores (needs n spare bytes of HBM), or bit words with atomicOr when memory is short
+    "classic_bytes": {"EB_NAV_COMPLEMENT": "0", "EB_NAV_BYTES": "1"},
+    "classic_words": {"EB_NAV_COMPLEMENT": "0", "EB_NAV_BYTES": "0"},
+}
+
+
+@pytest.mark.parametrize("nav_mode", list(NAV_MODES))
 @pytest.mark.parametrize("case", FLAG_CASES, ids=lambda c: c["name"])
-def test_flag_vectors_bit_exact(oracle, monkeypatch, case, nav_bytes):
-    """Both ways the traversal collects the LCP thresholds: one byte per position with plain stores (needs n spare bytes of
-    HBM), and -- EB_NAV_BYTES=0, the path a BWT too large for that takes (configs[4]: 151 GB of bytes do not fit) --
-    interleaved K/R bit words set with atomicOr."""
-    monkeypatch.setenv("EB_NAV_BYTES", nav_bytes)
+def test_flag_vectors_bit_exact(oracle, monkeypatch, case, nav_mode):
+    """Every way the traversal collects the LCP thresholds gives the oracle's vectors, bit for bit."""
+    for k, v in NAV_MODES[nav_mode].items():
+        monkeypatch.setenv(k, v)
     p, e1, e2, da = _flag_case(oracle, case)
     o1 = oracle.index(e1, p.term)
     o2 = oracle.index(e2, p.term) if e2 is not None else None
@@ -198,12 +209,48 @@ def test_flags_batch_size_does_not_change_result(oracle, monkeypatch):
     e = golden_bytes("dip.ebwt")
     g = api.DnaBwt(e)
     ref = api.Flags.build(g, None, 16, 30).export()
-    for batch, nav_bytes in (("64", "1"), ("1000", "1"), ("777", "0")):   # tiny batches: many launches, depth-first order
-        monkeypatch.setenv("EB_NAV_BATCH", batch)
-        monkeypatch.setenv("EB_NAV_BYTES", nav_bytes)
+    for batch, mode in (("64", "complement"), ("1000", "classic_bytes"), ("777", "classic_words"), ("300", "complement_one_stream")):
+        monkeypatch.setenv("EB_NAV_BATCH", batch)                 # tiny batches: many launches, depth-first order
+        for k in ("EB_NAV_COMPLEMENT", "EB_NAV_BYTES", "EB_NAV_CONCURRENT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in NAV_MODES[mode].items():
+            monkeypatch.setenv(k, v)
         got = api.Flags.build(g, None, 16, 30).export()
         for a, b in zip(got[:3], ref[:3]):
             assert np.array_equal(a, b)
+
+
+NOT_EBWT = {
+    # legal input files (the reference takes any string over A,C,G,T,TERM) that are the eBWT of no read collection and whose
+    # traversal leaves LCP slots unwritten (oracle: lcp_values 1723 / 4999 / 1 of n)
+    "runs": lambda r: np.frombuffer((b"A" * 50 + b"C" * 50 + b"#" * 3 + b"G" * 50 + b"T" * 50) * 10, dtype=np.uint8),
+    "hardly_any_terminator": lambda r: r.choice(np.frombuffer(b"ACGT#", dtype=np.uint8), size=5000, p=[0.2499] * 4 + [0.0004]),
+    "one_letter": lambda r: np.frombuffer(b"A" * 300, dtype=np.uint8),
+}
+
+
+@pytest.mark.parametrize("name", list(NOT_EBWT))
+def test_input_that_is_no_ebwt_falls_back_to_the_reference_form(oracle, monkeypatch, name):
+    """When the traversal does not write every LCP slot the reference leaves the others at 0; the complement form (which
+    would leave them at 1) must notice (lcp_values != n) and walk again the reference's way."""
+    for seed in range(40):                                        # the random one: first seed that leaves slots unwritten
+        e = NOT_EBWT[name](np.random.Generator(np.random.PCG64(seed)))
+        o = oracle.index(e)
+        of = _oracle.OracleFlags(oracle, o, None, 16, 30)
+        oc = of.counters()
+        if oc["lcp_values"] != len(e):
+            break
+    assert oc["lcp_values"] != len(e)                              # the premise
+    g = api.DnaBwt(e)
+    got = api.Flags.build(g, None, 16, 30)
+    monkeypatch.setenv("EB_NAV_COMPLEMENT", "0")
+    classic = api.Flags.build(g, None, 16, 30)
+    for a, b, c in zip(got.export()[:3], classic.export()[:3], of.export()[:3]):
+        assert np.array_equal(a, b) and np.array_equal(a, c)
+    assert got.stats.lcp_values == classic.stats.lcp_values == oc["lcp_values"]
+    want, _ = oracle.run(e)
+    monkeypatch.delenv("EB_NAV_COMPLEMENT")
+    assert api.run_one_dataset(e) == want
 
 
 def test_short_document_array_repeats_its_last_byte(oracle):
