@@ -421,17 +421,28 @@ def main():
                              "what": "the same phase-4 scan, range sharded over host threads"},
                "reference": reference}
 
-    # HBM traffic of the dominant kernel from the PMC passes committed under profiles/ (FETCH_SIZE / WRITE_SIZE cannot be
-    # collected from inside this process); used only when it was measured on the same launch size.
-    traffic = None
+    # HBM traffic of the kernels from the PMC passes committed under profiles/ (counters cannot be collected from inside this
+    # process): bytes per launch from the request-size split -- TCC_EA0_RDREQ_128B x 128 + TCC_EA0_RDREQ_64B x 64 + WRITE_SIZE
+    # (scripts/profile_round.sh, scripts/pmc_summary.py) -- divided by the launch time measured HERE; used only when the
+    # profile was taken on the same launch size.  GB/s, the unit of `achieved`.
+    traffic = ctx_traffic = rank_traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as fh:
             pmc = json.load(fh)
-        ks = pmc["kernels"]["k_scan<1>"]
-        if abs(pmc["workload_positions"] - positions_per_launch) <= 0.01 * positions_per_launch and scan_avg_ms > 0:
-            traffic = round(ks["hbm_bytes_per_launch_corrected"] / (scan_avg_ms * 1e-3) / 1e9, 2)   # GB/s, same unit as `achieved`
+        same = abs(pmc["workload_positions"] - positions_per_launch) <= 0.01 * positions_per_launch
+        if same and scan_avg_ms > 0:
+            traffic = round(pmc["kernels"]["k_scan<1>"]["hbm_bytes_per_launch_by_request_size"] / (scan_avg_ms * 1e-3) / 1e9, 2)
+        if same and ctx_ms and np.mean(ctx_ms) > 0:
+            b = pmc["kernels"]["k_extend"]["hbm_bytes_per_launch_by_request_size"] + pmc["kernels"]["k_right"]["hbm_bytes_per_launch_by_request_size"]
+            ctx_traffic = round(b / (float(np.mean(ctx_ms)) * 1e-3) / 1e9, 2)
+        if rank_info is not None and abs(pmc["workload_positions"] - n) <= 0.01 * n and pmc["rank_kernel"]["queries"] == rank_info["queries"]:
+            rank_traffic = round(pmc["rank_kernel"]["hbm_bytes_per_launch_by_request_size"] / (rank_info["ms"] * 1e-3) / 1e9, 2)
+            rank_info["traffic"] = rank_traffic
+            rank_info["traffic_note"] = ("every fabric read of this kernel is a 128-byte request (PMC: TCC_EA0_RDREQ_128B == TCC_EA0_RDREQ): a query moves "
+                                         "128 B (line of its 64-byte block) + 8 B (position) + 32 B (result) = 168 B of HBM traffic, so 64 B/query at "
+                                         "the chip's ~6 TB/s streaming limit caps at ~36 GQ/s = 0.29 of this roofline for uniformly random queries")
     except Exception:
-        traffic = None
+        pass
 
     if rank == 0:
         line = {
@@ -449,17 +460,18 @@ def main():
                               "frac": round(0.75 * n / (ms_per_step * 1e-3) / 1e9 / (8000.0 * world), 5),
                               "what": "0.75 algorithmic bytes x all positions / ms_per_step, against the HBM peak of the GPUs used: scan + "
                                       "survivor ordering + both context kernels + hand-over of the records"},
-            # the kernels that dominate the step: k_extend || k_right (side by side on two streams), dependent random reads.  Requests
+            # the kernels that dominate the step: k_extend, then k_right (a large call set runs them one behind the other; a small one
+            # side by side on two streams), dependent random reads.  Requests
             # are counted on the device where they are issued (eb_scan_stats.requests_*), 64 bytes each, over first start .. last end.
             "context_roofline": {"bound": "hbm", "achieved": round((np.mean(req_ext) + np.mean(req_right)) * 64 / (max(np.mean(ctx_ms), 1e-9) * 1e-3) / 1e9, 2),
                                  "peak": 8000.0, "unit": "GB/s",
                                  "frac": round((np.mean(req_ext) + np.mean(req_right)) * 64 / (max(np.mean(ctx_ms), 1e-9) * 1e-3) / 1e9 / 8000.0, 5),
-                                 "traffic": None, "kernel": "k_extend || k_right", "ms": round(float(np.mean(ctx_ms)), 4),
+                                 "traffic": ctx_traffic, "kernel": "k_extend, then k_right", "ms": round(float(np.mean(ctx_ms)), 4),
                                  "requests_extend": int(np.mean(req_ext)), "requests_right": int(np.mean(req_right)),
                                  "bytes_per_request": 64, "requests_per_s": round((np.mean(req_ext) + np.mean(req_right)) / (max(np.mean(ctx_ms), 1e-9) * 1e-3), 1),
                                  "what": "rank 0's shard; k_extend: one request per 64-byte block of a rank pair (1-2 per LF step); k_right: one per "
-                                         "select-directory read + one per block probed; ceiling for independent random 64-byte reads on this chip: "
-                                         "profiles/r02_rank_probe.txt"},
+                                         "select-directory read + one per block probed; the chip serves ~47 G independent random 64-byte reads per second, "
+                                         "each as a 128-byte line (profiles/r02_rank_probe.txt, r02_rank_probe_cache_policy.txt, r02_pmc_traffic.json)"},
             "rank_roofline": rank_info,
             "cpu_baseline": cpu,
             "phase4_device_ms": {"scan": round(scan_sum_ms, 4), "extend": round(float(np.mean(ext_ms)), 4),

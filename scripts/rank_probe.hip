@@ -30,6 +30,33 @@ __global__ void __launch_bounds__(256) k_gather(const uint4* __restrict__ chunks
     }
     if (acc == 0x12345678u) sink[0] = acc;
 }
+// gather only with a cache policy on the block loads (inline asm: hipcc has no builtin for sc0/sc1 on global loads):
+// POLICY 1 = sc1, 2 = sc0 sc1, 3 = nt, 4 = sc0 sc1 nt.  Does a policy make the L2 ask the fabric for 64 bytes instead of a
+// 128-byte line (TCC_EA0_RDREQ_64B / _128B under rocprofv3), and does the request rate change?
+template <int K, int POLICY>
+__global__ void __launch_bounds__(256) k_gather_pol(const uint4* __restrict__ chunks, const uint64_t* __restrict__ pos, uint64_t m, uint64_t* __restrict__ sink) {
+    const uint32_t j = threadIdx.x & 3;
+    uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    const uint64_t stride = ((uint64_t)gridDim.x * blockDim.x) >> 2;
+    uint32_t acc = 0;
+    for (; q + (K - 1) * stride < m; q += K * stride) {
+        uint64_t i[K]; uint4 c[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) i[k] = pos[q + k * stride];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint4* a = chunks + ((i[k] >> 7) << 2) + j;
+            if (POLICY == 1) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(c[k]) : "v"(a) : "memory");
+            else if (POLICY == 2) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(c[k]) : "v"(a) : "memory");
+            else if (POLICY == 3) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(c[k]) : "v"(a) : "memory");
+            else asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1 nt" : "=v"(c[k]) : "v"(a) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc += counts(c[k], pmask(i[k] & 127, j)) + c[k].w;
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
 // full rank with output, K in flight
 template <int K, bool NT>
 __global__ void __launch_bounds__(256) k_rank(const uint4* __restrict__ chunks, const uint64_t* __restrict__ pos, uint64_t m, uint64_t* __restrict__ out4) {
@@ -88,6 +115,14 @@ int main(int argc, char** argv) {
         float n4 = time_ms([&] { hipLaunchKernelGGL((k_rank<4, true>), dim3(g), dim3(256), 0, 0, chunks, pos, m, out); });
         float n8 = time_ms([&] { hipLaunchKernelGGL((k_rank<8, true>), dim3(g), dim3(256), 0, 0, chunks, pos, m, out); });
         printf("grid %5d rank+output  K=2 %.1f  K=4 %.1f  K=8 %.1f  nt K=4 %.1f  nt K=8 %.1f GQ/s\n", g, m / r2 / 1e6, m / r4 / 1e6, m / r8 / 1e6, m / n4 / 1e6, m / n8 / 1e6);
+    }
+    {
+        const int g = 256 * 16;
+        float p1 = time_ms([&] { hipLaunchKernelGGL((k_gather_pol<4, 1>), dim3(g), dim3(256), 0, 0, chunks, pos, m, sink); });
+        float p2 = time_ms([&] { hipLaunchKernelGGL((k_gather_pol<4, 2>), dim3(g), dim3(256), 0, 0, chunks, pos, m, sink); });
+        float p3 = time_ms([&] { hipLaunchKernelGGL((k_gather_pol<4, 3>), dim3(g), dim3(256), 0, 0, chunks, pos, m, sink); });
+        float p4 = time_ms([&] { hipLaunchKernelGGL((k_gather_pol<4, 4>), dim3(g), dim3(256), 0, 0, chunks, pos, m, sink); });
+        printf("grid %5d gather-only K=4 by cache policy: sc1 %.1f  sc0 sc1 %.1f  nt %.1f  sc0 sc1 nt %.1f GQ/s\n", g, m / p1 / 1e6, m / p2 / 1e6, m / p3 / 1e6, m / p4 / 1e6);
     }
     float w = time_ms([&] { hipLaunchKernelGGL(k_write_only, dim3(256 * 16), dim3(256), 0, 0, m, out); });
     printf("write-only 32 B/query: %.1f GQ/s (%.2f TB/s)\n", m / w / 1e6, m * 32 / w / 1e9);
