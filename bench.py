@@ -190,8 +190,9 @@ def main():
     ns = flags.stats
     if rank == 0:
         log(f"[bench] index {t_index*1e3:.1f} ms ({bwt.device_bytes/1e9:.2f} GB); phases 2-3 on GPU {t_nav:.3f}s: {ns.nodes} nodes, {ns.leaves} leaves, "
-            f"{ns.rank_queries} rank queries in {ns.batches} launches; traversals {ns.seconds_leaves + ns.seconds_nodes:.3f}s -> "
-            f"{ns.rank_queries/max(ns.seconds_leaves + ns.seconds_nodes,1e-9)/1e9:.2f} GQ/s in situ (wall time also covers HBM allocation and, for N > 1, the all-reduce of the bit vectors)")
+            f"{ns.rank_queries} rank queries in {ns.batches} launches; traversals {ns.seconds_traversal:.3f}s -> "
+            f"{ns.rank_queries/max(ns.seconds_traversal,1e-9)/1e9:.2f} GQ/s in situ (the wall time also covers HBM allocation -- right after the generator "
+            f"freed ~100 GB the driver's wipe of that memory can stall a hipMalloc for seconds -- and, for N > 1, the all-reduce of the bit vectors)")
     assert ns.lcp_values == n, "phases 2-3 did not cover every LCP slot"
 
     begin, end = ebd.shard_range(n, rank, world)
@@ -477,9 +478,13 @@ def main():
             "phase4_device_ms": {"scan": round(scan_sum_ms, 4), "extend": round(float(np.mean(ext_ms)), 4),
                                  "right": round(float(np.mean(right_ms)), 4), "context_span": round(float(np.mean(ctx_ms)), 4),
                                  "total": round(float(np.mean(tot_ms)), 4)},
-            "phases23_gpu": {"seconds": round(t_nav, 4), "traversal_shards": world if use_dist else 1, "traversal_seconds": round(float(ns.seconds_leaves + ns.seconds_nodes), 4),
-                             "rank_gq_per_s": round(ns.rank_queries / max(ns.seconds_leaves + ns.seconds_nodes, 1e-9) / 1e9, 2), "nodes": int(ns.nodes), "leaves": int(ns.leaves), "rank_queries": int(ns.rank_queries),
-                             "launches": int(ns.batches), "e2e_positions_per_s": round(n / (t_nav + ms_per_step * 1e-3), 1)},
+            # seconds: the two traversals (leaves and nodes side by side) + packing of the bit vectors, first launch to last result;
+            # wall_seconds: the whole call, i.e. also HBM allocation (which, right behind the generator's 100 GB of frees, can wait
+            # seconds for the driver's wipe) and, for N > 1, the all-reduce of the vectors
+            "phases23_gpu": {"seconds": round(float(ns.seconds_traversal), 4), "wall_seconds": round(t_nav, 4), "traversal_shards": world if use_dist else 1,
+                             "seconds_leaves": round(float(ns.seconds_leaves), 4), "seconds_nodes": round(float(ns.seconds_nodes), 4),
+                             "rank_gq_per_s": round(ns.rank_queries / max(ns.seconds_traversal, 1e-9) / 1e9, 2), "nodes": int(ns.nodes), "leaves": int(ns.leaves), "rank_queries": int(ns.rank_queries),
+                             "launches": int(ns.batches), "e2e_positions_per_s": round(n / (float(ns.seconds_traversal) + ms_per_step * 1e-3), 1)},
         }
         line.update(out)
         print(json.dumps(line), flush=True)

@@ -31,7 +31,7 @@ class IndexInfo(C.Structure):
 
 class NavStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("n", "leaves", "nodes", "lcp_values", "da_values", "minima", "rank_queries", "batches")] + \
-               [("seconds_leaves", C.c_double), ("seconds_nodes", C.c_double)]
+               [("seconds_leaves", C.c_double), ("seconds_nodes", C.c_double), ("seconds_traversal", C.c_double)]
 
 
 class Cluster(C.Structure):

@@ -539,7 +539,7 @@ int main(int argc, char** argv) {
     double t4 = now_s();
 
     print_report(ns, ss, two_bwts, with_da, events, cluster_nr);
-    printf("\nTimings (s): load+index %.3f, phases 2-3 %.3f (leaves %.3f, nodes %.3f, %llu rank queries, %llu launches), "
+    printf("\nTimings (s): load+index %.3f, phases 2-3 %.3f (leaves %.3f and nodes %.3f side by side, %llu rank queries, %llu launches), "
            "phase 4 device %.3f (scan %.3f ms, extend %.3f ms, right %.3f ms), write %.3f\n",
            t1 - t0, t2 - t1, ns.seconds_leaves, ns.seconds_nodes, (unsigned long long)ns.rank_queries, (unsigned long long)ns.batches,
            t3 - t2, ss.ms_scan, ss.ms_extend, ss.ms_right, t4 - t3);

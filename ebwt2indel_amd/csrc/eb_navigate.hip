@@ -842,6 +842,7 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
     EB_HIP(hipStreamSynchronize(st));
     EB_HIP(hipGetLastError());
     lap("threshold bits packed");
+    s.seconds_traversal = now_s() - t0;
     f->complemented = complement;
     if (n_shards == 1 && (rc = eb_flags_derive(f)) != EB_OK) return rc; // shards: eb_flags_finalize, after the reduction
     NavCounters c;

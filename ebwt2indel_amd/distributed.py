@@ -200,7 +200,7 @@ def navigate_sharded(bwt1, params, bwt2=None, group=None, device=None):
     if dev.type == "cuda":
         fl.finalize()
     cnt = torch.tensor([int(getattr(st, k)) for k in _NAV_COUNTERS], dtype=torch.int64, device=dev)
-    sec = torch.tensor([st.seconds_leaves, st.seconds_nodes], dtype=torch.float64, device=dev)
+    sec = torch.tensor([st.seconds_leaves, st.seconds_nodes, st.seconds_traversal], dtype=torch.float64, device=dev)
     dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
     dist.all_reduce(sec, op=dist.ReduceOp.MAX, group=group)
     for k, v in zip(_NAV_COUNTERS, cnt.tolist()):
@@ -209,7 +209,7 @@ def navigate_sharded(bwt1, params, bwt2=None, group=None, device=None):
         # the shards collected the complement of the LCP thresholds, which is exact only if every position has one writer
         raise RuntimeError(f"sharded traversal wrote {st.lcp_values} of {st.n} LCP slots: the input is not the eBWT of a read collection "
                            f"(the single-GPU path handles such inputs the reference's way)")
-    st.seconds_leaves, st.seconds_nodes = float(sec[0]), float(sec[1])
+    st.seconds_leaves, st.seconds_nodes, st.seconds_traversal = float(sec[0]), float(sec[1]), float(sec[2])
     return fl
 
 

@@ -126,7 +126,8 @@ typedef struct {
     uint64_t minima;     /* "Found ... LCP minima" */
     uint64_t rank_queries; /* parallel_rank evaluations issued */
     uint64_t batches;    /* frontier kernel launches */
-    double   seconds_leaves, seconds_nodes;
+    double   seconds_leaves, seconds_nodes; /* wall time of each traversal; they run side by side, so these overlap */
+    double   seconds_traversal;             /* both traversals + packing of the vectors, first launch to last result */
 } eb_nav_stats;
 int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_right, eb_flags** out, eb_nav_stats* stats);
 /* Phases 2-3 split over GPUs (no reference counterpart; the reference is one process).  Shard `shard` of `n_shards`
