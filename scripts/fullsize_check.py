@@ -27,6 +27,7 @@ from ebwt2indel_amd import distributed as ebd  # noqa: E402
 from tests import _oracle  # noqa: E402
 
 READS = int(sys.argv[1]) if len(sys.argv) > 1 else 50_000_000
+MODE3 = len(sys.argv) > 2 and sys.argv[2] == "mode3"   # READS reads per sample, two samples: merged BWT + document array
 READ_LEN, COVERAGE, SEED = 150, 30.0, 1
 THREADS = int(os.environ.get("EB_CHECK_THREADS", str(min(os.cpu_count() or 8, 32))))
 
@@ -56,7 +57,107 @@ class Heartbeat:
         log(f"{self.what}: {time.time() - self.t0:.1f}s")
 
 
+def main_mode3():
+    """BASELINE configs[3] when READS = 50 M: two samples of READS reads each (one per haplotype, scripts/modes23_scale.py's
+    recipe), merged eBWT + document array, mode 3 -- GPU against the oracle (threaded index + traversal, scan sharded)."""
+    n_each = READS
+    glen = int(2 * n_each * READ_LEN / 30)
+    g = sim.random_genome(glen, 5)
+    h2 = sim.mutate_haplotype(g, 5)
+    text, offs = sim.haplotype_text([g, h2])
+    rng = np.random.Generator(np.random.PCG64(99))
+    s0 = (rng.integers(0, len(g) - READ_LEN + 1, size=n_each, dtype=np.int64) + offs[0]).astype(np.uint64)
+    s1 = (rng.integers(0, len(h2) - READ_LEN + 1, size=n_each, dtype=np.int64) + offs[1]).astype(np.uint64)
+    del g, h2
+    with Heartbeat("merged eBWT + DA on the GPU"):
+        dev = sim.build_ebwt_gpu(text, np.concatenate([s0, s1]), READ_LEN, n_first=n_each, want_da=True)
+    del text, s0, s1
+    n = dev.n
+    log(f"n = {n}")
+    host, da_host = dev.to_host()
+    p = api.make_params()
+    t0 = time.time()
+    bwt = api.DnaBwt(None, device_ptr=dev.ptr, n=n)
+    dev.free()
+    flags = api.navigate_one_bwt(bwt, p)
+    flags.set_da(da_host)
+    calls = api.scan_clusters(bwt, flags, p)
+    got, cluster_nr, events = calls.format_snp(p, True)
+    t_gpu = time.time() - t0
+    gpu_sha = hashlib.sha256(got).hexdigest()
+    log(f"GPU mode 3: {got.count(b'>')} records, {len(calls)} clusters in the call set, sha256 {gpu_sha} ({t_gpu:.2f}s)")
+    ns = flags.stats
+    orc = _oracle.Oracle()
+    po = _oracle.Params.from_args([])
+    with Heartbeat(f"oracle index, {THREADS} threads"):
+        idx = orc.index(host, threads=THREADS)
+    with Heartbeat(f"oracle traversal (phases 2-3), {THREADS} threads"):
+        of = _oracle.OracleFlags(orc, idx, None, po.K, po.k_right, threads=THREADS)
+    with Heartbeat("oracle document array"):
+        d = _oracle._u8(da_host)
+        orc.lib.orc_flags_set_da(of.h, d.ctypes.data, len(d))
+        of.has_da = True
+    oc = of.counters()
+    log(f"oracle: {oc}")
+    assert (ns.leaves, ns.nodes, ns.minima, ns.lcp_values) == (oc["leaves"], oc["nodes"], oc["minima"], oc["lcp_values"]), "traversal counters differ"
+    for name, a, b in zip(("thrK", "thrR", "minima", "da"), flags.export(), of.export()):
+        assert np.array_equal(a, b), f"{name} differs"
+    log("flag vectors identical (thrK, thrR, minima, da)")
+    # Phase 4.  The oracle runs the reference's algorithm, which in the two-sample modes extends the contexts of nearly every
+    # cluster (one frequent letter on each side is enough, ebwt2InDel.cpp:1042-1052): at 15 G positions that is hours of CPU
+    # even on 32 threads (the first attempt of this script gave up after 13 minutes of its first pass).  Small inputs are
+    # compared in full; at scale the comparison is on WINDOWS: around every 2^32-symbol superblock boundary, at both ends of
+    # the BWT, and at seeded random places -- records (with contexts) and text of each window, GPU against oracle.
+    win = 1 << 22
+    if n <= (1 << 28):
+        windows = [(0, n)]
+    else:
+        rng = np.random.Generator(np.random.PCG64(7))
+        centres = [k << 32 for k in range(1, int(n >> 32) + 1)] + [win // 2, n - win // 2] + [int(v) for v in rng.integers(win, n - win, size=14)]
+        windows = sorted({(max(0, (c - win // 2) // 64 * 64), min(n, (c - win // 2) // 64 * 64 + win)) for c in centres})
+    log(f"{len(windows)} windows of {win if len(windows) > 1 else n} positions: {[w[0] for w in windows]}")
+
+    def oracle_window(be):
+        return of.scan(po, be[0], be[1], capture=True)
+    with Heartbeat("oracle scan of the windows"), ThreadPoolExecutor(min(THREADS, len(windows))) as ex:
+        wants = list(ex.map(oracle_window, windows))
+    recs = 0
+    got_parts, want_parts = [], []
+    for (b, e), want_w in zip(windows, wants):
+        c = api.scan_clusters(bwt, flags, p, begin=b, end=e)
+        cl, chains, left, right = c.arrays()
+        assert len(c) == want_w["count"], (b, e, len(c), want_w["count"])
+        assert np.array_equal(cl, want_w["clusters"]) and np.array_equal(chains, want_w["chains"]), (b, e)
+        assert np.array_equal(left, want_w["left"]) and np.array_equal(right, want_w["right"]), (b, e)
+        t, _, _ = c.format_snp(p, True)
+        assert t == want_w["text"], (b, e)
+        recs += t.count(b">")
+        got_parts.append(t)
+        want_parts.append(want_w["text"])
+    log(f"windows identical: {sum(w['count'] for w in wants)} clusters with contexts, {recs} records")
+    want = b"".join(want_parts)
+    if len(windows) > 1:
+        got_full_sha = gpu_sha
+        got = b"".join(got_parts)
+        gpu_sha = hashlib.sha256(got).hexdigest()
+    orc_sha = hashlib.sha256(want).hexdigest()
+    res = {"what": "BASELINE configs[3] scale (mode 3: merged BWT + document array) at full size: GPU .snp vs the CPU oracle's",
+           "input": {"reads_per_sample": n_each, "read_len": READ_LEN, "n": int(n), "recipe": "scripts/modes23_scale.py (genome seed 5, starts seed 99)",
+                     "ebwt_sha256": hashlib.sha256(host).hexdigest(), "da_sha256": hashlib.sha256(da_host).hexdigest()},
+           "options": "defaults", "phase4_compared_on": [list(w) for w in windows], "window_clusters": int(sum(w["count"] for w in wants)),
+           "gpu_windows_snp_sha256": gpu_sha, "oracle_windows_snp_sha256": orc_sha, "identical": got == want,
+           "gpu_whole_snp_sha256": got_full_sha if len(windows) > 1 else gpu_sha, "window_records": int(got.count(b">")), "flag_vectors_identical": True,
+           "counters": {k: int(oc[k]) for k in ("leaves", "nodes", "minima", "lcp_values")}, "oracle_threads": THREADS, "gpu_seconds": round(t_gpu, 2)}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", f"fullsize_check_mode3_{READS}.json"), "w") as f:
+        json.dump(res, f, indent=1)
+    log(json.dumps(res))
+    assert got == want, "GPU .snp differs from the oracle's at full size (mode 3)"
+
+
 def main():
+    if MODE3:
+        return main_mode3()
     genome_len = int(READS * READ_LEN / COVERAGE)
     g = sim.random_genome(genome_len, SEED)
     h2 = sim.mutate_haplotype(g, SEED)
