@@ -716,6 +716,115 @@ oflags* orc_navigate_two(const oindex* x1, const oindex* x2, int K, int k_right)
     return f;
 }
 
+/* ---- navigate_two_bwts on several host threads: the checker for two-BWT inputs at full size (see orc_navigate_one_mt;
+ * same visiting rule as orc_navigate_two, order free, atomic ORs, per-thread counters; max_stack not meaningful). */
+typedef struct { uint64_t leaves, nodes, lcp, da, n_min; } nav2_tally;
+
+static void leaf_pair_da_mt(oflags* f, const oleaf* L1, const oleaf* L2, int with_lcp, int K, int k_right, nav2_tally* t) {
+    uint64_t s1 = L1->rn.l + L2->rn.l, s2 = L2->rn.l + L1->rn.r, e = L1->rn.r + L2->rn.r;
+    t->da += e - s1;
+    bits_fill_atomic(f->da, s2, e);
+    if (with_lcp && e > s1 + 1) {
+        if ((int64_t)L1->depth >= K) bits_fill_atomic(f->thrK, s1 + 1, e);
+        if ((int64_t)L1->depth >= k_right) bits_fill_atomic(f->thrR, s1 + 1, e);
+        t->lcp += e - s1 - 1;
+    }
+}
+static void leaf2_visit_mt(const oindex* x1, const oindex* x2, oflags* f, int K, int k_right, const oleaf2* L, nav2_tally* t, leaf2_stack* S) {
+    t->leaves++;
+    leaf_pair_da_mt(f, &L->a, &L->b, 1, K, k_right, t);
+    prange_t e1 = LF_range(x1, L->a.rn), e2 = LF_range(x2, L->b.rn);
+    for (int c = 0; c < 4; ++c)
+        if ((e1.c[c].r - e1.c[c].l) + (e2.c[c].r - e2.c[c].l) >= 2) {
+            oleaf2 ch;
+            ch.a.rn = e1.c[c]; ch.a.depth = L->a.depth + 1;
+            ch.b.rn = e2.c[c]; ch.b.depth = L->b.depth + 1;
+            leaf2_stack_push(S, ch);
+        }
+}
+static void node2_visit_mt(const oindex* x1, const oindex* x2, oflags* f, int K, int k_right, const onode2* N, nav2_tally* t, node2_stack* S) {
+    t->nodes++;
+    onode M;
+    for (int j = 0; j < 6; ++j) M.b[j] = N->a.b[j] + N->b.b[j];
+    M.depth = N->a.depth;
+    for (int j = 0; j < 5; ++j) { /* find_leaves :474-527 */
+        uint64_t s1 = N->a.b[j + 1] - N->a.b[j], s2 = N->b.b[j + 1] - N->b.b[j];
+        if (s1 + s2 == 1) {
+            oleaf A = {{N->a.b[j], N->a.b[j + 1]}, 0}, B = {{N->b.b[j], N->b.b[j + 1]}, 0};
+            leaf_pair_da_mt(f, &A, &B, 0, K, k_right, t);
+        }
+    }
+    for (int j = 0; j < 4; ++j) /* update_lcp_threshold */
+        if (M.b[j + 1] > M.b[j] && M.b[j + 1] != M.b[5]) {
+            if ((int64_t)M.depth >= K) bit_set_atomic(f->thrK, M.b[j + 1]);
+            if ((int64_t)M.depth >= k_right) bit_set_atomic(f->thrR, M.b[j + 1]);
+            t->lcp++;
+        }
+    for (int j = 1; j <= 3; ++j) /* update_lcp_minima */
+        if (M.b[j + 1] - M.b[j] >= 2 && M.b[j + 1] < M.b[5] - 1) { bit_set_atomic(f->minima, M.b[j + 1]); t->n_min++; }
+    onode c1[4], c2[4];
+    LF_node(x1, &N->a, c1);
+    LF_node(x2, &N->b, c2);
+    for (int c = 0; c < 4; ++c) {
+        int k = 0;
+        for (int j = 0; j < 5; ++j) k += (c1[c].b[j + 1] > c1[c].b[j]) || (c2[c].b[j + 1] > c2[c].b[j]);
+        if (k >= 2) { onode2 ch; ch.a = c1[c]; ch.b = c2[c]; node2_stack_push(S, ch); }
+    }
+}
+
+oflags* orc_navigate_two_mt(const oindex* x1, const oindex* x2, int K, int k_right, int threads) {
+    if (threads < 1) threads = 1;
+    oflags* f = flags_new(x1->n + x2->n, 1);
+    const size_t want = (size_t)threads * 512;
+    nav2_tally tot = {0, 0, 0, 0, 0};
+    {
+        leaf2_stack cur = {0}, nxt = {0};
+        oleaf2 first = {{{0, x1->F[0]}, 0}, {{0, x2->F[0]}, 0}};
+        leaf2_stack_push(&cur, first);
+        while (cur.n && cur.n < want) {
+            nxt.n = 0;
+            for (size_t i = 0; i < cur.n; ++i) leaf2_visit_mt(x1, x2, f, K, k_right, &cur.a[i], &tot, &nxt);
+            leaf2_stack sw = cur; cur = nxt; nxt = sw;
+        }
+        uint64_t a_leaves = 0, a_lcp = 0, a_da = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(+ : a_leaves, a_lcp, a_da)
+        for (long long i = 0; i < (long long)cur.n; ++i) {
+            leaf2_stack S = {0};
+            nav2_tally t = {0, 0, 0, 0, 0};
+            leaf2_stack_push(&S, cur.a[i]);
+            while (S.n) { oleaf2 L = S.a[--S.n]; leaf2_visit_mt(x1, x2, f, K, k_right, &L, &t, &S); }
+            free(S.a);
+            a_leaves += t.leaves; a_lcp += t.lcp; a_da += t.da;
+        }
+        tot.leaves += a_leaves; tot.lcp += a_lcp; tot.da += a_da;
+        free(cur.a); free(nxt.a);
+    }
+    {
+        node2_stack cur = {0}, nxt = {0};
+        onode2 root = {{{0, x1->F[0], x1->F[1], x1->F[2], x1->F[3], x1->n}, 0}, {{0, x2->F[0], x2->F[1], x2->F[2], x2->F[3], x2->n}, 0}};
+        node2_stack_push(&cur, root);
+        while (cur.n && cur.n < want) {
+            nxt.n = 0;
+            for (size_t i = 0; i < cur.n; ++i) node2_visit_mt(x1, x2, f, K, k_right, &cur.a[i], &tot, &nxt);
+            node2_stack sw = cur; cur = nxt; nxt = sw;
+        }
+        uint64_t a_nodes = 0, a_lcp = 0, a_da = 0, a_min = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(+ : a_nodes, a_lcp, a_da, a_min)
+        for (long long i = 0; i < (long long)cur.n; ++i) {
+            node2_stack S = {0};
+            nav2_tally t = {0, 0, 0, 0, 0};
+            node2_stack_push(&S, cur.a[i]);
+            while (S.n) { onode2 N = S.a[--S.n]; node2_visit_mt(x1, x2, f, K, k_right, &N, &t, &S); }
+            free(S.a);
+            a_nodes += t.nodes; a_lcp += t.lcp; a_da += t.da; a_min += t.n_min;
+        }
+        tot.nodes += a_nodes; tot.lcp += a_lcp; tot.da += a_da; tot.n_min += a_min;
+        free(cur.a); free(nxt.a);
+    }
+    f->leaves = tot.leaves; f->nodes = tot.nodes; f->lcp_values += tot.lcp; f->da_values = tot.da; f->n_min = tot.n_min; f->max_stack = 0;
+    return f;
+}
+
 /* mode 3 DA reader: ebwt2InDel.cpp:1503-1508 ('1' -> 1, anything else -> 0).  Past the end of a short file the
  * reference's read() fails and leaves its one-byte buffer as it was: the remaining slots repeat the last byte read
  * (an empty file leaves that buffer uninitialised upstream; zeros here). */

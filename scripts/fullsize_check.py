@@ -28,6 +28,7 @@ from tests import _oracle  # noqa: E402
 
 READS = int(sys.argv[1]) if len(sys.argv) > 1 else 50_000_000
 MODE3 = len(sys.argv) > 2 and sys.argv[2] == "mode3"   # READS reads per sample, two samples: merged BWT + document array
+MODE2 = len(sys.argv) > 2 and sys.argv[2] == "mode2"   # the same two samples as two BWTs
 READ_LEN, COVERAGE, SEED = 150, 30.0, 1
 THREADS = int(os.environ.get("EB_CHECK_THREADS", str(min(os.cpu_count() or 8, 32))))
 
@@ -155,9 +156,93 @@ def main_mode3():
     assert got == want, "GPU .snp differs from the oracle's at full size (mode 3)"
 
 
+def main_mode2():
+    """BASELINE configs[2] when READS = 25 M: two samples of READS reads each as TWO BWTs (mode 2): the GPU's dual-BWT
+    traversal (DA rebuilt from interval arithmetic) and phase 4 against the oracle (threaded two-BWT traversal; phase 4 on
+    windows, see main_mode3)."""
+    n_each = READS
+    glen = int(2 * n_each * READ_LEN / 30)
+    g = sim.random_genome(glen, 5)
+    h2 = sim.mutate_haplotype(g, 5)
+    text, offs = sim.haplotype_text([g, h2])
+    rng = np.random.Generator(np.random.PCG64(99))
+    s0 = (rng.integers(0, len(g) - READ_LEN + 1, size=n_each, dtype=np.int64) + offs[0]).astype(np.uint64)
+    s1 = (rng.integers(0, len(h2) - READ_LEN + 1, size=n_each, dtype=np.int64) + offs[1]).astype(np.uint64)
+    del g, h2
+    hosts, gpus = [], []
+    t_gpu = 0.0
+    for starts in (s0, s1):
+        with Heartbeat("eBWT on the GPU"):
+            dev = sim.build_ebwt_gpu(text, starts, READ_LEN)
+        h, _ = dev.to_host()
+        hosts.append(h)
+        t0 = time.time()
+        gpus.append(api.DnaBwt(None, device_ptr=dev.ptr, n=dev.n))
+        t_gpu += time.time() - t0
+        dev.free()
+    del text, s0, s1
+    a, b = gpus
+    n = a.n + b.n
+    log(f"n = {a.n} + {b.n}")
+    p = api.make_params()
+    t0 = time.time()
+    flags = api.navigate_two_bwts(a, b, p)
+    calls = api.scan_clusters(a, flags, p, bwt2=b)
+    got_full, _, _ = calls.format_snp(p, True)
+    t_gpu += time.time() - t0
+    full_sha = hashlib.sha256(got_full).hexdigest()
+    log(f"GPU mode 2: {got_full.count(b'>')} records, {len(calls)} clusters in the call set, sha256 {full_sha} ({t_gpu:.2f}s)")
+    ns = flags.stats
+    orc = _oracle.Oracle()
+    po = _oracle.Params.from_args([])
+    with Heartbeat(f"oracle indexes, {THREADS} threads"):
+        i1, i2 = orc.index(hosts[0], threads=THREADS), orc.index(hosts[1], threads=THREADS)
+    with Heartbeat(f"oracle two-BWT traversal (phases 2-3), {THREADS} threads"):
+        of = _oracle.OracleFlags(orc, i1, i2, po.K, po.k_right, threads=THREADS)
+    oc = of.counters()
+    log(f"oracle: {oc}")
+    assert (ns.leaves, ns.nodes, ns.minima, ns.lcp_values, ns.da_values) == (oc["leaves"], oc["nodes"], oc["minima"], oc["lcp_values"], oc["da_values"]), "traversal counters differ"
+    for name, va, vb in zip(("thrK", "thrR", "minima", "da"), flags.export(), of.export()):
+        assert np.array_equal(va, vb), f"{name} differs"
+    log("flag vectors identical (thrK, thrR, minima, da)")
+    win = 1 << 22
+    if n <= (1 << 28):
+        windows = [(0, n)]
+    else:
+        rng = np.random.Generator(np.random.PCG64(7))
+        centres = [k << 32 for k in range(1, int(n >> 32) + 1)] + [win // 2, n - win // 2] + [int(v) for v in rng.integers(win, n - win, size=14)]
+        windows = sorted({(max(0, (c - win // 2) // 64 * 64), min(n, (c - win // 2) // 64 * 64 + win)) for c in centres})
+    log(f"{len(windows)} windows of {win if len(windows) > 1 else n} positions: {[w[0] for w in windows]}")
+    with Heartbeat("oracle scan of the windows"), ThreadPoolExecutor(min(THREADS, len(windows))) as ex:
+        wants = list(ex.map(lambda be: of.scan(po, be[0], be[1], capture=True), windows))
+    recs = 0
+    for (wb, we), want_w in zip(windows, wants):
+        c = api.scan_clusters(a, flags, p, bwt2=b, begin=wb, end=we)
+        cl, chains, left, right = c.arrays()
+        assert len(c) == want_w["count"], (wb, we, len(c), want_w["count"])
+        assert np.array_equal(cl, want_w["clusters"]) and np.array_equal(chains, want_w["chains"]), (wb, we)
+        assert np.array_equal(left, want_w["left"]) and np.array_equal(right, want_w["right"]), (wb, we)
+        t, _, _ = c.format_snp(p, True)
+        assert t == want_w["text"], (wb, we)
+        recs += t.count(b">")
+    log(f"windows identical: {sum(w['count'] for w in wants)} clusters with contexts, {recs} records")
+    res = {"what": "BASELINE configs[2] scale (mode 2: two BWTs) at full size: GPU vs the CPU oracle",
+           "input": {"reads_per_sample": n_each, "read_len": READ_LEN, "n1": int(a.n), "n2": int(b.n), "recipe": "scripts/modes23_scale.py (genome seed 5, starts seed 99)",
+                     "ebwt_sha256": [hashlib.sha256(h).hexdigest() for h in hosts]},
+           "options": "defaults", "flag_vectors_identical": True, "counters": {k: int(oc[k]) for k in ("leaves", "nodes", "minima", "lcp_values", "da_values")},
+           "phase4_compared_on": [list(w) for w in windows], "window_clusters": int(sum(w["count"] for w in wants)), "window_records": int(recs), "identical": True,
+           "gpu_whole_snp_sha256": full_sha, "gpu_whole_snp_records": int(got_full.count(b">")), "oracle_threads": THREADS, "gpu_seconds": round(t_gpu, 2)}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", f"fullsize_check_mode2_{READS}.json"), "w") as f:
+        json.dump(res, f, indent=1)
+    log(json.dumps(res))
+
+
 def main():
     if MODE3:
         return main_mode3()
+    if MODE2:
+        return main_mode2()
     genome_len = int(READS * READ_LEN / COVERAGE)
     g = sim.random_genome(genome_len, SEED)
     h2 = sim.mutate_haplotype(g, SEED)

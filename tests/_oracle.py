@@ -94,6 +94,8 @@ class Oracle:
         L.orc_index_equal.argtypes = [vp, vp]
         L.orc_navigate_two.restype = vp
         L.orc_navigate_two.argtypes = [vp, vp, C.c_int, C.c_int]
+        L.orc_navigate_two_mt.restype = vp
+        L.orc_navigate_two_mt.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int]
         L.orc_flags_set_da.argtypes = [vp, vp, u64]
         L.orc_flags_import.restype = vp
         L.orc_flags_import.argtypes = [u64, vp, vp, vp, vp]
@@ -207,7 +209,7 @@ class OracleFlags:
 
     def __init__(self, orc, idx1, idx2=None, K=16, k_right=30, da=None, vectors=None, threads=1):
         """vectors = (thrK, thrR, minima[, da words]) imports given flag words instead of navigating (scan stress tests).
-        threads > 1 (one BWT only): the threaded traversal -- same vectors and counters, for full-size checks."""
+        threads > 1: the threaded traversal -- same vectors and counters, for full-size checks."""
         self.o = orc
         self.idx1, self.idx2 = idx1, idx2
         L = orc.lib
@@ -221,7 +223,7 @@ class OracleFlags:
             self.has_da = len(v) > 3 and v[3] is not None
             return
         if idx2 is not None:
-            self.h = L.orc_navigate_two(idx1.h, idx2.h, K, k_right)
+            self.h = L.orc_navigate_two_mt(idx1.h, idx2.h, K, k_right, threads) if threads > 1 else L.orc_navigate_two(idx1.h, idx2.h, K, k_right)
         elif threads > 1:
             self.h = L.orc_navigate_one_mt(idx1.h, K, k_right, threads)
         else:

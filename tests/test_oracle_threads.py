@@ -46,3 +46,16 @@ def test_threaded_oracle_on_fresh_reads(oracle):
     for va, vb in zip(fa.export()[:3], fb.export()[:3]):
         assert np.array_equal(va, vb)
     assert fa.counters()["nodes"] == fb.counters()["nodes"] and fa.counters()["minima"] == fb.counters()["minima"]
+
+
+@pytest.mark.parametrize("a,b", [("hom_a.ebwt", "hom_b.ebwt"), ("het_a.ebwt", "het_b.ebwt"), ("edge_a.ebwt", "edge_b.ebwt")])
+@pytest.mark.parametrize("threads", [2, 7])
+def test_threaded_two_bwt_traversal_equals_serial(oracle, a, b, threads):
+    x1, x2 = oracle.index(golden_bytes(a)), oracle.index(golden_bytes(b))
+    fa = _oracle.OracleFlags(oracle, x1, x2, 16, 30)
+    fb = _oracle.OracleFlags(oracle, x1, x2, 16, 30, threads=threads)
+    for va, vb in zip(fa.export(), fb.export()):
+        assert np.array_equal(va, vb)
+    ca, cb = fa.counters(), fb.counters()
+    for k in ("leaves", "nodes", "lcp_values", "da_values", "minima"):
+        assert ca[k] == cb[k], k
