@@ -1,7 +1,8 @@
 // eb_main.cpp -- the `ebwt2InDel` command line, same flags / defaults / messages as the reference
 // (ebwt2InDel.cpp:76-103 help, :1677-1823 main), driving the GPU hot path through the C ABI only.
 // Extra flags (not in the reference): -D <device> selects the GPU (default 0); -G <n> runs on n GPUs of the node:
-// ONE process, one host thread per GPU, RCCL communicators from ncclCommInitAll -- the input files are read once and
+// ONE process, one host thread per GPU, RCCL communicators from ncclCommInitAll (set up in the background while the
+// ranks load and traverse) -- the input files come off the disk once (the ranks read the same page-cache pages) and are
 // uploaded to every GPU (BWT replicated), phases 2-3 are split by Weiner-link subtrees and combined by an in-place
 // ncclAllReduce (SUM == OR: one writer per bit, checked by popcounts), phase 4 is split by closing position and the
 // ranks' compact call-set images travel GPU -> GPU (ncclSend / ncclRecv over xGMI) to GPU 0, whose thread downloads
@@ -14,6 +15,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -114,7 +117,13 @@ struct MultiJob {
     bool host_backend = false;
     std::vector<int> dev;
     std::vector<ncclComm_t> comm;
-    const std::vector<uint8_t>*text1 = nullptr, *text2 = nullptr, *da = nullptr;
+    // inputs: mapped once, read-only; every rank uploads from the same pages (the page cache holds the files once)
+    std::string path1, path2;
+    const uint8_t* da = nullptr; // the document array is mapped once, read-only; every rank packs it from the same pages
+    uint64_t n_da = 0;
+    bool two = false;
+    std::thread* comm_init = nullptr; // ncclCommInitAll runs beside phase 1 and the traversal; joined before the first collective
+    ncclResult_t comm_rc = ncclSuccess;
     eb_params p;
     Barrier* bar = nullptr;
     // per rank
@@ -161,7 +170,7 @@ bool any_failed(MultiJob& J) {
 // that no rank enters a collective its peers will not join.
 void rank_main(MultiJob& J, int r) {
     const int device = J.dev[(size_t)r];
-    const bool two = J.text2 != nullptr;
+    const bool two = J.two;
     eb_index *b1 = nullptr, *b2 = nullptr;
     eb_flags* fl = nullptr;
     eb_scan_job* job = nullptr;
@@ -183,8 +192,10 @@ void rank_main(MultiJob& J, int r) {
     double t0 = now_s();
     (void)hipSetDevice(device);
     MJ_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    int rc = eb_index_create(J.text1->data(), J.text1->size(), (uint8_t)J.p.term, device, &b1);
-    if (rc == EB_OK && two) rc = eb_index_create(J.text2->data(), J.text2->size(), (uint8_t)J.p.term, device, &b2);
+    // (through the library's loader: parallel preads of the file into page-locked pieces, uploaded and packed while the next
+    // ones fill -- 2-4x faster than copying out of a mapping; the ranks all read the same page-cache pages)
+    int rc = eb_index_create_from_file(J.path1.c_str(), (uint8_t)J.p.term, device, &b1);
+    if (rc == EB_OK && two) rc = eb_index_create_from_file(J.path2.c_str(), (uint8_t)J.p.term, device, &b2);
     if (rc != EB_OK) {
         if (rc == EB_ERR_ALPHABET) eb_index_bad_symbol(&J.bad_sym, &J.bad_pos); // same symbol on every rank
         MJ_FAIL(rc, "%s", eb_last_error());
@@ -203,6 +214,12 @@ void rank_main(MultiJob& J, int r) {
     uint64_t words = 0;
     (void)eb_flags_device_vectors(fl, v, &words);
     if (!J.host_backend) {
+        // the communicators were being set up beside all the work so far (RCCL takes seconds to come up): needed from here on
+        if (r == 0 && J.comm_init) {
+            J.comm_init->join();
+            if (J.comm_rc != ncclSuccess) MJ_FAIL(EB_ERR_DEVICE, "ncclCommInitAll failed: %s", ncclGetErrorString(J.comm_rc));
+        }
+        if (!sync_ok()) return cleanup();
         // every bit has ONE writer over all ranks: integer SUM == OR (RCCL has no bitwise OR); in place, in HBM, over xGMI
         for (int k = 0; k < 4; ++k)
             if (v[k]) MJ_NCCL(ncclAllReduce(v[k], v[k], words, ncclUint64, ncclSum, J.comm[(size_t)r], st));
@@ -239,7 +256,7 @@ void rank_main(MultiJob& J, int r) {
         else if (!J.host_backend && (rc = eb_flags_finalize(fl)) != EB_OK) MJ_FAIL(rc, "%s", eb_last_error());
     }
     if (J.rc[(size_t)r] == EB_OK && J.da) {
-        rc = eb_flags_set_da(fl, J.da->data(), J.da->size());
+        rc = eb_flags_set_da(fl, J.da, J.n_da);
         if (rc != EB_OK) MJ_FAIL(rc, "%s", eb_last_error());
     }
     if (!sync_ok()) return cleanup();
@@ -334,18 +351,39 @@ static int run_multi(int world, const std::string& input1, const std::string& in
     printf(two_bwts ? "Phase 1/4: loading and indexing eBWTs on %d GPU(s) ... " : "Phase 1/4: loading and indexing eBWT on %d GPU(s) ... ", world);
     fflush(stdout);
     double t0 = now_s();
-    std::vector<uint8_t> text1, text2, da; // read ONCE; every rank uploads from here
-    if (read_file(input1, text1) != 0) { printf("Error: could not read file %s\n", input1.c_str()); return 1; }
-    if (two_bwts && read_file(input2, text2) != 0) { printf("Error: could not read file %s\n", input2.c_str()); return 1; }
-    if (with_da && read_file(input_da, da) != 0) { printf("Error: could not read file %s\n", input_da.c_str()); return 1; }
+    // the inputs are mapped, not copied: one set of pages in the page cache serves every rank's upload
+    struct Mapped {
+        const uint8_t* p = nullptr; uint64_t n = 0;
+        ~Mapped() { if (p && n) munmap(const_cast<uint8_t*>(p), n); }
+        bool open_file(const std::string& path) {
+            int fd = ::open(path.c_str(), O_RDONLY);
+            if (fd < 0) return false;
+            struct stat st;
+            if (fstat(fd, &st) != 0) { ::close(fd); return false; }
+            n = (uint64_t)st.st_size;
+            if (n) {
+                void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+                if (m == MAP_FAILED) { ::close(fd); n = 0; return false; }
+                (void)madvise(m, n, MADV_SEQUENTIAL);
+                p = static_cast<const uint8_t*>(m);
+            }
+            ::close(fd);
+            return true;
+        }
+    } mda;
+    if (with_da && !mda.open_file(input_da)) { printf("Error: could not read file %s\n", input_da.c_str()); return 1; }
     const double t_read = now_s() - t0;
-    J.text1 = &text1;
-    J.text2 = two_bwts ? &text2 : nullptr;
-    J.da = with_da ? &da : nullptr;
+    static const uint8_t empty = 0;
+    J.path1 = input1;
+    J.path2 = input2;
+    J.two = two_bwts;
+    J.da = with_da ? (mda.n ? mda.p : &empty) : nullptr;
+    J.n_da = mda.n;
+    std::thread comm_thread;
     if (!host_backend) {
         J.comm.resize((size_t)world);
-        ncclResult_t e = ncclCommInitAll(J.comm.data(), world, J.dev.data());
-        if (e != ncclSuccess) { printf("Error: ncclCommInitAll failed: %s\n", ncclGetErrorString(e)); return 1; }
+        comm_thread = std::thread([&J, world] { J.comm_rc = ncclCommInitAll(J.comm.data(), world, J.dev.data()); });
+        J.comm_init = &comm_thread;
     }
     Barrier bar(world);
     J.bar = &bar;
@@ -363,7 +401,8 @@ static int run_multi(int world, const std::string& input1, const std::string& in
     for (int r = 1; r < world; ++r) th.emplace_back(rank_main, std::ref(J), r);
     rank_main(J, 0);
     for (std::thread& t : th) t.join();
-    if (!host_backend) for (ncclComm_t c : J.comm) (void)ncclCommDestroy(c);
+    if (comm_thread.joinable()) comm_thread.join(); // a rank failed before the first collective
+    // (the communicators are not torn down one by one: the process is about to end, and ncclCommDestroy takes seconds)
     for (int r = 0; r < world; ++r)
         if (J.rc[(size_t)r] != EB_OK) {
             if (J.rc[(size_t)r] == EB_ERR_ALPHABET) {

@@ -17,4 +17,12 @@ t_cli = time.time() - t
 got = open("/tmp/scale.snp", "rb").read()
 print(f"n={len(ebwt)} api {t_api:.2f}s cli {t_cli:.2f}s rc={r.returncode} identical={got == want} records={got.count(b'>')} sha={hashlib.sha256(got).hexdigest()[:16]}")
 print(r.stdout.splitlines()[-1])
+# the same file through the multi-GPU mode of the executable with one rank (RCCL communicator, device images, unpack + writer)
+t = time.time()
+r = subprocess.run([_lib.CLI_PATH, "-1", path, "-o", "/tmp/scale_g1.snp", "-G", "1"], capture_output=True, text=True)
+t_g1 = time.time() - t
+got1 = open("/tmp/scale_g1.snp", "rb").read()
+print(f"-G 1: {t_g1:.2f}s rc={r.returncode} identical={got1 == want}")
+print(r.stdout.splitlines()[-1] if r.stdout else r.stderr[-500:])
+os.remove("/tmp/scale_g1.snp")
 os.remove(path); os.remove("/tmp/scale.snp")
