@@ -29,6 +29,7 @@ from tests import _oracle  # noqa: E402
 READS = int(sys.argv[1]) if len(sys.argv) > 1 else 50_000_000
 MODE3 = len(sys.argv) > 2 and sys.argv[2] == "mode3"   # READS reads per sample, two samples: merged BWT + document array
 MODE2 = len(sys.argv) > 2 and sys.argv[2] == "mode2"   # the same two samples as two BWTs
+COPIES = int(sys.argv[2][1:]) if len(sys.argv) > 2 and sys.argv[2].startswith("x") else 0   # "x10": every read 10 times (sim.replicated_ebwt_gpu)
 READ_LEN, COVERAGE, SEED = 150, 30.0, 1
 THREADS = int(os.environ.get("EB_CHECK_THREADS", str(min(os.cpu_count() or 8, 32))))
 
@@ -238,7 +239,114 @@ def main_mode2():
     log(json.dumps(res))
 
 
+def main_replicated():
+    """Mode 1 at sizes towards BASELINE configs[4] on ONE GPU: the bench's sample with every read COPIES times in a row --
+    eBWT = base eBWT with every symbol repeated (tests/test_sim.py) -- e.g. 50 M reads x10 = 75.5 G positions, 17
+    superblocks, positions beyond 2^36.  GPU against the oracle: all bit vectors at full size, phase 4 on windows around
+    EVERY superblock boundary, both ends and random places."""
+    import torch
+    genome_len = int(READS * READ_LEN / COVERAGE)
+    g = sim.random_genome(genome_len, SEED)
+    h2 = sim.mutate_haplotype(g, SEED)
+    text, offs = sim.haplotype_text([g, h2])
+    starts = sim.sample_read_starts([g, h2], offs, READS, READ_LEN, SEED)
+    del g, h2
+    with Heartbeat("base eBWT on the GPU"):
+        dev = sim.build_ebwt_gpu(text, starts, READ_LEN)
+    del text, starts
+    base_host = np.empty(dev.n, dtype=np.uint8)
+    sim._hip_copy_to_host(base_host, dev.ptr, dev.n)
+
+    class _Bytes:
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (ptr, False), "version": 3, "strides": None}
+    base = torch.as_tensor(_Bytes(dev.ptr, dev.n), device="cuda:0")
+    big = base[:, None].expand(-1, COPIES).reshape(-1)
+    torch.cuda.synchronize()
+    del base
+    dev.free()
+    n = int(big.numel())
+    log(f"n = {n} = {n / (1 << 32):.2f} superblocks")
+    p = api.make_params()
+    t0 = time.time()
+    bwt = api.DnaBwt(None, device_ptr=big.data_ptr(), n=n)
+    del big
+    torch.cuda.empty_cache()
+    t_index = time.time() - t0
+    t0 = time.time()
+    flags = api.navigate_one_bwt(bwt, p)
+    t_nav = time.time() - t0
+    ns = flags.stats
+    log(f"GPU: index {t_index:.2f}s ({bwt.device_bytes / 1e9:.1f} GB), phases 2-3 {t_nav:.2f}s (traversals {ns.seconds_traversal:.2f}s): {ns.nodes} nodes, {ns.leaves} leaves, lcp_values {ns.lcp_values}")
+    assert ns.lcp_values == n
+    t0 = time.time()
+    calls = api.scan_clusters(bwt, flags, p)
+    st = calls.stats
+    log(f"GPU phase 4 over the whole BWT: {time.time() - t0:.2f}s wall, scan {st.ms_scan:.1f} ms, {st.clusters} clusters analysed, {len(calls)} in the call set")
+    got_full, _, ev_full = calls.format_snp(p, False)
+    full_sha = hashlib.sha256(got_full).hexdigest()
+    log(f"GPU: {ev_full} records, sha256 {full_sha}")
+    del calls
+    # ---- oracle on the host: the replicated text is rebuilt from the base copy (no 75 GB download)
+    orc = _oracle.Oracle()
+    po = _oracle.Params.from_args([])
+    with Heartbeat("replicated text on the host"):
+        host = np.repeat(base_host, COPIES)
+    del base_host
+    with Heartbeat(f"oracle index, {THREADS} threads"):
+        idx = orc.index(host, threads=THREADS)
+    assert idx.ok
+    idx.buf = None
+    del host
+    with Heartbeat(f"oracle traversal (phases 2-3), {THREADS} threads"):
+        of = _oracle.OracleFlags(orc, idx, None, po.K, po.k_right, threads=THREADS)
+    oc = of.counters()
+    log(f"oracle: {oc}")
+    assert (ns.leaves, ns.nodes, ns.minima, ns.lcp_values) == (oc["leaves"], oc["nodes"], oc["minima"], oc["lcp_values"]), "traversal counters differ"
+    with Heartbeat("bit vectors, GPU against oracle"):
+        want_vec = of.export()[:3]
+        for name, k in (("thrK", 0), ("thrR", 1), ("minima", 2)):
+            pick = [None, None, None, None]
+            a = flags.export()[k]
+            assert np.array_equal(a, want_vec[k]), f"{name} differs"
+            del a
+    del want_vec
+    log("flag vectors identical (thrK, thrR, minima)")
+    win = 1 << 21
+    rng = np.random.Generator(np.random.PCG64(7))
+    centres = [k << 32 for k in range(1, int(n >> 32) + 1)] + [win // 2, n - win // 2] + [int(v) for v in rng.integers(win, n - win, size=12)]
+    windows = sorted({(max(0, (c - win // 2) // 64 * 64), min(n, (c - win // 2) // 64 * 64 + win)) for c in centres})
+    log(f"{len(windows)} windows of {win} positions")
+    with Heartbeat("oracle scan of the windows"), ThreadPoolExecutor(min(THREADS, len(windows))) as ex:
+        wants = list(ex.map(lambda be: of.scan(po, be[0], be[1], capture=True), windows))
+    recs = 0
+    for (wb, we), want_w in zip(windows, wants):
+        c = api.scan_clusters(bwt, flags, p, begin=wb, end=we)
+        cl, chains, left, right = c.arrays()
+        assert len(c) == want_w["count"], (wb, we, len(c), want_w["count"])
+        assert np.array_equal(cl, want_w["clusters"]) and np.array_equal(chains, want_w["chains"]), (wb, we)
+        assert np.array_equal(left, want_w["left"]) and np.array_equal(right, want_w["right"]), (wb, we)
+        t, _, _ = c.format_snp(p, False)
+        assert t == want_w["text"], (wb, we)
+        recs += t.count(b">")
+    log(f"windows identical: {sum(w['count'] for w in wants)} clusters with contexts, {recs} records")
+    res = {"what": f"mode 1, the bench's sample with every read {COPIES} times in a row: GPU vs the CPU oracle on one MI355X",
+           "input": {"reads_base": READS, "copies": COPIES, "read_len": READ_LEN, "seed": SEED, "n": n, "superblocks": n / (1 << 32)},
+           "gpu": {"index_seconds": round(t_index, 2), "index_device_bytes": int(bwt.device_bytes), "phases23_wall_seconds": round(t_nav, 2),
+                   "traversal_seconds": round(float(ns.seconds_traversal), 3), "scan_ms": round(float(st.ms_scan), 2), "clusters_analysed": int(st.clusters),
+                   "snp_records": int(ev_full), "snp_sha256": full_sha},
+           "flag_vectors_identical": True, "counters": {k: int(oc[k]) for k in ("leaves", "nodes", "minima", "lcp_values")},
+           "phase4_windows": len(windows), "window_positions": win, "window_clusters": int(sum(w["count"] for w in wants)), "window_records": int(recs),
+           "windows_identical": True, "oracle_threads": THREADS}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", f"fullsize_check_x{COPIES}_{READS}.json"), "w") as f:
+        json.dump(res, f, indent=1)
+    log(json.dumps(res))
+
+
 def main():
+    if COPIES:
+        return main_replicated()
     if MODE3:
         return main_mode3()
     if MODE2:
