@@ -187,6 +187,40 @@ __device__ __forceinline__ uint64_t eb_select(const eb_dev_index& x, uint64_t r,
     return eb_select(x, r, c, probes);
 }
 
+// The same select by FOUR adjacent lanes (lane & 3 = j, qbase = first lane of the quad inside the wave; all four pass the
+// same r and c): each probe is one coalesced 64-byte request -- lane j loads chunk j -- instead of four 16-byte loads by one
+// lane, and a wave holds 16 walks instead of 64, so fewer lanes wait for the walk that needs a third probe.
+__device__ __forceinline__ uint64_t eb_select_quad(const eb_dev_index& x, uint64_t r, int c, uint32_t j, uint32_t qbase, uint32_t& probes) {
+    const uint32_t* dir = x.sel_dir + (c == 0 ? x.sel_off[0] : c == 1 ? x.sel_off[1] : c == 2 ? x.sel_off[2] : x.sel_off[3]);
+    uint64_t m = r >> EB_SEL_SHIFT;
+    uint64_t lo = dir[m], hi = dir[m + 1]; // same address in all four lanes: one request
+    uint64_t g = lo + (((r - (m << EB_SEL_SHIFT)) * (hi - lo + 1)) >> EB_SEL_SHIFT);
+    if (g > hi) g = hi;
+    ++probes;
+    for (;;) {
+        ++probes;
+        const uint4 ch = x.chunks[(g << 2) + j];
+        const uint32_t mk = ~ch.z & ((c & 2) ? ch.y : ~ch.y) & ((c & 1) ? ch.x : ~ch.x);
+        const uint32_t kj = (uint32_t)__popc(mk);
+        const uint32_t k0 = (uint32_t)__shfl((int)kj, qbase), k1 = (uint32_t)__shfl((int)kj, qbase + 1), k2 = (uint32_t)__shfl((int)kj, qbase + 2),
+                       k3 = (uint32_t)__shfl((int)kj, qbase + 3);
+        const uint32_t w = (uint32_t)__shfl((int)ch.w, qbase + c); // chunk c carries letter c's counter
+        const uint64_t before = x.super[((g >> 25) << 2) + c] + w;
+        const uint32_t k = k0 + k1 + k2 + k3;
+        if (r < before) { g -= ((before - r - 1) >> 7) + 1; continue; }   // uniform inside the quad
+        if (r >= before + k) { g += ((r - before - k) >> 7) + 1; continue; }
+        uint32_t need = (uint32_t)(r - before);
+        uint32_t t;
+        if (need < k0) t = 0;
+        else if (need < k0 + k1) { t = 1; need -= k0; }
+        else if (need < k0 + k1 + k2) { t = 2; need -= k0 + k1; }
+        else { t = 3; need -= k0 + k1 + k2; }
+        uint32_t mt = (uint32_t)__shfl((int)mk, qbase + t);
+        for (uint32_t q = 0; q < need; ++q) mt &= mt - 1; // drop the `need` lowest set bits
+        return (g << 7) + 32u * t + (uint32_t)__ffs((int)mt) - 1u;
+    }
+}
+
 // F[letter] by selects: a dynamic index into a kernel-argument array would send the whole struct to scratch memory
 __device__ __forceinline__ uint64_t eb_F_of(const eb_dev_index& x, int letter) {
     return letter == 0 ? x.F[0] : letter == 1 ? x.F[1] : letter == 2 ? x.F[2] : x.F[3];

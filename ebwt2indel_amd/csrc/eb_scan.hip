@@ -772,14 +772,15 @@ __global__ void __launch_bounds__(256) k_extend(eb_dev_index x1, eb_dev_index x2
 // It needs nothing but the survivors in BWT order, so it is launched as soon as they are -- before the host knows their
 // number (ns_ptr, device memory) and before the call set's image exists: records and contexts go to temporaries,
 // k_right_finish moves them into the image and adds the chain offsets.
-template <bool TWO>
+template <bool TWO, int LANES> // LANES = 1: one lane per cluster; 4: a quad per cluster (eb_select_quad)
 __global__ void __launch_bounds__(256) k_right(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, ScanParams p,
                                               const Survivor* __restrict__ surv, const uint32_t* __restrict__ ns_ptr,
                                               const uint32_t* __restrict__ chain_off /* null: temporaries, k_right_finish adds it */, uint32_t chain_base,
                                               eb_cluster* __restrict__ recs, uint64_t* __restrict__ right, uint32_t right_words,
                                               unsigned long long* __restrict__ req_slots, const eb_chain* __restrict__ gate_chains) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t n_req = 0; // directory reads + 64-byte blocks probed by this lane's FL steps
+    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES;
+    const uint32_t j = LANES == 4 ? threadIdx.x & 3u : 0u, qbase = (threadIdx.x & 63u) & ~3u;
+    uint32_t n_req = 0; // directory reads + 64-byte blocks probed by this cluster's FL steps (counted by its first lane)
     if (i < *ns_ptr) {
     Survivor s = surv[i];
     // Gate (large call sets, launched behind k_extend): the writer touches a cluster's right context only when it prints,
@@ -829,11 +830,12 @@ __global__ void __launch_bounds__(256) k_right(eb_dev_index x1, eb_dev_index x2,
         while (c >= 0 && len < (uint32_t)p.k_right) {
             word |= (uint64_t)c << (2u * (len & 31u));
             ++len;
-            if ((len & 31u) == 0) { out[(len >> 5) - 1] = word; word = 0; }
-            row = eb_FL(x, row, c, n_req);
+            if ((len & 31u) == 0) { if (j == 0) out[(len >> 5) - 1] = word; word = 0; }
+            if (LANES == 4) row = eb_select_quad(x, row - eb_F_of(x, c), c, j, qbase, n_req);
+            else row = eb_FL(x, row, c, n_req);
             c = eb_F_letter(x, row);
         }
-        if (len & 31u) out[len >> 5] = word;
+        if ((len & 31u) && j == 0) out[len >> 5] = word;
     }
     eb_cluster r;
     r.begin = s.b;
@@ -843,9 +845,9 @@ __global__ void __launch_bounds__(256) k_right(eb_dev_index x1, eb_dev_index x2,
     r.right_found = pos != ~0ull ? 1 : 0;
     r.right_len = len;
     r.reserved = walk ? 0u : EB_RIGHT_SKIPPED;
-    recs[i] = r;
+    if (j == 0) recs[i] = r;
     }
-    count_requests(req_slots, n_req);
+    count_requests(req_slots, j == 0 ? n_req : 0u);
 }
 
 __global__ void k_req_sum(ScanCounters* __restrict__ c) {
@@ -1042,7 +1044,9 @@ static int launch_contexts(eb_scan_job* job) {
     const uint32_t options = job->options;
     std::vector<SubShard>& sh = job->sh;
     auto kern_extend = p.mode == 2 ? k_extend<true> : k_extend<false>;
-    auto kern_right = p.mode == 2 ? k_right<true> : k_right<false>;
+    // the late walk of a large call set: a quad per cluster (EB_RIGHT_LANES=1: one lane, the form the early walk keeps)
+    static const int right_lanes = getenv("EB_RIGHT_LANES") && atoi(getenv("EB_RIGHT_LANES")) == 1 ? 1 : 4;
+    auto kern_right = p.mode == 2 ? (right_lanes == 4 ? k_right<true, 4> : k_right<true, 1>) : (right_lanes == 4 ? k_right<false, 4> : k_right<false, 1>);
     int rc;
     for (int k = 0; k < S; ++k) {
         SubShard& x = sh[(size_t)k];
@@ -1063,7 +1067,7 @@ static int launch_contexts(eb_scan_job* job) {
             // out too short to ever print (see the gate in k_right): straight into the image, one request in nine saved.
             EB_HIP(hipStreamWaitEvent(sC, x.e[E_EXT_DONE], 0));
             EB_HIP(hipEventRecord(x.e[E_RIGHT0], sC));
-            hipLaunchKernelGGL(kern_right, dim3(grid_of(x.ns)), dim3(256), 0, sC, x1, x2, df, p, x.sorted.as<Survivor>(), x.d_ns,
+            hipLaunchKernelGGL(kern_right, dim3(grid_of(x.ns * (uint64_t)right_lanes)), dim3(256), 0, sC, x1, x2, df, p, x.sorted.as<Survivor>(), x.d_ns,
                                x.choff.as<uint32_t>(), (uint32_t)x.chain_base, x.d_recs, x.d_right, rw, x.cnt.as<ScanCounters>()->req_right,
                                (const eb_chain*)x.d_crec);
         } else
@@ -1248,7 +1252,7 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
     job->ev_end = ev_end;
     int rc;
     auto kern = p.mode == 1 ? k_scan<1> : (p.mode == 2 ? k_scan<2> : k_scan<3>);
-    auto kern_right = p.mode == 2 ? k_right<true> : k_right<false>;
+    auto kern_right = p.mode == 2 ? k_right<true, 1> : k_right<false, 1>; // the early walk of a small call set
     auto launch_scan = [&](SubShard& x) -> int {
         ScanParams q = p;
         q.begin = x.begin;
