@@ -1252,7 +1252,8 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
     job->ev_end = ev_end;
     int rc;
     auto kern = p.mode == 1 ? k_scan<1> : (p.mode == 2 ? k_scan<2> : k_scan<3>);
-    auto kern_right = p.mode == 2 ? k_right<true, 1> : k_right<false, 1>; // the early walk of a small call set
+    static const int early_lanes = getenv("EB_RIGHT_LANES_EARLY") && atoi(getenv("EB_RIGHT_LANES_EARLY")) == 4 ? 4 : 1; // the early walk of a small call set
+    auto kern_right = p.mode == 2 ? (early_lanes == 4 ? k_right<true, 4> : k_right<true, 1>) : (early_lanes == 4 ? k_right<false, 4> : k_right<false, 1>);
     auto launch_scan = [&](SubShard& x) -> int {
         ScanParams q = p;
         q.begin = x.begin;
@@ -1356,7 +1357,7 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
         // large one saturates the memory system at once and the small kernels that follow here crawl (1.2 ms instead
         // of 0.1 at 790 k clusters), so there it starts with k_extend as before.
         const bool right_early = x.ns_raw <= right_early_max;
-        const unsigned right_grid = grid_of(x.ns_raw);
+        const unsigned right_grid = grid_of(x.ns_raw * (uint64_t)early_lanes);
         if (right_early) {
             if ((rc = x.rt_rec.alloc(x.ns_raw * sizeof(eb_cluster))) != EB_OK || (rc = x.rt_right.alloc(x.ns_raw * (size_t)rw * 8)) != EB_OK) return rc;
             EB_HIP(hipEventRecord(x.e[E_SORTED], sP));
