@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--rank-queries", type=int, default=1 << 28)   # SURVEY.md §8(d) metric 2: 2^28 uniform random positions
     ap.add_argument("--cpu-sample-reads", type=int, default=400_000, help="reads in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--rehearse-rank-of", type=int, default=0, metavar="W",
+                    help="one-GPU rehearsal of ONE rank's share of a W-GPU run: scan range W//2 of W, collectives with a single rank "
+                         "(needs EB_BENCH_FORCE_DIST=1); the JSON line is labelled and its value counts the share only")
     ap.add_argument("--no-pipeline", action="store_true", help="finish every step before the next begins (profiling: under rocprofv3 the "
                     "overlapped record download runs as a blit kernel and slows the scan it overlaps)")
     args = ap.parse_args()
@@ -196,6 +199,9 @@ def main():
     assert ns.lcp_values == n, "phases 2-3 did not cover every LCP slot"
 
     begin, end = ebd.shard_range(n, rank, world)
+    if args.rehearse_rank_of > 1:
+        assert world == 1 and use_dist, "--rehearse-rank-of: one rank with EB_BENCH_FORCE_DIST=1"
+        begin, end = ebd.shard_range(n, args.rehearse_rank_of // 2, args.rehearse_rank_of)
 
     # One step = one phase-4 pass over the whole BWT + hand-over of the cluster records to rank 0's host memory.
     # Steps are software-pipelined, as a caller with a queue of work would run them (run_steps below): passes are begun
@@ -207,12 +213,16 @@ def main():
     device_gather = use_dist and comm_dev.type == "cuda" and os.environ.get("EB_BENCH_HOST_GATHER", "0") != "1"
 
     def begin_step():
-        return api.scan_clusters_begin(bwt, flags, p, begin=begin, end=end, device_only=device_gather, wire=device_gather)
+        return api.scan_clusters_begin(bwt, flags, p, begin=begin, end=end, device_only=device_gather, wire=device_gather, pipelined=not args.no_pipeline)
 
     # collect(job) hands the job's records over and may leave the hand-over in flight; resolve() completes it.
+    wait_us = []
+
     def collect(job):
         if device_gather:
+            t0 = time.perf_counter()
             job.wait()
+            wait_us.append((time.perf_counter() - t0) * 1e6)
             ptr, length = job.device_wire()      # compact image: rank 0's PCIe link carries every record of the job
             return ebd.gather_device_async(ptr, length, comm_dev, keep=job)
         calls = job.finish()                                             # records now in page-locked host memory
@@ -243,27 +253,81 @@ def main():
             for _ in range(k):
                 done(collect(begin_step()))
             return last
-        # A caller with a queue of work keeps TWO passes begun ahead of the one it collects: begin(i+1) puts its scan on the
-        # GPU and, behind that scan, the context kernels pass i was holding back (eb_scan.hip: launch_contexts) -- so the small
-        # kernels and the host round trip between a scan and its own context kernels lie under the previous pass's context
-        # kernels -- and begin(i+2) is issued before pass i's records are waited for, so that their download (PCIe) or their
-        # RCCL gather runs under pass i+1's kernels.  The hand-over of pass i is resolved one collect later.
-        from collections import deque
-        begun, pending = deque(), None
-        for _ in range(k):
-            begun.append(begin_step())
-            if len(begun) > 2:
-                started = collect(begun.popleft())
+        # A caller with a queue of work runs the two halves of a pass on two host threads: this one begins passes
+        # (eb_scan_clusters_begin: scan, ordering, context kernels; it waits twice for a few words from the device), the
+        # helper takes each begun pass, waits for its records and hands them over (PCIe download, or size exchange + RCCL
+        # gather + rank 0's download) and resolves the previous pass's hand-over.  At most five passes are in flight (one just begun and held here, one being handed over, one awaiting its resolution, two of slack).  The
+        # device work of consecutive passes overlaps as the library orders it (eb_scan.hip); the hand-over of pass i runs under
+        # the kernels of the passes behind it.  Exactly k passes start and finish inside this call.
+        import queue
+        import threading
+        sys.setswitchinterval(2e-5)   # the two threads hand the interpreter lock over within microseconds, not CPython's default 5 ms
+        begun_q = queue.Queue()
+        in_flight = threading.Semaphore(5)
+        failure = []
+
+        def helper():
+            try:
+                torch.cuda.set_device(dev)
+                pending = None
+                while True:
+                    job = begun_q.get()
+                    if job is None:
+                        break
+                    started = (collect_t if trace else collect)(job)
+                    if pending is not None:
+                        done(pending)
+                        in_flight.release()
+                    pending = started
                 if pending is not None:
                     done(pending)
-                pending = started
-        while begun:
-            started = collect(begun.popleft())
-            if pending is not None:
-                done(pending)
-            pending = started
-        if pending is not None:
-            done(pending)
+                    in_flight.release()
+            except BaseException as e:           # noqa: BLE001 -- reported by the main thread
+                failure.append(e)
+                for _ in range(k + 5):
+                    in_flight.release()
+
+        trace = os.environ.get("EB_BENCH_TRACE") == "1"   # host-side timing of the two threads (stderr)
+        t_begin, t_collect = [], []
+        if trace:
+            _collect, _begin = collect, begin_step
+
+            def collect_t(job):
+                t0 = time.perf_counter()
+                r = _collect(job)
+                t_collect.append((t0, time.perf_counter()))
+                return r
+
+            def begin_t():
+                t0 = time.perf_counter()
+                r = _begin()
+                t_begin.append((t0, time.perf_counter()))
+                return r
+        th = threading.Thread(target=helper, name="hand-over")
+        th.start()
+        try:
+            newest = None                       # handed to the helper once the NEXT pass is begun: that sends its last part out
+            for _ in range(k):
+                in_flight.acquire()
+                if failure:
+                    break
+                job = (begin_t if trace else begin_step)()
+                if newest is not None:
+                    begun_q.put(newest)
+                newest = job
+            if newest is not None:
+                begun_q.put(newest)
+        finally:
+            begun_q.put(None)
+            th.join()
+        if failure:
+            raise failure[0]
+        if trace and len(t_begin) > 8 and rank == 0:
+            b = np.array(t_begin[4:]) * 1e6
+            c = np.array(t_collect[4:]) * 1e6
+            log(f"[bench] host trace, us: begin call {np.mean(b[:, 1] - b[:, 0]):.0f}, between begin calls {np.mean(b[1:, 0] - b[:-1, 1]):.0f}, "
+                f"begin period {np.mean(np.diff(b[:, 0])):.0f}; hand-over call {np.mean(c[:, 1] - c[:, 0]):.0f} (of which waiting for the job "
+                f"{np.mean(wait_us[-len(c):]) if wait_us else 0:.0f}), period {np.mean(np.diff(c[:, 0])):.0f}")
         return last
 
     if args.warmup > 0:
@@ -292,7 +356,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
-    value = n * args.steps / elapsed
+    value = (end - begin if args.rehearse_rank_of > 1 else n) * args.steps / elapsed
 
     # ---------------- dominant kernel of the step: k_scan (HIP events on the stream it is launched on, inside the library).
     # A step launches it once per sub-shard; ms_scan is the sum of those launches, so the per-launch average covers
@@ -355,7 +419,7 @@ def main():
                 known = json.load(fh)
         except OSError:
             known = None
-        if known is not None and known["input"] == {"reads": args.reads, "read_len": args.read_len, "coverage": args.coverage, "seed": args.seed,
+        if args.rehearse_rank_of <= 1 and known is not None and known["input"] == {"reads": args.reads, "read_len": args.read_len, "coverage": args.coverage, "seed": args.seed,
                                                     "n": int(n), "ebwt_sha256": known["input"]["ebwt_sha256"]}:
             if out["snp_sha256"] != known["oracle_snp_sha256"] or out["snp_records"] != known["snp_records"]:
                 raise SystemExit(f"[bench] .snp of the timed path differs from the full-size CPU oracle run (profiles/r02_fullsize_config2.json): "
@@ -447,18 +511,20 @@ def main():
 
     if rank == 0:
         line = {
+            **({"rehearsal": f"ONE rank's share of a {args.rehearse_rank_of}-GPU run on one GPU (positions [{begin}, {end}), collectives with a single rank): "
+                             "value and step_roofline count this share only; not a benchmark result"} if args.rehearse_rank_of > 1 else {}),
             "metric": "BWT positions scanned/sec (whole node)", "value": round(value, 1), "unit": "positions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": workload, "mode": 1, "options": "-L31 -R30 -k16 -g10 -v2 -m3 -c20 -q0",
-                       "parallelism": f"scan range split over {world} GPU(s), BWT+flags replicated, gather of cluster records to rank 0; " + ("steps back to back" if args.no_pipeline else "steps pipelined (two begun ahead of the one collected)")},
+                       "parallelism": f"scan range split over {world} GPU(s), BWT+flags replicated, gather of cluster records to rank 0; " + ("steps back to back" if args.no_pipeline else "steps pipelined (one host thread begins passes, a second hands their records over; at most five in flight)")},
             "roofline": {"bound": "hbm", "achieved": round(scan_gbs, 2), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(scan_gbs / 8000.0, 5), "traffic": traffic, "kernel": "k_scan",
                          "avg_launch_ms": round(scan_avg_ms, 4), "launches_per_step": scan_launches, "positions_per_launch": int(positions_per_launch),
                          "algorithmic_bytes_per_position": 0.75},
             # the whole step against the scan's roofline (SURVEY.md 8(d) metric 1: 0.75 B x positions / step time): what `value` is worth
-            "step_roofline": {"bound": "hbm", "achieved": round(0.75 * n / (ms_per_step * 1e-3) / 1e9, 2), "peak": 8000.0 * world, "unit": "GB/s",
-                              "frac": round(0.75 * n / (ms_per_step * 1e-3) / 1e9 / (8000.0 * world), 5),
+            "step_roofline": {"bound": "hbm", "achieved": round(0.75 * value / 1e9, 2), "peak": 8000.0 * world, "unit": "GB/s",
+                              "frac": round(0.75 * value / 1e9 / (8000.0 * world), 5),
                               "what": "0.75 algorithmic bytes x all positions / ms_per_step, against the HBM peak of the GPUs used: scan + "
                                       "survivor ordering + both context kernels + hand-over of the records"},
             # the kernels that dominate the step: k_extend, then k_right (a large call set runs them one behind the other; a small one

@@ -268,10 +268,12 @@ class Calls:
                 grab(v.left, m * lw * 8), grab(v.right, k * rw * 8))
 
     def blob(self) -> memoryview:
-        """Zero-copy view of the call set's wire image (valid while this object lives)."""
+        """Zero-copy view of the call set's wire image; the view keeps this object (and so the memory) alive."""
         p, n = C.c_void_p(), C.c_uint64(0)
         _check(lib().eb_calls_blob(self._h, C.byref(p), C.byref(n)))
-        return memoryview((C.c_uint8 * n.value).from_address(p.value))
+        arr = (C.c_uint8 * n.value).from_address(p.value)
+        arr._owner = self                     # a ctypes array is the memoryview's exporter: it lives as long as any view of it
+        return memoryview(arr)
 
     def pack(self) -> bytes:
         n = lib().eb_calls_packed_size(self._h)
@@ -366,17 +368,19 @@ class ScanJob:
 
 SCAN_DEVICE_ONLY = 1
 SCAN_WIRE = 2
+SCAN_PIPELINED = 4
 
 
 def scan_clusters_begin(bwt1: DnaBwt, flags: Flags, params: Params, bwt2: Optional[DnaBwt] = None, begin: int = 0,
-                        end: Optional[int] = None, device_only: bool = False, wire: bool = False) -> ScanJob:
+                        end: Optional[int] = None, device_only: bool = False, wire: bool = False, pipelined: bool = False) -> ScanJob:
     """Enqueue phase 4 and return at once; the record download overlaps whatever the caller launches next.
     device_only: keep the call set in HBM (ScanJob.device_blob) -- for ranks that forward it with RCCL;
-    wire: the job also packs the compact wire image (ScanJob.device_wire) as its last step."""
+    wire: the job also packs the compact wire image (ScanJob.device_wire) as its last step;
+    pipelined: the caller keeps jobs coming (EB_SCAN_PIPELINED): a small call set's last part goes out with the next begin."""
     n = bwt1.n + (bwt2.n if bwt2 is not None else 0)
     h = C.c_void_p()
     _check(lib().eb_scan_clusters_begin_ex(bwt1._h, bwt2._h if bwt2 is not None else None, flags._h, begin, n if end is None else end,
-                                           C.byref(params), (SCAN_DEVICE_ONLY if device_only else 0) | (SCAN_WIRE if wire else 0), C.byref(h)))
+                                           C.byref(params), (SCAN_DEVICE_ONLY if device_only else 0) | (SCAN_WIRE if wire else 0) | (SCAN_PIPELINED if pipelined else 0), C.byref(h)))
     return ScanJob(h)
 
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -25,8 +26,12 @@ struct eb_scan_ctx {
     hipStream_t prep = nullptr, ext = nullptr, right = nullptr, copy = nullptr;
     std::vector<hipEvent_t> events;
     hipEvent_t last_ext = nullptr, last_right = nullptr; // end of the most recent job's context kernels
+    bool last_small = false;                             // the most recent job's call set was a small one (early right-context walk)
     void* h_pinned = nullptr;
     std::vector<unsigned long long*> h_bad_pool; // pinned words recycled between jobs
+    std::mutex half_mu;                          // half_job and the jobs' `half` flags
+    struct eb_scan_job* half_job = nullptr;      // EB_SCAN_PIPELINED: the job whose last part is held back until the next _begin
+    std::mutex pool_mu;                          // events / h_bad_pool: a job may be ended on one host thread while the next is begun on another
 };
 void eb_scan_ctx_destroy(eb_scan_ctx* c);
 

@@ -919,6 +919,7 @@ struct SubShard {
     uint64_t *d_left = nullptr, *d_right = nullptr;
     uint64_t ns_raw = 0, ns = 0, n_chains = 0, rec_base = 0, chain_base = 0;
     bool right_early = false;        // k_right was launched with the preparation (small call set); only its finishing kernel is left
+    uint64_t n_buckets = 0;          // position buckets of the ordering step
     const uint32_t* d_ns = nullptr;  // survivors kept, in device memory (k_right's bound)
     hipEvent_t e[E_PER_SHARD]; // scan_t0, scan_t1, scan_done, prep_cnt, prep_done, ext_t0, ext_done, right_t0, right_done, sorted
     ScanCounters* h_cnt = nullptr;
@@ -950,6 +951,12 @@ struct eb_scan_job {
     eb_dev_flags df;
     ScanParams p;
     uint32_t lw = 0, rw = 0;
+    // EB_SCAN_PIPELINED: the job's last part (finish_begin) is held back until the next _begin on the index, or until the
+    // job is waited for / ended; rc_tail is what that part returned
+    hipStream_t s_ext = nullptr, s_right = nullptr; // this job's pair of context streams
+    bool half = false;
+    int rc_tail = EB_OK;
+    char err_tail[256] = "";
 };
 
 // friendly records -> compact wire records (eb_scan_job_device_wire); *bad counts fields that do not fit
@@ -1034,7 +1041,7 @@ static int launch_contexts(eb_scan_job* job) {
     eb_index* b1 = job->b1;
     eb_scan_ctx* ctx = b1->scan_ctx;
     EB_HIP(hipSetDevice(b1->device));
-    const hipStream_t sB = ctx->ext, sC = ctx->right, sD = ctx->copy;
+    const hipStream_t sB = job->s_ext, sC = job->s_right, sD = ctx->copy;
     const eb_dev_index& x1 = job->x1;
     const eb_dev_index& x2 = job->x2;
     const eb_dev_flags& df = job->df;
@@ -1137,6 +1144,91 @@ static int launch_contexts(eb_scan_job* job) {
     return EB_OK;
 }
 
+// Last part of _begin: once the ordering step's counts are on the host, lay out the call set's image, build the chain
+// list, launch the context kernels and the hand-over (launch_contexts).
+static int finish_begin(eb_scan_job* job) {
+    eb_index* b1 = job->b1;
+    eb_scan_ctx* ctx = b1->scan_ctx;
+    EB_HIP(hipSetDevice(b1->device));
+    const hipStream_t sP = ctx->prep;
+    const int S = job->S;
+    const uint32_t lw = job->lw, rw = job->rw;
+    uint64_t rec_total = 0, chain_total = 0;
+    int rc;
+    for (int k = 0; k < S; ++k) {
+        SubShard& x = job->sh[(size_t)k];
+        x.rec_base = rec_total;
+        x.chain_base = chain_total;
+        if (x.ns_raw == 0) continue;
+        EB_HIP(hipEventSynchronize(x.e[E_PREP_CNT]));
+        x.ns = x.h_last[0];
+        x.n_chains = x.h_last[1];
+        if (x.ns == 0) continue;
+        if (chain_total + x.n_chains > 0xFFFFFFFFull) { eb_set_error("too many chains in one call; shard the range"); return EB_ERR_STATE; }
+        const size_t left_bytes = x.n_chains * (size_t)lw * 8, right_bytes = x.ns * (size_t)rw * 8;
+        if ((rc = x.chains.alloc(x.n_chains * 8)) != EB_OK) return rc;
+        if (S == 1) {
+            // one shard: the kernels write straight into a contiguous image of the call set (the wire / host format)
+            const uint64_t bytes = eb_calls_blob_size(x.ns, x.n_chains, job->k_left, job->k_right);
+            if ((rc = x.blob.alloc(bytes)) != EB_OK) return rc;
+            uint8_t* q = x.blob.as<uint8_t>() + sizeof(eb_calls_header);
+            x.d_recs = reinterpret_cast<eb_cluster*>(q);
+            q += x.ns * sizeof(eb_cluster);
+            x.d_crec = reinterpret_cast<eb_chain*>(q);
+            q += (x.n_chains * sizeof(eb_chain) + 7) & ~(size_t)7;
+            x.d_left = reinterpret_cast<uint64_t*>(q);
+            q += left_bytes;
+            x.d_right = reinterpret_cast<uint64_t*>(q);
+            job->has_blob = true;
+            job->blob_bytes = bytes;
+            job->header = eb_calls_header{EB_CALLS_MAGIC, x.ns, x.n_chains, (uint64_t)(uint32_t)job->k_left, (uint64_t)(uint32_t)job->k_right, {0, 0, 0}};
+            EB_HIP(hipMemsetAsync(x.blob.p, 0, bytes, sP));
+            hipLaunchKernelGGL(k_blob_header, dim3(1), dim3(64), 0, sP, job->header, x.blob.as<uint64_t>());
+        } else {
+            if ((rc = x.recs.alloc(x.ns * sizeof(eb_cluster))) != EB_OK || (rc = x.crec.alloc(x.n_chains * sizeof(eb_chain))) != EB_OK ||
+                (rc = x.left.alloc(left_bytes)) != EB_OK || (rc = x.right.alloc(right_bytes)) != EB_OK)
+                return rc;
+            x.d_recs = x.recs.as<eb_cluster>();
+            x.d_crec = x.crec.as<eb_chain>();
+            x.d_left = x.left.as<uint64_t>();
+            x.d_right = x.right.as<uint64_t>();
+            EB_HIP(hipMemsetAsync(x.left.p, 0, left_bytes, sP));
+            EB_HIP(hipMemsetAsync(x.right.p, 0, right_bytes, sP));
+        }
+        hipLaunchKernelGGL(k_chain_list, dim3(grid_of(x.ns)), dim3(256), 0, sP, x.sorted.as<Survivor>(), x.choff.as<uint32_t>(), x.ns, x.chains.as<uint64_t>());
+        EB_HIP(hipEventRecord(x.e[E_PREP_DONE], sP));
+        x.d_ns = x.boff.as<uint32_t>() + x.n_buckets;
+        rec_total += x.ns;
+        chain_total += x.n_chains;
+    }
+    job->ns = rec_total;
+    job->n_chains = chain_total;
+    return launch_contexts(job);
+}
+
+// the held-back last part of `job` (EB_SCAN_PIPELINED), if it is still pending; ctx->half_mu is held by the caller
+static void finish_held(eb_scan_ctx* ctx, eb_scan_job* job) {
+    if (!job->half) return;
+    job->half = false;
+    if (ctx->half_job == job) ctx->half_job = nullptr;
+    job->rc_tail = finish_begin(job);
+    if (job->rc_tail != EB_OK) snprintf(job->err_tail, sizeof job->err_tail, "%s", eb_last_error());
+}
+static int finish_pending(eb_scan_ctx* ctx) { // called by the next _begin on the index; a failure surfaces when that job is ended
+    std::lock_guard<std::mutex> lk(ctx->half_mu);
+    if (ctx->half_job) finish_held(ctx, ctx->half_job);
+    return EB_OK;
+}
+static int ensure_begun(eb_scan_job* job) { // every entry point that takes a job
+    eb_scan_ctx* ctx = job->b1->scan_ctx;
+    {
+        std::lock_guard<std::mutex> lk(ctx->half_mu);
+        finish_held(ctx, job);
+    }
+    if (job->rc_tail != EB_OK) eb_set_error("%s", job->err_tail);
+    return job->rc_tail;
+}
+
 extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f, uint64_t begin, uint64_t end, const eb_params* prm,
                                          uint32_t options, eb_scan_job** out_job) {
     if (!b1 || !f || !prm || !out_job) { eb_set_error("null argument"); return EB_ERR_ARG; }
@@ -1197,7 +1289,7 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
         EB_HIP(hipEventRecord(ctx->last_ext, ctx->ext));
         EB_HIP(hipEventRecord(ctx->last_right, ctx->right));
     }
-    const hipStream_t sA = b1->stream, sP = ctx->prep, sC = ctx->right;
+    const hipStream_t sA = b1->stream, sP = ctx->prep;
     uint64_t w_lo = begin >> 6, w_hi = (end + 63) >> 6;
     uint64_t w_total = w_hi > w_lo ? w_hi - w_lo : 0;
     // Measured at 7.55 G positions (EB_SCAN_SUBSHARDS=1/2/4/8): 6.5 / 6.1 / 6.4 / 11.0 ms per call -- the streaming scan and
@@ -1216,21 +1308,31 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
         ~JobGuard() {
             if (!*j) return;
             (void)hipDeviceSynchronize(); // nothing may still use the job's buffers
-            for (hipEvent_t e : (*j)->events) ctx->events.push_back(e);
-            if ((*j)->h_bad) ctx->h_bad_pool.push_back((*j)->h_bad);
+            {
+                std::lock_guard<std::mutex> lk(ctx->pool_mu);
+                for (hipEvent_t e : (*j)->events) ctx->events.push_back(e);
+                if ((*j)->h_bad) ctx->h_bad_pool.push_back((*j)->h_bad);
+            }
             if ((*j)->calls) eb_calls_free((*j)->calls);
             delete *j;
         }
     } job_guard{&job, ctx};
     job->b1 = b1;
     job->S = S;
-    if (ctx->h_bad_pool.empty()) {
+    job->s_ext = ctx->ext;
+    job->s_right = ctx->right;
+    const hipStream_t sC = job->s_right;
+    {
+        std::lock_guard<std::mutex> lk(ctx->pool_mu);
+        if (!ctx->h_bad_pool.empty()) {
+            job->h_bad = ctx->h_bad_pool.back();
+            ctx->h_bad_pool.pop_back();
+        }
+    }
+    if (!job->h_bad) {
         void* hb = nullptr;
         EB_HIP(hipHostMalloc(&hb, 512, hipHostMallocDefault)); // [0] wire overflow count, [1 + 2k, 2 + 2k] request counts of sub-shard k (<= 16)
         job->h_bad = static_cast<unsigned long long*>(hb);
-    } else {
-        job->h_bad = ctx->h_bad_pool.back();
-        ctx->h_bad_pool.pop_back();
     }
     memset(job->h_bad, 0, 512);
     job->k_left = prm->k_left;
@@ -1243,8 +1345,11 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
     const size_t n_events = 2 + (size_t)E_PER_SHARD * (size_t)S;
     for (size_t i = 0; i < n_events; ++i) { // events are recycled through the context's pool
         hipEvent_t e = nullptr;
-        if (!ctx->events.empty()) { e = ctx->events.back(); ctx->events.pop_back(); }
-        else EB_HIP(hipEventCreate(&e));
+        {
+            std::lock_guard<std::mutex> lk(ctx->pool_mu);
+            if (!ctx->events.empty()) { e = ctx->events.back(); ctx->events.pop_back(); }
+        }
+        if (!e) EB_HIP(hipEventCreate(&e));
         job->events.push_back(e);
     }
     hipEvent_t ev_begin = job->events[0], ev_end = job->events[1];
@@ -1279,8 +1384,14 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
     // itself starts only after job i's context kernels (they would just slow each other down: same memory system).
     // (measured again in round 2 with the serialised context kernels: letting the scan start under the previous job's
     // right-context walk or under both context kernels: 4.41 / 4.37 ms per step against 3.89)
-    EB_HIP(hipStreamWaitEvent(sA, ctx->last_ext, 0));
-    EB_HIP(hipStreamWaitEvent(sA, ctx->last_right, 0));
+    // A SMALL call set (a rank's share of a multi-GPU job) is different: its context kernels are short chains of dependent
+    // loads that leave the memory system room, and the scan -> counters on the host -> ordering kernels -> lists chain
+    // of the next job is mostly waiting; there the next scan starts at once (EB_SCAN_AFTER_CONTEXTS=1: always wait).
+    static const bool always_wait = getenv("EB_SCAN_AFTER_CONTEXTS") && atoi(getenv("EB_SCAN_AFTER_CONTEXTS")) == 1;
+    if (always_wait || !ctx->last_small) {
+        EB_HIP(hipStreamWaitEvent(sA, ctx->last_ext, 0));
+        EB_HIP(hipStreamWaitEvent(sA, ctx->last_right, 0));
+    }
     EB_HIP(hipEventRecord(ev_begin, sA));
     for (int k = 0; k < S; ++k) {
         SubShard& x = sh[(size_t)k];
@@ -1301,11 +1412,21 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
     }
 
     const uint32_t lw = (uint32_t)((prm->k_left + 31) / 32), rw = (uint32_t)((prm->k_right + 31) / 32);
-    uint64_t rec_total = 0, chain_total = 0;
+    job->x1 = x1;
+    job->x2 = x2;
+    job->df = df;
+    job->p = p;
+    job->lw = lw;
+    job->rw = rw;
+    // EB_SCAN_PIPELINED: the previous job's last part goes out now, behind this job's scan: the host's wait for that job's
+    // ordering counts and the wait for this scan below overlap instead of adding up
+    if ((rc = finish_pending(ctx)) != EB_OK) return rc;
     ScanCounters c;
     memset(&c, 0, sizeof c);
+    bool small = true;
     for (int k = 0; k < S; ++k) {
         SubShard& x = sh[(size_t)k];
+        if (S == 1) x.h_last = reinterpret_cast<uint32_t*>(job->h_bad + 40); // the job's own pinned words: a held-back tail reads them later
         for (;;) {
             EB_HIP(hipEventSynchronize(x.e[E_SCAN_DONE]));
             if (x.h_cnt->nsurv <= x.cap) break;
@@ -1320,8 +1441,6 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
         c.clusters += hc.clusters;
         c.bases += hc.bases;
         for (int i = 0; i < 201; ++i) c.hist[i] += hc.hist[i];
-        x.rec_base = rec_total;
-        x.chain_base = chain_total;
         if (x.ns_raw == 0) { x.ns = 0; continue; }
         // BWT order: deal the survivors into position buckets (x.ns, the count without the dropped candidates, comes back
         // with the chain count)
@@ -1329,6 +1448,7 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
         const uint64_t range_end = x.end > n ? n : x.end;
         const uint64_t n_buckets = ((range_end > bucket_base ? range_end - bucket_base : 0) >> EB_BUCKET_SHIFT) + 2;
         if (n_buckets > 0x7FFFFFFEull) { eb_set_error("range too long for one call; shard it"); return EB_ERR_STATE; }
+        x.n_buckets = n_buckets;
         // bcnt = [count | fill] (zeroed), boff = offsets (n_buckets + 1)
         if ((rc = x.bcnt.alloc((n_buckets + 1) * 8)) != EB_OK || (rc = x.boff.alloc((n_buckets + 2) * 4)) != EB_OK ||
             (rc = x.sorted.alloc(x.ns_raw * sizeof(Survivor))) != EB_OK || (rc = x.nch.alloc(x.ns_raw * 4)) != EB_OK ||
@@ -1356,9 +1476,10 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
         // 1.32 -> 1.24 at 197 k, 2.30 -> 2.16 at 395 k, no difference at 793 k); a
         // large one saturates the memory system at once and the small kernels that follow here crawl (1.2 ms instead
         // of 0.1 at 790 k clusters), so there it starts with k_extend as before.
-        const bool right_early = x.ns_raw <= right_early_max;
+        x.right_early = x.ns_raw <= right_early_max;
+        small = small && x.right_early;
         const unsigned right_grid = grid_of(x.ns_raw * (uint64_t)early_lanes);
-        if (right_early) {
+        if (x.right_early) {
             if ((rc = x.rt_rec.alloc(x.ns_raw * sizeof(eb_cluster))) != EB_OK || (rc = x.rt_right.alloc(x.ns_raw * (size_t)rw * 8)) != EB_OK) return rc;
             EB_HIP(hipEventRecord(x.e[E_SORTED], sP));
             EB_HIP(hipStreamWaitEvent(sC, x.e[E_SORTED], 0));
@@ -1375,59 +1496,19 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
         hipLaunchKernelGGL(k_prep_totals, dim3(1), dim3(1), 0, sP, d_boff + n_buckets, x.choff.as<uint32_t>(), x.nch.as<uint32_t>(), d_tot);
         EB_HIP(hipMemcpyAsync(&x.h_last[0], d_tot, 8, hipMemcpyDeviceToHost, sP));
         EB_HIP(hipEventRecord(x.e[E_PREP_CNT], sP));
-        EB_HIP(hipEventSynchronize(x.e[E_PREP_CNT]));
         EB_HIP(hipGetLastError());
-        x.ns = x.h_last[0];
-        x.n_chains = x.h_last[1];
-        if (x.ns == 0) continue;
-        if (chain_total + x.n_chains > 0xFFFFFFFFull) { eb_set_error("too many chains in one call; shard the range"); return EB_ERR_STATE; }
-        const size_t left_bytes = x.n_chains * (size_t)lw * 8, right_bytes = x.ns * (size_t)rw * 8;
-        if ((rc = x.chains.alloc(x.n_chains * 8)) != EB_OK) return rc;
-        if (S == 1) {
-            // one shard: the kernels write straight into a contiguous image of the call set (the wire / host format)
-            const uint64_t bytes = eb_calls_blob_size(x.ns, x.n_chains, prm->k_left, prm->k_right);
-            if ((rc = x.blob.alloc(bytes)) != EB_OK) return rc;
-            uint8_t* q = x.blob.as<uint8_t>() + sizeof(eb_calls_header);
-            x.d_recs = reinterpret_cast<eb_cluster*>(q);
-            q += x.ns * sizeof(eb_cluster);
-            x.d_crec = reinterpret_cast<eb_chain*>(q);
-            q += (x.n_chains * sizeof(eb_chain) + 7) & ~(size_t)7;
-            x.d_left = reinterpret_cast<uint64_t*>(q);
-            q += left_bytes;
-            x.d_right = reinterpret_cast<uint64_t*>(q);
-            job->has_blob = true;
-            job->blob_bytes = bytes;
-            job->header = eb_calls_header{EB_CALLS_MAGIC, x.ns, x.n_chains, (uint64_t)(uint32_t)prm->k_left, (uint64_t)(uint32_t)prm->k_right, {0, 0, 0}};
-            EB_HIP(hipMemsetAsync(x.blob.p, 0, bytes, sP));
-            hipLaunchKernelGGL(k_blob_header, dim3(1), dim3(64), 0, sP, job->header, x.blob.as<uint64_t>());
-        } else {
-            if ((rc = x.recs.alloc(x.ns * sizeof(eb_cluster))) != EB_OK || (rc = x.crec.alloc(x.n_chains * sizeof(eb_chain))) != EB_OK ||
-                (rc = x.left.alloc(left_bytes)) != EB_OK || (rc = x.right.alloc(right_bytes)) != EB_OK)
-                return rc;
-            x.d_recs = x.recs.as<eb_cluster>();
-            x.d_crec = x.crec.as<eb_chain>();
-            x.d_left = x.left.as<uint64_t>();
-            x.d_right = x.right.as<uint64_t>();
-            EB_HIP(hipMemsetAsync(x.left.p, 0, left_bytes, sP));
-            EB_HIP(hipMemsetAsync(x.right.p, 0, right_bytes, sP));
-        }
-        hipLaunchKernelGGL(k_chain_list, dim3(grid_of(x.ns)), dim3(256), 0, sP, x.sorted.as<Survivor>(), x.choff.as<uint32_t>(), x.ns, x.chains.as<uint64_t>());
-        EB_HIP(hipEventRecord(x.e[E_PREP_DONE], sP));
-        x.right_early = right_early;
-        x.d_ns = x.boff.as<uint32_t>() + n_buckets;
-        rec_total += x.ns;
-        chain_total += x.n_chains;
     }
-    job->ns = rec_total;
-    job->n_chains = chain_total;
     job->c = c;
-    job->x1 = x1;
-    job->x2 = x2;
-    job->df = df;
-    job->p = p;
-    job->lw = lw;
-    job->rw = rw;
-    if ((rc = launch_contexts(job)) != EB_OK) return rc;
+    ctx->last_small = small;
+    // Last part: the call set's image, the chain list, the context kernels and the hand-over.  It needs the ordering
+    // step's counts on the host.  A pipelining caller (EB_SCAN_PIPELINED, one shard, small call set) gets the job back
+    // now; the part goes out with the next _begin on this index, or when the job is waited for / ended.
+    if ((options & EB_SCAN_PIPELINED) && S == 1 && small) {
+        std::lock_guard<std::mutex> lk(ctx->half_mu);
+        job->half = true;
+        ctx->half_job = job;
+    } else if ((rc = finish_begin(job)) != EB_OK)
+        return rc;
     *out_job = job;
     job = nullptr;
     return EB_OK;
@@ -1439,12 +1520,14 @@ extern "C" int eb_scan_clusters_end(eb_scan_job* job, eb_calls** out, eb_scan_st
     eb_index* b1 = job->b1;
     eb_scan_ctx* ctx = b1->scan_ctx;
     EB_HIP(hipSetDevice(b1->device));
-    hipError_t werr = hipEventSynchronize(job->ev_end);
-    if (werr == hipSuccess) werr = hipStreamSynchronize(ctx->ext);
-    if (werr == hipSuccess) werr = hipStreamSynchronize(ctx->right);
+    const int tail_rc = ensure_begun(job);
+    if (tail_rc != EB_OK) (void)hipDeviceSynchronize(); // whatever part of the tail went out must be done with the job's buffers
+    // ev_end lies behind both context kernels' end events (launch_contexts); the streams themselves may already hold the
+    // next job's kernels, begun on another host thread, and are not waited for
+    hipError_t werr = tail_rc == EB_OK ? hipEventSynchronize(job->ev_end) : hipSuccess;
     float ms_scan = 0, ms_ext = 0, ms_right = 0, ms_total = 0, ms_context = 0;
     uint64_t req_ext = 0, req_right = 0;
-    if (werr == hipSuccess) {
+    if (werr == hipSuccess && tail_rc == EB_OK) {
         (void)hipEventElapsedTime(&ms_total, job->ev_begin, job->ev_end);
         for (int k = 0; k < job->S; ++k) {
             SubShard& x = job->sh[(size_t)k];
@@ -1468,7 +1551,7 @@ extern "C" int eb_scan_clusters_end(eb_scan_job* job, eb_calls** out, eb_scan_st
             req_right += job->h_bad[2 + 2 * k];
         }
     }
-    if (werr == hipSuccess && getenv("EB_SCAN_TRACE") && job->S == 1) {
+    if (werr == hipSuccess && tail_rc == EB_OK && getenv("EB_SCAN_TRACE") && job->S == 1) {
         SubShard& x = job->sh[0];
         auto at = [&](hipEvent_t e) { float t = 0; (void)hipEventElapsedTime(&t, job->ev_begin, e); return t; };
         if (x.ns)
@@ -1476,7 +1559,7 @@ extern "C" int eb_scan_clusters_end(eb_scan_job* job, eb_calls** out, eb_scan_st
                     at(x.e[E_SCAN0]), at(x.e[E_SCAN1]), at(x.e[E_SCAN_DONE]), at(x.e[E_PREP_CNT]), at(x.e[E_PREP_DONE]), at(x.e[E_EXT0]), at(x.e[E_EXT_DONE]),
                     at(x.e[E_RIGHT0]), at(x.e[E_RIGHT_DONE]), at(job->ev_end));
     }
-    if (stats && werr == hipSuccess) {
+    if (stats && werr == hipSuccess && tail_rc == EB_OK) {
         memset(stats, 0, sizeof *stats);
         stats->begin = job->begin;
         stats->end = job->end;
@@ -1495,10 +1578,19 @@ extern "C" int eb_scan_clusters_end(eb_scan_job* job, eb_calls** out, eb_scan_st
         stats->requests_extend = req_ext;
         stats->requests_right = req_right;
     }
-    for (hipEvent_t e : job->events) ctx->events.push_back(e);
-    if (job->h_bad) ctx->h_bad_pool.push_back(job->h_bad);
+    {
+        std::lock_guard<std::mutex> lk(ctx->pool_mu);
+        for (hipEvent_t e : job->events) ctx->events.push_back(e);
+        if (job->h_bad) ctx->h_bad_pool.push_back(job->h_bad);
+    }
     eb_calls* calls = job->calls;
+    const std::string job_err = job->err_tail;
     delete job; // releases the device scratch to the cache
+    if (tail_rc != EB_OK) { // the held-back last part failed: its message is the job's
+        if (calls) eb_calls_free(calls);
+        eb_set_error("%s", job_err.c_str());
+        return tail_rc;
+    }
     if (werr != hipSuccess) {
         eb_set_error("phase-4 job failed: %s", hipGetErrorString(werr));
         if (calls) eb_calls_free(calls);
@@ -1517,12 +1609,16 @@ extern "C" int eb_scan_clusters_begin(eb_index* b1, eb_index* b2, eb_flags* f, u
 extern "C" int eb_scan_job_wait(eb_scan_job* job) {
     if (!job) { eb_set_error("null argument"); return EB_ERR_ARG; }
     EB_HIP(hipSetDevice(job->b1->device));
+    int rc = ensure_begun(job);
+    if (rc != EB_OK) return rc;
     EB_HIP(hipEventSynchronize(job->ev_end));
     return EB_OK;
 }
 
 extern "C" int eb_scan_job_device_blob(eb_scan_job* job, const void** d_data, uint64_t* len) {
     if (!job || !d_data || !len) { eb_set_error("null argument"); return EB_ERR_ARG; }
+    EB_HIP(hipSetDevice(job->b1->device));
+    { int rc = ensure_begun(job); if (rc != EB_OK) return rc; }
     if (!job->has_blob) { eb_set_error("the job was split into sub-shards: no contiguous device image"); return EB_ERR_STATE; }
     *d_data = job->sh[0].blob.p;
     *len = job->blob_bytes;
@@ -1572,8 +1668,9 @@ static int wire_enqueue(eb_scan_job* job, hipStream_t st, unsigned long long* h_
 
 extern "C" int eb_scan_job_device_wire(eb_scan_job* job, const void** d_data, uint64_t* len) {
     if (!job || !d_data || !len) { eb_set_error("null argument"); return EB_ERR_ARG; }
-    if (!job->has_blob) { eb_set_error("the job was split into sub-shards: no contiguous device image"); return EB_ERR_STATE; }
     EB_HIP(hipSetDevice(job->b1->device));
+    { int rc = ensure_begun(job); if (rc != EB_OK) return rc; }
+    if (!job->has_blob) { eb_set_error("the job was split into sub-shards: no contiguous device image"); return EB_ERR_STATE; }
     EB_HIP(hipEventSynchronize(job->ev_end)); // the records (and, with EB_SCAN_WIRE, the packing) are complete
     hipStream_t st = job->b1->scan_ctx->copy;
     if (!job->wire.p) {                       // not asked for at _begin: pack now

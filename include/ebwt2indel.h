@@ -232,7 +232,11 @@ int eb_scan_clusters(eb_index* b1, eb_index* b2, eb_flags* f, uint64_t begin, ui
  * _end waits for those and hands over the results.  (Making _begin enqueue-only was tried twice in round 2 -- sizing
  * everything by the survivor list's capacity with device-resident counts, and holding the context kernels back for the
  * next job's scan -- and measured slower both times: DESIGN.md section 3.)
- * Several jobs may be in flight on the same handles; each must be ended (or cancelled) exactly once, in any order. */
+ * Several jobs may be in flight on the same handles; each must be ended (or cancelled) exactly once, in any order.
+ * Threads: _begin calls on one index are made from one host thread at a time; _wait / _end / the device-image accessors
+ * of a begun job may be called from another thread while the next job is being begun (bench.py hands records over
+ * that way).  A job with a small call set (a rank's share of a multi-GPU run) lets the next job's scan start under its
+ * context kernels; large ones keep the scan behind them (they would only slow each other down). */
 typedef struct eb_scan_job eb_scan_job;
 int eb_scan_clusters_begin(eb_index* b1, eb_index* b2, eb_flags* f, uint64_t begin, uint64_t end, const eb_params* p,
                            eb_scan_job** job);
@@ -244,6 +248,12 @@ void eb_scan_clusters_cancel(eb_scan_job* job);
 /* EB_SCAN_WIRE: the job also packs the compact wire image (eb_scan_job_device_wire) as its last step, so that asking
  * for it later costs no extra launch or wait. */
 #define EB_SCAN_WIRE 2u
+/* EB_SCAN_PIPELINED: the caller keeps jobs coming on this index (or ends this one promptly).  For a small call set
+ * (a rank's share of a multi-GPU run; one sub-shard) _begin then returns after ONE host wait -- the scan's -- and holds
+ * the job's last part (image layout, chain list, context kernels, hand-over; it needs the ordering step's counts on
+ * the host) back until the next _begin on the index, which sends it out behind its own scan, so that the two waits of
+ * consecutive jobs overlap; _wait / _end / the device-image accessors send it out themselves if it is still pending. */
+#define EB_SCAN_PIPELINED 4u
 int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f, uint64_t begin, uint64_t end, const eb_params* p,
                               uint32_t options, eb_scan_job** job);
 /* Blocks until the job's kernels and copies are complete; the job stays valid. */

@@ -532,6 +532,66 @@ def test_device_image_equals_host_blob(dip):
         assert back.format_snp(p, False)[0] == host.format_snp(p, False)[0]
 
 
+def test_pipelined_jobs_hold_back_their_last_part(dip):
+    """EB_SCAN_PIPELINED: a job's last part (image, chain list, context kernels, hand-over) goes out with the next _begin on
+    the index, or when the job is waited for / ended / asked for its image -- whichever comes first, from whichever host
+    thread.  Every order gives the blob of a plain job."""
+    import threading
+    e, g, _ = dip
+    n = len(e)
+    p = api.make_params()
+    fl = api.navigate_one_bwt(g, p)
+    cuts = [(0, n), (n // 3 // 64 * 64, n // 3 * 2 // 64 * 64), (64, 64), (n // 2 // 64 * 64, n)]
+
+    def blob_of(job):                      # the view returned by blob() is only valid while its Calls object lives
+        calls = job.finish()
+        return bytes(calls.blob())
+    want = [blob_of(api.scan_clusters_begin(g, fl, p, begin=b, end=e_)) for b, e_ in cuts]
+    # ended at once; ended after the next begin; ended in reverse order
+    for order in ([0, 1, 2, 3], [3, 2, 1, 0], [1, 0, 3, 2]):
+        jobs = [api.scan_clusters_begin(g, fl, p, begin=b, end=e_, pipelined=True) for b, e_ in cuts]
+        got = {}
+        for k in order:
+            got[k] = blob_of(jobs[k])
+        assert [got[k] for k in range(len(cuts))] == want
+    for k, (b, e_) in enumerate(cuts):
+        assert blob_of(api.scan_clusters_begin(g, fl, p, begin=b, end=e_, pipelined=True)) == want[k]
+    # device images + wire, handed over on another thread while this one keeps beginning: a job is passed on either at once
+    # (the helper may send its last part out itself, concurrently with the next _begin) or after the next _begin returned
+    import queue
+    for lag in (0, 1):
+        q, out = queue.Queue(), []
+
+        def hand_over():
+            while True:
+                job = q.get()
+                if job is None:
+                    return
+                job.wait()
+                ptr, length = job.device_wire()
+                wire = np.empty(length, dtype=np.uint8)
+                sim._hip_copy_to_host(wire, ptr, length)
+                job.finish()
+                unpacked = api.Calls.unpack(wire.tobytes())
+                out.append(bytes(unpacked.blob()))
+        th = threading.Thread(target=hand_over)
+        th.start()
+        held = []
+        for b, e_ in cuts * 4:
+            held.append(api.scan_clusters_begin(g, fl, p, begin=b, end=e_, device_only=True, wire=True, pipelined=True))
+            while len(held) > lag:
+                q.put(held.pop(0))
+        for job in held:
+            q.put(job)
+        q.put(None)
+        th.join()
+        assert out == want * 4
+    # a cancelled (never waited for) pipelined job, and one whose index sees no further begin
+    j = api.scan_clusters_begin(g, fl, p, pipelined=True)
+    del j
+    assert blob_of(api.scan_clusters_begin(g, fl, p)) == want[0]
+
+
 def _bits(rng, n, p_one):
     return rng.random(n) < p_one
 
