@@ -102,6 +102,14 @@ int main(int argc, char** argv) {
     for (uint64_t k = 0; k < m; ++k) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; h[k] = s % (nblocks * 128); }
     CK(hipMemcpy(pos, h.data(), m * 8, hipMemcpyHostToDevice));
     printf("table %.2f GB, %llu queries\n", nblocks * 64 / 1e9, (unsigned long long)m);
+    const bool sweep = argc > 2; // table-size sweep (second argument): one grid, one line
+    if (sweep) {
+        const int g = 256 * 16;
+        float a4 = time_ms([&] { hipLaunchKernelGGL(k_gather<4>, dim3(g), dim3(256), 0, 0, chunks, pos, m, sink); });
+        float r4 = time_ms([&] { hipLaunchKernelGGL((k_rank<4, false>), dim3(g), dim3(256), 0, 0, chunks, pos, m, out); });
+        printf("table %8.1f MB: gather-only K=4 %.1f G reads/s, rank+output K=4 %.1f GQ/s\n", nblocks * 64 / 1048576.0, m / a4 / 1e6, m / r4 / 1e6);
+        return 0;
+    }
     int grids[] = {256 * 4, 256 * 8, 256 * 16, 256 * 32};
     for (int g : grids) {
         float a1 = time_ms([&] { hipLaunchKernelGGL(k_gather<1>, dim3(g), dim3(256), 0, 0, chunks, pos, m, sink); });
