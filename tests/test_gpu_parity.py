@@ -317,6 +317,7 @@ def test_cluster_records_match_oracle(oracle, monkeypatch, case, early_max):
     skipped = 0
     for cuts in ([0, n], [0, n // 3, n // 2 + 17, n]):
         text, cluster_nr, events = b"", 1, 0
+        plain = []
         for b, e in zip(cuts[:-1], cuts[1:]):
             want = of.scan(p, b, e, capture=True)
             if early_max == "0":
@@ -337,6 +338,7 @@ def test_cluster_records_match_oracle(oracle, monkeypatch, case, early_max):
                         survivors=st.survivors, chains=st.chains) == want["stats"]
             t, cluster_nr, events = calls.format_snp(pp, case["mode"] != 1, cluster_nr, events)
             text += t
+            plain.append(bytes(calls.blob()))
             if early_max == "0" and len(calls):                   # the compact wire image carries the flag too
                 job = api.scan_clusters_begin(g1, gf, pp, bwt2=g2, begin=b, end=e, device_only=True, wire=True)
                 job.wait()
@@ -346,6 +348,9 @@ def test_cluster_records_match_oracle(oracle, monkeypatch, case, early_max):
                 job.finish()
                 assert bytes(api.Calls.unpack(wire.tobytes()).blob()) == bytes(calls.blob())
         assert text == golden_bytes(case["snp"])
+        # the same shards as jobs of a pipelining caller (EB_SCAN_PIPELINED), all begun before the first is ended
+        jobs = [api.scan_clusters_begin(g1, gf, pp, bwt2=g2, begin=b, end=e, pipelined=True) for b, e in zip(cuts[:-1], cuts[1:])]
+        assert [bytes(j.finish().blob()) for j in jobs] == plain
     if early_max == "0" and case["name"] in ("m1_default", "m2_het_default", "m3_het_default"):
         assert skipped > 0                                           # the gate is exercised, not just present
 
