@@ -322,6 +322,11 @@ def main():
             th.join()
         if failure:
             raise failure[0]
+        if trace and rank == 0 and len(t_begin) <= 24:
+            z = t_begin[0][0]
+            log("[bench] host trace, ms since the first begin: begin calls " + " ".join(f"{(a - z) * 1e3:.2f}-{(b - z) * 1e3:.2f}" for a, b in t_begin))
+            log("[bench] host trace, ms since the first begin: hand-overs   " + " ".join(f"{(a - z) * 1e3:.2f}-{(b - z) * 1e3:.2f}" for a, b in t_collect)
+                + f"; all done {(time.perf_counter() - z) * 1e3:.2f}")
         if trace and len(t_begin) > 8 and rank == 0:
             b = np.array(t_begin[4:]) * 1e6
             c = np.array(t_collect[4:]) * 1e6
