@@ -603,7 +603,9 @@ __global__ void __launch_bounds__(256) k_long_runs(eb_dev_index x1, eb_dev_index
 // 0.2 ms) they are dealt into buckets of 2^EB_BUCKET_SHIFT positions -- count, exclusive scan, place -- and the few
 // buckets that receive more than one are put in order by one thread each.  Dropped long-run candidates (begin = ~0)
 // are left out here.
+#ifndef EB_BUCKET_SHIFT
 #define EB_BUCKET_SHIFT 11
+#endif
 __device__ __forceinline__ uint32_t bucket_of(uint64_t b, uint64_t base) { return b <= base ? 0u : (uint32_t)((b - base) >> EB_BUCKET_SHIFT); }
 
 __global__ void __launch_bounds__(256) k_bucket_place(const Survivor* __restrict__ s, uint64_t n, uint64_t base, const uint32_t* __restrict__ off,
@@ -1041,7 +1043,7 @@ static int launch_contexts(eb_scan_job* job) {
     eb_index* b1 = job->b1;
     eb_scan_ctx* ctx = b1->scan_ctx;
     EB_HIP(hipSetDevice(b1->device));
-    const hipStream_t sB = job->s_ext, sC = job->s_right, sD = ctx->copy;
+    const hipStream_t sD = ctx->copy;
     const eb_dev_index& x1 = job->x1;
     const eb_dev_index& x2 = job->x2;
     const eb_dev_flags& df = job->df;
@@ -1059,7 +1061,11 @@ static int launch_contexts(eb_scan_job* job) {
         SubShard& x = sh[(size_t)k];
         if (x.ns == 0) continue;
         const bool right_early = x.right_early;
-        // the two context kernels are independent dependent-load chains: one stream each
+        // Small call set: the two context kernels are independent chains of dependent loads, one stream each (the walk
+        // was launched with the ordering step).  Large call set: the walk runs BEHIND the extension, so both simply follow
+        // the ordering step on its stream -- a hand-over between streams costs 15-25 us of idle device each time.
+        const bool own_streams = right_early || S > 1; // (sub-shards overlap one shard's ordering with the previous one's kernels)
+        const hipStream_t sB = own_streams ? job->s_ext : ctx->prep, sC = own_streams ? job->s_right : ctx->prep;
         EB_HIP(hipStreamWaitEvent(sB, x.e[E_PREP_DONE], 0));
         EB_HIP(hipEventRecord(x.e[E_EXT0], sB));
         if (x.n_chains)
