@@ -25,4 +25,10 @@ got1 = open("/tmp/scale_g1.snp", "rb").read()
 print(f"-G 1: {t_g1:.2f}s rc={r.returncode} identical={got1 == want}")
 print(r.stdout.splitlines()[-1] if r.stdout else r.stderr[-500:])
 os.remove("/tmp/scale_g1.snp")
+for rep in range(int(os.environ.get("CLI_REPEATS", "0"))):     # run-to-run spread of both forms (HBM just freed by the previous process)
+    for extra in ([], ["-G", "1"]):
+        t = time.time()
+        r = subprocess.run([_lib.CLI_PATH, "-1", path, "-o", "/tmp/scale_rep.snp"] + extra, capture_output=True, text=True)
+        print(f"repeat {rep} {' '.join(extra) or 'plain'}: {time.time() - t:.2f}s rc={r.returncode} :: {r.stdout.splitlines()[-1][:160] if r.stdout else r.stderr[-200:]}")
+    os.remove("/tmp/scale_rep.snp")
 os.remove(path); os.remove("/tmp/scale.snp")

@@ -597,6 +597,36 @@ def test_pipelined_jobs_hold_back_their_last_part(dip):
     assert blob_of(api.scan_clusters_begin(g, fl, p)) == want[0]
 
 
+@pytest.mark.parametrize("case", [c for c in CASES if c["name"] in ("m1_default", "m2_het_default", "m3_het_default")], ids=lambda c: c["name"])
+@pytest.mark.parametrize("subshards", ["2", "3", "7"])
+def test_sub_shards_give_the_same_call_set(oracle, monkeypatch, case, subshards):
+    """EB_SCAN_SUBSHARDS (experiments knob of the phase-4 driver): a range cut into sub-shards inside one call gives the
+    records, counters and .snp of the uncut call -- whole range and an odd slice, early and late context walks."""
+    p, e1, e2, da = _flag_case(oracle, case)
+    pp = api.make_params(case["args"])
+    g1 = api.DnaBwt(e1, term=p.term)
+    g2 = api.DnaBwt(e2, term=p.term) if e2 is not None else None
+    gf = api.Flags.build(g1, g2, p.K, p.k_right)
+    if da is not None:
+        gf.set_da(da)
+    n = g1.n + (g2.n if g2 is not None else 0)
+    for early in (None, "0"):
+        if early is not None:
+            monkeypatch.setenv("EB_RIGHT_EARLY_MAX", early)
+        for b, e in ((0, n), (n // 5 + 3, n - n // 7)):
+            monkeypatch.delenv("EB_SCAN_SUBSHARDS", raising=False)
+            plain = api.scan_clusters(g1, gf, pp, bwt2=g2, begin=b, end=e)
+            monkeypatch.setenv("EB_SCAN_SUBSHARDS", subshards)
+            cut = api.scan_clusters(g1, gf, pp, bwt2=g2, begin=b, end=e)
+            assert cut.stats.scan_launches == int(subshards)
+            assert bytes(cut.blob()) == bytes(plain.blob())
+            a, c = plain.stats, cut.stats
+            assert (a.runs_closed, a.clusters, a.bases_in_runs, a.survivors, a.chains, list(a.hist)) == \
+                   (c.runs_closed, c.clusters, c.bases_in_runs, c.survivors, c.chains, list(c.hist))
+            if (b, e) == (0, n) and early is None:
+                assert cut.format_snp(pp, case["mode"] != 1)[0] == golden_bytes(case["snp"])
+
+
 def _bits(rng, n, p_one):
     return rng.random(n) < p_one
 
