@@ -70,6 +70,7 @@ struct eb_flags {
     uint64_t *d_thrK = nullptr, *d_thrR = nullptr, *d_min = nullptr, *d_da = nullptr, *d_da_rank = nullptr;
     uint64_t* d_flag = nullptr; // thrK & ~minima
     uint4* d_mxy = nullptr;     // two-BWT mode: merged scan planes, built by the first phase-4 call
+    uint64_t da_ones = 0;       // ones in d_da (set with the rank directory): two-BWT phase 4 indexes the second BWT by DA ranks
     bool derived = false;       // d_flag / d_da_rank match the vectors (false between a sharded build and eb_flags_finalize)
     bool complemented = false;  // d_thrK / d_thrR hold the complement (bit = LCP BELOW the threshold) until eb_flags_derive inverts them
     eb_dev_flags dev() const {

@@ -608,6 +608,7 @@ int eb_flags_build_da_rank(eb_flags* f) {
     int rc = eb_scan4_exclusive(d_vec, groups, nullptr, f->stream);
     if (rc != EB_OK) return rc;
     hipLaunchKernelGGL(k_take_first, dim3(grid), dim3(256), 0, f->stream, d_vec, groups, f->d_da_rank);
+    EB_HIP(hipMemcpyAsync(&f->da_ones, f->d_da_rank + (groups - 1), sizeof(uint64_t), hipMemcpyDeviceToHost, f->stream)); // the extra last group: ones before the end
     EB_HIP(hipStreamSynchronize(f->stream));
     EB_HIP(hipGetLastError());
     EB_HIP(hipFree(d_vec));

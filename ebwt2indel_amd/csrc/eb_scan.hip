@@ -1243,6 +1243,14 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
     if (f->n != n) { eb_set_error("flag vectors cover %llu positions, BWT has %llu", (unsigned long long)f->n, (unsigned long long)n); return EB_ERR_ARG; }
     if (b1->device != f->device || (b2 && b2->device != b1->device)) { eb_set_error("handles live on different devices"); return EB_ERR_ARG; }
     if (b2 && !f->d_da) { eb_set_error("two-BWT mode needs flags built from both indexes"); return EB_ERR_STATE; }
+    // Two-BWT mode addresses the BWTs by document-array ranks (row i of the merge is row rank1(DA, i) of the second BWT,
+    // ebwt2InDel.cpp:1431-1432): that stays inside them iff the array holds exactly |bwt2| ones.  Two files that are not the
+    // eBWTs of two collections can leave the traversal short of that (the reference then reads past its vectors).
+    if (b2 && f->da_ones != b2->n) {
+        eb_set_error("the document array of the merge holds %llu ones but the second BWT %llu symbols: not the eBWTs of two collections",
+                     (unsigned long long)f->da_ones, (unsigned long long)b2->n);
+        return EB_ERR_STATE;
+    }
     if (prm->k_left < 1 || prm->k_right < 1 || prm->mcov_out < 1) { eb_set_error("parameters not resolved (call eb_params_resolve)"); return EB_ERR_ARG; }
     if (!f->derived) { eb_set_error("flags of a sharded build must be combined and finalised first (eb_flags_finalize)"); return EB_ERR_STATE; }
     if (end > n) end = n;

@@ -253,6 +253,28 @@ def test_input_that_is_no_ebwt_falls_back_to_the_reference_form(oracle, monkeypa
     assert api.run_one_dataset(e) == want
 
 
+def test_two_files_that_are_no_ebwt_pair_are_refused_before_phase_4():
+    """Two-BWT mode addresses the BWTs by document-array ranks; two legal files that are not the eBWTs of two collections can
+    leave the rebuilt array short of ones (the reference would then read past its vectors).  The library checks the count
+    and refuses phase 4 with a message -- it never lets a kernel index a BWT out of range."""
+    refused = 0
+    for name, make in NOT_EBWT.items():
+        for seed in (0, 1, 2):
+            e1 = make(np.random.Generator(np.random.PCG64(seed)))
+            e2 = make(np.random.Generator(np.random.PCG64(100 + seed)))[: len(e1) - 37]
+            g1, g2 = api.DnaBwt(e1), api.DnaBwt(e2)
+            p = api.make_params()
+            fl = api.navigate_two_bwts(g1, g2, p)
+            ones = fl.popcounts()[3]
+            if ones == g2.n:
+                api.scan_clusters(g1, fl, p, bwt2=g2)               # consistent: phase 4 runs
+            else:
+                refused += 1
+                with pytest.raises(api.EbError, match="document array"):
+                    api.scan_clusters(g1, fl, p, bwt2=g2)
+    assert refused > 0                                              # the premise: some pair does leave the array short
+
+
 def test_short_document_array_repeats_its_last_byte(oracle):
     """A -d file shorter than the BWT: the reference's failed read() leaves its one-byte buffer unchanged, so the rest of
     the DA repeats the last byte read (ebwt2InDel.cpp:1503-1508; oracle pinned on this against the reference binary in
