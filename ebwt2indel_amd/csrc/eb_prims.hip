@@ -19,8 +19,12 @@ __global__ void __launch_bounds__(256) k_rank4_batch(eb_dev_index x, const uint6
     for (; q < m; q += 2 * stride) {
         uint64_t q1 = q + stride;
         bool has1 = q1 < m; // uniform inside a quad
+        // positions past the end count as the end: the host form has checked them (check_positions), the device form
+        // (eb_rank4_batch_device) takes them as they are, and a block index out of range would be a GPU fault
         uint64_t i0 = pos[q];
         uint64_t i1 = has1 ? pos[q1] : i0;
+        i0 = i0 < x.n ? i0 : x.n;
+        i1 = i1 < x.n ? i1 : x.n;
         uint4 c0 = x.chunks[((i0 >> 7) << 2) + j];
         uint4 c1 = x.chunks[((i1 >> 7) << 2) + j];
         uint32_t p0 = eb_chunk_counts(c0, eb_prefix_mask32((uint32_t)(i0 & 127u), j));

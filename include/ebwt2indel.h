@@ -106,7 +106,8 @@ int eb_lf_node_batch(eb_index* h, const uint64_t* nodes7, uint64_t m, uint64_t* 
 
 /* Device-buffer form of eb_rank4_batch for benchmarks: d_pos / d_out4 are device
  * pointers on the handle's device; the launch goes on the handle's stream and, when
- * kernel_ms != NULL, is bracketed by HIP events on that stream. */
+ * kernel_ms != NULL, is bracketed by HIP events on that stream.  Positions are not
+ * checked on the host; one past the end of the BWT counts as the end. */
 int eb_rank4_batch_device(eb_index* h, const void* d_pos, uint64_t m, void* d_out4, float* kernel_ms);
 
 /* ------------------------------------------------------------------ phases 2-3
