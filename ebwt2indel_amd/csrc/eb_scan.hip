@@ -30,6 +30,11 @@ struct ScanParams {
     int k_left, k_right;
     uint64_t begin, end; // closing positions owned by this call
     uint64_t n;          // merged length
+    // ordered != 0: every workgroup scans ONE contiguous range of tiles_per_wg tiles and hands its survivors over in batches
+    // of EB_BATCH_TILES tiles, batch b of workgroup g into slots [ (g * batches_per_wg + b) * EB_BATCH_SLOTS, ... ): the batches
+    // are in BWT order as they lie, only their few dozen members need sorting (k_batch_compact).  ordered == 0: the
+    // workgroups stride over the tiles and append to one list in arrival order (position buckets put it in order).
+    uint32_t ordered, tiles_per_wg;
 #ifdef EB_SCAN_EXPERIMENTS
     uint32_t dbg;        // EB_SCAN_DEBUG bits: 1 no length histogram, 2 no cluster analysis, 4 no run loop, 8 no queues, 16 no statistics
 #endif
@@ -54,8 +59,10 @@ struct alignas(16) Survivor {
 #define EB_SCAN_PARTIAL 204 /* runs, clusters, bases, hist[201] */
 
 #define EB_REQ_SLOTS 64
+#define EB_BATCH_TILES 32u  /* tiles per batch (32 x 256 words x 64 = 524 288 positions: ~50 survivors on read data) */
+#define EB_BATCH_SLOTS 128u /* survivors a batch can hold = the scan's staging buffer; more than that: spilled, the scan runs again unordered */
 struct ScanCounters {
-    unsigned long long nsurv, runs_closed, clusters, bases, n_long, dropped;
+    unsigned long long nsurv, runs_closed, clusters, bases, n_long, dropped, spilled;
     unsigned long long hist[201];
     unsigned long long req_ext[EB_REQ_SLOTS], req_right[EB_REQ_SLOTS]; // memory requests counted by k_extend / k_right (count_requests)
     unsigned long long req_sum[2];                                     // their sums (k_req_sum), copied to the job's pinned words
@@ -176,9 +183,11 @@ __device__ __forceinline__ RunGeom run_geometry(const eb_dev_flags& f, uint64_t 
 template <int MODE>
 __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, ScanParams p, uint64_t w_lo,
                                              uint64_t w_count, Survivor* __restrict__ surv, uint64_t surv_cap,
-                                             ScanCounters* __restrict__ cnt, unsigned long long* __restrict__ partial) {
+                                             ScanCounters* __restrict__ cnt, unsigned long long* __restrict__ partial,
+                                             Survivor* __restrict__ slots, uint32_t* __restrict__ bcount) {
     __shared__ unsigned int sh_hist[202]; // [201]: sink for runs that CLUST_SIZES does not count
-    constexpr int STAGE = 128; // survivors are ~1 per 10^4 positions: a workgroup rarely fills this before its next flush
+    constexpr int STAGE = (int)EB_BATCH_SLOTS; // survivors are ~1 per 10^4 positions: a workgroup rarely fills this before its next flush
+    const bool ordered = p.ordered != 0;
     __shared__ uint4 s_buf[STAGE * (sizeof(Survivor) / 16)];
     __shared__ uint32_t s_count;
     __shared__ unsigned long long s_base;
@@ -251,10 +260,10 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
             if (slot < (uint32_t)STAGE) {
                 const uint4* src = reinterpret_cast<const uint4*>(&s);
                 for (int k = 0; k < (int)(sizeof(Survivor) / 16); ++k) s_buf[slot * (sizeof(Survivor) / 16) + k] = src[k];
-            } else {
+            } else if (!ordered) {
                 unsigned long long gl = atomicAdd(&cnt->nsurv, 1ull);
                 if (gl < surv_cap) surv[gl] = s;
-            }
+            } // ordered: the batch is over-full; the flush sees s_count > STAGE and reports the spill
         }
     };
     // Queue primitives.  Only this wave touches its queues and every lane executes every call (wave-uniform control
@@ -350,8 +359,28 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
         }
         return d;
     };
+    // what is left in this wave's queues (fewer than 64 entries each): filtered / analysed now
+    auto drain = [&]() {
+        if (hot_n) {
+            bool have = lane < hot_n;
+            unsigned long long e = have ? q_hot[wave][lane] : 0ull;
+            hot_n = 0;
+            __builtin_amdgcn_wave_barrier();
+            filter(have, e);
+        }
+        if (todo_n) {
+            bool have = lane < todo_n;
+            unsigned long long e = have ? q_todo[wave][lane] : 0ull;
+            todo_n = 0;
+            __builtin_amdgcn_wave_barrier();
+            if (!(EB_DBG(p) & 2u)) analyse(have, e);
+        }
+    };
     uint32_t trips = 0;
-    for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const uint64_t T = p.tiles_per_wg;
+    const uint64_t iters = ordered ? T : (tiles > blockIdx.x ? (tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0);
+    for (uint64_t it = 0; it < iters; ++it) {
+        const uint64_t tile = ordered ? (uint64_t)blockIdx.x * T + it : (uint64_t)blockIdx.x + it * gridDim.x;
         TileData td = load_tile(tile);
         uint64_t t = tile * 256 + threadIdx.x;
         bool active = t < w_count;
@@ -498,29 +527,38 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
         // Survivors are rare (~1 per 10^4 positions = ~2 per tile): empty the staging buffer every 16 tiles.  No
         // barrier in between (they would serialise the tiles of a workgroup); a buffer that fills up earlier sends
         // the excess straight to the list (analyse), so the schedule never affects the result.
-        if ((++trips & 15u) == 0) {
+        if (ordered) {
+            // a batch ends: every cluster that closed in its tiles must be in the staging buffer before it leaves, so the
+            // queues are emptied first (two part-filled rounds per wave and batch)
+            if (((it + 1) % EB_BATCH_TILES) == 0 || it + 1 == iters) {
+                drain();
+                __syncthreads();
+                const uint32_t staged = s_count;
+                const uint32_t m = staged < (uint32_t)STAGE ? staged : (uint32_t)STAGE;
+                const uint64_t batch = (uint64_t)blockIdx.x * ((T + EB_BATCH_TILES - 1) / EB_BATCH_TILES) + it / EB_BATCH_TILES;
+                uint4* dst = reinterpret_cast<uint4*>(slots + batch * EB_BATCH_SLOTS);
+                for (uint32_t k = threadIdx.x; k < m * (uint32_t)(sizeof(Survivor) / 16); k += blockDim.x) dst[k] = s_buf[k];
+                if (threadIdx.x == 0) {
+                    bcount[batch] = m;
+                    if (m) atomicAdd(&cnt->nsurv, (unsigned long long)m);
+                    if (staged > (uint32_t)STAGE) cnt->spilled = 1ull;
+                }
+                __syncthreads();
+                if (threadIdx.x == 0) s_count = 0;
+                __syncthreads();
+            }
+        } else if ((++trips & 15u) == 0) {
             __syncthreads();
             if (threadIdx.x == 0 && s_count > (uint32_t)STAGE) s_count = STAGE;
             stage.flush(surv, surv_cap, &cnt->nsurv);
         }
     }
-    // what is left in the queues (fewer than 64 each)
-    if (hot_n) {
-        bool have = lane < hot_n;
-        unsigned long long e = have ? q_hot[wave][lane] : 0ull;
-        hot_n = 0;
-        __builtin_amdgcn_wave_barrier();
-        filter(have, e);
+    if (!ordered) {
+        drain();
+        __syncthreads();
+        if (threadIdx.x == 0 && s_count > (uint32_t)STAGE) s_count = STAGE;
+        stage.flush(surv, surv_cap, &cnt->nsurv);
     }
-    if (todo_n) {
-        bool have = lane < todo_n;
-        unsigned long long e = have ? q_todo[wave][lane] : 0ull;
-        todo_n = 0;
-        if (!(EB_DBG(p) & 2u)) analyse(have, e);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0 && s_count > (uint32_t)STAGE) s_count = STAGE;
-    stage.flush(surv, surv_cap, &cnt->nsurv);
     // Statistics leave the kernel as one row of plain stores per workgroup (k_scan_reduce adds the rows up): thousands of
     // waves hammering three counters in one cache line with atomics cost ~0.25 ms per launch, whatever the range size.
     for (int o = 32; o > 0; o >>= 1) {
@@ -557,20 +595,14 @@ __global__ void __launch_bounds__(256) k_scan_reduce(const unsigned long long* _
 // Histogram + frequent-symbol filter of the clusters k_scan could not analyse from registers (runs longer than
 // 64..128 positions).  Dropped ones get begin = ~0, which the sort moves behind the real survivors.
 __device__ __forceinline__ uint32_t bucket_of(uint64_t b, uint64_t base);
-__global__ void __launch_bounds__(256) k_long_runs(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, ScanParams p, Survivor* __restrict__ surv, uint64_t n,
-                                                  unsigned long long* __restrict__ dropped, uint64_t bucket_base, uint32_t* __restrict__ bucket_cnt) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Survivor s = surv[i];
-    if (s.fmask0 != EB_NEEDS_HIST) { // the usual survivor: only counted into its position bucket (see k_bucket_place)
-        atomicAdd(&bucket_cnt[bucket_of(s.b, bucket_base)], 1u);
-        return;
-    }
+// the histogram and frequent-letter test of one such candidate; false: dropped (begin = ~0)
+__device__ __forceinline__ bool resolve_long_run(const eb_dev_index& x1, const eb_dev_index& x2, const eb_dev_flags& f, const ScanParams& p, Survivor& s) {
     uint32_t c0[4], c1[4];
     bool keep;
     if (p.mode == 1) {
         hist_by_rank(x1, s.b, s.e, c0);
         s.fmask0 = frequent_mask(c0, p.mcov);
+        s.fmask1 = 0;
         int nf = __popc(s.fmask0);
         keep = nf >= 2 && !(p.q > 0 && nf > p.q);
     } else {
@@ -591,11 +623,76 @@ __global__ void __launch_bounds__(256) k_long_runs(eb_dev_index x1, eb_dev_index
     if (!keep) {
         s.b = ~0ull;
         s.fmask0 = s.fmask1 = 0;
-        atomicAdd(dropped, 1ull);
-    } else {
-        atomicAdd(&bucket_cnt[bucket_of(s.b, bucket_base)], 1u);
     }
+    return keep;
+}
+__global__ void __launch_bounds__(256) k_long_runs(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, ScanParams p, Survivor* __restrict__ surv, uint64_t n,
+                                                  unsigned long long* __restrict__ dropped, uint64_t bucket_base, uint32_t* __restrict__ bucket_cnt) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Survivor s = surv[i];
+    if (s.fmask0 != EB_NEEDS_HIST) { // the usual survivor: only counted into its position bucket (see k_bucket_place)
+        atomicAdd(&bucket_cnt[bucket_of(s.b, bucket_base)], 1u);
+        return;
+    }
+    if (!resolve_long_run(x1, x2, f, p, s)) atomicAdd(dropped, 1ull);
+    else atomicAdd(&bucket_cnt[bucket_of(s.b, bucket_base)], 1u);
     surv[i] = s;
+}
+
+// ---- ordered scan (ScanParams.ordered): the batches lie in BWT order in `slots`, batch b holding bcount[b] survivors in
+// arrival order.  One wave per batch.
+// (1) long-run candidates get their histogram; every batch reports how many survivors it keeps (kept[n_batches] = 0 for the
+//     exclusive scan that follows, whose last element is then the total)
+__global__ void __launch_bounds__(256) k_batch_resolve(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, ScanParams p, Survivor* __restrict__ slots,
+                                                      const uint32_t* __restrict__ bcount, uint64_t n_batches, uint32_t* __restrict__ kept,
+                                                      unsigned long long* __restrict__ dropped) {
+    const uint64_t b = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (b >= n_batches) return; // whole waves
+    const uint32_t c = bcount[b];
+    uint32_t mine = 0;
+    for (uint32_t i = lane; i < c; i += 64u) {
+        Survivor* q = slots + b * EB_BATCH_SLOTS + i;
+        if (q->fmask0 == EB_NEEDS_HIST) {
+            Survivor s = *q;
+            bool keep = resolve_long_run(x1, x2, f, p, s);
+            if (!keep) atomicAdd(dropped, 1ull);
+            *q = s;
+            mine += keep ? 1u : 0u;
+        } else
+            ++mine;
+    }
+    for (int o = 32; o > 0; o >>= 1) mine += (uint32_t)__shfl_xor((int)mine, o);
+    if (lane == 0) {
+        kept[b] = mine;
+        if (b == 0) kept[n_batches] = 0;
+    }
+}
+// (2) each batch puts its members in order (rank by counting: a few dozen keys in LDS) and writes them to their place in the
+//     dense list; the chain count of every survivor goes out with it (k_surv_chains of the unordered path).  n_chains[]
+//     beyond the survivors kept has been zeroed by the caller.
+__global__ void __launch_bounds__(256) k_batch_compact(const Survivor* __restrict__ slots, const uint32_t* __restrict__ bcount, const uint32_t* __restrict__ off,
+                                                      uint64_t n_batches, Survivor* __restrict__ sorted, uint32_t* __restrict__ n_chains) {
+    __shared__ unsigned long long keys[4][EB_BATCH_SLOTS];
+    const uint64_t b = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (b >= n_batches) return; // whole waves
+    const uint32_t c = bcount[b];
+    const uint32_t base = off[b];
+    const Survivor* q = slots + b * EB_BATCH_SLOTS;
+    for (uint32_t i = lane; i < c; i += 64u) keys[wave][i] = q[i].b;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = lane; i < c; i += 64u) {
+        const unsigned long long key = keys[wave][i];
+        if (key == ~0ull) continue; // a dropped long-run candidate
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < c; ++j) rank += keys[wave][j] < key ? 1u : 0u; // begins of distinct clusters are distinct
+        Survivor v = q[i];
+        sorted[base + rank] = v;
+        n_chains[base + rank] = (uint32_t)(__popc(v.fmask0) + __popc(v.fmask1));
+    }
 }
 
 // ---- BWT order of the survivors.  They leave the scan in queue order; their begins are spread evenly over the range
@@ -915,7 +1012,10 @@ namespace {
 enum { E_SCAN0, E_SCAN1, E_SCAN_DONE, E_PREP_CNT, E_PREP_DONE, E_EXT0, E_EXT_DONE, E_RIGHT0, E_RIGHT_DONE, E_SORTED, E_PER_SHARD };
 struct SubShard {
     uint64_t begin = 0, end = 0, w_lo = 0, w_count = 0, cap = 0;
-    DevMem cnt, part, surv, sorted, bcnt, boff, tmp, nch, choff, chains, recs, crec, left, right, blob, rt_rec, rt_right; // bcnt/boff: position buckets; rt_*: k_right's temporaries
+    DevMem cnt, part, surv, sorted, bcnt, boff, tmp, nch, choff, chains, recs, crec, left, right, blob, rt_rec, rt_right; // bcnt/boff: position buckets (ordered scan: survivors kept per batch / their offsets); rt_*: k_right's temporaries
+    DevMem slots, bcount;            // ordered scan: the batches' survivors and counts
+    bool ordered = false;            // this sub-shard's scan ran in ordered mode
+    uint64_t n_batches = 0;
     eb_cluster* d_recs = nullptr; // sections: inside `blob` (one shard) or the separate buffers above (sub-shards)
     eb_chain* d_crec = nullptr;
     uint64_t *d_left = nullptr, *d_right = nullptr;
@@ -956,6 +1056,7 @@ struct eb_scan_job {
     // EB_SCAN_PIPELINED: the job's last part (finish_begin) is held back until the next _begin on the index, or until the
     // job is waited for / ended; rc_tail is what that part returned
     hipStream_t s_ext = nullptr, s_right = nullptr; // this job's pair of context streams
+    uint32_t reruns = 0;            // scans run a second time (ordered hand-over spilled / survivor list too short)
     bool half = false;
     int rc_tail = EB_OK;
     char err_tail[256] = "";
@@ -1373,19 +1474,34 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
     auto kern = p.mode == 1 ? k_scan<1> : (p.mode == 2 ? k_scan<2> : k_scan<3>);
     static const int early_lanes = getenv("EB_RIGHT_LANES_EARLY") && atoi(getenv("EB_RIGHT_LANES_EARLY")) == 4 ? 4 : 1; // the early walk of a small call set
     auto kern_right = p.mode == 2 ? (early_lanes == 4 ? k_right<true, 4> : k_right<true, 1>) : (early_lanes == 4 ? k_right<false, 4> : k_right<false, 1>);
-    auto launch_scan = [&](SubShard& x) -> int {
+    // The scan hands its survivors over in BWT-ordered batches (ScanParams.ordered) unless a batch overflows, which it
+    // reports (ScanCounters.spilled): that scan is then run again the unordered way, into one list that position buckets put
+    // in order.  EB_SCAN_ORDERED=0: always the unordered way.
+    const bool ordered_ok = !(getenv("EB_SCAN_ORDERED") && atoi(getenv("EB_SCAN_ORDERED")) == 0);
+    auto launch_scan = [&](SubShard& x, bool ordered) -> int {
         ScanParams q = p;
         q.begin = x.begin;
         q.end = x.end;
         int r;
-        if ((r = x.surv.alloc(x.cap * sizeof(Survivor))) != EB_OK) return r;
+        x.ordered = ordered && x.w_count != 0;
+        const unsigned grid = scan_grid(x.w_count);
+        if (x.ordered) {
+            const uint64_t tiles = (x.w_count + 255) / 256;
+            q.ordered = 1;
+            q.tiles_per_wg = (uint32_t)((tiles + grid - 1) / grid);
+            x.n_batches = (uint64_t)grid * ((q.tiles_per_wg + EB_BATCH_TILES - 1) / EB_BATCH_TILES);
+            if ((r = x.slots.alloc(x.n_batches * EB_BATCH_SLOTS * sizeof(Survivor))) != EB_OK || (r = x.bcount.alloc(x.n_batches * 4)) != EB_OK) return r;
+        } else {
+            q.ordered = 0;
+            q.tiles_per_wg = 0;
+            if ((r = x.surv.alloc(x.cap * sizeof(Survivor))) != EB_OK) return r;
+        }
         EB_HIP(hipMemsetAsync(x.cnt.p, 0, sizeof(ScanCounters), sA));
         EB_HIP(hipEventRecord(x.e[E_SCAN0], sA));
         if (x.w_count) {
-            const unsigned grid = scan_grid(x.w_count);
             if ((r = x.part.alloc((size_t)grid * EB_SCAN_PARTIAL * 8)) != EB_OK) return r;
             hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, sA, x1, x2, df, q, x.w_lo, x.w_count, x.surv.as<Survivor>(), x.cap,
-                               x.cnt.as<ScanCounters>(), x.part.as<unsigned long long>());
+                               x.cnt.as<ScanCounters>(), x.part.as<unsigned long long>(), x.slots.as<Survivor>(), x.bcount.as<uint32_t>());
             hipLaunchKernelGGL(k_scan_reduce, dim3(EB_SCAN_PARTIAL), dim3(256), 0, sA, x.part.as<unsigned long long>(), grid, x.cnt.as<ScanCounters>());
         }
         EB_HIP(hipEventRecord(x.e[E_SCAN1], sA));
@@ -1409,7 +1525,7 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
     EB_HIP(hipEventRecord(ev_begin, sA));
     for (int k = 0; k < S; ++k) {
         SubShard& x = sh[(size_t)k];
-        for (DevMem* m : {&x.cnt, &x.part, &x.surv, &x.sorted, &x.bcnt, &x.boff, &x.tmp, &x.nch, &x.choff, &x.chains, &x.recs, &x.crec, &x.left, &x.right, &x.blob, &x.rt_rec, &x.rt_right})
+        for (DevMem* m : {&x.cnt, &x.part, &x.surv, &x.sorted, &x.bcnt, &x.boff, &x.tmp, &x.nch, &x.choff, &x.chains, &x.recs, &x.crec, &x.left, &x.right, &x.blob, &x.rt_rec, &x.rt_right, &x.slots, &x.bcount})
             m->device = b1->device;
         for (int i = 0; i < E_PER_SHARD; ++i) x.e[i] = job->events[2 + (size_t)E_PER_SHARD * (size_t)k + (size_t)i];
         x.h_cnt = reinterpret_cast<ScanCounters*>(static_cast<uint8_t*>(ctx->h_pinned) + (size_t)k * (sizeof(ScanCounters) + 64));
@@ -1422,7 +1538,7 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
         x.end = k == S - 1 ? end : wb << 6;
         x.cap = x.w_count / 16 + 4096; // survivors are ~1e-4 per position; grown on demand
         if ((rc = x.cnt.alloc(sizeof(ScanCounters))) != EB_OK) return rc;
-        if ((rc = launch_scan(x)) != EB_OK) return rc;
+        if ((rc = launch_scan(x, ordered_ok && EB_DBG(p) == 0)) != EB_OK) return rc;
     }
 
     const uint32_t lw = (uint32_t)((prm->k_left + 31) / 32), rw = (uint32_t)((prm->k_right + 31) / 32);
@@ -1443,9 +1559,16 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
         if (S == 1) x.h_last = reinterpret_cast<uint32_t*>(job->h_bad + 40); // the job's own pinned words: a held-back tail reads them later
         for (;;) {
             EB_HIP(hipEventSynchronize(x.e[E_SCAN_DONE]));
+            if (x.ordered) {
+                if (!x.h_cnt->spilled) break;
+                ++job->reruns;
+                if ((rc = launch_scan(x, false)) != EB_OK) return rc; // rare: a batch held more than its slots
+                continue;
+            }
             if (x.h_cnt->nsurv <= x.cap) break;
             x.cap = x.h_cnt->nsurv + 1024; // rare: rerun this sub-shard's scan with room for every survivor
-            if ((rc = launch_scan(x)) != EB_OK) return rc;
+            ++job->reruns;
+            if ((rc = launch_scan(x, false)) != EB_OK) return rc;
         }
         ScanCounters hc = *x.h_cnt;
         x.ns_raw = hc.nsurv;
@@ -1456,11 +1579,37 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
         c.bases += hc.bases;
         for (int i = 0; i < 201; ++i) c.hist[i] += hc.hist[i];
         if (x.ns_raw == 0) { x.ns = 0; continue; }
+        uint32_t* d_boff = nullptr;  // exclusive offsets of the buckets / batches; [n_buckets] = survivors kept
+        uint64_t n_buckets = 0;
+        size_t tmp_bytes = 0, scan_bytes = 0;
+        if (x.ordered) {
+            // the batches lie in BWT order already: resolve the long-run candidates, count what every batch keeps, scan, and
+            // let every batch sort its few dozen members into place (k_batch_compact also writes the chain counts)
+            n_buckets = x.n_batches;
+            x.n_buckets = n_buckets;
+            if ((rc = x.bcnt.alloc((n_buckets + 1) * 4)) != EB_OK || (rc = x.boff.alloc((n_buckets + 2) * 4)) != EB_OK ||
+                (rc = x.sorted.alloc(x.ns_raw * sizeof(Survivor))) != EB_OK || (rc = x.nch.alloc(x.ns_raw * 4)) != EB_OK ||
+                (rc = x.choff.alloc((x.ns_raw + 3) * 4)) != EB_OK)
+                return rc;
+            uint32_t* d_kept = x.bcnt.as<uint32_t>();
+            d_boff = x.boff.as<uint32_t>();
+            EB_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_kept, d_boff, (int)(n_buckets + 1), sP));
+            EB_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, x.nch.as<uint32_t>(), x.choff.as<uint32_t>(), (int)x.ns_raw, sP));
+            if (scan_bytes > tmp_bytes) tmp_bytes = scan_bytes;
+            if ((rc = x.tmp.alloc(tmp_bytes)) != EB_OK) return rc;
+            const unsigned wave_grid = grid_of(n_buckets * 64);
+            EB_HIP(hipMemsetAsync(x.nch.p, 0, x.ns_raw * 4, sP));
+            hipLaunchKernelGGL(k_batch_resolve, dim3(wave_grid), dim3(256), 0, sP, x1, x2, df, p, x.slots.as<Survivor>(), x.bcount.as<uint32_t>(), n_buckets,
+                               d_kept, &x.cnt.as<ScanCounters>()->dropped);
+            EB_HIP(hipcub::DeviceScan::ExclusiveSum(x.tmp.p, tmp_bytes, d_kept, d_boff, (int)(n_buckets + 1), sP)); // d_boff[n_batches] = survivors kept
+            hipLaunchKernelGGL(k_batch_compact, dim3(wave_grid), dim3(256), 0, sP, x.slots.as<Survivor>(), x.bcount.as<uint32_t>(), d_boff, n_buckets,
+                               x.sorted.as<Survivor>(), x.nch.as<uint32_t>());
+        } else {
         // BWT order: deal the survivors into position buckets (x.ns, the count without the dropped candidates, comes back
         // with the chain count)
         const uint64_t bucket_base = x.begin & ~((1ull << EB_BUCKET_SHIFT) - 1ull);
         const uint64_t range_end = x.end > n ? n : x.end;
-        const uint64_t n_buckets = ((range_end > bucket_base ? range_end - bucket_base : 0) >> EB_BUCKET_SHIFT) + 2;
+        n_buckets = ((range_end > bucket_base ? range_end - bucket_base : 0) >> EB_BUCKET_SHIFT) + 2;
         if (n_buckets > 0x7FFFFFFEull) { eb_set_error("range too long for one call; shard it"); return EB_ERR_STATE; }
         x.n_buckets = n_buckets;
         // bcnt = [count | fill] (zeroed), boff = offsets (n_buckets + 1)
@@ -1470,8 +1619,7 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
             return rc;
         uint32_t* d_bcnt = x.bcnt.as<uint32_t>();
         uint32_t* d_bfill = d_bcnt + (n_buckets + 1);
-        uint32_t* d_boff = x.boff.as<uint32_t>();
-        size_t tmp_bytes = 0, scan_bytes = 0;
+        d_boff = x.boff.as<uint32_t>();
         EB_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_bcnt, d_boff, (int)(n_buckets + 1), sP));
         EB_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, x.nch.as<uint32_t>(), x.choff.as<uint32_t>(), (int)x.ns_raw, sP));
         if (scan_bytes > tmp_bytes) tmp_bytes = scan_bytes;
@@ -1485,6 +1633,7 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
         hipLaunchKernelGGL(k_bucket_place, dim3(grid_of(x.ns_raw)), dim3(256), 0, sP, x.surv.as<Survivor>(), x.ns_raw, bucket_base, d_boff, d_bfill,
                            x.sorted.as<Survivor>());
         hipLaunchKernelGGL(k_bucket_fix, dim3(grid_of(n_buckets)), dim3(256), 0, sP, d_boff, n_buckets, x.sorted.as<Survivor>());
+        }
         // The right-context walk needs nothing else.  For a small call set (a rank's slice of a multi-GPU job) it starts
         // now, under the rest of the preparation and the host round trip (per step: 0.78 -> 0.69 ms at 98 k clusters,
         // 1.32 -> 1.24 at 197 k, 2.30 -> 2.16 at 395 k, no difference at 793 k); a
@@ -1503,7 +1652,7 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
                                (const uint32_t*)nullptr, 0u, x.rt_rec.as<eb_cluster>(), x.rt_right.as<uint64_t>(), rw, x.cnt.as<ScanCounters>()->req_right,
                                (const eb_chain*)nullptr);
         }
-        hipLaunchKernelGGL(k_surv_chains, dim3(grid_of(x.ns_raw)), dim3(256), 0, sP, x.sorted.as<Survivor>(), d_boff + n_buckets, x.ns_raw, x.nch.as<uint32_t>());
+        if (!x.ordered) hipLaunchKernelGGL(k_surv_chains, dim3(grid_of(x.ns_raw)), dim3(256), 0, sP, x.sorted.as<Survivor>(), d_boff + n_buckets, x.ns_raw, x.nch.as<uint32_t>());
         // dense chain list: exclusive scan of the per-cluster chain counts
         EB_HIP(hipcub::DeviceScan::ExclusiveSum(x.tmp.p, tmp_bytes, x.nch.as<uint32_t>(), x.choff.as<uint32_t>(), (int)x.ns_raw, sP));
         uint32_t* d_tot = x.choff.as<uint32_t>() + x.ns_raw + 1;
@@ -1591,6 +1740,7 @@ extern "C" int eb_scan_clusters_end(eb_scan_job* job, eb_calls** out, eb_scan_st
         stats->ms_context = ms_context;
         stats->requests_extend = req_ext;
         stats->requests_right = req_right;
+        stats->scan_reruns = job->reruns;
     }
     {
         std::lock_guard<std::mutex> lk(ctx->pool_mu);

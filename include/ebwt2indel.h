@@ -214,6 +214,9 @@ typedef struct {
     /* memory requests the context kernels issued, counted on the device where they are issued: k_extend one per
      * 64-byte block of a rank pair (1 or 2 per LF step), k_right one per select-directory read + one per block probed */
     uint64_t requests_extend, requests_right;
+    /* scans that ran a second time: a batch of the ordered hand-over held more survivors than its slots (the scan then
+     * runs again the unordered way), or the unordered survivor list was too short (it runs again with room for all) */
+    uint32_t scan_reruns, reserved;
 } eb_scan_stats;
 
 /* Replaces the phase-4 loops run_one_dataset (:1609-1655), run_two_datasets (:1395-1445)

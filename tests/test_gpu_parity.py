@@ -658,6 +658,7 @@ def _pack_bits(bits):
     return np.packbits(np.concatenate([bits, np.zeros(pad, dtype=bool)]), bitorder="little").view(np.uint64).copy()
 
 
+_STRESS_RERUNS = {}
 _STRESS = {
     # name: (n, P(symbol is TERM), flag pattern)
     "dense_runs_of_20": (200_000, 0.02, lambda r, n: _bits(r, n, 0.95)),
@@ -704,7 +705,7 @@ def test_scan_on_adversarial_flag_patterns(oracle, name, mode):
         g1 = api.DnaBwt(sym, term=p.term)
     of = _oracle.OracleFlags(oracle, o1, o2, vectors=(thrK, thrR, minima, da))
     gf = api.Flags.from_host(n, thrK, thrR, minima, da)
-    seen = []
+    seen, reruns = [], []
     for cuts in ([0, n], [0, 64 * 700 + 1, n // 2 + 17, n - 5, n]):
         for b, e in zip(cuts[:-1], cuts[1:]):
             want = of.scan(p, b, e, capture=True)
@@ -712,6 +713,7 @@ def test_scan_on_adversarial_flag_patterns(oracle, name, mode):
             calls = api.scan_clusters(g1, gf, pp, bwt2=g2, begin=b, end=e)
             cl, chains, left, right = calls.arrays()
             st = calls.stats
+            reruns.append(st.scan_reruns)
             assert dict(runs_closed=st.runs_closed, clusters=st.clusters, bases_in_runs=st.bases_in_runs,
                         survivors=st.survivors, chains=st.chains) == want["stats"]
             assert np.array_equal(np.array(list(st.hist), dtype=np.uint64), want["hist"])
@@ -720,6 +722,32 @@ def test_scan_on_adversarial_flag_patterns(oracle, name, mode):
             assert np.array_equal(left, want["left"])
             assert np.array_equal(right, want["right"])
     assert seen[0] == sum(seen[1:]) and seen[0] > 0              # the cuts partition the clusters; the input is not trivial
+    _STRESS_RERUNS[(name, mode)] = max(reruns)
+
+
+def test_adversarial_patterns_reach_the_unordered_scan():
+    """The scan hands its survivors over in BWT-ordered batches of 128 slots; a batch that overflows makes it run again the
+    unordered way (eb_scan_stats.scan_reruns).  Read data never does that, the dense patterns above must -- or the fallback
+    would go untested."""
+    if not _STRESS_RERUNS:
+        pytest.skip("runs after test_scan_on_adversarial_flag_patterns")
+    assert max(_STRESS_RERUNS.values()) > 0, _STRESS_RERUNS
+
+
+def test_ordered_and_unordered_scan_give_the_same_call_set(dip, monkeypatch):
+    """EB_SCAN_ORDERED=0 (one survivor list put in order by position buckets) against the default (ordered batches) on
+    read data: same bytes, and the ordered scan needs no second run."""
+    e, g, _ = dip
+    n = len(e)
+    p = api.make_params()
+    fl = api.navigate_one_bwt(g, p)
+    for b, e_ in ((0, n), (n // 3, n - n // 5), (64, 64)):
+        monkeypatch.delenv("EB_SCAN_ORDERED", raising=False)
+        a = api.scan_clusters(g, fl, p, begin=b, end=e_)
+        monkeypatch.setenv("EB_SCAN_ORDERED", "0")
+        c = api.scan_clusters(g, fl, p, begin=b, end=e_)
+        assert bytes(a.blob()) == bytes(c.blob())
+        assert a.stats.scan_reruns == 0 and c.stats.scan_reruns == 0
 
 
 @pytest.mark.skipif(not os.path.exists(_oracle.REF_BIN), reason="reference binary did not travel with the tree")
