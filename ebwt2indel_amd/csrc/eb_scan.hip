@@ -56,11 +56,12 @@ struct alignas(16) Survivor {
 };
 
 #define EB_NEEDS_HIST 0x80000000u
-#define EB_SCAN_PARTIAL 204 /* runs, clusters, bases, hist[201] */
+#define EB_SCAN_PARTIAL 205 /* runs, clusters, bases, hist[201], survivors (ordered scan) */
 
 #define EB_REQ_SLOTS 64
-#define EB_BATCH_TILES 32u  /* tiles per batch (32 x 256 words x 64 = 524 288 positions: ~50 survivors on read data) */
-#define EB_BATCH_SLOTS 128u /* survivors a batch can hold = the scan's staging buffer; more than that: spilled, the scan runs again unordered */
+#define EB_BATCH_TILES 128u /* tiles per batch (128 x 256 words x 64 = 2 097 152 positions: ~210 survivors on read data) */
+#define EB_BATCH_SLOTS 512u /* survivors a batch can hold; more than that: spilled, the scan runs again unordered */
+#define EB_STAGE_SLOTS 128u /* the unordered scan's staging buffer in LDS */
 struct ScanCounters {
     unsigned long long nsurv, runs_closed, clusters, bases, n_long, dropped, spilled;
     unsigned long long hist[201];
@@ -186,7 +187,7 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
                                              ScanCounters* __restrict__ cnt, unsigned long long* __restrict__ partial,
                                              Survivor* __restrict__ slots, uint32_t* __restrict__ bcount) {
     __shared__ unsigned int sh_hist[202]; // [201]: sink for runs that CLUST_SIZES does not count
-    constexpr int STAGE = (int)EB_BATCH_SLOTS; // survivors are ~1 per 10^4 positions: a workgroup rarely fills this before its next flush
+    constexpr int STAGE = (int)EB_STAGE_SLOTS; // survivors are ~1 per 10^4 positions: a workgroup rarely fills this before its next flush
     const bool ordered = p.ordered != 0;
     __shared__ uint4 s_buf[STAGE * (sizeof(Survivor) / 16)];
     __shared__ uint32_t s_count;
@@ -202,7 +203,8 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
     // scan planes in the coordinates the flags live in: the index's own (modes 1, 3) or the two BWTs merged by the DA (mode 2)
     const uint4* __restrict__ xy = MODE == 2 ? f.mxy : x1.xy;
     const uint64_t n_bwt_words = MODE == 2 ? f.words : (x1.n_blocks << 1); // 64-symbol words backed by the planes
-    uint64_t n_runs = 0, n_clusters = 0, n_bases = 0;
+    uint64_t n_runs = 0, n_clusters = 0, n_bases = 0, n_surv = 0;
+    uint64_t cur_batch = 0;                           // ordered mode: the batch of the tile at hand (wave-uniform)
     uint32_t hot_n = 0, todo_n = 0;                   // queue fill, the same in every lane of the wave
     const uint64_t tiles = (w_count + 255) / 256;
     constexpr bool local_syms = true;
@@ -254,16 +256,23 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
                 }
             }
         }
-        if (keep) {
-            // LDS staging (no per-survivor global atomic); a full buffer spills straight to the list
+        if (keep && ordered) {
+            // straight into the slots of the batch at hand: one cursor per batch (thousands of them: no contention).  A wave
+            // empties its queues before it enters the next batch, so nothing of this batch is staged later.
+            const uint32_t pos = atomicAdd(&bcount[cur_batch], 1u);
+            if (pos < EB_BATCH_SLOTS) slots[cur_batch * EB_BATCH_SLOTS + pos] = s;
+            else cnt->spilled = 1ull;
+            ++n_surv;
+        } else if (keep) {
+            // LDS staging (no per-survivor global atomic on the one list cursor); a full buffer spills straight to the list
             uint32_t slot = atomicAdd(&s_count, 1u);
             if (slot < (uint32_t)STAGE) {
                 const uint4* src = reinterpret_cast<const uint4*>(&s);
                 for (int k = 0; k < (int)(sizeof(Survivor) / 16); ++k) s_buf[slot * (sizeof(Survivor) / 16) + k] = src[k];
-            } else if (!ordered) {
+            } else {
                 unsigned long long gl = atomicAdd(&cnt->nsurv, 1ull);
                 if (gl < surv_cap) surv[gl] = s;
-            } // ordered: the batch is over-full; the flush sees s_count > STAGE and reports the spill
+            }
         }
     };
     // Queue primitives.  Only this wave touches its queues and every lane executes every call (wave-uniform control
@@ -381,6 +390,7 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
     const uint64_t iters = ordered ? T : (tiles > blockIdx.x ? (tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0);
     for (uint64_t it = 0; it < iters; ++it) {
         const uint64_t tile = ordered ? (uint64_t)blockIdx.x * T + it : (uint64_t)blockIdx.x + it * gridDim.x;
+        if (ordered) cur_batch = (uint64_t)blockIdx.x * ((T + EB_BATCH_TILES - 1) / EB_BATCH_TILES) + it / EB_BATCH_TILES;
         TileData td = load_tile(tile);
         uint64_t t = tile * 256 + threadIdx.x;
         bool active = t < w_count;
@@ -528,25 +538,9 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
         // barrier in between (they would serialise the tiles of a workgroup); a buffer that fills up earlier sends
         // the excess straight to the list (analyse), so the schedule never affects the result.
         if (ordered) {
-            // a batch ends: every cluster that closed in its tiles must be in the staging buffer before it leaves, so the
-            // queues are emptied first (two part-filled rounds per wave and batch)
-            if (((it + 1) % EB_BATCH_TILES) == 0 || it + 1 == iters) {
-                drain();
-                __syncthreads();
-                const uint32_t staged = s_count;
-                const uint32_t m = staged < (uint32_t)STAGE ? staged : (uint32_t)STAGE;
-                const uint64_t batch = (uint64_t)blockIdx.x * ((T + EB_BATCH_TILES - 1) / EB_BATCH_TILES) + it / EB_BATCH_TILES;
-                uint4* dst = reinterpret_cast<uint4*>(slots + batch * EB_BATCH_SLOTS);
-                for (uint32_t k = threadIdx.x; k < m * (uint32_t)(sizeof(Survivor) / 16); k += blockDim.x) dst[k] = s_buf[k];
-                if (threadIdx.x == 0) {
-                    bcount[batch] = m;
-                    if (m) atomicAdd(&cnt->nsurv, (unsigned long long)m);
-                    if (staged > (uint32_t)STAGE) cnt->spilled = 1ull;
-                }
-                __syncthreads();
-                if (threadIdx.x == 0) s_count = 0;
-                __syncthreads();
-            }
+            // a batch ends: every cluster that closed in its tiles must be in its slots before this wave moves on, so the wave
+            // empties its queues (two part-filled rounds per wave and batch; no barrier: the batch cursor is global)
+            if (((it + 1) % EB_BATCH_TILES) == 0 || it + 1 == iters) drain();
         } else if ((++trips & 15u) == 0) {
             __syncthreads();
             if (threadIdx.x == 0 && s_count > (uint32_t)STAGE) s_count = STAGE;
@@ -565,17 +559,19 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
         n_runs += __shfl_xor((unsigned long long)n_runs, o);
         n_clusters += __shfl_xor((unsigned long long)n_clusters, o);
         n_bases += __shfl_xor((unsigned long long)n_bases, o);
+        n_surv += __shfl_xor((unsigned long long)n_surv, o);
     }
-    __shared__ unsigned long long sh_red[3][4];
-    if (lane == 0) { sh_red[0][threadIdx.x >> 6] = n_runs; sh_red[1][threadIdx.x >> 6] = n_clusters; sh_red[2][threadIdx.x >> 6] = n_bases; }
+    __shared__ unsigned long long sh_red[4][4];
+    if (lane == 0) { sh_red[0][threadIdx.x >> 6] = n_runs; sh_red[1][threadIdx.x >> 6] = n_clusters; sh_red[2][threadIdx.x >> 6] = n_bases; sh_red[3][threadIdx.x >> 6] = n_surv; }
     __syncthreads();
     unsigned long long* row = partial + (uint64_t)blockIdx.x * EB_SCAN_PARTIAL;
     if (threadIdx.x < 3) row[threadIdx.x] = sh_red[threadIdx.x][0] + sh_red[threadIdx.x][1] + sh_red[threadIdx.x][2] + sh_red[threadIdx.x][3];
+    if (threadIdx.x == 3) row[204] = sh_red[3][0] + sh_red[3][1] + sh_red[3][2] + sh_red[3][3]; // survivors handed over by the ordered scan
     for (int k = threadIdx.x; k < 201; k += blockDim.x) row[3 + k] = (unsigned long long)sh_hist[k] * (unsigned long long)k; // CLUST_SIZES[len] += len
 }
 
 // column sums of the per-workgroup statistics rows -> ScanCounters (one workgroup per column)
-__global__ void __launch_bounds__(256) k_scan_reduce(const unsigned long long* __restrict__ partial, uint32_t rows, ScanCounters* __restrict__ cnt) {
+__global__ void __launch_bounds__(256) k_scan_reduce(const unsigned long long* __restrict__ partial, uint32_t rows, ScanCounters* __restrict__ cnt, int ordered) {
     __shared__ unsigned long long sh[4];
     const uint32_t col = blockIdx.x;
     unsigned long long s = 0;
@@ -588,6 +584,7 @@ __global__ void __launch_bounds__(256) k_scan_reduce(const unsigned long long* _
         if (col == 0) cnt->runs_closed = s;
         else if (col == 1) cnt->clusters = s;
         else if (col == 2) cnt->bases = s;
+        else if (col == 204) { if (ordered) cnt->nsurv = s; } // the unordered scan counts its survivors with the list cursor
         else cnt->hist[col - 3] = s;
     }
 }
@@ -1497,12 +1494,13 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
             if ((r = x.surv.alloc(x.cap * sizeof(Survivor))) != EB_OK) return r;
         }
         EB_HIP(hipMemsetAsync(x.cnt.p, 0, sizeof(ScanCounters), sA));
+        if (x.ordered) EB_HIP(hipMemsetAsync(x.bcount.p, 0, x.n_batches * 4, sA)); // the batches' cursors
         EB_HIP(hipEventRecord(x.e[E_SCAN0], sA));
         if (x.w_count) {
             if ((r = x.part.alloc((size_t)grid * EB_SCAN_PARTIAL * 8)) != EB_OK) return r;
             hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, sA, x1, x2, df, q, x.w_lo, x.w_count, x.surv.as<Survivor>(), x.cap,
                                x.cnt.as<ScanCounters>(), x.part.as<unsigned long long>(), x.slots.as<Survivor>(), x.bcount.as<uint32_t>());
-            hipLaunchKernelGGL(k_scan_reduce, dim3(EB_SCAN_PARTIAL), dim3(256), 0, sA, x.part.as<unsigned long long>(), grid, x.cnt.as<ScanCounters>());
+            hipLaunchKernelGGL(k_scan_reduce, dim3(EB_SCAN_PARTIAL), dim3(256), 0, sA, x.part.as<unsigned long long>(), grid, x.cnt.as<ScanCounters>(), x.ordered ? 1 : 0);
         }
         EB_HIP(hipEventRecord(x.e[E_SCAN1], sA));
         EB_HIP(hipMemcpyAsync(x.h_cnt, x.cnt.p, sizeof(ScanCounters), hipMemcpyDeviceToHost, sA));
@@ -1561,6 +1559,7 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
             EB_HIP(hipEventSynchronize(x.e[E_SCAN_DONE]));
             if (x.ordered) {
                 if (!x.h_cnt->spilled) break;
+                if (getenv("EB_SCAN_TRACE")) fprintf(stderr, "[scan] a batch of the ordered hand-over overflowed: scanning again unordered\n");
                 ++job->reruns;
                 if ((rc = launch_scan(x, false)) != EB_OK) return rc; // rare: a batch held more than its slots
                 continue;
