@@ -671,21 +671,18 @@ __global__ void __launch_bounds__(256) k_batch_resolve(eb_dev_index x1, eb_dev_i
 //     beyond the survivors kept has been zeroed by the caller.
 __global__ void __launch_bounds__(256) k_batch_compact(const Survivor* __restrict__ slots, const uint32_t* __restrict__ bcount, const uint32_t* __restrict__ off,
                                                       uint64_t n_batches, Survivor* __restrict__ sorted, uint32_t* __restrict__ n_chains) {
-    __shared__ unsigned long long keys[4][EB_BATCH_SLOTS];
-    const uint64_t b = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if (b >= n_batches) return; // whole waves
+    __shared__ unsigned long long keys[EB_BATCH_SLOTS];
+    const uint64_t b = blockIdx.x; // one workgroup per batch: the rank loop is c compares per member
     const uint32_t c = bcount[b];
     const uint32_t base = off[b];
     const Survivor* q = slots + b * EB_BATCH_SLOTS;
-    for (uint32_t i = lane; i < c; i += 64u) keys[wave][i] = q[i].b;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (uint32_t i = lane; i < c; i += 64u) {
-        const unsigned long long key = keys[wave][i];
+    for (uint32_t i = threadIdx.x; i < c; i += blockDim.x) keys[i] = q[i].b;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < c; i += blockDim.x) {
+        const unsigned long long key = keys[i];
         if (key == ~0ull) continue; // a dropped long-run candidate
         uint32_t rank = 0;
-        for (uint32_t j = 0; j < c; ++j) rank += keys[wave][j] < key ? 1u : 0u; // begins of distinct clusters are distinct
+        for (uint32_t j = 0; j < c; ++j) rank += keys[j] < key ? 1u : 0u; // begins of distinct clusters are distinct
         Survivor v = q[i];
         sorted[base + rank] = v;
         n_chains[base + rank] = (uint32_t)(__popc(v.fmask0) + __popc(v.fmask1));
@@ -1601,7 +1598,7 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
             hipLaunchKernelGGL(k_batch_resolve, dim3(wave_grid), dim3(256), 0, sP, x1, x2, df, p, x.slots.as<Survivor>(), x.bcount.as<uint32_t>(), n_buckets,
                                d_kept, &x.cnt.as<ScanCounters>()->dropped);
             EB_HIP(hipcub::DeviceScan::ExclusiveSum(x.tmp.p, tmp_bytes, d_kept, d_boff, (int)(n_buckets + 1), sP)); // d_boff[n_batches] = survivors kept
-            hipLaunchKernelGGL(k_batch_compact, dim3(wave_grid), dim3(256), 0, sP, x.slots.as<Survivor>(), x.bcount.as<uint32_t>(), d_boff, n_buckets,
+            hipLaunchKernelGGL(k_batch_compact, dim3((unsigned)n_buckets), dim3(256), 0, sP, x.slots.as<Survivor>(), x.bcount.as<uint32_t>(), d_boff, n_buckets,
                                x.sorted.as<Survivor>(), x.nch.as<uint32_t>());
         } else {
         // BWT order: deal the survivors into position buckets (x.ns, the count without the dropped candidates, comes back
