@@ -44,6 +44,21 @@ struct eb_dev_flags {
     uint64_t words;   // ceil(n/64)
 };
 
+// One 16-byte chunk of a block.  EB_NT_LOADS: with the nontemporal hint -- random block reads that nothing reads again soon
+// (scripts/rank_probe.hip: 50.8 against 47.6 G random reads/s on a 4 GB table).
+#ifndef EB_NT_LOADS
+#define EB_NT_LOADS 0
+#endif
+typedef uint32_t eb_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 eb_load_chunk(const uint4* p) {
+#if EB_NT_LOADS
+    eb_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const eb_u32x4*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+
 struct rank4_t {
     uint64_t v[4];
 };
@@ -81,7 +96,7 @@ __device__ __forceinline__ rank4_t eb_rank4(const eb_dev_index& x, uint64_t i) {
 // parallel_rank by FOUR adjacent lanes (lane&3 = j): each loads chunk j; returns the rank of letter j.
 // All four lanes of the quad must be active and pass the same i.
 __device__ __forceinline__ uint64_t eb_rank4_quad(const eb_dev_index& x, uint64_t i, uint32_t j) {
-    uint4 c = x.chunks[((i >> 7) << 2) + j];
+    uint4 c = eb_load_chunk(x.chunks + ((i >> 7) << 2) + j);
     uint32_t p = eb_chunk_counts(c, eb_prefix_mask32((uint32_t)(i & 127u), j));
     p += (uint32_t)__shfl_xor((int)p, 1);
     p += (uint32_t)__shfl_xor((int)p, 2);
@@ -89,7 +104,7 @@ __device__ __forceinline__ uint64_t eb_rank4_quad(const eb_dev_index& x, uint64_
 }
 
 // The same in two steps, so that a kernel can put the loads of many queries in flight before it needs the first result.
-__device__ __forceinline__ uint4 eb_rank4_quad_load(const eb_dev_index& x, uint64_t i, uint32_t j) { return x.chunks[((i >> 7) << 2) + j]; }
+__device__ __forceinline__ uint4 eb_rank4_quad_load(const eb_dev_index& x, uint64_t i, uint32_t j) { return eb_load_chunk(x.chunks + ((i >> 7) << 2) + j); }
 __device__ __forceinline__ uint64_t eb_rank4_quad_finish(const eb_dev_index& x, uint4 c, uint64_t i, uint32_t j) {
     uint32_t p = eb_chunk_counts(c, eb_prefix_mask32((uint32_t)(i & 127u), j));
     p += (uint32_t)__shfl_xor((int)p, 1);
@@ -100,9 +115,9 @@ __device__ __forceinline__ uint64_t eb_rank4_quad_finish(const eb_dev_index& x, 
 // Ranks at both ends of an interval [lo, hi] by one quad: a narrow interval (the usual case when following a
 // cluster's left context, width ~ coverage) lies in ONE block, which is then loaded once.
 __device__ __forceinline__ void eb_rank4_quad_pair(const eb_dev_index& x, uint64_t lo, uint64_t hi, uint32_t j, uint64_t& a, uint64_t& b) {
-    uint4 c = x.chunks[((lo >> 7) << 2) + j];
+    uint4 c = eb_load_chunk(x.chunks + ((lo >> 7) << 2) + j);
     uint4 d = c;
-    if ((hi >> 7) != (lo >> 7)) d = x.chunks[((hi >> 7) << 2) + j]; // uniform inside the quad
+    if ((hi >> 7) != (lo >> 7)) d = eb_load_chunk(x.chunks + ((hi >> 7) << 2) + j); // uniform inside the quad
     uint32_t p = eb_chunk_counts(c, eb_prefix_mask32((uint32_t)(lo & 127u), j));
     uint32_t q = eb_chunk_counts(d, eb_prefix_mask32((uint32_t)(hi & 127u), j));
     p += (uint32_t)__shfl_xor((int)p, 1);
@@ -199,7 +214,7 @@ __device__ __forceinline__ uint64_t eb_select_quad(const eb_dev_index& x, uint64
     ++probes;
     for (;;) {
         ++probes;
-        const uint4 ch = x.chunks[(g << 2) + j];
+        const uint4 ch = eb_load_chunk(x.chunks + (g << 2) + j);
         const uint32_t mk = ~ch.z & ((c & 2) ? ch.y : ~ch.y) & ((c & 1) ? ch.x : ~ch.x);
         const uint32_t kj = (uint32_t)__popc(mk);
         const uint32_t k0 = (uint32_t)__shfl((int)kj, qbase), k1 = (uint32_t)__shfl((int)kj, qbase + 1), k2 = (uint32_t)__shfl((int)kj, qbase + 2),

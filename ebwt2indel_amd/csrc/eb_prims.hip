@@ -25,8 +25,8 @@ __global__ void __launch_bounds__(256) k_rank4_batch(eb_dev_index x, const uint6
         uint64_t i1 = has1 ? pos[q1] : i0;
         i0 = i0 < x.n ? i0 : x.n;
         i1 = i1 < x.n ? i1 : x.n;
-        uint4 c0 = x.chunks[((i0 >> 7) << 2) + j];
-        uint4 c1 = x.chunks[((i1 >> 7) << 2) + j];
+        uint4 c0 = eb_load_chunk(x.chunks + ((i0 >> 7) << 2) + j);
+        uint4 c1 = eb_load_chunk(x.chunks + ((i1 >> 7) << 2) + j);
         uint32_t p0 = eb_chunk_counts(c0, eb_prefix_mask32((uint32_t)(i0 & 127u), j));
         uint32_t p1 = eb_chunk_counts(c1, eb_prefix_mask32((uint32_t)(i1 & 127u), j));
         p0 += (uint32_t)__shfl_xor((int)p0, 1);
