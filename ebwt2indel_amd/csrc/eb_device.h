@@ -50,12 +50,26 @@ struct eb_dev_flags {
 #define EB_NT_LOADS 0
 #endif
 typedef uint32_t eb_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint4 eb_load_chunk(const uint4* p) {
-#if EB_NT_LOADS
+__device__ __forceinline__ uint4 eb_load_chunk_nt(const uint4* p) {
     eb_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const eb_u32x4*>(p));
     return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint4 eb_load_chunk(const uint4* p) {
+#if EB_NT_LOADS
+    return eb_load_chunk_nt(p);
 #else
     return *p;
+#endif
+}
+// the probes of a select (the right-context walk): blocks nobody looks at twice
+#ifndef EB_NT_SELECT
+#define EB_NT_SELECT 1
+#endif
+__device__ __forceinline__ uint4 eb_load_chunk_select(const uint4* p) {
+#if EB_NT_SELECT
+    return eb_load_chunk_nt(p);
+#else
+    return eb_load_chunk(p);
 #endif
 }
 
@@ -214,7 +228,7 @@ __device__ __forceinline__ uint64_t eb_select_quad(const eb_dev_index& x, uint64
     ++probes;
     for (;;) {
         ++probes;
-        const uint4 ch = eb_load_chunk(x.chunks + (g << 2) + j);
+        const uint4 ch = eb_load_chunk_select(x.chunks + (g << 2) + j);
         const uint32_t mk = ~ch.z & ((c & 2) ? ch.y : ~ch.y) & ((c & 1) ? ch.x : ~ch.x);
         const uint32_t kj = (uint32_t)__popc(mk);
         const uint32_t k0 = (uint32_t)__shfl((int)kj, qbase), k1 = (uint32_t)__shfl((int)kj, qbase + 1), k2 = (uint32_t)__shfl((int)kj, qbase + 2),
