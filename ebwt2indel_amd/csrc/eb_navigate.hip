@@ -268,7 +268,14 @@ __global__ void __launch_bounds__(256) k_nodes(eb_dev_index x1, eb_dev_index x2,
             memset(&N[u], 0, sizeof(Node));
             if (active[u]) unpack_rec(in[i], N[u]);
         }
-        // all rank loads of the trip, back to back
+        // All rank loads of the trip, back to back.  With two BWTs a block is loaded ONCE: the six boundaries of a node are
+        // sorted and, below the top of the tree, a few dozen rows apart, so most of them share the block of their left
+        // neighbour; the skipped lanes are masked off in the load instruction (no request), and which block a boundary
+        // uses is resolved when the results are consumed, so no load waits for another.  Twelve quad loads per node
+        // become about four: two-BWT traversal 0.98 -> 0.91-0.94 s at 2 x 3.775 G positions.  (With one BWT the same trade -- six
+        // loads become two, 20 more registers -- LOSES: 0.433 -> 0.463 s; repeated loads hit in the L2 and cost less there
+        // than the bookkeeping.)
+        bool la[NB == 2 ? U : 1][6], lb[NB == 2 ? U : 1][6];
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -276,8 +283,10 @@ __global__ void __launch_bounds__(256) k_nodes(eb_dev_index x1, eb_dev_index x2,
                 if constexpr (NB == 1) {
                     ca[u][k] = eb_rank4_quad_load(x1, N[u].b[k], j);
                 } else {
-                    ca[u][k] = eb_rank4_quad_load(x1, N[u].a[k], j);
-                    cb[u][k] = eb_rank4_quad_load(x2, N[u].b[k], j);
+                    la[u][k] = k == 0 || (N[u].a[k] >> 7) != (N[u].a[k - 1] >> 7);
+                    lb[u][k] = k == 0 || (N[u].b[k] >> 7) != (N[u].b[k - 1] >> 7);
+                    if (la[u][k]) ca[u][k] = eb_rank4_quad_load(x1, N[u].a[k], j);
+                    if (lb[u][k]) cb[u][k] = eb_rank4_quad_load(x2, N[u].b[k], j);
                 }
             }
 #pragma unroll
@@ -346,9 +355,13 @@ __global__ void __launch_bounds__(256) k_nodes(eb_dev_index x1, eb_dev_index x2,
             } else {
                 uint64_t F1 = pick4(x1.F, j), F2 = pick4(x2.F, j);
                 int kids = 0;
+                uint4 cur_a = ca[u][0], cur_b = cb[u][0];
+#pragma unroll
                 for (int k = 0; k < 6; ++k) {
-                    child.a[k] = F1 + eb_rank4_quad_finish(x1, ca[u][k], Nu.a[k], j);
-                    child.b[k] = F2 + eb_rank4_quad_finish(x2, cb[u][k], Nu.b[k], j);
+                    if (la[u][k]) cur_a = ca[u][k]; // else: the block of the boundary to the left
+                    if (lb[u][k]) cur_b = cb[u][k];
+                    child.a[k] = F1 + eb_rank4_quad_finish(x1, cur_a, Nu.a[k], j);
+                    child.b[k] = F2 + eb_rank4_quad_finish(x2, cur_b, Nu.b[k], j);
                 }
                 for (int k = 0; k < 5; ++k) kids += (child.a[k + 1] > child.a[k]) || (child.b[k + 1] > child.b[k]); // include.hpp:784-792
                 child.depth = Nu.depth + 1;
