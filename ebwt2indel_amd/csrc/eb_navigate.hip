@@ -94,7 +94,7 @@ struct NavParams {
     // stores of the traversal (phases 2-3 at 7.55 G positions: 0.58 -> 0.47 s).
     int below;
 #ifdef EB_SCAN_EXPERIMENTS
-    uint32_t dbg;  // EB_NAV_DEBUG (profiling build only; results are wrong): 1 no LCP stores, 2 no minima, 4 children not appended below depth 40
+    uint32_t dbg;  // EB_NAV_DEBUG (profiling build only; results are wrong): 1 no LCP stores, 2 no minima, 4 children not appended below depth 40, 8 no DA bits of singleton rows (two BWTs; phase 4 then refuses the flags)
 #endif
 };
 #ifdef EB_SCAN_EXPERIMENTS
@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(256) k_nodes(eb_dev_index x1, eb_dev_index x2,
                         if ((uint32_t)(k & 3) != j || (k == 4 && j != 0)) continue;
                         uint64_t s1 = Nu.a[k + 1] - Nu.a[k], s2 = Nu.b[k + 1] - Nu.b[k];
                         if (s1 + s2 == 1) {
-                            if (s2) eb_bit_set_atomic(f.da, Nu.b[k] + Nu.a[k + 1]);
+                            if (s2 && !(EB_NDBG(p) & 8u)) eb_bit_set_atomic(f.da, Nu.b[k] + Nu.a[k + 1]);
                             ++n_da;
                         }
                     }
