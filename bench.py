@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--rank-queries", type=int, default=1 << 28)   # SURVEY.md §8(d) metric 2: 2^28 uniform random positions
     ap.add_argument("--cpu-sample-reads", type=int, default=400_000, help="reads in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-dram-reads", type=int, default=7_000_000, help="reads in the DRAM-resident CPU-baseline sample (n = 151 x reads; 0 = skip)")
     ap.add_argument("--rehearse-rank-of", type=int, default=0, metavar="W",
                     help="one-GPU rehearsal of ONE rank's share of a W-GPU run: scan range W//2 of W, collectives with a single rank "
                          "(needs EB_BENCH_FORCE_DIST=1); the JSON line is labelled and its value counts the share only")
@@ -182,7 +183,13 @@ def main():
     probe_len = min(n, 1 << 20)
     head = np.empty(probe_len, dtype=np.uint8)
     sim._hip_copy_to_host(head, dev_ebwt.ptr, probe_len)
-    dev_ebwt.free()
+    # The 7.55 GB ASCII text is released only AFTER phases 2-3: a large hipFree is followed by a driver-side wipe and the next
+    # large hipMalloc of the process waits for it ("HBM allocation") -- round 2 freed it here and the
+    # traversal's first allocations then sat behind the wipe for ~2 s of "phases 2-3" wall time that was no work of the path.
+    # EB_BENCH_FREE_EARLY=1: the round-2 order.
+    free_early = os.environ.get("EB_BENCH_FREE_EARLY") == "1"
+    if free_early:
+        dev_ebwt.free()
     t1 = time.time()
     # N > 1: the traversal itself is split over the ranks (Weiner-link subtrees) and the bit vectors are combined by
     # one all-reduce each; N = 1: the plain build.
@@ -190,6 +197,8 @@ def main():
     if use_dist:
         dist.barrier()
     t_nav = time.time() - t1
+    if not free_early:
+        dev_ebwt.free()
     ns = flags.stats
     if rank == 0:
         log(f"[bench] index {t_index*1e3:.1f} ms ({bwt.device_bytes/1e9:.2f} GB); phases 2-3 on GPU {t_nav:.3f}s: {ns.nodes} nodes, {ns.leaves} leaves, "
@@ -240,6 +249,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    step_done = []     # completion time of every timed step (its records in rank 0's host memory)
+
     def run_steps(k, record=None):
         last = None
 
@@ -248,6 +259,7 @@ def main():
             last = resolve(pending)
             if record is not None:
                 record(last[0].stats)
+                step_done.append(time.perf_counter())
 
         if args.no_pipeline:
             for _ in range(k):
@@ -361,6 +373,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
+    # spread over the timed steps: intervals between consecutive completions (steps are pipelined, so a step's own duration is
+    # not observable from outside; in steady state the interval IS the step time); the first interval holds the pipeline fill
+    gaps = np.diff(np.array([t0] + step_done)) * 1e3
+    steady = gaps[1:] if len(gaps) > 2 else gaps
+    step_spread = {"ms_per_step_min": round(float(steady.min()), 4), "ms_per_step_median": round(float(np.median(steady)), 4),
+                   "ms_per_step_max": round(float(steady.max()), 4), "what": "intervals between consecutive step completions on this rank, first (pipeline fill) excluded"} if len(gaps) else None
     value = (end - begin if args.rehearse_rank_of > 1 else n) * args.steps / elapsed
 
     # ---------------- dominant kernel of the step: k_scan (HIP events on the stream it is launched on, inside the library).
@@ -392,9 +410,17 @@ def main():
         got = bwt.parallel_rank(chk)
         pref = np.stack([np.concatenate([[0], np.cumsum(head == c)]) for c in b"ACGT"], axis=1)
         assert np.array_equal(got, pref[chk.astype(np.int64)]), "rank kernel disagrees with the definition"
+        # Beside SURVEY 8(d)'s accounting (64 B per query against the 8 TB/s peak): what the memory system allows.  Every block read is
+        # served as a 128-byte line (PMC, profiles/r02_pmc_traffic.json), and the chip streams 6.29 TB/s at best (MI355X guide,
+        # float4 copy; scripts/stream_probe.hip: 6.2-6.3): frac_of_line_bound counts the lines alone (<= 49.1 GQ/s), and
+        # frac_of_traffic_bound everything a query moves through HBM: the line + its 8-byte position + its 32-byte result = 168 B
+        # (<= 37.4 GQ/s for this ABI, whatever the kernel).
+        STREAM = 6290.0
         rank_info = {"bound": "hbm", "achieved": round(64 * gqs, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(64 * gqs / 8000.0, 4),
                      "traffic": None, "gq_per_s": round(gqs, 3), "queries": m, "ms": round(rank_ms, 4),
-                     "index_bytes": int(bwt.device_bytes)}
+                     "index_bytes": int(bwt.device_bytes),
+                     "frac_of_line_bound": round(128 * gqs / STREAM, 4), "frac_of_traffic_bound": round(168 * gqs / STREAM, 4),
+                     "line_bound_gq_per_s": round(STREAM / 128, 2), "traffic_bound_gq_per_s": round(STREAM / 168, 2), "measured_stream_gb_per_s": STREAM}
         # the same kernel on the query pattern the traversal issues: the six boundaries of a deep suffix-tree node lie within
         # a few dozen rows, so they share blocks (nodes in random order; SURVEY.md 8(d) metric 2 (ii) in isolation)
         m_nodes = min(1 << 24, m // 6)
@@ -482,6 +508,56 @@ def main():
             assert rr.returncode == 0 and ref_snp == got, "GPU .snp differs from the reference binary's on the baseline sample"
             reference = {"binary": "oracle/_ref/ebwt2InDel_ref (g++ -Ofast build of the unmodified upstream sources)", "cores": 1,
                          "e2e_seconds": round(t_ref, 2), "e2e_positions_per_s": round(n_s / t_ref, 1), "snp_identical_to_gpu": True}
+        # ---- the same on a DRAM-resident sample (>= 1 G positions: index 0.5 GB + flag vectors 0.4 GB, far beyond the host's L3):
+        # the 60 M-position sample above lives in cache and flatters the CPU (36-47 M positions/s for the
+        # phase-4 loop once the index is DRAM-resident).  The sample is built by the GPU generator (the host suffix sorter
+        # would take minutes), the oracle's index and traversal run on all host threads, its scan sharded over them; ONE
+        # thread then scans a 128 M-position sub-range of that index: the single-core figure `value` reports.
+        dram = None
+        if args.cpu_dram_reads > 0:
+            from tests import _fullsize as fsz
+            b_reads = args.cpu_dram_reads
+            b_glen = int(b_reads * args.read_len / args.coverage)
+            bg = sim.random_genome(b_glen, args.seed + 2000)
+            bh = sim.mutate_haplotype(bg, args.seed + 2000)
+            btext, boffs = sim.haplotype_text([bg, bh])
+            bstarts = sim.sample_read_starts([bg, bh], boffs, b_reads, args.read_len, args.seed + 2000)
+            del bg, bh
+            bdev = sim.build_ebwt_gpu(btext, bstarts, args.read_len, device=local)
+            del btext, bstarts
+            bhost, _ = bdev.to_host()
+            bb = api.DnaBwt(None, device_ptr=bdev.ptr, n=bdev.n, device=local)
+            bdev.free()
+            bfl = api.navigate_one_bwt(bb, p)
+            b_got = api.scan_clusters(bb, bfl, p).format_snp(p, False)[0]
+            del bfl, bb
+            n_b = len(bhost)
+            t0 = time.perf_counter()
+            bidx = orc.index(bhost, threads=cores)
+            t_bidx = time.perf_counter() - t0
+            del bhost
+            t0 = time.perf_counter()
+            bof = _oracle.OracleFlags(orc, bidx, None, po.K, po.k_right, threads=cores)
+            t_bnav = time.perf_counter() - t0
+            bcuts = [ebd.shard_range(n_b, i, cores * 4) for i in range(cores * 4)]
+            with ThreadPoolExecutor(cores) as ex:
+                t0 = time.perf_counter()
+                bparts = list(ex.map(lambda be: bof.scan(po, be[0], be[1]), bcuts))
+                t_bscan = time.perf_counter() - t0
+            b_want = fsz.renumber([r["text"] for r in bparts], [r["cluster_nr"] - 1 for r in bparts])
+            assert b_want == b_got, "GPU .snp differs from the CPU oracle on the DRAM-resident baseline sample"
+            sub = (n_b // 2 // 64 * 64, min(n_b, n_b // 2 // 64 * 64 + (1 << 27)))
+            t0 = time.perf_counter()
+            bof.scan(po, sub[0], sub[1])
+            t_b1 = time.perf_counter() - t0
+            brt = orc.lib.orc_rank_bench(bidx.h, 20_000_000, 7, None)
+            dram = {"sample": f"{b_reads} x {args.read_len} bp reads (n={n_b}), same generator, built on the GPU; oracle index + flag vectors {n_b * 7 // 8 / 1e9:.2f} GB",
+                    "single_thread_phase4_positions_per_s": round((sub[1] - sub[0]) / t_b1, 1), "single_thread_subrange": [int(sub[0]), int(sub[1])],
+                    "single_thread_seconds": round(t_b1, 2), "rank_queries_per_s": round(20_000_000 / brt, 1),
+                    "all_cores": {"cores": cores, "index_seconds": round(t_bidx, 2), "phases23_seconds": round(t_bnav, 2), "phase4_seconds": round(t_bscan, 3),
+                                  "phase4_positions_per_s": round(n_b / t_bscan, 1), "e2e_positions_per_s": round(n_b / (t_bnav + t_bscan), 1)},
+                    "snp_identical_to_gpu": True, "snp_records": b_got.count(b">")}
+            del bof, bidx
         cpu = {"value": round(n_s / t_scan_cpu, 1), "unit": "positions/s", "cores": 1, "kind": "port",
                "sample": f"{s_reads} x {args.read_len} bp reads (n={n_s}), same generator; phase-4 scan only ({t_scan_cpu:.3f}s); "
                          f"phases 2-3 took {t_nav_cpu:.2f}s",
@@ -490,6 +566,14 @@ def main():
                "all_cores": {"value": round(n_s / t_scan_all, 1), "unit": "positions/s", "cores": cores,
                              "what": "the same phase-4 scan, range sharded over host threads"},
                "reference": reference}
+        if dram is not None:
+            # the headline figure is the DRAM-resident one; the cache-resident sample keeps its own keys
+            cpu["cache_resident_value"] = cpu["value"]
+            cpu["cache_resident_sample"] = cpu["sample"]
+            cpu["value"] = dram["single_thread_phase4_positions_per_s"]
+            cpu["sample"] = (f"phase-4 scan of a {sub[1] - sub[0]}-position sub-range by ONE thread ({dram['single_thread_seconds']} s) inside a DRAM-resident sample: " + dram["sample"]
+                             + f"; the 60 M-position (cache-resident) sample of round 2 is under cache_resident_* / e2e_* / reference")
+            cpu["dram_resident"] = dram
 
     # HBM traffic of the kernels from the PMC passes committed under profiles/ (counters cannot be collected from inside this
     # process): bytes per launch from the request-size split -- TCC_EA0_RDREQ_128B x 128 + TCC_EA0_RDREQ_64B x 64 + WRITE_SIZE
@@ -521,7 +605,10 @@ def main():
             "metric": "BWT positions scanned/sec (whole node)", "value": round(value, 1), "unit": "positions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "step_spread": step_spread,
             "config": {"workload": workload, "mode": 1, "options": "-L31 -R30 -k16 -g10 -v2 -m3 -c20 -q0",
+                       # every path-selecting switch of the library / this script that is set in the environment (none: the defaults ran)
+                       "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith(("EB_", "EBGEN_")) or k in ("GPU_MAX_HW_QUEUES", "HSA_ENABLE_IPC_MODE_LEGACY")},
                        "parallelism": f"scan range split over {world} GPU(s), BWT+flags replicated, gather of cluster records to rank 0; " + ("steps back to back" if args.no_pipeline else "steps pipelined (one host thread begins passes, a second hands their records over; at most five in flight)")},
             "roofline": {"bound": "hbm", "achieved": round(scan_gbs, 2), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(scan_gbs / 8000.0, 5), "traffic": traffic, "kernel": "k_scan",
@@ -555,7 +642,11 @@ def main():
             "phases23_gpu": {"seconds": round(float(ns.seconds_traversal), 4), "wall_seconds": round(t_nav, 4), "traversal_shards": world if use_dist else 1,
                              "seconds_leaves": round(float(ns.seconds_leaves), 4), "seconds_nodes": round(float(ns.seconds_nodes), 4),
                              "rank_gq_per_s": round(ns.rank_queries / max(ns.seconds_traversal, 1e-9) / 1e9, 2), "nodes": int(ns.nodes), "leaves": int(ns.leaves), "rank_queries": int(ns.rank_queries),
-                             "launches": int(ns.batches), "e2e_positions_per_s": round(n / (float(ns.seconds_traversal) + ms_per_step * 1e-3), 1)},
+                             "launches": int(ns.batches),
+                             # end to end = the WHOLE phases 2-3 call (allocations, and for N > 1 the all-reduce + popcount check + finalize) + one phase-4 pass;
+                             # the traversal-only rate has its own key (round-2 advisor finding: the two had been mixed)
+                             "e2e_positions_per_s": round(n / (t_nav + ms_per_step * 1e-3), 1),
+                             "traversal_only_positions_per_s": round(n / max(float(ns.seconds_traversal), 1e-9), 1)},
         }
         line.update(out)
         print(json.dumps(line), flush=True)

@@ -73,6 +73,26 @@ __device__ __forceinline__ uint4 eb_load_chunk_select(const uint4* p) {
 #endif
 }
 
+// A pointer that was LOADED from memory (launch arguments kept in device memory) is a generic pointer to the compiler, and
+// accesses through it become flat_load / flat_store, which count in lgkmcnt as well as vmcnt: every wait for an LDS read
+// then also waits for them.  These move whole 16-byte-multiple records through explicit global-memory (address space 1)
+// accesses instead.
+#define EB_GLOBAL_AS __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ T eb_load_global(const T* p) {
+    static_assert(sizeof(T) % 16 == 0, "records are moved as 16-byte pieces");
+    T r;
+    const EB_GLOBAL_AS eb_u32x4* g = (const EB_GLOBAL_AS eb_u32x4*)p;
+    eb_u32x4* d = reinterpret_cast<eb_u32x4*>(&r);
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(T) / 16); ++k) d[k] = g[k];
+    return r;
+}
+__device__ __forceinline__ void eb_store_global(uint4* p, uint4 v) {
+    eb_u32x4 t = {v.x, v.y, v.z, v.w};
+    *(EB_GLOBAL_AS eb_u32x4*)p = t;
+}
+
 struct rank4_t {
     uint64_t v[4];
 };
@@ -312,7 +332,7 @@ struct Stager {
         unsigned long long base = *s_base;
         uint4* dst = reinterpret_cast<uint4*>(out);
         if (base + n <= out_cap)
-            for (uint32_t k = threadIdx.x; k < n * W; k += blockDim.x) dst[base * W + k] = buf[k];
+            for (uint32_t k = threadIdx.x; k < n * W; k += blockDim.x) eb_store_global(dst + base * W + k, buf[k]); // `out` is global memory (it may come from a pointer the kernel loaded)
         __syncthreads();
         if (threadIdx.x == 0) *s_count = 0;
         __syncthreads();

@@ -166,6 +166,18 @@ bool any_failed(MultiJob& J) {
         if (e_ != ncclSuccess && J.rc[(size_t)r] == EB_OK) MJ_FAIL(EB_ERR_DEVICE, "%s: %s", #call, ncclGetErrorString(e_)); \
     } while (0)
 
+// A failure INSIDE a collective (ncclAllReduce / ncclSend / ncclRecv or the stream synchronisation behind them) is different
+// from every other failure: the peers may already be blocked in the same collective, with no timeout, and would never reach
+// the barrier + common check below.  The failing rank therefore prints its error, aborts every communicator (a blocked
+// peer's stream then returns) and ends the process non-zero -- no hang, no partial output mistaken for a result.
+[[noreturn]] void collective_failure(MultiJob& J, int r) {
+    printf("GPU %d: a collective failed: %s\n", J.dev[(size_t)r], J.err[(size_t)r].c_str());
+    fflush(stdout);
+    for (ncclComm_t c : J.comm)
+        if (c) (void)ncclCommAbort(c);
+    _exit(1);
+}
+
 // One rank = one host thread bound to one GPU.  Every step that can fail is followed by a barrier and a common check, so
 // that no rank enters a collective its peers will not join.
 void rank_main(MultiJob& J, int r) {
@@ -224,6 +236,7 @@ void rank_main(MultiJob& J, int r) {
         for (int k = 0; k < 4; ++k)
             if (v[k]) MJ_NCCL(ncclAllReduce(v[k], v[k], words, ncclUint64, ncclSum, J.comm[(size_t)r], st));
         MJ_HIP(hipStreamSynchronize(st));
+        if (J.rc[(size_t)r] != EB_OK) collective_failure(J, r);
     } else {
         std::vector<uint64_t> h[4];
         for (int k = 0; k < 4; ++k) if (v[k]) h[k].resize(words);
@@ -286,6 +299,7 @@ void rank_main(MultiJob& J, int r) {
             MJ_NCCL(ncclSend(J.wire_ptr[(size_t)r], J.wire_len[(size_t)r], ncclUint8, 0, J.comm[(size_t)r], st));
         }
         MJ_HIP(hipStreamSynchronize(st));
+        if (J.rc[(size_t)r] != EB_OK) collective_failure(J, r);
         if (r == 0) {
             for (int q = 0; q < J.world; ++q) {
                 J.image[(size_t)q].resize(J.wire_len[(size_t)q]);

@@ -103,6 +103,17 @@ struct NavParams {
 #define EB_NDBG(p) 0u
 #endif
 
+// What one expansion launch works on.  It lives in DEVICE memory and is written by k_plan (below), so that the host can enqueue
+// several launches back to back without knowing how many children the previous one pushed.
+struct NavLaunch {
+    const void* in;    // `count` records, popped from the top of the source stack (expanded where they lie)
+    uint64_t count;
+    void* out;         // children are appended here through NavCounters::pushed ...
+    uint64_t out_cap;  // ... up to this many
+    int32_t write;     // 0: expand only (the shared top of the tree on shards other than 0): no bit writes, no statistics
+    int32_t pad;
+};
+
 __device__ __forceinline__ uint64_t wave_sum(uint64_t v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor((unsigned long long)v, o);
     return v;
@@ -130,11 +141,16 @@ __device__ __forceinline__ uint64_t pick4(const uint64_t* F, uint32_t c) { retur
 // (dna_bwt.hpp:358-379; two BWTs: ebwt2InDel.cpp:452-472).  Four lanes per leaf: lane j owns letter j --
 // it loads the j-th chunk of each rank query and builds the child leaf obtained by prepending "ACGT"[j].
 template <int NB>
-__global__ void __launch_bounds__(256) k_leaves(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, uint64_t* __restrict__ kr, NavParams p, const void* in_,
-                                               uint64_t count, void* out_, uint64_t out_cap, NavCounters* cnt, unsigned long long* __restrict__ stat_rows) {
+__global__ void __launch_bounds__(256) k_leaves(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, uint64_t* __restrict__ kr, NavParams p,
+                                               const NavLaunch* __restrict__ la, NavCounters* cnt, unsigned long long* __restrict__ stat_rows) {
     using Leaf = typename std::conditional<NB == 1, Leaf1, Leaf2>::type;
     using Rec = typename std::conditional<NB == 1, Leaf1, Leaf2P>::type; // the record as it lies in the stacks
     constexpr int STAGE = 1024;
+    const void* in_ = la->in;
+    void* out_ = la->out;
+    const uint64_t count = la->count, out_cap = la->out_cap;
+    p.write = la->write;
+    if ((uint64_t)blockIdx.x * 64 >= count) return; // the grid is sized for a full batch: nothing for this workgroup (uniform)
     __shared__ uint4 s_buf[STAGE * (sizeof(Rec) / 16)];
     __shared__ uint32_t s_count;
     __shared__ unsigned long long s_base;
@@ -152,7 +168,7 @@ __global__ void __launch_bounds__(256) k_leaves(eb_dev_index x1, eb_dev_index x2
         bool active = i < count;
         Leaf L;
         memset(&L, 0, sizeof L);
-        if (active) unpack_rec(in[i], L);
+        if (active) unpack_rec(eb_load_global(in + i), L);
         Leaf child;
         memset(&child, 0, sizeof child);
         bool keep = false;
@@ -239,12 +255,17 @@ __global__ void __launch_bounds__(256) k_leaves(eb_dev_index x1, eb_dev_index x2
 // U nodes per quad and trip: the kernel is bound by memory latency x occupancy (three workgroups per CU because of the staging
 // buffer), so every lane puts the 6 U block loads of its U nodes in flight before it touches the first result.
 template <int NB, int U>
-__global__ void __launch_bounds__(256) k_nodes(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, uint64_t* __restrict__ kr, NavParams p, const void* in_,
-                                              uint64_t count, void* out_, uint64_t out_cap, NavCounters* cnt, unsigned long long* __restrict__ stat_rows) {
+__global__ void __launch_bounds__(256) k_nodes(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, uint64_t* __restrict__ kr, NavParams p,
+                                              const NavLaunch* __restrict__ la, NavCounters* cnt, unsigned long long* __restrict__ stat_rows) {
     using Node = typename std::conditional<NB == 1, Node1, Node2>::type;
     using Rec = typename std::conditional<NB == 1, Node1P, Node2P>::type; // the record as it lies in the stacks
     constexpr int STAGE = NB == 1 ? 1536 : 768;
     static_assert(STAGE % (256 * U) == 0, "a whole number of trips fills the staging buffer");
+    const void* in_ = la->in;
+    void* out_ = la->out;
+    const uint64_t count = la->count, out_cap = la->out_cap;
+    p.write = la->write;
+    if ((uint64_t)blockIdx.x * 64 * U >= count) return; // the grid is sized for a full batch: nothing for this workgroup (uniform)
     __shared__ uint4 s_buf[STAGE * (sizeof(Rec) / 16)];
     __shared__ uint32_t s_count;
     __shared__ unsigned long long s_base;
@@ -266,7 +287,7 @@ __global__ void __launch_bounds__(256) k_nodes(eb_dev_index x1, eb_dev_index x2,
             const uint64_t i = (tile * U + u) * 64 + q;
             active[u] = i < count;
             memset(&N[u], 0, sizeof(Node));
-            if (active[u]) unpack_rec(in[i], N[u]);
+            if (active[u]) unpack_rec(eb_load_global(in + i), N[u]);
         }
         // All rank loads of the trip, back to back.  With two BWTs a block is loaded ONCE: the six boundaries of a node are
         // sorted and, below the top of the tree, a few dozen rows apart, so most of them share the block of their left
@@ -383,12 +404,142 @@ __global__ void __launch_bounds__(256) k_nodes(eb_dev_index x1, eb_dev_index x2,
     flush_stats(stat_rows, st);
 }
 
+// ---- phase 3, one BWT, software-pipelined (round 3).  Same work per node as k_nodes<1, U>, one node per quad and trip, but the
+// memory operations of the NEXT trips are under way while a trip is worked on:
+//   stage A  the record of trip t+1 (loaded during trip t-1) is unpacked; its LCP / minimum bits are set at once -- they
+//            depend on the record alone (borders and depth), not on any rank -- and its six block loads are issued;
+//   stage C  the record of trip t+2 is requested;
+//   stage D  trip t: its six blocks have landed meanwhile (vector-memory operations complete in issue order, so the wait for
+//            record t+1 in stage A covered them); ranks, the four Weiner-link children, staging.
+// k_nodes issued the record load, waited, issued the block loads, waited, computed: two exposed memory latencies per trip with
+// three waves per SIMD to cover them (49 KB of staging per workgroup), ~6.8 us per trip for ~1 us of arithmetic.  Here the only
+// vector-memory operations inside stage D are the staging flush's, so nothing in D waits for the loads issued in A / C.  The
+// superblock table (a global load per rank in eb_rank4_quad_finish) is read from LDS for that reason.
+#define EB_NAV_SUPER_LDS 40 /* superblocks held in LDS (n <= 171 G symbols); beyond that the table is read from memory */
+template <bool SUPER_LDS> // the superblock table fits EB_NAV_SUPER_LDS entries of LDS (a select between an LDS and a global address would become flat loads)
+__global__ void __launch_bounds__(256) k_nodes1p(eb_dev_index x1, eb_dev_flags f, uint64_t* __restrict__ kr, NavParams p, const NavLaunch* __restrict__ la,
+                                                NavCounters* cnt, unsigned long long* __restrict__ stat_rows) {
+    using Rec = Node1P;
+    constexpr int STAGE = 1536;
+    __shared__ uint4 s_buf[STAGE * (sizeof(Rec) / 16)];
+    __shared__ uint32_t s_count;
+    __shared__ unsigned long long s_base;
+    __shared__ unsigned long long s_super[EB_NAV_SUPER_LDS * 4];
+    const Rec* __restrict__ in = static_cast<const Rec*>(la->in);
+    Rec* out = static_cast<Rec*>(la->out);
+    const uint64_t count = la->count, out_cap = la->out_cap;
+    p.write = la->write;
+    const uint64_t tiles = (count + 63) / 64;
+    if ((uint64_t)blockIdx.x >= tiles) return; // the grid is sized for a full batch: nothing for this workgroup (uniform)
+    Stager<Rec, STAGE> stage{s_buf, &s_count, &s_base};
+    if (SUPER_LDS) {
+        const uint64_t n_super = (x1.n >> EB_SUPER_SHIFT) + 1;
+        for (uint32_t k = threadIdx.x; k < n_super * 4; k += blockDim.x) s_super[k] = x1.super[k];
+    }
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
+    const uint32_t j = threadIdx.x & 3u, q = threadIdx.x >> 2;
+    const uint64_t G = gridDim.x;
+    uint64_t n_node = 0, n_lcp = 0, n_rank = 0, n_min = 0;
+    const uint64_t Fj = pick4(x1.F, j);
+
+    auto load_rec = [&](uint64_t tile) -> Rec {
+        Rec r;
+        r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0;
+        const uint64_t i = tile * 64 + q;
+        if (tile < tiles && i < count) r = eb_load_global(in + i);
+        return r;
+    };
+    // stage A for one record: border bits (update_lcp_threshold include.hpp:826-860, update_lcp_minima ebwt2InDel.cpp:357-391)
+    auto mark = [&](const Node1& N) {
+        uint64_t lo = 0, hi = 0;
+        for (int k = 0; k < 4; ++k) if (j == (uint32_t)k) { lo = N.b[k]; hi = N.b[k + 1]; }
+        if (hi > lo && hi != N.b[5]) {
+            const bool setK = ((int64_t)N.depth >= p.K) != (p.below != 0), setR = ((int64_t)N.depth >= p.k_right) != (p.below != 0);
+            if (p.lcpb) {
+                uint8_t v = (uint8_t)((setK ? 1 : 0) | (setR ? 2 : 0));
+                if (v && !(EB_NDBG(p) & 1u)) p.lcpb[hi] = v;
+            } else {
+                if (setK) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * (hi >> 6)), 1ull << (hi & 63u));
+                if (setR) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * (hi >> 6) + 1), 1ull << (hi & 63u));
+            }
+            ++n_lcp;
+        }
+        if (j >= 1 && hi - lo >= 2 && hi < N.b[5] - 1) {
+            if (!(EB_NDBG(p) & 2u)) eb_bit_set_atomic(f.minima, hi);
+            ++n_min;
+        }
+    };
+
+    uint64_t tile = blockIdx.x;
+    Node1 Nn;          // the node of the next trip (stage A done)
+    uint4 cn[6];       // its six blocks, in flight
+    bool act_n;
+    {
+        Rec r0 = load_rec(tile);
+        unpack_rec(r0, Nn);
+        act_n = tile * 64 + q < count;
+        if (act_n && p.write) mark(Nn);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) cn[k] = eb_rank4_quad_load(x1, Nn.b[k], j);
+    }
+    Rec rr = load_rec(tile + G); // stage C of the prologue
+    uint32_t trips = 0;
+    for (; tile < tiles; tile += G) {
+        const Node1 Nc = Nn;
+        const bool act_c = act_n;
+        uint4 cc[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) cc[k] = cn[k];
+        // stage A: the next trip's record -> node, border bits, block loads
+        unpack_rec(rr, Nn);
+        act_n = tile + G < tiles && (tile + G) * 64 + q < count;
+        if (act_n && p.write) mark(Nn);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) cn[k] = eb_rank4_quad_load(x1, Nn.b[k], j);
+        // stage C: the record after that
+        rr = load_rec(tile + 2 * G);
+        // stage D: this trip's ranks and children (LF(sa_node) dna_bwt.hpp:323-356, next_nodes :381-404)
+        Node1 child;
+        child.pad = 0;
+        int kids = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const uint64_t i = Nc.b[k];
+            uint32_t pc = eb_chunk_counts(cc[k], eb_prefix_mask32((uint32_t)(i & 127u), j));
+            pc += (uint32_t)__shfl_xor((int)pc, 1);
+            pc += (uint32_t)__shfl_xor((int)pc, 2);
+            uint64_t sup;
+            if constexpr (SUPER_LDS) sup = s_super[((i >> EB_SUPER_SHIFT) << 2) + j];
+            else sup = x1.super[((i >> EB_SUPER_SHIFT) << 2) + j];
+            child.b[k] = Fj + sup + cc[k].w + ((pc >> (8u * j)) & 0xFFu);
+        }
+        for (int k = 0; k < 5; ++k) kids += child.b[k + 1] > child.b[k];
+        child.depth = Nc.depth + 1;
+        const bool keep = act_c && kids >= 2; // number_of_children (include.hpp:760-768)
+        if (act_c && p.write && j == 0) {
+            ++n_node;
+            n_rank += 1;
+            for (int k = 1; k < 6; ++k) n_rank += Nc.b[k] != Nc.b[k - 1]; // the reference shares the query of equal neighbours
+        }
+        stage.push(keep, pack_rec(child));
+        // every trip adds at most 256 records: flushing every STAGE / 256 trips never overflows the buffer, and the decision is
+        // the same in every thread without looking at shared state
+        if (++trips % (STAGE / 256) == 0) stage.flush(out, out_cap, &cnt->pushed);
+    }
+    stage.flush(out, out_cap, &cnt->pushed);
+    const uint64_t st[EB_NAV_STATS] = {0, n_node, n_lcp, 0, n_min, n_rank};
+    flush_stats(stat_rows, st);
+}
+
 // Sharded traversal: at the first level wide enough, every shard keeps the records whose interval start
 // hashes to it -- content-addressed, so all shards agree whatever order their own launches left the level in.
 // W2 >= 0: a second word of the record is added to the key (packed two-BWT records: more of the two interval starts).
 template <typename Item, int W2>
-__global__ void __launch_bounds__(256) k_keep_shard(const Item* __restrict__ in, uint64_t count, Item* __restrict__ out, uint32_t shard, uint32_t n_shards,
-                                                   NavCounters* cnt) {
+__global__ void __launch_bounds__(256) k_keep_shard(const NavLaunch* __restrict__ la, uint32_t shard, uint32_t n_shards, NavCounters* cnt) {
+    const Item* __restrict__ in = static_cast<const Item*>(la->in);
+    Item* __restrict__ out = static_cast<Item*>(la->out);
+    const uint64_t count = la->count; // 0 unless k_drain_plan found the level to cut
     const uint64_t total = (uint64_t)gridDim.x * blockDim.x;
     const uint32_t lane = threadIdx.x & 63u;
     for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < count; base += total) {
@@ -408,9 +559,10 @@ __global__ void __launch_bounds__(256) k_keep_shard(const Item* __restrict__ in,
         wbase = __shfl(wbase, 0);
         if (keep) {
             uint64_t slot = wbase + (uint64_t)__popcll(mask & ((1ull << lane) - 1ull));
-            const uint4* src = reinterpret_cast<const uint4*>(in + i);
+            const Item v = eb_load_global(in + i);
+            const uint4* src = reinterpret_cast<const uint4*>(&v);
             uint4* dst = reinterpret_cast<uint4*>(out + slot);
-            for (int k = 0; k < (int)(sizeof(Item) / 16); ++k) dst[k] = src[k];
+            for (int k = 0; k < (int)(sizeof(Item) / 16); ++k) eb_store_global(dst + k, src[k]);
         }
     }
 }
@@ -480,12 +632,98 @@ __global__ void __launch_bounds__(256) k_take_first(const uint64_t* __restrict__
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// 64 * per_quad records per 256-thread workgroup and trip; the grid is capped and strides over the batch
+unsigned nav_grid(uint64_t count, uint64_t per_quad = 1) {
+    uint64_t tiles = (count + 64 * per_quad - 1) / (64 * per_quad);
+    const uint64_t cap = 256ull * 8;
+    return (unsigned)(tiles < 1 ? 1 : (tiles > cap ? cap : tiles));
+}
+unsigned nav_grid_for(uint64_t batch) { return nav_grid(batch, 1); } // per_quad > 1 only lowers the number of tiles: the cap is what large batches see
+
+// ---- the drain's bookkeeping, on the DEVICE.  Round 2 ran it on the host: after every launch the host read back how many
+// children it had pushed (8 bytes, a blocking round trip: ~700 of them at 7.55 G positions) and chose the next batch.  Now a
+// one-thread kernel does exactly that between two expansions, so the host enqueues EB_NAV_GROUP launches back to back, reads the
+// state once per group, and always keeps one group queued ahead of the one it waits for: the device never idles on the host.
+enum { DRAIN_NONE = 0, DRAIN_EXPAND = 1, DRAIN_SPLIT = 2 };
+enum { DRAIN_ERR_CAPACITY = 1, DRAIN_ERR_OVERFLOW = 2 };
+struct DrainState {
+    unsigned long long stack[2];          // device addresses of the two LIFO stacks
+    unsigned long long top[2];            // records on each
+    unsigned long long cap, batch;        // records a stack holds; most records popped per launch
+    unsigned long long launches, max_top; // expansions that had work; most records pending at once
+    unsigned long long split_min;
+    uint32_t item_bytes;
+    uint32_t recent;                      // stack that received records last
+    uint32_t last, last_src;              // what the previous step was (DRAIN_*) and which stack it popped
+    unsigned long long last_base, last_room;
+    uint32_t shard, n_shards, split_done, error;
+    NavLaunch expand;                     // what the next expansion kernel works on (count 0: nothing)
+    NavLaunch split;                      // ... and the next k_keep_shard (count 0: nothing)
+};
+
+// books the children of the previous step
+__device__ __forceinline__ void drain_account(DrainState* st, NavCounters* cnt) {
+    const unsigned long long pushed = cnt->pushed;
+    cnt->pushed = 0;
+    if (st->last == DRAIN_EXPAND) {
+        const uint32_t src = st->last_src, dst = 1u - src;
+        if (pushed > st->last_room) st->error = DRAIN_ERR_OVERFLOW;
+        st->top[src] = st->last_base;
+        st->top[dst] += pushed;
+        if (pushed) st->recent = dst;
+    } else if (st->last == DRAIN_SPLIT) {
+        const uint32_t src = st->last_src, dst = 1u - src;
+        st->top[src] = 0;
+        st->top[dst] = pushed;
+        st->recent = dst;
+        st->split_done = 1;
+    }
+    st->last = DRAIN_NONE;
+    if (st->top[0] + st->top[1] > st->max_top) st->max_top = st->top[0] + st->top[1];
+}
+__global__ void k_drain_account(DrainState* st, NavCounters* cnt) { drain_account(st, cnt); }
+// ... and chooses the next step: TWO stacks alternate; a batch is popped from the top of one and expanded in place (the
+// kernel reads it where it lies -- no staging copy), its children are pushed onto the other, which becomes the one to pop from
+// next.  Popping the most recently pushed records first keeps a depth-first footprint.
+__global__ void k_drain_plan(DrainState* st, NavCounters* cnt) {
+    drain_account(st, cnt);
+    st->expand.count = 0;
+    st->split.count = 0;
+    if (st->error || st->top[0] + st->top[1] == 0) return;
+    const uint32_t recent = st->recent;
+    const uint32_t src = st->top[recent] > 0 ? recent : 1u - recent, dst = 1u - src;
+    const unsigned long long ib = st->item_bytes;
+    if (st->n_shards > 1 && !st->split_done && st->top[dst] == 0 && st->top[src] >= st->split_min * st->n_shards) {
+        // so far every launch expanded one whole level: cut it (k_keep_shard)
+        st->split.in = reinterpret_cast<const void*>(st->stack[src]);
+        st->split.count = st->top[src];
+        st->split.out = reinterpret_cast<void*>(st->stack[dst]);
+        st->split.out_cap = st->cap;
+        st->last = DRAIN_SPLIT;
+        st->last_src = src;
+        return;
+    }
+    const unsigned long long room = st->cap - st->top[dst];
+    unsigned long long B = st->top[src] < st->batch ? st->top[src] : st->batch;
+    if (4 * B > room) B = room / 4; // a record has at most four children
+    if (B == 0) { st->error = DRAIN_ERR_CAPACITY; return; }
+    const unsigned long long base = st->top[src] - B;
+    st->expand.in = reinterpret_cast<const void*>(st->stack[src] + base * ib);
+    st->expand.count = B;
+    st->expand.out = reinterpret_cast<void*>(st->stack[dst] + st->top[dst] * ib);
+    st->expand.out_cap = room;
+    st->expand.write = (st->n_shards == 1 || st->split_done || st->shard == 0) ? 1 : 0;
+    st->last = DRAIN_EXPAND;
+    st->last_src = src;
+    st->last_base = base;
+    st->last_room = room;
+    ++st->launches;
+}
+
 template <typename Item>
 struct Drain {
-    // Drains LIFO work stacks in HBM with batched launches.  `launch(in, count, out, out_cap)` must append children
-    // through NavCounters::pushed.  TWO stacks alternate: a batch is popped from the top of one and expanded in place
-    // (the kernel reads it where it lies -- no staging copy), its children are pushed onto the other, which becomes
-    // the one to pop from next.  Popping the most recently pushed records first keeps a depth-first footprint.
+    // Drains LIFO work stacks in HBM with batched launches.  `launch(const NavLaunch* la, grid)` must append children
+    // through NavCounters::pushed.
     int device;
     hipStream_t stream;
     Item* d_stack[2] = {nullptr, nullptr};
@@ -495,11 +733,10 @@ struct Drain {
     // down to the first level of at least split_min * n_shards records, which is then cut by k_keep_shard
     uint32_t shard = 0, n_shards = 1;
     uint64_t split_min = 4096;
-    bool split_done = false;
 
     // The stacks live in one arena shared by both phases (allocating HBM costs ~20 ms per GB, so the arena is sized from
     // the batch, not from n).  A depth-first drain needs a few batches of room (observed: < 7 batches at 7.55 G
-    // positions); if a stack ever fills, run() shrinks the batch -- in the limit a plain depth-first walk that needs
+    // positions); if a stack ever fills, the planner shrinks the batch -- in the limit a plain depth-first walk that needs
     // 4 x depth records -- so capacity never affects results.
     int init(void* arena, uint64_t arena_bytes, uint64_t n_bound, uint64_t batch_max) {
         batch = batch_max;
@@ -522,60 +759,78 @@ struct Drain {
         ++top[0];
         return EB_OK;
     }
+    // d_state: sizeof(DrainState) bytes of device memory; h_state: two DrainState in page-locked host memory
     template <int W2, typename Launch>
-    int run(NavCounters* d_cnt, unsigned long long* h_pushed /* pinned */, Launch launch) {
+    int run(NavCounters* d_cnt, DrainState* d_state, DrainState* h_state, Launch launch) {
         const bool trace = getenv("EB_NAV_TRACE") != nullptr;
         const double t_start = now_s();
-        int recent = 0; // stack that received records last
-        while (top[0] + top[1] > 0) {
-            const int src = top[recent] > 0 ? recent : 1 - recent, dst = 1 - src;
-            if (n_shards > 1 && !split_done && top[dst] == 0 && top[src] >= split_min * n_shards) {
-                // so far every launch expanded one whole level: cut it
-                EB_HIP(hipMemsetAsync(&d_cnt->pushed, 0, sizeof(unsigned long long), stream));
-                uint64_t blocks = (top[src] + 255) / 256;
-                hipLaunchKernelGGL((k_keep_shard<Item, W2>), dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, stream, d_stack[src], top[src],
-                                   d_stack[dst], shard, n_shards, d_cnt);
-                EB_HIP(hipGetLastError());
-                EB_HIP(hipMemcpyAsync(h_pushed, &d_cnt->pushed, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-                EB_HIP(hipStreamSynchronize(stream));
-                if (trace) fprintf(stderr, "[nav] shard %u/%u keeps %llu of %llu records\n", shard, n_shards, (unsigned long long)*h_pushed, (unsigned long long)top[src]);
-                top[src] = 0;
-                top[dst] = *h_pushed;
-                recent = dst;
-                split_done = true;
-                continue;
+        const int group = [] { const char* e = getenv("EB_NAV_GROUP"); int v = e ? atoi(e) : 8; return v < 1 ? 1 : (v > 64 ? 64 : v); }(); // launches per read-back
+        DrainState init;
+        memset(&init, 0, sizeof init);
+        init.stack[0] = reinterpret_cast<unsigned long long>(d_stack[0]);
+        init.stack[1] = reinterpret_cast<unsigned long long>(d_stack[1]);
+        init.top[0] = top[0];
+        init.top[1] = top[1];
+        init.cap = cap;
+        init.batch = batch;
+        init.split_min = split_min;
+        init.item_bytes = (uint32_t)sizeof(Item);
+        init.shard = shard;
+        init.n_shards = n_shards;
+        init.max_top = top[0] + top[1];
+        h_state[0] = init;
+        EB_HIP(hipMemsetAsync(&d_cnt->pushed, 0, sizeof(unsigned long long), stream));
+        EB_HIP(hipMemcpyAsync(d_state, &h_state[0], sizeof(DrainState), hipMemcpyHostToDevice, stream));
+        EB_HIP(hipStreamSynchronize(stream)); // h_state[0] is reused as a snapshot buffer below
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        struct EvGuard { hipEvent_t* e; ~EvGuard() { for (int k = 0; k < 2; ++k) if (e[k]) (void)hipEventDestroy(e[k]); } } evg{ev};
+        EB_HIP(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+        EB_HIP(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+        // full-batch grid: the launch does not know its batch (k_drain_plan decides it on the device); workgroups beyond it leave at once
+        const unsigned full_grid = nav_grid_for(batch);
+        bool split_pending = n_shards > 1;
+        auto enqueue_group = [&](int slot) -> int {
+            for (int k = 0; k < group; ++k) {
+                hipLaunchKernelGGL(k_drain_plan, dim3(1), dim3(1), 0, stream, d_state, d_cnt);
+                if (split_pending)
+                    hipLaunchKernelGGL((k_keep_shard<Item, W2>), dim3(2048), dim3(256), 0, stream, &d_state->split, shard, n_shards, d_cnt);
+                launch(&d_state->expand, full_grid);
             }
-            const int write = (n_shards == 1 || split_done || shard == 0) ? 1 : 0;
-            uint64_t room = cap - top[dst];
-            uint64_t B = top[src] < batch ? top[src] : batch;
-            if (4 * B > room) B = room / 4; // a record has at most four children
-            if (B == 0) { eb_set_error("traversal stack capacity exceeded (cap %llu records)", (unsigned long long)cap); return EB_ERR_NOMEM; }
-            const uint64_t base = top[src] - B;
-            EB_HIP(hipMemsetAsync(&d_cnt->pushed, 0, sizeof(unsigned long long), stream));
-            launch(d_stack[src] + base, B, d_stack[dst] + top[dst], room, write);
+            hipLaunchKernelGGL(k_drain_account, dim3(1), dim3(1), 0, stream, d_state, d_cnt);
             EB_HIP(hipGetLastError());
-            EB_HIP(hipMemcpyAsync(h_pushed, &d_cnt->pushed, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-            EB_HIP(hipStreamSynchronize(stream));
-            if (*h_pushed > room) { eb_set_error("traversal stack overflow"); return EB_ERR_STATE; }
-            top[src] = base;
-            top[dst] += *h_pushed;
-            if (*h_pushed) recent = dst;
-            if (top[0] + top[1] > max_top) max_top = top[0] + top[1];
-            ++launches;
-            if (trace && (launches % 200 == 0 || top[0] + top[1] == 0))
-                fprintf(stderr, "[nav] launch %llu: B=%llu pushed=%llu pending=%llu max=%llu t=%.3fs\n", (unsigned long long)launches, (unsigned long long)B,
-                        (unsigned long long)*h_pushed, (unsigned long long)(top[0] + top[1]), (unsigned long long)max_top, now_s() - t_start);
+            EB_HIP(hipMemcpyAsync(&h_state[slot], d_state, sizeof(DrainState), hipMemcpyDeviceToHost, stream));
+            EB_HIP(hipEventRecord(ev[slot], stream));
+            return EB_OK;
+        };
+        int rc = EB_OK, g = 0;
+        if ((rc = enqueue_group(0)) != EB_OK) return rc;
+        for (;;) {
+            // one group queued ahead of the one waited for
+            if ((rc = enqueue_group((g + 1) & 1)) != EB_OK) break;
+            EB_HIP(hipEventSynchronize(ev[g & 1]));
+            const DrainState& s = h_state[g & 1];
+            if (trace)
+                fprintf(stderr, "[nav] group %d: launches=%llu pending=%llu max=%llu t=%.3fs\n", g, (unsigned long long)s.launches,
+                        (unsigned long long)(s.top[0] + s.top[1]), (unsigned long long)s.max_top, now_s() - t_start);
+            if (s.split_done) split_pending = false;
+            if (s.error || s.top[0] + s.top[1] == 0) {
+                // the group queued ahead finds nothing to do (or the same error): wait for it, it still uses the buffers
+                EB_HIP(hipEventSynchronize(ev[(g + 1) & 1]));
+                const DrainState& e = h_state[(g + 1) & 1];
+                top[0] = e.top[0];
+                top[1] = e.top[1];
+                launches = e.launches;
+                max_top = e.max_top;
+                if (e.error == DRAIN_ERR_CAPACITY) { eb_set_error("traversal stack capacity exceeded (cap %llu records)", (unsigned long long)cap); return EB_ERR_NOMEM; }
+                if (e.error) { eb_set_error("traversal stack overflow"); return EB_ERR_STATE; }
+                return EB_OK;
+            }
+            ++g;
         }
-        return EB_OK;
+        (void)hipStreamSynchronize(stream);
+        return rc;
     }
 };
-
-// 64 * per_quad records per 256-thread workgroup and trip; the grid is capped and strides over the batch
-unsigned nav_grid(uint64_t count, uint64_t per_quad = 1) {
-    uint64_t tiles = (count + 64 * per_quad - 1) / (64 * per_quad);
-    const uint64_t cap = 256ull * 8;
-    return (unsigned)(tiles < 1 ? 1 : (tiles > cap ? cap : tiles));
-}
 
 uint64_t env_u64(const char* name, uint64_t dflt) {
     const char* s = getenv(name);
@@ -649,8 +904,10 @@ int eb_flags_derive(eb_flags* f) {
     return EB_OK;
 }
 
+// derive: finish the vectors (inversion of the complement form, fused flag word, DA ranks) -- eb_flags_build; false: leave them in
+// the form the traversal collected them in, for a caller that still has to combine shards (eb_flags_build_shard)
 static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_right, uint32_t shard, uint32_t n_shards, eb_flags** out,
-                            eb_nav_stats* stats, bool complement) {
+                            eb_nav_stats* stats, bool complement, bool derive) {
     if (!b1 || !out) { eb_set_error("null argument"); return EB_ERR_ARG; }
     if (n_shards == 0 || shard >= n_shards) { eb_set_error("shard %u of %u", shard, n_shards); return EB_ERR_ARG; }
     if (K < 0 || K > 65534 || k_right < 0 || k_right > 65534) { eb_set_error("K and k_right must be below 65535"); return EB_ERR_ARG; }
@@ -673,30 +930,36 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
     lap("flag vectors allocated + cleared");
     struct Guard { eb_flags* f; ~Guard() { if (f) eb_flags_destroy(f); } } guard{f};
 
-    NavCounters* d_cnt = nullptr;
-    unsigned long long* h_pushed = nullptr;
-    EB_HIP(hipMalloc(&d_cnt, sizeof(NavCounters)));
-    EB_HIP(hipMemset(d_cnt, 0, sizeof(NavCounters)));
-    EB_HIP(hipHostMalloc(&h_pushed, sizeof(unsigned long long)));
-    unsigned long long* d_rows = nullptr; // EB_NAV_STATS counters per workgroup (nav_grid() launches at most 2048)
-    EB_HIP(hipMalloc(&d_rows, 2048 * EB_NAV_STATS * sizeof(unsigned long long)));
-    EB_HIP(hipMemset(d_rows, 0, 2048 * EB_NAV_STATS * sizeof(unsigned long long)));
-    struct GuardR { void* p; ~GuardR() { (void)hipFree(p); } } guard_r{d_rows};
-    struct Guard2 { NavCounters* c; unsigned long long* h; ~Guard2() { (void)hipFree(c); (void)hipHostFree(h); } } guard2{d_cnt, h_pushed};
+    // per traversal: the hot counter, the drain's state (device) with two snapshots of it (page-locked host), statistics rows
+    struct NavBufs {
+        NavCounters* cnt = nullptr;
+        DrainState* state = nullptr;
+        DrainState* h_state = nullptr;
+        unsigned long long* rows = nullptr; // EB_NAV_STATS counters per workgroup (nav_grid() launches at most 2048)
+        ~NavBufs() {
+            if (cnt) (void)hipFree(cnt);
+            if (state) (void)hipFree(state);
+            if (h_state) (void)hipHostFree(h_state);
+            if (rows) (void)hipFree(rows);
+        }
+        int alloc() {
+            EB_HIP(hipMalloc(&cnt, sizeof(NavCounters)));
+            EB_HIP(hipMemset(cnt, 0, sizeof(NavCounters)));
+            EB_HIP(hipMalloc(&state, sizeof(DrainState)));
+            EB_HIP(hipHostMalloc(&h_state, 2 * sizeof(DrainState)));
+            EB_HIP(hipMalloc(&rows, 2048 * EB_NAV_STATS * sizeof(unsigned long long)));
+            EB_HIP(hipMemset(rows, 0, 2048 * EB_NAV_STATS * sizeof(unsigned long long)));
+            return EB_OK;
+        }
+    };
     // The two traversals are independent (leaves write leaf interiors, nodes write child borders: disjoint positions), so
     // they run side by side -- the leaves on a second stream driven by a second host thread, with counters, statistics
     // rows and stacks of their own: the short leaf launches fill the gaps of the node launches (0.06 s hidden at config 2).
-    NavCounters* d_cnt2 = nullptr;
-    unsigned long long* h_pushed2 = nullptr;
-    unsigned long long* d_rows2 = nullptr;
+    NavBufs nb1, nb2;
+    if ((rc = nb1.alloc()) != EB_OK || (rc = nb2.alloc()) != EB_OK) return rc;
     hipStream_t st2 = nullptr;
-    EB_HIP(hipMalloc(&d_cnt2, sizeof(NavCounters)));
-    EB_HIP(hipMemset(d_cnt2, 0, sizeof(NavCounters)));
-    EB_HIP(hipHostMalloc(&h_pushed2, sizeof(unsigned long long)));
-    EB_HIP(hipMalloc(&d_rows2, 2048 * EB_NAV_STATS * sizeof(unsigned long long)));
-    EB_HIP(hipMemset(d_rows2, 0, 2048 * EB_NAV_STATS * sizeof(unsigned long long)));
     EB_HIP(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
-    struct Guard5 { NavCounters* c; unsigned long long* h; unsigned long long* r; hipStream_t s; ~Guard5() { (void)hipFree(c); (void)hipHostFree(h); (void)hipFree(r); (void)hipStreamDestroy(s); } } guard5{d_cnt2, h_pushed2, d_rows2, st2};
+    struct Guard5 { hipStream_t s; ~Guard5() { (void)hipStreamDestroy(s); } } guard5{st2};
 
     eb_dev_index x1 = b1->dev(), x2 = b2 ? b2->dev() : b1->dev();
     eb_dev_flags df = f->dev();
@@ -764,18 +1027,18 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
     EB_HIP(hipStreamSynchronize(f->stream)); // the cleared threshold words, before either traversal touches them
     uint64_t launches_l = 0, launches_n = 0;
     // phase 2 (ebwt2InDel.cpp:577-615 / :708-756); first_leaf = {[0,F_A), 0} (dna_bwt.hpp:313-317)
-    auto phase_leaves = [&](hipStream_t sx, NavCounters* dc, unsigned long long* hp, unsigned long long* rows, void* arena, uint64_t bytes) -> int {
+    auto phase_leaves = [&](hipStream_t sx, NavBufs& nb, void* arena, uint64_t bytes) -> int {
         int r;
+        NavCounters* dc = nb.cnt;
+        unsigned long long* rows = nb.rows;
         if (!b2) {
             Drain<Leaf1> d;
             d.device = b1->device; d.stream = sx;
             d.shard = shard; d.n_shards = n_shards; d.split_min = split_min;
             if ((r = d.init(arena, bytes, n, batch_max)) != EB_OK) return r;
             if ((r = d.push_host(Leaf1{0, b1->F[0], 0, 0})) != EB_OK) return r;
-            r = d.run<-1>(dc, hp, [&](Leaf1* in, uint64_t cnt, Leaf1* o, uint64_t ocap, int write) {
-                NavParams q = p;
-                q.write = write;
-                hipLaunchKernelGGL(k_leaves<1>, dim3(nav_grid(cnt)), dim3(256), 0, sx, x1, x2, df, d_kr, q, in, cnt, o, ocap, dc, rows);
+            r = d.run<-1>(dc, nb.state, nb.h_state, [&](const NavLaunch* la, unsigned grid) {
+                hipLaunchKernelGGL(k_leaves<1>, dim3(grid), dim3(256), 0, sx, x1, x2, df, d_kr, p, la, dc, rows);
             });
             launches_l = d.launches;
             return r;
@@ -785,17 +1048,19 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
         d.shard = shard; d.n_shards = n_shards; d.split_min = split_min;
         if ((r = d.init(arena, bytes, n, batch_max)) != EB_OK) return r;
         if ((r = d.push_host(pack_rec(Leaf2{0, b1->F[0], 0, b2->F[0], 0, {0, 0, 0}}))) != EB_OK) return r;
-        r = d.run<1>(dc, hp, [&](Leaf2P* in, uint64_t cnt, Leaf2P* o, uint64_t ocap, int write) {
-            NavParams q = p;
-            q.write = write;
-            hipLaunchKernelGGL(k_leaves<2>, dim3(nav_grid(cnt)), dim3(256), 0, sx, x1, x2, df, d_kr, q, in, cnt, o, ocap, dc, rows);
+        r = d.run<1>(dc, nb.state, nb.h_state, [&](const NavLaunch* la, unsigned grid) {
+            hipLaunchKernelGGL(k_leaves<2>, dim3(grid), dim3(256), 0, sx, x1, x2, df, d_kr, p, la, dc, rows);
         });
         launches_l = d.launches;
         return r;
     };
     // phase 3 (ebwt2InDel.cpp:622-673 / :764-823); root (dna_bwt.hpp:296-308)
-    auto phase_nodes = [&](hipStream_t sx, NavCounters* dc, unsigned long long* hp, unsigned long long* rows, void* arena, uint64_t bytes) -> int {
+    // EB_NAV_PIPELINED=0: the round-2 one-BWT node kernel (record load, wait, block loads, wait, compute) instead of k_nodes1p
+    const bool pipelined_nodes = env_u64("EB_NAV_PIPELINED", 1) != 0;
+    auto phase_nodes = [&](hipStream_t sx, NavBufs& nb, void* arena, uint64_t bytes) -> int {
         int r;
+        NavCounters* dc = nb.cnt;
+        unsigned long long* rows = nb.rows;
         if (!b2) {
             Drain<Node1P> d;
             d.device = b1->device; d.stream = sx;
@@ -803,10 +1068,10 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
             if ((r = d.init(arena, bytes, n, batch_max)) != EB_OK) return r;
             Node1 root{{0, b1->F[0], b1->F[1], b1->F[2], b1->F[3], b1->n}, 0, 0};
             if ((r = d.push_host(pack_rec(root))) != EB_OK) return r;
-            r = d.run<-1>(dc, hp, [&](Node1P* in, uint64_t cnt, Node1P* o, uint64_t ocap, int write) {
-                NavParams q = p;
-                q.write = write;
-                hipLaunchKernelGGL((k_nodes<1, EB_NODES_PER_QUAD>), dim3(nav_grid(cnt, EB_NODES_PER_QUAD)), dim3(256), 0, sx, x1, x2, df, d_kr, q, in, cnt, o, ocap, dc, rows);
+            r = d.run<-1>(dc, nb.state, nb.h_state, [&](const NavLaunch* la, unsigned grid) {
+                if (pipelined_nodes && (b1->n >> EB_SUPER_SHIFT) + 1 <= EB_NAV_SUPER_LDS) hipLaunchKernelGGL((k_nodes1p<true>), dim3(grid), dim3(256), 0, sx, x1, df, d_kr, p, la, dc, rows);
+                else if (pipelined_nodes) hipLaunchKernelGGL((k_nodes1p<false>), dim3(grid), dim3(256), 0, sx, x1, df, d_kr, p, la, dc, rows);
+                else hipLaunchKernelGGL((k_nodes<1, EB_NODES_PER_QUAD>), dim3(grid), dim3(256), 0, sx, x1, x2, df, d_kr, p, la, dc, rows);
             });
             launches_n = d.launches;
             return r;
@@ -817,10 +1082,8 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
         if ((r = d.init(arena, bytes, n, batch_max)) != EB_OK) return r;
         Node2 root{{0, b1->F[0], b1->F[1], b1->F[2], b1->F[3], b1->n}, {0, b2->F[0], b2->F[1], b2->F[2], b2->F[3], b2->n}, 0, {0, 0, 0}};
         if ((r = d.push_host(pack_rec(root))) != EB_OK) return r;
-        r = d.run<1>(dc, hp, [&](Node2P* in, uint64_t cnt, Node2P* o, uint64_t ocap, int write) {
-            NavParams q = p;
-            q.write = write;
-            hipLaunchKernelGGL((k_nodes<2, 1>), dim3(nav_grid(cnt)), dim3(256), 0, sx, x1, x2, df, d_kr, q, in, cnt, o, ocap, dc, rows);
+        r = d.run<1>(dc, nb.state, nb.h_state, [&](const NavLaunch* la, unsigned grid) {
+            hipLaunchKernelGGL((k_nodes<2, 1>), dim3(grid), dim3(256), 0, sx, x1, x2, df, d_kr, p, la, dc, rows);
         });
         launches_n = d.launches;
         return r;
@@ -832,21 +1095,21 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
         double t_l = 0;
         std::thread leaf_thread([&] {
             (void)hipSetDevice(device);
-            rc_l = phase_leaves(st2, d_cnt2, h_pushed2, d_rows2, d_arena2, arena2_bytes);
+            rc_l = phase_leaves(st2, nb2, d_arena2, arena2_bytes);
             if (rc_l != EB_OK) err_l = eb_last_error(); // the message is thread-local
             t_l = now_s() - t0;
         });
-        rc = phase_nodes(st, d_cnt, h_pushed, d_rows, d_arena, arena_bytes);
+        rc = phase_nodes(st, nb1, d_arena, arena_bytes);
         s.seconds_nodes = now_s() - t0;
         leaf_thread.join();
         s.seconds_leaves = t_l;
         if (rc == EB_OK && rc_l != EB_OK) { eb_set_error("%s", err_l.c_str()); rc = rc_l; }
         if (rc != EB_OK) return rc;
     } else {
-        if ((rc = phase_leaves(st, d_cnt, h_pushed, d_rows, d_arena, arena_bytes)) != EB_OK) return rc;
+        if ((rc = phase_leaves(st, nb1, d_arena, arena_bytes)) != EB_OK) return rc;
         double t1 = now_s();
         s.seconds_leaves = t1 - t0;
-        if ((rc = phase_nodes(st, d_cnt, h_pushed, d_rows, d_arena, arena_bytes)) != EB_OK) return rc;
+        if ((rc = phase_nodes(st, nb1, d_arena, arena_bytes)) != EB_OK) return rc;
         s.seconds_nodes = now_s() - t1;
     }
     const uint64_t launches = launches_l + launches_n;
@@ -858,13 +1121,13 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
     lap("threshold bits packed");
     s.seconds_traversal = now_s() - t0;
     f->complemented = complement;
-    if (n_shards == 1 && (rc = eb_flags_derive(f)) != EB_OK) return rc; // shards: eb_flags_finalize, after the reduction
+    if (derive && (rc = eb_flags_derive(f)) != EB_OK) return rc; // shards: eb_flags_finalize, after the reduction
     NavCounters c;
     memset(&c, 0, sizeof c);
     {
         std::vector<unsigned long long> rows(2048 * EB_NAV_STATS), rows2(2048 * EB_NAV_STATS);
-        EB_HIP(hipMemcpy(rows.data(), d_rows, rows.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        EB_HIP(hipMemcpy(rows2.data(), d_rows2, rows2.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        EB_HIP(hipMemcpy(rows.data(), nb1.rows, rows.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        EB_HIP(hipMemcpy(rows2.data(), nb2.rows, rows2.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         for (size_t k = 0; k < rows.size(); ++k) rows[k] += rows2[k];
         for (size_t r = 0; r < 2048; ++r) {
             c.leaves += rows[r * EB_NAV_STATS + 0];
@@ -912,7 +1175,7 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
     if (!out) { eb_set_error("null argument"); return EB_ERR_ARG; }
     const bool complement = env_u64("EB_NAV_COMPLEMENT", 1) != 0;
     eb_nav_stats s;
-    int rc = flags_build_impl(b1, b2, K, k_right, 0, 1, out, &s, complement);
+    int rc = flags_build_impl(b1, b2, K, k_right, 0, 1, out, &s, complement, true);
     if (rc != EB_OK) return rc;
     if (complement && s.lcp_values != s.n) {
         // Not every LCP slot was written exactly once: the input is not the eBWT of a read collection.  The reference leaves
@@ -920,7 +1183,7 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
         // the reference's way (writers at or above the thresholds set their bits).
         eb_flags_destroy(*out);
         *out = nullptr;
-        rc = flags_build_impl(b1, b2, K, k_right, 0, 1, out, &s, false);
+        rc = flags_build_impl(b1, b2, K, k_right, 0, 1, out, &s, false, true);
         if (rc != EB_OK) return rc;
     }
     if (stats) *stats = s;
@@ -931,7 +1194,10 @@ extern "C" int eb_flags_build_shard(eb_index* b1, eb_index* b2, int32_t K, int32
                                     eb_nav_stats* stats) {
     // shards collect the complement (see NavParams::below): their vectors still add up (one writer per marked bit), and
     // eb_flags_finalize inverts the sum.  Callers check that the shards' lcp_values add up to n (a valid eBWT).
-    return flags_build_impl(b1, b2, K, k_right, shard, n_shards, out, stats, n_shards > 1 ? true : env_u64("EB_NAV_COMPLEMENT", 1) != 0);
+    // ALWAYS shard form, never derived -- also for n_shards == 1: the callers' next step (all-reduce + eb_flags_finalize, or
+    // eb_flags_export + eb_flags_import_shard_sum) is the same for any number of shards, and a one-shard build that came
+    // back finished would be inverted a second time on the host-exchange paths (round-2 advisor finding).
+    return flags_build_impl(b1, b2, K, k_right, shard, n_shards, out, stats, true, false);
 }
 
 extern "C" int eb_flags_device_vectors(eb_flags* f, uint64_t* d_vectors[4], uint64_t* words) {

@@ -56,6 +56,7 @@ struct alignas(16) Survivor {
 };
 
 #define EB_NEEDS_HIST 0x80000000u
+
 #define EB_SCAN_PARTIAL 205 /* runs, clusters, bases, hist[201], survivors (ordered scan) */
 
 #define EB_REQ_SLOTS 64
@@ -388,6 +389,9 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
     uint32_t trips = 0;
     const uint64_t T = p.tiles_per_wg;
     const uint64_t iters = ordered ? T : (tiles > blockIdx.x ? (tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0);
+    // (Round 3 measured a software pipeline over the tiles -- the loads of tile it+1 issued before tile it is worked on, 12 more
+    // registers, 6 instead of 7 waves per SIMD: 1.144 against 1.090 ms on the same box.  The kernel is not short of bytes in
+    // flight: its ~480 vector instructions per 64-position word are what it waits for)
     for (uint64_t it = 0; it < iters; ++it) {
         const uint64_t tile = ordered ? (uint64_t)blockIdx.x * T + it : (uint64_t)blockIdx.x + it * gridDim.x;
         if (ordered) cur_batch = (uint64_t)blockIdx.x * ((T + EB_BATCH_TILES - 1) / EB_BATCH_TILES) + it / EB_BATCH_TILES;
@@ -977,6 +981,7 @@ __global__ void __launch_bounds__(256) k_right_finish(const eb_cluster* __restri
     for (uint32_t k = 0; k < right_words; ++k) right[i * (uint64_t)right_words + k] = tmp_right[i * (uint64_t)right_words + k];
 }
 
+#define EB_JOB_PINNED_BYTES (512 + 16 * (sizeof(ScanCounters) + 64)) /* page-locked words of one job (<= 16 sub-shards) */
 struct DevMem { // per-call temporary from the caching scratch allocator
     void* p = nullptr;
     size_t cap = 0;
@@ -1392,7 +1397,6 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
         EB_HIP(hipStreamCreateWithFlags(&ctx->ext, hipStreamNonBlocking));
         EB_HIP(hipStreamCreateWithFlags(&ctx->right, hipStreamNonBlocking));
         EB_HIP(hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking));
-        EB_HIP(hipHostMalloc(&ctx->h_pinned, 16 * (sizeof(ScanCounters) + 64), hipHostMallocDefault));
         EB_HIP(hipEventCreateWithFlags(&ctx->last_ext, hipEventDisableTiming));
         EB_HIP(hipEventCreateWithFlags(&ctx->last_right, hipEventDisableTiming));
         EB_HIP(hipEventRecord(ctx->last_ext, ctx->ext));
@@ -1440,7 +1444,10 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
     }
     if (!job->h_bad) {
         void* hb = nullptr;
-        EB_HIP(hipHostMalloc(&hb, 512, hipHostMallocDefault)); // [0] wire overflow count, [1 + 2k, 2 + 2k] request counts of sub-shard k (<= 16)
+        // [0] wire overflow count, [1 + 2k, 2 + 2k] request counts of sub-shard k (<= 16), [40, 41] ordering counts; behind the
+        // first 512 bytes: the job's OWN read-back block of every sub-shard's ScanCounters (+ 64 bytes of ordering counts) -- a
+        // block shared by all jobs of the index was safe only while _begin calls never overlapped (round-2 advisor finding)
+        EB_HIP(hipHostMalloc(&hb, EB_JOB_PINNED_BYTES, hipHostMallocDefault));
         job->h_bad = static_cast<unsigned long long*>(hb);
     }
     memset(job->h_bad, 0, 512);
@@ -1523,7 +1530,7 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
         for (DevMem* m : {&x.cnt, &x.part, &x.surv, &x.sorted, &x.bcnt, &x.boff, &x.tmp, &x.nch, &x.choff, &x.chains, &x.recs, &x.crec, &x.left, &x.right, &x.blob, &x.rt_rec, &x.rt_right, &x.slots, &x.bcount})
             m->device = b1->device;
         for (int i = 0; i < E_PER_SHARD; ++i) x.e[i] = job->events[2 + (size_t)E_PER_SHARD * (size_t)k + (size_t)i];
-        x.h_cnt = reinterpret_cast<ScanCounters*>(static_cast<uint8_t*>(ctx->h_pinned) + (size_t)k * (sizeof(ScanCounters) + 64));
+        x.h_cnt = reinterpret_cast<ScanCounters*>(reinterpret_cast<uint8_t*>(job->h_bad) + 512 + (size_t)k * (sizeof(ScanCounters) + 64));
         x.h_last = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(x.h_cnt) + sizeof(ScanCounters));
         // cut on flag-word boundaries; clusters belong to the sub-shard that holds their closing position
         uint64_t wa = w_lo + w_total * (uint64_t)k / (uint64_t)S, wb = w_lo + w_total * (uint64_t)(k + 1) / (uint64_t)S;

@@ -1,13 +1,26 @@
-"""The bench's own input at full size (BASELINE configs[1]: 50 M x 150 bp, n = 7.55 G, seed 1) through the CPU oracle.
+"""The BASELINE configurations at full size through the CPU oracle, on the GPU box's host threads: what the `-m gpu` tests of
+tests/test_gpu_fullsize.py hold the product to (profiles/r03_fullsize_<config>.json).
 
-The unmodified reference needs ~45 min for this input (single thread, 2.9 M positions/s at DRAM-resident sizes: SURVEY.md
-section 6), more than a GPU-box call may last; its word at this scale is taken on the replicated input of
+The unmodified reference needs ~45 min for 7.55 G positions (single thread, 2.9 M positions/s at DRAM-resident sizes:
+SURVEY.md section 6), more than a GPU-box call may last; its word past 2^32 is taken on the replicated input of
 scripts/ref_past_2p32.py.  Here the ORACLE -- pinned to the reference by the golden fixtures, by the fresh-input runs
-against the reference binary and, past 2^32, by tests/test_gpu_superblocks.py -- walks the very eBWT the bench builds,
-on the GPU box's host threads (threaded index + traversal, scan sharded over threads), and its .snp must equal the GPU's
-byte for byte.  The SHA-256 goes to profiles/r02_fullsize_config2.json; bench.py asserts it on every default run.
+against the reference binary and, past 2^32, by tests/test_gpu_superblocks.py -- walks the very inputs the tests regenerate:
 
-    gpurun --timeout 1200 -- 'python scripts/fullsize_check.py > gpurun_out/fullsize.log 2>&1'
+  part "traversal": threaded index + traversal (orc_navigate_one_mt / orc_navigate_two_mt: same expansion rule, subtrees
+                    over threads; bit-identical to the serial, reference-ordered code on the fixtures,
+                    tests/test_oracle_threads.py) -> counters and the SHA-256 of each bit vector, compared with the GPU's;
+  part "phase4":    phase 4 over the WHOLE range in all three modes (round 2 compared modes 2 / 3 on windows only): the
+                    range is cut into shards that the host threads scan side by side, every shard numbering its clusters
+                    from 1, and the texts are renumbered into the single pass's running cluster_nr
+                    (tests/_fullsize.py::renumber; tests/test_oracle_threads.py holds that to a one-piece scan) -> SHA-256
+                    of the whole .snp, compared with the GPU's.  It runs on the GPU's bit vectors, whose SHA-256 it
+                    records: they must equal the ones part "traversal" recorded for the oracle's own (merge checks it).
+
+    gpurun --timeout 1200 -- 'python scripts/fullsize_check.py config2 all     > gpurun_out/fs2.log 2>&1'
+    gpurun --timeout 1200 -- 'python scripts/fullsize_check.py config4 traversal > gpurun_out/fs4t.log 2>&1'
+    gpurun --timeout 1200 -- 'python scripts/fullsize_check.py config4 phase4    > gpurun_out/fs4p.log 2>&1'
+    python scripts/fullsize_check.py config4 merge      # gpurun_out/r03_fullsize_config4_*.json -> profiles/r03_fullsize_config4.json
+    (also: python scripts/fullsize_check.py 50000000 x10 -- the replicated input towards configs[4], as in round 2)
 """
 import hashlib
 import json
@@ -24,14 +37,19 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 from ebwt2indel_amd import api, sim  # noqa: E402
 from ebwt2indel_amd import distributed as ebd  # noqa: E402
+from tests import _fullsize as fs  # noqa: E402
 from tests import _oracle  # noqa: E402
 
-READS = int(sys.argv[1]) if len(sys.argv) > 1 else 50_000_000
-MODE3 = len(sys.argv) > 2 and sys.argv[2] == "mode3"   # READS reads per sample, two samples: merged BWT + document array
-MODE2 = len(sys.argv) > 2 and sys.argv[2] == "mode2"   # the same two samples as two BWTs
-COPIES = int(sys.argv[2][1:]) if len(sys.argv) > 2 and sys.argv[2].startswith("x") else 0   # "x10": every read 10 times (sim.replicated_ebwt_gpu)
+NAME = sys.argv[1] if len(sys.argv) > 1 else "config2"
+PART = sys.argv[2] if len(sys.argv) > 2 else "all"
+READS = int(NAME) if NAME.isdigit() else 0
+COPIES = int(PART[1:]) if PART.startswith("x") and PART[1:].isdigit() else 0   # "x10": every read 10 times (sim.replicated_ebwt_gpu)
 READ_LEN, COVERAGE, SEED = 150, 30.0, 1
-THREADS = int(os.environ.get("EB_CHECK_THREADS", str(min(os.cpu_count() or 8, 32))))
+try:
+    _cpus = len(os.sched_getaffinity(0))
+except AttributeError:
+    _cpus = os.cpu_count() or 8
+THREADS = int(os.environ.get("EB_CHECK_THREADS", str(min(_cpus, 64))))
 
 
 def log(*a):
@@ -56,187 +74,120 @@ class Heartbeat:
 
     def __exit__(self, *exc):
         self.stop.set()
-        log(f"{self.what}: {time.time() - self.t0:.1f}s")
+        self.seconds = time.time() - self.t0
+        log(f"{self.what}: {self.seconds:.1f}s")
 
 
-def main_mode3():
-    """BASELINE configs[3] when READS = 50 M: two samples of READS reads each (one per haplotype, scripts/modes23_scale.py's
-    recipe), merged eBWT + document array, mode 3 -- GPU against the oracle (threaded index + traversal, scan sharded)."""
-    n_each = READS
-    glen = int(2 * n_each * READ_LEN / 30)
-    g = sim.random_genome(glen, 5)
-    h2 = sim.mutate_haplotype(g, 5)
-    text, offs = sim.haplotype_text([g, h2])
-    rng = np.random.Generator(np.random.PCG64(99))
-    s0 = (rng.integers(0, len(g) - READ_LEN + 1, size=n_each, dtype=np.int64) + offs[0]).astype(np.uint64)
-    s1 = (rng.integers(0, len(h2) - READ_LEN + 1, size=n_each, dtype=np.int64) + offs[1]).astype(np.uint64)
-    del g, h2
-    with Heartbeat("merged eBWT + DA on the GPU"):
-        dev = sim.build_ebwt_gpu(text, np.concatenate([s0, s1]), READ_LEN, n_first=n_each, want_da=True)
-    del text, s0, s1
-    n = dev.n
-    log(f"n = {n}")
-    host, da_host = dev.to_host()
-    p = api.make_params()
-    t0 = time.time()
-    bwt = api.DnaBwt(None, device_ptr=dev.ptr, n=n)
-    dev.free()
-    flags = api.navigate_one_bwt(bwt, p)
-    flags.set_da(da_host)
-    calls = api.scan_clusters(bwt, flags, p)
-    got, cluster_nr, events = calls.format_snp(p, True)
-    t_gpu = time.time() - t0
-    gpu_sha = hashlib.sha256(got).hexdigest()
-    log(f"GPU mode 3: {got.count(b'>')} records, {len(calls)} clusters in the call set, sha256 {gpu_sha} ({t_gpu:.2f}s)")
-    ns = flags.stats
-    orc = _oracle.Oracle()
-    po = _oracle.Params.from_args([])
+def out_path(name, part):
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    return os.path.join(ROOT, "gpurun_out", f"r03_fullsize_{name}_{part}.json")
+
+
+def oracle_indexes(orc, inp):
     with Heartbeat(f"oracle index, {THREADS} threads"):
-        idx = orc.index(host, threads=THREADS)
-    with Heartbeat(f"oracle traversal (phases 2-3), {THREADS} threads"):
-        of = _oracle.OracleFlags(orc, idx, None, po.K, po.k_right, threads=THREADS)
-    with Heartbeat("oracle document array"):
-        d = _oracle._u8(da_host)
-        orc.lib.orc_flags_set_da(of.h, d.ctypes.data, len(d))
-        of.has_da = True
+        idx = [orc.index(h, threads=THREADS) for h in inp.hosts]
+    assert all(i.ok for i in idx)
+    return idx
+
+
+def part_traversal(inp, res, orc, po, idx):
+    """The oracle's own traversal against the GPU's: counters and every bit vector (SHA-256 + word for word)."""
+    with Heartbeat(f"oracle traversal (phases 2-3), {THREADS} threads") as hb_t:
+        of = _oracle.OracleFlags(orc, idx[0], idx[1] if inp.mode == 2 else None, po.K, po.k_right, threads=THREADS)
+    if inp.mode == 3:
+        with Heartbeat("oracle document array"):
+            d = _oracle._u8(inp.da_host)
+            orc.lib.orc_flags_set_da(of.h, d.ctypes.data, len(d))
+            of.has_da = True
     oc = of.counters()
     log(f"oracle: {oc}")
-    assert (ns.leaves, ns.nodes, ns.minima, ns.lcp_values) == (oc["leaves"], oc["nodes"], oc["minima"], oc["lcp_values"]), "traversal counters differ"
-    for name, a, b in zip(("thrK", "thrR", "minima", "da"), flags.export(), of.export()):
-        assert np.array_equal(a, b), f"{name} differs"
-    log("flag vectors identical (thrK, thrR, minima, da)")
-    # Phase 4.  The oracle runs the reference's algorithm, which in the two-sample modes extends the contexts of nearly every
-    # cluster (one frequent letter on each side is enough, ebwt2InDel.cpp:1042-1052): at 15 G positions that is hours of CPU
-    # even on 32 threads (the first attempt of this script gave up after 13 minutes of its first pass).  Small inputs are
-    # compared in full; at scale the comparison is on WINDOWS: around every 2^32-symbol superblock boundary, at both ends of
-    # the BWT, and at seeded random places -- records (with contexts) and text of each window, GPU against oracle.
-    win = 1 << 22
-    if n <= (1 << 28):
-        windows = [(0, n)]
-    else:
-        rng = np.random.Generator(np.random.PCG64(7))
-        centres = [k << 32 for k in range(1, int(n >> 32) + 1)] + [win // 2, n - win // 2] + [int(v) for v in rng.integers(win, n - win, size=14)]
-        windows = sorted({(max(0, (c - win // 2) // 64 * 64), min(n, (c - win // 2) // 64 * 64 + win)) for c in centres})
-    log(f"{len(windows)} windows of {win if len(windows) > 1 else n} positions: {[w[0] for w in windows]}")
+    keys = ("leaves", "nodes", "minima", "lcp_values") + (("da_values",) if inp.mode == 2 else ())
+    assert all(res.counters[k] == oc[k] for k in keys), ("traversal counters differ", res.counters, oc)
+    with Heartbeat("bit vectors: SHA-256, GPU against oracle"):
+        want = of.export()
+        want_sha = dict(zip(fs.VECTORS, fs.sha256_many(list(want))))
+        got_sha, got = res.vector_shas()
+        for name, a, b in zip(fs.VECTORS, got, want):
+            assert (a is None) == (b is None) and (a is None or np.array_equal(a, b)), f"{name} differs"
+    assert got_sha == want_sha
+    log(f"flag vectors identical: {want_sha}")
+    return of, {"oracle_vector_sha256": want_sha, "gpu_vector_sha256": got_sha, "counters": {k: int(oc[k]) for k in keys},
+                "oracle_traversal_seconds": round(hb_t.seconds, 1)}
 
-    def oracle_window(be):
-        return of.scan(po, be[0], be[1], capture=True)
-    with Heartbeat("oracle scan of the windows"), ThreadPoolExecutor(min(THREADS, len(windows))) as ex:
-        wants = list(ex.map(oracle_window, windows))
-    recs = 0
-    got_parts, want_parts = [], []
-    for (b, e), want_w in zip(windows, wants):
-        c = api.scan_clusters(bwt, flags, p, begin=b, end=e)
-        cl, chains, left, right = c.arrays()
-        assert len(c) == want_w["count"], (b, e, len(c), want_w["count"])
-        assert np.array_equal(cl, want_w["clusters"]) and np.array_equal(chains, want_w["chains"]), (b, e)
-        assert np.array_equal(left, want_w["left"]) and np.array_equal(right, want_w["right"]), (b, e)
-        t, _, _ = c.format_snp(p, True)
-        assert t == want_w["text"], (b, e)
-        recs += t.count(b">")
-        got_parts.append(t)
-        want_parts.append(want_w["text"])
-    log(f"windows identical: {sum(w['count'] for w in wants)} clusters with contexts, {recs} records")
-    want = b"".join(want_parts)
-    if len(windows) > 1:
-        got_full_sha = gpu_sha
-        got = b"".join(got_parts)
-        gpu_sha = hashlib.sha256(got).hexdigest()
+
+def part_phase4(inp, res, orc, po, idx, of=None):
+    """The oracle's phase 4 over the WHOLE range, sharded over the host threads; on the GPU's vectors unless the oracle's own
+    (`of`, from part_traversal in the same process) are at hand."""
+    rec = {}
+    if of is None:
+        got_sha, vec = res.vector_shas()
+        rec["phase4_ran_on_gpu_vectors_sha256"] = got_sha
+        with Heartbeat("oracle flags imported from the GPU's vectors"):
+            of = _oracle.OracleFlags(orc, idx[0], idx[1] if inp.mode == 2 else None, po.K, po.k_right, vectors=vec)
+        del vec
+    n = inp.n
+    shards = THREADS * 16
+    cuts = [ebd.shard_range(n, i, shards) for i in range(shards)]
+    done = [0]
+
+    def one(be):
+        r = of.scan(po, be[0], be[1])
+        done[0] += 1
+        return r["text"], r["cluster_nr"] - 1, r["events"], r["stats"]
+    with Heartbeat(f"oracle phase 4, whole range, {shards} shards on {THREADS} threads") as hb, ThreadPoolExecutor(THREADS) as ex:
+        parts = list(ex.map(one, cuts))
+    want = fs.renumber([p[0] for p in parts], [p[1] for p in parts])
     orc_sha = hashlib.sha256(want).hexdigest()
-    res = {"what": "BASELINE configs[3] scale (mode 3: merged BWT + document array) at full size: GPU .snp vs the CPU oracle's",
-           "input": {"reads_per_sample": n_each, "read_len": READ_LEN, "n": int(n), "recipe": "scripts/modes23_scale.py (genome seed 5, starts seed 99)",
-                     "ebwt_sha256": hashlib.sha256(host).hexdigest(), "da_sha256": hashlib.sha256(da_host).hexdigest()},
-           "options": "defaults", "phase4_compared_on": [list(w) for w in windows], "window_clusters": int(sum(w["count"] for w in wants)),
-           "gpu_windows_snp_sha256": gpu_sha, "oracle_windows_snp_sha256": orc_sha, "identical": got == want,
-           "gpu_whole_snp_sha256": got_full_sha if len(windows) > 1 else gpu_sha, "window_records": int(got.count(b">")), "flag_vectors_identical": True,
-           "counters": {k: int(oc[k]) for k in ("leaves", "nodes", "minima", "lcp_values")}, "oracle_threads": THREADS, "gpu_seconds": round(t_gpu, 2)}
-    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", f"fullsize_check_mode3_{READS}.json"), "w") as f:
-        json.dump(res, f, indent=1)
-    log(json.dumps(res))
-    assert got == want, "GPU .snp differs from the oracle's at full size (mode 3)"
+    stats = {k: int(sum(p[3][k] for p in parts)) for k in ("runs_closed", "clusters", "bases_in_runs")}
+    log(f"oracle: {want.count(b'>')} records, {sum(p[1] for p in parts)} cluster numbers, sha256 {orc_sha}; {stats}")
+    st = res.calls.stats
+    assert (int(st.runs_closed), int(st.clusters), int(st.bases_in_runs)) == (stats["runs_closed"], stats["clusters"], stats["bases_in_runs"]), "scan counters differ"
+    assert res.text == want, "GPU .snp differs from the oracle's whole-range .snp"
+    assert res.cluster_nr - 1 == sum(p[1] for p in parts)
+    rec.update({"oracle_snp_sha256": orc_sha, "gpu_snp_sha256": res.snp_sha256, "identical": True, "snp_records": int(res.snp_records), "snp_bytes": len(want),
+                "cluster_numbers": int(res.cluster_nr - 1), "scan_counters": stats, "oracle_phase4_seconds": round(hb.seconds, 1), "oracle_shards": shards})
+    return rec
 
 
-def main_mode2():
-    """BASELINE configs[2] when READS = 25 M: two samples of READS reads each as TWO BWTs (mode 2): the GPU's dual-BWT
-    traversal (DA rebuilt from interval arithmetic) and phase 4 against the oracle (threaded two-BWT traversal; phase 4 on
-    windows, see main_mode3)."""
-    n_each = READS
-    glen = int(2 * n_each * READ_LEN / 30)
-    g = sim.random_genome(glen, 5)
-    h2 = sim.mutate_haplotype(g, 5)
-    text, offs = sim.haplotype_text([g, h2])
-    rng = np.random.Generator(np.random.PCG64(99))
-    s0 = (rng.integers(0, len(g) - READ_LEN + 1, size=n_each, dtype=np.int64) + offs[0]).astype(np.uint64)
-    s1 = (rng.integers(0, len(h2) - READ_LEN + 1, size=n_each, dtype=np.int64) + offs[1]).astype(np.uint64)
-    del g, h2
-    hosts, gpus = [], []
-    t_gpu = 0.0
-    for starts in (s0, s1):
-        with Heartbeat("eBWT on the GPU"):
-            dev = sim.build_ebwt_gpu(text, starts, READ_LEN)
-        h, _ = dev.to_host()
-        hosts.append(h)
-        t0 = time.time()
-        gpus.append(api.DnaBwt(None, device_ptr=dev.ptr, n=dev.n))
-        t_gpu += time.time() - t0
-        dev.free()
-    del text, s0, s1
-    a, b = gpus
-    n = a.n + b.n
-    log(f"n = {a.n} + {b.n}")
-    p = api.make_params()
-    t0 = time.time()
-    flags = api.navigate_two_bwts(a, b, p)
-    calls = api.scan_clusters(a, flags, p, bwt2=b)
-    got_full, _, _ = calls.format_snp(p, True)
-    t_gpu += time.time() - t0
-    full_sha = hashlib.sha256(got_full).hexdigest()
-    log(f"GPU mode 2: {got_full.count(b'>')} records, {len(calls)} clusters in the call set, sha256 {full_sha} ({t_gpu:.2f}s)")
-    ns = flags.stats
+def main_config():
+    if PART == "merge":
+        return merge()
+    inp = fs.Inputs(NAME, keep_host=True, log=log)
+    res = fs.Result(inp, log=log)
     orc = _oracle.Oracle()
     po = _oracle.Params.from_args([])
-    with Heartbeat(f"oracle indexes, {THREADS} threads"):
-        i1, i2 = orc.index(hosts[0], threads=THREADS), orc.index(hosts[1], threads=THREADS)
-    with Heartbeat(f"oracle two-BWT traversal (phases 2-3), {THREADS} threads"):
-        of = _oracle.OracleFlags(orc, i1, i2, po.K, po.k_right, threads=THREADS)
-    oc = of.counters()
-    log(f"oracle: {oc}")
-    assert (ns.leaves, ns.nodes, ns.minima, ns.lcp_values, ns.da_values) == (oc["leaves"], oc["nodes"], oc["minima"], oc["lcp_values"], oc["da_values"]), "traversal counters differ"
-    for name, va, vb in zip(("thrK", "thrR", "minima", "da"), flags.export(), of.export()):
-        assert np.array_equal(va, vb), f"{name} differs"
-    log("flag vectors identical (thrK, thrR, minima, da)")
-    win = 1 << 22
-    if n <= (1 << 28):
-        windows = [(0, n)]
+    out = {"what": f"BASELINE {fs.CONFIGS[NAME]['baseline']} at full size: the product on one MI355X against the CPU oracle on the box's host threads",
+           "input": inp.describe(), "options": "defaults (-L31 -R30 -k16 -g10 -v2 -m3 -c20 -q0)", "oracle_threads": THREADS, "gpu_seconds": res.seconds}
+    idx = oracle_indexes(orc, inp)
+    inp.hosts = []          # the oracle indexes hold what they need
+    of = None
+    if PART in ("traversal", "all"):
+        of, rec = part_traversal(inp, res, orc, po, idx)
+        out.update(rec)
+    if PART in ("phase4", "all"):
+        out.update(part_phase4(inp, res, orc, po, idx, of))
+    with open(out_path(NAME, PART), "w") as f:
+        json.dump(out, f, indent=1)
+    log(json.dumps(out))
+
+
+def merge():
+    """gpurun_out/r03_fullsize_<name>_{all | traversal + phase4}.json -> profiles/r03_fullsize_<name>.json"""
+    if os.path.exists(out_path(NAME, "all")):
+        m = json.load(open(out_path(NAME, "all")))
     else:
-        rng = np.random.Generator(np.random.PCG64(7))
-        centres = [k << 32 for k in range(1, int(n >> 32) + 1)] + [win // 2, n - win // 2] + [int(v) for v in rng.integers(win, n - win, size=14)]
-        windows = sorted({(max(0, (c - win // 2) // 64 * 64), min(n, (c - win // 2) // 64 * 64 + win)) for c in centres})
-    log(f"{len(windows)} windows of {win if len(windows) > 1 else n} positions: {[w[0] for w in windows]}")
-    with Heartbeat("oracle scan of the windows"), ThreadPoolExecutor(min(THREADS, len(windows))) as ex:
-        wants = list(ex.map(lambda be: of.scan(po, be[0], be[1], capture=True), windows))
-    recs = 0
-    for (wb, we), want_w in zip(windows, wants):
-        c = api.scan_clusters(a, flags, p, bwt2=b, begin=wb, end=we)
-        cl, chains, left, right = c.arrays()
-        assert len(c) == want_w["count"], (wb, we, len(c), want_w["count"])
-        assert np.array_equal(cl, want_w["clusters"]) and np.array_equal(chains, want_w["chains"]), (wb, we)
-        assert np.array_equal(left, want_w["left"]) and np.array_equal(right, want_w["right"]), (wb, we)
-        t, _, _ = c.format_snp(p, True)
-        assert t == want_w["text"], (wb, we)
-        recs += t.count(b">")
-    log(f"windows identical: {sum(w['count'] for w in wants)} clusters with contexts, {recs} records")
-    res = {"what": "BASELINE configs[2] scale (mode 2: two BWTs) at full size: GPU vs the CPU oracle",
-           "input": {"reads_per_sample": n_each, "read_len": READ_LEN, "n1": int(a.n), "n2": int(b.n), "recipe": "scripts/modes23_scale.py (genome seed 5, starts seed 99)",
-                     "ebwt_sha256": [hashlib.sha256(h).hexdigest() for h in hosts]},
-           "options": "defaults", "flag_vectors_identical": True, "counters": {k: int(oc[k]) for k in ("leaves", "nodes", "minima", "lcp_values", "da_values")},
-           "phase4_compared_on": [list(w) for w in windows], "window_clusters": int(sum(w["count"] for w in wants)), "window_records": int(recs), "identical": True,
-           "gpu_whole_snp_sha256": full_sha, "gpu_whole_snp_records": int(got_full.count(b">")), "oracle_threads": THREADS, "gpu_seconds": round(t_gpu, 2)}
-    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", f"fullsize_check_mode2_{READS}.json"), "w") as f:
-        json.dump(res, f, indent=1)
-    log(json.dumps(res))
+        t, p4 = json.load(open(out_path(NAME, "traversal"))), json.load(open(out_path(NAME, "phase4")))
+        assert t["input"] == p4["input"], "the two parts ran on different inputs"
+        assert p4["phase4_ran_on_gpu_vectors_sha256"] == t["oracle_vector_sha256"], "phase 4 ran on vectors the oracle's traversal did not produce"
+        m = dict(t)
+        m["gpu_seconds"] = p4["gpu_seconds"]
+        for k, v in p4.items():
+            if k not in m:
+                m[k] = v
+        m["parts"] = "traversal and phase 4 in two GPU-box calls (each inside the 20-minute cap); phase 4 ran on the GPU's vectors, SHA-256 equal to the oracle's own"
+    with open(fs.profile_path(NAME), "w") as f:
+        json.dump(m, f, indent=1)
+    print("wrote", fs.profile_path(NAME))
 
 
 def main_replicated():
@@ -347,71 +298,7 @@ def main_replicated():
 def main():
     if COPIES:
         return main_replicated()
-    if MODE3:
-        return main_mode3()
-    if MODE2:
-        return main_mode2()
-    genome_len = int(READS * READ_LEN / COVERAGE)
-    g = sim.random_genome(genome_len, SEED)
-    h2 = sim.mutate_haplotype(g, SEED)
-    text, offs = sim.haplotype_text([g, h2])
-    starts = sim.sample_read_starts([g, h2], offs, READS, READ_LEN, SEED)
-    del g, h2
-    with Heartbeat("eBWT on the GPU"):
-        dev = sim.build_ebwt_gpu(text, starts, READ_LEN)
-    del text, starts
-    n = dev.n
-    log(f"n = {n}")
-    host = np.empty(n, dtype=np.uint8)
-    sim._hip_copy_to_host(host, dev.ptr, n)
-    p = api.make_params()
-    t0 = time.time()
-    bwt = api.DnaBwt(None, device_ptr=dev.ptr, n=n)
-    dev.free()
-    flags = api.navigate_one_bwt(bwt, p)
-    calls = api.scan_clusters(bwt, flags, p)
-    got, cluster_nr, events = calls.format_snp(p, False)
-    t_gpu = time.time() - t0
-    gpu_sha = hashlib.sha256(got).hexdigest()
-    log(f"GPU: {events} records, {len(calls)} clusters in the call set, sha256 {gpu_sha} ({t_gpu:.2f}s index + traversal + scan + text)")
-    ns = flags.stats
-
-    orc = _oracle.Oracle()
-    po = _oracle.Params.from_args([])
-    with Heartbeat(f"oracle index, {THREADS} threads"):
-        idx = orc.index(host, threads=THREADS)
-    assert idx.ok
-    with Heartbeat(f"oracle traversal (phases 2-3), {THREADS} threads"):
-        of = _oracle.OracleFlags(orc, idx, None, po.K, po.k_right, threads=THREADS)
-    oc = of.counters()
-    log(f"oracle: {oc}")
-    assert (ns.leaves, ns.nodes, ns.minima, ns.lcp_values) == (oc["leaves"], oc["nodes"], oc["minima"], oc["lcp_values"]), "traversal counters differ"
-    # flag vectors, bit for bit
-    for name, a, b in zip(("thrK", "thrR", "minima"), flags.export()[:3], of.export()[:3]):
-        assert np.array_equal(a, b), f"{name} differs"
-    log("flag vectors identical (thrK, thrR, minima)")
-    # phase 4 sharded over the host threads: pass 1 finds how many cluster numbers each shard uses, pass 2 writes the text
-    cuts = [ebd.shard_range(n, i, THREADS * 4) for i in range(THREADS * 4)]
-    with Heartbeat("oracle scan, pass 1"), ThreadPoolExecutor(THREADS) as ex:
-        used = list(ex.map(lambda be: of.scan(po, be[0], be[1])["cluster_nr"] - 1, cuts))
-    first = np.concatenate([[1], 1 + np.cumsum(used)[:-1]]).astype(int)
-    with Heartbeat("oracle scan, pass 2"), ThreadPoolExecutor(THREADS) as ex:
-        parts = list(ex.map(lambda a: of.scan(po, a[0][0], a[0][1], cluster_nr=int(a[1]))["text"], zip(cuts, first)))
-    want = b"".join(parts)
-    orc_sha = hashlib.sha256(want).hexdigest()
-    log(f"oracle: {want.count(b'>')} records, sha256 {orc_sha}")
-    res = {"what": "BASELINE configs[1] at full size, bench.py's own input: GPU .snp vs the CPU oracle's (threaded index + traversal, scan sharded over host threads)",
-           "input": {"reads": READS, "read_len": READ_LEN, "coverage": COVERAGE, "seed": SEED, "n": int(n), "ebwt_sha256": hashlib.sha256(host).hexdigest()},
-           "options": "defaults (-L31 -R30 -k16 -g10 -v2 -m3 -c20 -q0)",
-           "gpu_snp_sha256": gpu_sha, "oracle_snp_sha256": orc_sha, "identical": got == want, "snp_records": int(events), "snp_bytes": len(got),
-           "flag_vectors_identical": True, "counters": {k: int(oc[k]) for k in ("leaves", "nodes", "minima", "lcp_values")}, "oracle_threads": THREADS,
-           "why_not_the_reference_binary": "single-threaded, ~45 min for 7.55 G positions; a GPU-box call is capped at 20 min. It vouches past 2^32 "
-                                           "on the replicated input of profiles/r02_reference_past_2p32.json instead."}
-    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", f"fullsize_check_{READS}.json"), "w") as f:
-        json.dump(res, f, indent=1)
-    log(json.dumps(res))
-    assert got == want, "GPU .snp differs from the oracle's at full size"
+    return main_config()
 
 
 if __name__ == "__main__":

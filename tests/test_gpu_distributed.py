@@ -118,6 +118,26 @@ def test_two_ranks_one_gpu_reproduce_golden(tmp_path, name):
     assert out.read_bytes() == golden_bytes(case["snp"])
 
 
+def _worker_forced(rank, world, port, case, out_path, complement):
+    os.environ["EB_FORCE_COLLECTIVES"] = "1"
+    os.environ["EB_NAV_COMPLEMENT"] = complement
+    _worker(rank, world, port, case, out_path)
+
+
+@pytest.mark.parametrize("name", ["m1_default", "m2_het_default"])
+@pytest.mark.parametrize("complement", ["1", "0"])
+def test_one_rank_forced_collectives_host_exchange(tmp_path, name, complement):
+    """ONE gloo rank with the collectives forced (EB_FORCE_COLLECTIVES=1): export -> SUM -> eb_flags_import_shard_sum.  A one-shard
+    build that came back finished would be inverted twice there (round-2 advisor finding); _worker also holds the vectors
+    to the plain build's bit for bit."""
+    import torch.multiprocessing as mp
+
+    case = _case(name)
+    out = tmp_path / "out.snp"
+    mp.spawn(_worker_forced, args=(1, _free_port(), case, str(out), complement), nprocs=1, join=True)
+    assert out.read_bytes() == golden_bytes(case["snp"])
+
+
 @pytest.mark.parametrize("name", ["m1_default", "m2_het_default", "m3_hom_default"])
 def test_multi_gpu_launcher_two_ranks(tmp_path, name):
     """`python -m ebwt2indel_amd.run_distributed` (the executable's flags, one process per GPU) with two gloo ranks on

@@ -1,0 +1,43 @@
+"""BASELINE configs[1], [2] and [3] at FULL SIZE (7.55 G / 2 x 3.775 G / 15.1 G positions; modes 1, 2, 3) on the GPU box, held
+to what the CPU oracle computed for the very same inputs (scripts/fullsize_check.py -> profiles/r03_fullsize_<config>.json):
+the input's SHA-256 (so the regenerated input IS the one the oracle walked), the traversal's counters, the SHA-256 of
+every bit vector, the whole-run .snp's SHA-256 and record count.  The oracle runs behind each profile took 5-20 minutes of
+64 host threads; the product's side of the comparison is seconds, which is why it can live here.
+
+Nothing in this file calls the oracle: the expected values are data under profiles/."""
+import json
+import os
+
+import pytest
+
+from tests import _fullsize as fs
+
+pytestmark = pytest.mark.gpu
+
+
+def _expected(name):
+    path = fs.profile_path(name)
+    if not os.path.exists(path):
+        pytest.fail(f"{path} is missing: record it with scripts/fullsize_check.py {name}")
+    with open(path) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("name", ["config2", "config3", "config4"])
+def test_full_size_config_equals_the_oracle_record(name):
+    want = _expected(name)
+    inp = fs.Inputs(name)
+    # the regenerated input is the one the oracle walked
+    assert inp.describe() == want["input"], "the regenerated input is not the recorded one"
+    res = fs.Result(inp)
+    for k, v in want["counters"].items():
+        assert res.counters[k] == v, (k, res.counters[k], v)
+    assert res.counters["lcp_values"] == inp.n
+    got_sha, vec = res.vector_shas()
+    del vec
+    assert got_sha == want["oracle_vector_sha256"], "a bit vector differs from the oracle's"
+    assert res.snp_records == want["snp_records"]
+    assert res.snp_sha256 == want["oracle_snp_sha256"], ".snp differs from the oracle's whole-run .snp"
+    assert res.cluster_nr - 1 == want["cluster_numbers"]
+    st, sc = res.calls.stats, want["scan_counters"]
+    assert (int(st.runs_closed), int(st.clusters), int(st.bases_in_runs)) == (sc["runs_closed"], sc["clusters"], sc["bases_in_runs"])

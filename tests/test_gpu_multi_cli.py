@@ -56,6 +56,19 @@ def test_cli_G_ranks_share_the_gpu_through_host_exchange(tmp_path, name, gpus):
     assert pick(r.stdout) == pick(one.stdout)
 
 
+@pytest.mark.parametrize("name", ["m1_default", "m2_het_default", "m3_hom_default"])
+@pytest.mark.parametrize("complement", ["1", "0"])
+def test_cli_G1_host_exchange_single_rank(tmp_path, name, complement):
+    """ONE rank through the host-exchange path: a one-shard build must come back in shard form like any other, or
+    eb_flags_import_shard_sum inverts the threshold vectors a second time (round-2 advisor finding).  EB_NAV_COMPLEMENT=0
+    (the reference's form for the plain build) must not change what a shard hands out."""
+    case = _case(name)
+    r, out = _run(tmp_path, case, 1, {"EB_MULTI_BACKEND": "host", "EB_NAV_COMPLEMENT": complement})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert out.read_bytes() == golden_bytes(case["snp"])
+    assert "on 1 GPU(s) [host-memory exchange]" in r.stdout
+
+
 def test_cli_G_needs_one_gpu_per_rank_and_reports_bad_input(tmp_path):
     import torch
     case = _case("m1_default")

@@ -59,3 +59,29 @@ def test_threaded_two_bwt_traversal_equals_serial(oracle, a, b, threads):
     ca, cb = fa.counters(), fb.counters()
     for k in ("leaves", "nodes", "lcp_values", "da_values", "minima"):
         assert ca[k] == cb[k], k
+
+
+@pytest.mark.parametrize("name", ["m1_default", "m1_edge_default", "m1_edge_m2", "m2_het_default", "m2_edge_default", "m3_het_default", "m3_hom_default"])
+@pytest.mark.parametrize("shards", [3, 16])
+def test_sharded_scan_renumbered_equals_the_reference_snp(oracle, name, shards):
+    """scripts/fullsize_check.py's whole-range phase 4: the range cut into shards, each shard's clusters numbered from 1 (on
+    any thread), the texts renumbered into the single pass's running cluster_nr -- byte for byte the reference-written .snp,
+    in all three modes (mode 1 leaves gaps in the numbering, ebwt2InDel.cpp:1328; modes 2 / 3 do not, :1250)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from ebwt2indel_amd import distributed as ebd
+    from tests import _fullsize as fs
+    from tests.conftest import CASES
+    case = [c for c in CASES if c["name"] == name][0]
+    p = _oracle.Params.from_args(case["args"])
+    inp = case["inputs"]
+    x1 = oracle.index(golden_bytes(inp["bwt1"]), p.term)
+    x2 = oracle.index(golden_bytes(inp["bwt2"]), p.term) if case["mode"] == 2 else None
+    da = golden_bytes(inp["da"]) if case["mode"] == 3 else None
+    fl = _oracle.OracleFlags(oracle, x1, x2, p.K, p.k_right, da)
+    n = x1.n + (x2.n if x2 is not None else 0)
+    cuts = [ebd.shard_range(n, i, shards) for i in range(shards)]
+    with ThreadPoolExecutor(4) as ex:
+        parts = list(ex.map(lambda be: fl.scan(p, be[0], be[1]), cuts))
+    text = fs.renumber([r["text"] for r in parts], [r["cluster_nr"] - 1 for r in parts])
+    assert text == golden_bytes(case["snp"])
