@@ -375,10 +375,13 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     # spread over the timed steps: intervals between consecutive completions (steps are pipelined, so a step's own duration is
     # not observable from outside; in steady state the interval IS the step time); the first interval holds the pipeline fill
-    gaps = np.diff(np.array([t0] + step_done)) * 1e3
-    steady = gaps[1:] if len(gaps) > 2 else gaps
-    step_spread = {"ms_per_step_min": round(float(steady.min()), 4), "ms_per_step_median": round(float(np.median(steady)), 4),
-                   "ms_per_step_max": round(float(steady.max()), 4), "what": "intervals between consecutive step completions on this rank, first (pipeline fill) excluded"} if len(gaps) else None
+    # (single intervals are no use: the hand-over thread often resolves two passes back to back; windows of four steps are)
+    td = np.array([t0] + step_done)
+    W = 4 if len(td) > 8 else 1
+    win = (td[W:] - td[:-W])[1:] / W * 1e3 if len(td) > W + 1 else np.diff(td) * 1e3
+    step_spread = {"ms_per_step_min": round(float(win.min()), 4), "ms_per_step_median": round(float(np.median(win)), 4),
+                   "ms_per_step_max": round(float(win.max()), 4), "window_steps": W,
+                   "what": "time per step over sliding windows of `window_steps` consecutive step completions on this rank (the window holding the pipeline fill excluded)"} if len(win) else None
     value = (end - begin if args.rehearse_rank_of > 1 else n) * args.steps / elapsed
 
     # ---------------- dominant kernel of the step: k_scan (HIP events on the stream it is launched on, inside the library).
@@ -441,21 +444,22 @@ def main():
         out["snp_sha256"] = hashlib.sha256(text).hexdigest()
         out["snp_records"] = text.count(b">")
         out["clusters_emitted"] = total_recs
-        # The default workload's .snp is known: scripts/fullsize_check.py walked this very eBWT (7.55 G positions) through the
+        # The default workload's .snp is known: scripts/fullsize_check.py config2 walked this very eBWT (7.55 G positions) through the
         # CPU oracle on the GPU box's host threads -- flag vectors and .snp identical to the GPU's -- and left the SHA-256
         # under profiles/.  Every default run is held to it (any number of GPUs: the shards' call sets concatenate to the same text).
         out["snp_verified"] = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r02_fullsize_config2.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r03_fullsize_config2.json")) as fh:
                 known = json.load(fh)
         except OSError:
             known = None
-        if args.rehearse_rank_of <= 1 and known is not None and known["input"] == {"reads": args.reads, "read_len": args.read_len, "coverage": args.coverage, "seed": args.seed,
-                                                    "n": int(n), "ebwt_sha256": known["input"]["ebwt_sha256"]}:
+        default_input = (args.read_len, args.coverage, args.seed) == (150, 30.0, 1)
+        if args.rehearse_rank_of <= 1 and known is not None and default_input and known["input"]["reads_per_collection"] == args.reads and known["input"]["n"] == [int(n)]:
             if out["snp_sha256"] != known["oracle_snp_sha256"] or out["snp_records"] != known["snp_records"]:
-                raise SystemExit(f"[bench] .snp of the timed path differs from the full-size CPU oracle run (profiles/r02_fullsize_config2.json): "
+                raise SystemExit(f"[bench] .snp of the timed path differs from the full-size CPU oracle run (profiles/r03_fullsize_config2.json): "
                                  f"{out['snp_sha256']} vs {known['oracle_snp_sha256']}")
-            out["snp_verified"] = "sha256 equals the CPU oracle's .snp of this very input at full size (profiles/r02_fullsize_config2.json)"
+            out["snp_verified"] = ("sha256 equals the CPU oracle's whole-run .snp of this very input at full size (profiles/r03_fullsize_config2.json; "
+                                   "tests/test_gpu_fullsize.py also holds the input's SHA-256 and every bit vector to that record)")
 
     # ---------------- CPU baseline on a bounded sample of the same workload family (rank 0, N=1 only)
     cpu = None

@@ -31,7 +31,8 @@ class IndexInfo(C.Structure):
 
 class NavStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("n", "leaves", "nodes", "lcp_values", "da_values", "minima", "rank_queries", "batches")] + \
-               [("seconds_leaves", C.c_double), ("seconds_nodes", C.c_double), ("seconds_traversal", C.c_double)]
+               [("seconds_leaves", C.c_double), ("seconds_nodes", C.c_double), ("seconds_traversal", C.c_double)] + \
+               [("lcp_pos_sum", C.c_uint64), ("lcp_pos_sq_sum", C.c_uint64)]
 
 
 class Cluster(C.Structure):
@@ -60,7 +61,7 @@ ABI_SYMBOLS = [
     "eb_params_init", "eb_params_resolve", "eb_last_error", "eb_device_count",
     "eb_index_create", "eb_index_create_from_file", "eb_index_create_from_device", "eb_index_destroy", "eb_index_bad_symbol",
     "eb_index_info", "eb_rank4_batch", "eb_access_batch", "eb_lf_range_batch", "eb_lf_range_sym_batch", "eb_fl_batch",
-    "eb_lf_node_batch", "eb_rank4_batch_device", "eb_flags_build", "eb_flags_build_shard", "eb_flags_device_vectors", "eb_flags_popcounts", "eb_flags_finalize", "eb_flags_set_da", "eb_flags_words", "eb_flags_has_da",
+    "eb_lf_node_batch", "eb_rank4_batch_device", "eb_flags_build", "eb_nav_covers_every_slot_once", "eb_flags_build_shard", "eb_flags_device_vectors", "eb_flags_popcounts", "eb_flags_finalize", "eb_flags_set_da", "eb_flags_words", "eb_flags_has_da",
     "eb_flags_export", "eb_flags_import", "eb_flags_import_shard_sum", "eb_flags_destroy", "eb_scan_clusters", "eb_scan_clusters_begin", "eb_scan_clusters_end",
     "eb_scan_clusters_cancel", "eb_scan_clusters_begin_ex", "eb_scan_job_wait", "eb_scan_job_device_blob", "eb_scan_job_device_wire", "eb_calls_get", "eb_calls_free",
     "eb_calls_packed_size", "eb_calls_pack", "eb_calls_unpack", "eb_calls_blob", "eb_write_snp", "eb_format_snp", "eb_free",
@@ -110,6 +111,8 @@ def load():
     L.eb_lf_range_sym_batch.argtypes = [vp, vp, vp, u64, vp]
     L.eb_rank4_batch_device.argtypes = [vp, vp, u64, vp, P(C.c_float)]
     L.eb_flags_build.argtypes = [vp, vp, i32, i32, P(vp), P(NavStats)]
+    L.eb_nav_covers_every_slot_once.argtypes = [P(NavStats)]
+    L.eb_nav_covers_every_slot_once.restype = C.c_int
     L.eb_flags_build_shard.argtypes = [vp, vp, i32, i32, C.c_uint32, C.c_uint32, P(vp), P(NavStats)]
     L.eb_flags_device_vectors.argtypes = [vp, P(vp), P(u64)]
     L.eb_flags_finalize.argtypes = [vp]

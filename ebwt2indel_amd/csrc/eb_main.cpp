@@ -439,6 +439,7 @@ static int run_multi(int world, const std::string& input1, const std::string& in
         const eb_nav_stats& a = J.ns[(size_t)r];
         ns.n = a.n;
         ns.leaves += a.leaves; ns.nodes += a.nodes; ns.lcp_values += a.lcp_values; ns.da_values += a.da_values; ns.minima += a.minima;
+        ns.lcp_pos_sum += a.lcp_pos_sum; ns.lcp_pos_sq_sum += a.lcp_pos_sq_sum; // modulo 2^64
         ns.rank_queries += a.rank_queries; ns.batches += a.batches;
         if (a.seconds_leaves > ns.seconds_leaves) ns.seconds_leaves = a.seconds_leaves;
         if (a.seconds_nodes > ns.seconds_nodes) ns.seconds_nodes = a.seconds_nodes;
@@ -449,7 +450,7 @@ static int run_multi(int world, const std::string& input1, const std::string& in
         if (b.ms_extend > ss.ms_extend) ss.ms_extend = b.ms_extend;
         if (b.ms_right > ss.ms_right) ss.ms_right = b.ms_right;
     }
-    if (ns.n > 0 && ns.lcp_values != ns.n) {
+    if (ns.n > 0 && !eb_nav_covers_every_slot_once(&ns)) {
         // the shards collect the complement of the LCP thresholds, exact only when every position has one writer
         printf("\nError: the traversal wrote %llu of %llu LCP slots: the input is not the eBWT of a read collection; run without -G "
                "(the single-GPU path handles such inputs the reference's way)\n", (unsigned long long)ns.lcp_values, (unsigned long long)ns.n);

@@ -80,7 +80,7 @@ __host__ __device__ __forceinline__ void unpack_rec(const Leaf1& p, Leaf1& l) { 
 struct NavCounters {
     unsigned long long pushed;     // children appended by the current launch
     unsigned long long pad0[7];    // keep the hot word on its own 64-byte line
-    unsigned long long leaves, nodes, lcp_values, da_values, minima, ranks;
+    unsigned long long leaves, nodes, lcp_values, da_values, minima, ranks, pos_sum, pos_sq_sum;
 };
 
 struct NavParams {
@@ -114,6 +114,16 @@ struct NavLaunch {
     int32_t pad;
 };
 
+// Power sums of the LCP positions written, modulo 2^64 (eb_nav_stats.lcp_pos_sum / lcp_pos_sq_sum).  The count alone
+// (lcp_values == n) cannot tell "every position 1..n-1 once" from "one twice, one never" -- which the complement form of the
+// thresholds would turn into a wrong bit, and atomicOr hides duplicates -- while sum and sum of squares do (round-2 advisor
+// finding).  Ranges (leaf interiors) use the closed forms: tri(x) = sum of i < x, sq(x) = sum of i^2 < x.
+__host__ __device__ __forceinline__ uint64_t eb_tri(uint64_t x) { return (x & 1ull) ? x * ((x - 1) >> 1) : (x >> 1) * (x - 1); }
+__host__ __device__ __forceinline__ uint64_t eb_sq(uint64_t x) {
+    // (x-1) x (2x-1) / 6: the halving is exact on one factor; the product is a multiple of 3, and 3 is invertible modulo 2^64
+    return eb_tri(x) * (2 * x - 1) * 0xAAAAAAAAAAAAAAABull;
+}
+
 __device__ __forceinline__ uint64_t wave_sum(uint64_t v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor((unsigned long long)v, o);
     return v;
@@ -121,7 +131,7 @@ __device__ __forceinline__ uint64_t wave_sum(uint64_t v) {
 
 // Statistics: every workgroup owns one row of counters in HBM and adds its totals with plain read-modify-writes
 // (launches are sequential; rows are summed on the host at the end) -- no per-wave atomics on shared words.
-#define EB_NAV_STATS 6 /* leaves, nodes, lcp_values, da_values, minima, ranks */
+#define EB_NAV_STATS 8 /* leaves, nodes, lcp_values, da_values, minima, ranks, sum of the LCP positions written, sum of their squares */
 __device__ __forceinline__ void flush_stats(unsigned long long* rows, const uint64_t* v /* EB_NAV_STATS values of this lane */) {
     __shared__ unsigned long long sh[EB_NAV_STATS][4];
     for (int k = 0; k < EB_NAV_STATS; ++k) {
@@ -160,7 +170,7 @@ __global__ void __launch_bounds__(256) k_leaves(eb_dev_index x1, eb_dev_index x2
     const Rec* in = static_cast<const Rec*>(in_);
     Rec* out = static_cast<Rec*>(out_);
     const uint32_t j = threadIdx.x & 3u, q = threadIdx.x >> 2;
-    uint64_t n_leaf = 0, n_lcp = 0, n_da = 0, n_rank = 0;
+    uint64_t n_leaf = 0, n_lcp = 0, n_da = 0, n_rank = 0, n_s1 = 0, n_s2 = 0;
     const uint64_t tiles = (count + 63) / 64;
     uint32_t trips = 0;
     for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
@@ -195,7 +205,7 @@ __global__ void __launch_bounds__(256) k_leaves(eb_dev_index x1, eb_dev_index x2
                         if (setR) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * w + 1), m);
                     }
                 }
-                if (j == 0) n_lcp += hi - lo;
+                if (j == 0) { n_lcp += hi - lo; n_s1 += eb_tri(hi) - eb_tri(lo); n_s2 += eb_sq(hi) - eb_sq(lo); }
             }
             if (active && p.write && j == 0) { ++n_leaf; n_rank += L.r > L.l ? 2 : 1; }
         } else {
@@ -232,7 +242,7 @@ __global__ void __launch_bounds__(256) k_leaves(eb_dev_index x1, eb_dev_index x2
                 if (j == 0) {
                     ++n_leaf;
                     n_da += e - s1;
-                    if (e > s1 + 1) n_lcp += e - s1 - 1;
+                    if (e > s1 + 1) { n_lcp += e - s1 - 1; n_s1 += eb_tri(e) - eb_tri(s1 + 1); n_s2 += eb_sq(e) - eb_sq(s1 + 1); }
                     n_rank += (L.r1 > L.l1 ? 2 : 1) + (L.r2 > L.l2 ? 2 : 1);
                 }
             }
@@ -243,7 +253,7 @@ __global__ void __launch_bounds__(256) k_leaves(eb_dev_index x1, eb_dev_index x2
         if (++trips % (STAGE / 256) == 0) stage.flush(out, out_cap, &cnt->pushed);
     }
     stage.flush(out, out_cap, &cnt->pushed);
-    const uint64_t st[EB_NAV_STATS] = {n_leaf, 0, n_lcp, n_da, 0, n_rank};
+    const uint64_t st[EB_NAV_STATS] = {n_leaf, 0, n_lcp, n_da, 0, n_rank, n_s1, n_s2};
     flush_stats(stat_rows, st);
 }
 
@@ -275,7 +285,7 @@ __global__ void __launch_bounds__(256) k_nodes(eb_dev_index x1, eb_dev_index x2,
     const Rec* in = static_cast<const Rec*>(in_);
     Rec* out = static_cast<Rec*>(out_);
     const uint32_t j = threadIdx.x & 3u, q = threadIdx.x >> 2;
-    uint64_t n_node = 0, n_lcp = 0, n_da = 0, n_rank = 0, n_min = 0;
+    uint64_t n_node = 0, n_lcp = 0, n_da = 0, n_rank = 0, n_min = 0, n_s1 = 0, n_s2 = 0;
     const uint64_t tiles = (count + 64 * U - 1) / (64 * U);
     uint32_t trips = 0;
     for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
@@ -336,6 +346,8 @@ __global__ void __launch_bounds__(256) k_nodes(eb_dev_index x1, eb_dev_index x2,
                         if (setR) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * (hi >> 6) + 1), 1ull << (hi & 63u));
                     }
                     ++n_lcp;
+                    n_s1 += hi;
+                    n_s2 += hi * hi;
                 }
                 // a local LCP minimum follows each child A,C,G of size >= 2 that ends before last-1
                 if (j >= 1 && hi - lo >= 2 && hi < m[5] - 1) {
@@ -400,7 +412,7 @@ __global__ void __launch_bounds__(256) k_nodes(eb_dev_index x1, eb_dev_index x2,
         if (++trips % (STAGE / (256 * U)) == 0) stage.flush(out, out_cap, &cnt->pushed);
     }
     stage.flush(out, out_cap, &cnt->pushed);
-    const uint64_t st[EB_NAV_STATS] = {0, n_node, n_lcp, n_da, n_min, n_rank};
+    const uint64_t st[EB_NAV_STATS] = {0, n_node, n_lcp, n_da, n_min, n_rank, n_s1, n_s2};
     flush_stats(stat_rows, st);
 }
 
@@ -440,7 +452,7 @@ __global__ void __launch_bounds__(256) k_nodes1p(eb_dev_index x1, eb_dev_flags f
     __syncthreads();
     const uint32_t j = threadIdx.x & 3u, q = threadIdx.x >> 2;
     const uint64_t G = gridDim.x;
-    uint64_t n_node = 0, n_lcp = 0, n_rank = 0, n_min = 0;
+    uint64_t n_node = 0, n_lcp = 0, n_rank = 0, n_min = 0, n_s1 = 0, n_s2 = 0;
     const uint64_t Fj = pick4(x1.F, j);
 
     auto load_rec = [&](uint64_t tile) -> Rec {
@@ -464,6 +476,8 @@ __global__ void __launch_bounds__(256) k_nodes1p(eb_dev_index x1, eb_dev_flags f
                 if (setR) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * (hi >> 6) + 1), 1ull << (hi & 63u));
             }
             ++n_lcp;
+            n_s1 += hi;
+            n_s2 += hi * hi;
         }
         if (j >= 1 && hi - lo >= 2 && hi < N.b[5] - 1) {
             if (!(EB_NDBG(p) & 2u)) eb_bit_set_atomic(f.minima, hi);
@@ -528,7 +542,164 @@ __global__ void __launch_bounds__(256) k_nodes1p(eb_dev_index x1, eb_dev_flags f
         if (++trips % (STAGE / 256) == 0) stage.flush(out, out_cap, &cnt->pushed);
     }
     stage.flush(out, out_cap, &cnt->pushed);
-    const uint64_t st[EB_NAV_STATS] = {0, n_node, n_lcp, 0, n_min, n_rank};
+    const uint64_t st[EB_NAV_STATS] = {0, n_node, n_lcp, 0, n_min, n_rank, n_s1, n_s2};
+    flush_stats(stat_rows, st);
+}
+
+// ---- phase 3, two BWTs, software-pipelined the same way (k_nodes1p).  A merged node is two sa_nodes (12 boundaries); as in
+// k_nodes<2, 1> a block is loaded ONCE for the boundaries of a node that share it (they are sorted and a few dozen rows apart):
+// which boundaries issue a load is decided in stage A and kept as a 12-bit mask for stage D.
+template <bool SUPER_LDS>
+__global__ void __launch_bounds__(256) k_nodes2p(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, uint64_t* __restrict__ kr, NavParams p,
+                                                const NavLaunch* __restrict__ la, NavCounters* cnt, unsigned long long* __restrict__ stat_rows) {
+    using Rec = Node2P;
+    constexpr int STAGE = 768;
+    __shared__ uint4 s_buf[STAGE * (sizeof(Rec) / 16)];
+    __shared__ uint32_t s_count;
+    __shared__ unsigned long long s_base;
+    __shared__ unsigned long long s_super[2][EB_NAV_SUPER_LDS * 4];
+    const Rec* __restrict__ in = static_cast<const Rec*>(la->in);
+    Rec* out = static_cast<Rec*>(la->out);
+    const uint64_t count = la->count, out_cap = la->out_cap;
+    p.write = la->write;
+    const uint64_t tiles = (count + 63) / 64;
+    if ((uint64_t)blockIdx.x >= tiles) return; // the grid is sized for a full batch: nothing for this workgroup (uniform)
+    Stager<Rec, STAGE> stage{s_buf, &s_count, &s_base};
+    if (SUPER_LDS) {
+        const uint64_t ns1 = (x1.n >> EB_SUPER_SHIFT) + 1, ns2 = (x2.n >> EB_SUPER_SHIFT) + 1;
+        for (uint32_t k = threadIdx.x; k < ns1 * 4; k += blockDim.x) s_super[0][k] = x1.super[k];
+        for (uint32_t k = threadIdx.x; k < ns2 * 4; k += blockDim.x) s_super[1][k] = x2.super[k];
+    }
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
+    const uint32_t j = threadIdx.x & 3u, q = threadIdx.x >> 2;
+    const uint64_t G = gridDim.x;
+    uint64_t n_node = 0, n_lcp = 0, n_da = 0, n_rank = 0, n_min = 0, n_s1 = 0, n_s2 = 0;
+    const uint64_t F1 = pick4(x1.F, j), F2 = pick4(x2.F, j);
+
+    auto load_rec = [&](uint64_t tile) -> Rec {
+        Rec r;
+        for (uint64_t& w : r.w) w = 0;
+        const uint64_t i = tile * 64 + q;
+        if (tile < tiles && i < count) r = eb_load_global(in + i);
+        return r;
+    };
+    // stage A for one record: border bits in merged coordinates (merge_nodes, include.hpp:476-490), DA slots of singleton leaves
+    auto mark = [&](const Node2& N) {
+        uint64_t lo = 0, hi = 0;
+        const uint64_t last = N.a[5] + N.b[5];
+        for (int k = 0; k < 4; ++k) if (j == (uint32_t)k) { lo = N.a[k] + N.b[k]; hi = N.a[k + 1] + N.b[k + 1]; }
+        if (hi > lo && hi != last) {
+            const bool setK = ((int64_t)N.depth >= p.K) != (p.below != 0), setR = ((int64_t)N.depth >= p.k_right) != (p.below != 0);
+            if (p.lcpb) {
+                uint8_t v = (uint8_t)((setK ? 1 : 0) | (setR ? 2 : 0));
+                if (v && !(EB_NDBG(p) & 1u)) p.lcpb[hi] = v;
+            } else {
+                if (setK) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * (hi >> 6)), 1ull << (hi & 63u));
+                if (setR) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * (hi >> 6) + 1), 1ull << (hi & 63u));
+            }
+            ++n_lcp;
+            n_s1 += hi;
+            n_s2 += hi * hi;
+        }
+        if (j >= 1 && hi - lo >= 2 && hi < last - 1) {
+            if (!(EB_NDBG(p) & 2u)) eb_bit_set_atomic(f.minima, hi);
+            ++n_min;
+        }
+        // leaves of merged size 1 were not visited in phase 2: write their DA slot now (find_leaves, ebwt2InDel.cpp:474-527)
+        for (int k = 0; k < 5; ++k) {
+            if ((uint32_t)(k & 3) != j || (k == 4 && j != 0)) continue;
+            uint64_t s1 = N.a[k + 1] - N.a[k], s2 = N.b[k + 1] - N.b[k];
+            if (s1 + s2 == 1) {
+                if (s2 && !(EB_NDBG(p) & 8u)) eb_bit_set_atomic(f.da, N.b[k] + N.a[k + 1]);
+                ++n_da;
+            }
+        }
+    };
+    // which boundaries start a new block (bit k: a[k], bit 6 + k: b[k]); the others reuse their left neighbour's
+    auto load_mask = [&](const Node2& N) -> uint32_t {
+        uint32_t m = 1u | (1u << 6);
+#pragma unroll
+        for (int k = 1; k < 6; ++k) {
+            m |= ((N.a[k] >> 7) != (N.a[k - 1] >> 7) ? 1u : 0u) << k;
+            m |= ((N.b[k] >> 7) != (N.b[k - 1] >> 7) ? 1u : 0u) << (6 + k);
+        }
+        return m;
+    };
+
+    uint64_t tile = blockIdx.x;
+    Node2 Nn;
+    uint4 cna[6], cnb[6];
+    uint32_t mn = 0;
+    bool act_n;
+    {
+        Rec r0 = load_rec(tile);
+        unpack_rec(r0, Nn);
+        act_n = tile * 64 + q < count;
+        if (act_n && p.write) mark(Nn);
+        mn = load_mask(Nn);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            if ((mn >> k) & 1u) cna[k] = eb_rank4_quad_load(x1, Nn.a[k], j);
+            if ((mn >> (6 + k)) & 1u) cnb[k] = eb_rank4_quad_load(x2, Nn.b[k], j);
+        }
+    }
+    Rec rr = load_rec(tile + G);
+    uint32_t trips = 0;
+    for (; tile < tiles; tile += G) {
+        const Node2 Nc = Nn;
+        const bool act_c = act_n;
+        const uint32_t mc = mn;
+        uint4 cca[6], ccb[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { cca[k] = cna[k]; ccb[k] = cnb[k]; }
+        // stage A: the next trip's record -> node, bits, block loads
+        unpack_rec(rr, Nn);
+        act_n = tile + G < tiles && (tile + G) * 64 + q < count;
+        if (act_n && p.write) mark(Nn);
+        mn = load_mask(Nn);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            if ((mn >> k) & 1u) cna[k] = eb_rank4_quad_load(x1, Nn.a[k], j);
+            if ((mn >> (6 + k)) & 1u) cnb[k] = eb_rank4_quad_load(x2, Nn.b[k], j);
+        }
+        // stage C: the record after that
+        rr = load_rec(tile + 2 * G);
+        // stage D: this trip's ranks and children (LF on both BWTs, next_nodes ebwt2InDel.cpp:529-553)
+        Node2 child;
+        child.pad[0] = child.pad[1] = child.pad[2] = 0;
+        int kids = 0;
+        uint4 cur_a = cca[0], cur_b = ccb[0];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            if ((mc >> k) & 1u) cur_a = cca[k]; // else: the block of the boundary to the left
+            if ((mc >> (6 + k)) & 1u) cur_b = ccb[k];
+            const uint64_t ia = Nc.a[k], ib = Nc.b[k];
+            uint32_t pa = eb_chunk_counts(cur_a, eb_prefix_mask32((uint32_t)(ia & 127u), j));
+            uint32_t pb = eb_chunk_counts(cur_b, eb_prefix_mask32((uint32_t)(ib & 127u), j));
+            pa += (uint32_t)__shfl_xor((int)pa, 1);
+            pb += (uint32_t)__shfl_xor((int)pb, 1);
+            pa += (uint32_t)__shfl_xor((int)pa, 2);
+            pb += (uint32_t)__shfl_xor((int)pb, 2);
+            uint64_t sa, sb;
+            if constexpr (SUPER_LDS) { sa = s_super[0][((ia >> EB_SUPER_SHIFT) << 2) + j]; sb = s_super[1][((ib >> EB_SUPER_SHIFT) << 2) + j]; }
+            else { sa = x1.super[((ia >> EB_SUPER_SHIFT) << 2) + j]; sb = x2.super[((ib >> EB_SUPER_SHIFT) << 2) + j]; }
+            child.a[k] = F1 + sa + cur_a.w + ((pa >> (8u * j)) & 0xFFu);
+            child.b[k] = F2 + sb + cur_b.w + ((pb >> (8u * j)) & 0xFFu);
+        }
+        for (int k = 0; k < 5; ++k) kids += (child.a[k + 1] > child.a[k]) || (child.b[k + 1] > child.b[k]); // include.hpp:784-792
+        child.depth = Nc.depth + 1;
+        const bool keep = act_c && kids >= 2;
+        if (act_c && p.write && j == 0) {
+            ++n_node;
+            n_rank += 2;
+            for (int k = 1; k < 6; ++k) n_rank += (Nc.a[k] != Nc.a[k - 1]) + (Nc.b[k] != Nc.b[k - 1]);
+        }
+        stage.push(keep, pack_rec(child));
+        if (++trips % (STAGE / 256) == 0) stage.flush(out, out_cap, &cnt->pushed);
+    }
+    stage.flush(out, out_cap, &cnt->pushed);
+    const uint64_t st[EB_NAV_STATS] = {0, n_node, n_lcp, n_da, n_min, n_rank, n_s1, n_s2};
     flush_stats(stat_rows, st);
 }
 
@@ -1082,8 +1253,11 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
         if ((r = d.init(arena, bytes, n, batch_max)) != EB_OK) return r;
         Node2 root{{0, b1->F[0], b1->F[1], b1->F[2], b1->F[3], b1->n}, {0, b2->F[0], b2->F[1], b2->F[2], b2->F[3], b2->n}, 0, {0, 0, 0}};
         if ((r = d.push_host(pack_rec(root))) != EB_OK) return r;
+        const bool super_fits = (b1->n >> EB_SUPER_SHIFT) + 1 <= EB_NAV_SUPER_LDS && (b2->n >> EB_SUPER_SHIFT) + 1 <= EB_NAV_SUPER_LDS;
         r = d.run<1>(dc, nb.state, nb.h_state, [&](const NavLaunch* la, unsigned grid) {
-            hipLaunchKernelGGL((k_nodes<2, 1>), dim3(grid), dim3(256), 0, sx, x1, x2, df, d_kr, p, la, dc, rows);
+            if (pipelined_nodes && super_fits) hipLaunchKernelGGL((k_nodes2p<true>), dim3(grid), dim3(256), 0, sx, x1, x2, df, d_kr, p, la, dc, rows);
+            else if (pipelined_nodes) hipLaunchKernelGGL((k_nodes2p<false>), dim3(grid), dim3(256), 0, sx, x1, x2, df, d_kr, p, la, dc, rows);
+            else hipLaunchKernelGGL((k_nodes<2, 1>), dim3(grid), dim3(256), 0, sx, x1, x2, df, d_kr, p, la, dc, rows);
         });
         launches_n = d.launches;
         return r;
@@ -1136,6 +1310,8 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
             c.da_values += rows[r * EB_NAV_STATS + 3];
             c.minima += rows[r * EB_NAV_STATS + 4];
             c.ranks += rows[r * EB_NAV_STATS + 5];
+            c.pos_sum += rows[r * EB_NAV_STATS + 6];
+            c.pos_sq_sum += rows[r * EB_NAV_STATS + 7];
         }
     }
     s.leaves = c.leaves;
@@ -1144,6 +1320,8 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
     s.da_values = c.da_values;
     s.minima = c.minima;
     s.rank_queries = c.ranks;
+    s.lcp_pos_sum = c.pos_sum;
+    s.lcp_pos_sq_sum = c.pos_sq_sum;
     s.batches = launches;
     if (stats) *stats = s;
     guard.f = nullptr;
@@ -1171,13 +1349,20 @@ extern "C" int eb_selftest_pack_fields(int32_t n_fields, const uint64_t* fields,
     return EB_OK;
 }
 
+extern "C" int eb_nav_covers_every_slot_once(const eb_nav_stats* s) {
+    if (!s) return 0;
+    // positions 1 .. n-1, each exactly once: their number (the reference's counter starts at 1, ebwt2InDel.cpp:575), their
+    // sum and the sum of their squares, modulo 2^64
+    return s->lcp_values == s->n && (s->n == 0 || (s->lcp_pos_sum == eb_tri(s->n) && s->lcp_pos_sq_sum == eb_sq(s->n)));
+}
+
 extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_right, eb_flags** out, eb_nav_stats* stats) {
     if (!out) { eb_set_error("null argument"); return EB_ERR_ARG; }
     const bool complement = env_u64("EB_NAV_COMPLEMENT", 1) != 0;
     eb_nav_stats s;
     int rc = flags_build_impl(b1, b2, K, k_right, 0, 1, out, &s, complement, true);
     if (rc != EB_OK) return rc;
-    if (complement && s.lcp_values != s.n) {
+    if (complement && !eb_nav_covers_every_slot_once(&s)) {
         // Not every LCP slot was written exactly once: the input is not the eBWT of a read collection.  The reference leaves
         // unwritten slots at 0 (vector<bool>(n,false), ebwt2InDel.cpp:571), which the complement form cannot know: walk again
         // the reference's way (writers at or above the thresholds set their bits).

@@ -150,6 +150,12 @@ class _DeviceWords:
 
 
 _NAV_COUNTERS = ("leaves", "nodes", "lcp_values", "da_values", "minima", "rank_queries", "batches")
+_NAV_SUMS = ("lcp_pos_sum", "lcp_pos_sq_sum")      # modulo 2^64: they travel as int64 and wrap the same way
+
+
+def _signed(v: int) -> int:
+    v &= (1 << 64) - 1
+    return v - (1 << 64) if v >= (1 << 63) else v
 
 
 def navigate_sharded(bwt1, params, bwt2=None, group=None, device=None):
@@ -199,15 +205,15 @@ def navigate_sharded(bwt1, params, bwt2=None, group=None, device=None):
                            f"sum of the ranks' ones {ones.tolist()}; order thrK, thrR, minima, da)")
     if dev.type == "cuda":
         fl.finalize()
-    cnt = torch.tensor([int(getattr(st, k)) for k in _NAV_COUNTERS], dtype=torch.int64, device=dev)
+    cnt = torch.tensor([int(getattr(st, k)) for k in _NAV_COUNTERS] + [_signed(int(getattr(st, k))) for k in _NAV_SUMS], dtype=torch.int64, device=dev)
     sec = torch.tensor([st.seconds_leaves, st.seconds_nodes, st.seconds_traversal], dtype=torch.float64, device=dev)
     dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
     dist.all_reduce(sec, op=dist.ReduceOp.MAX, group=group)
-    for k, v in zip(_NAV_COUNTERS, cnt.tolist()):
-        setattr(st, k, int(v))
-    if st.n > 0 and st.lcp_values != st.n:
+    for k, v in zip(_NAV_COUNTERS + _NAV_SUMS, cnt.tolist()):
+        setattr(st, k, int(v) & ((1 << 64) - 1))
+    if st.n > 0 and not api.lib().eb_nav_covers_every_slot_once(st):
         # the shards collected the complement of the LCP thresholds, which is exact only if every position has one writer
-        raise RuntimeError(f"sharded traversal wrote {st.lcp_values} of {st.n} LCP slots: the input is not the eBWT of a read collection "
+        raise RuntimeError(f"sharded traversal wrote {st.lcp_values} of {st.n} LCP slots (or some of them twice): the input is not the eBWT of a read collection "
                            f"(the single-GPU path handles such inputs the reference's way)")
     st.seconds_leaves, st.seconds_nodes, st.seconds_traversal = float(sec[0]), float(sec[1]), float(sec[2])
     return fl

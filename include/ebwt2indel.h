@@ -129,7 +129,15 @@ typedef struct {
     uint64_t batches;    /* frontier kernel launches */
     double   seconds_leaves, seconds_nodes; /* wall time of each traversal; they run side by side, so these overlap */
     double   seconds_traversal;             /* both traversals + packing of the vectors, first launch to last result */
+    /* Sum of the positions whose LCP slot was written, and of their squares, modulo 2^64.  "Every position 1 .. n-1 exactly
+     * once" (ebwt2InDel.cpp:575,617,670) means lcp_values == n AND these equal the closed forms -- eb_nav_covers_every_slot_once
+     * checks all three; the count alone would let "one slot twice, one never" through (an input that is no eBWT). */
+    uint64_t lcp_pos_sum, lcp_pos_sq_sum;
 } eb_nav_stats;
+/* 1 iff the statistics (of one build, or summed over the shards of a sharded one: all fields add, the sums modulo 2^64) say
+ * that every LCP slot 1 .. n-1 was written exactly once.  eb_flags_build collects the COMPLEMENT of the thresholds, which is
+ * exact only then, and walks again the reference's way otherwise; callers of eb_flags_build_shard must check it themselves. */
+int eb_nav_covers_every_slot_once(const eb_nav_stats* stats);
 int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_right, eb_flags** out, eb_nav_stats* stats);
 /* Phases 2-3 split over GPUs (no reference counterpart; the reference is one process).  Shard `shard` of `n_shards`
  * walks its share of the Weiner-link subtrees: all shards expand the top of the tree breadth-first, the first level of
@@ -143,7 +151,7 @@ int eb_flags_build_shard(eb_index* b1, eb_index* b2, int32_t K, int32_t k_right,
  * wrote position i with an LCP BELOW the threshold (with reads of 100+ bases nearly all writers lie deeper than K and
  * k_right, so the traversal marks the few shallow ones and skips ~95 % of its scattered stores); minima and da are plain.
  * Every position 1..n-1 has one writer over all shards when the input is the eBWT of a read collection -- callers check
- * that the shards' lcp_values add up to n -- so the shards' vectors still combine with SUM, and eb_flags_finalize turns
+ * eb_nav_covers_every_slot_once on the summed statistics -- so the shards' vectors still combine with SUM, and eb_flags_finalize turns
  * the sum into thrK / thrR (inverts it on positions 1..n-1).  eb_flags_device_vectors and eb_flags_export hand out the
  * vectors as they are stored; eb_flags_import_shard_sum takes the sum back when it was formed in host memory. */
 /* Device pointers of thrK, thrR, minima, da (NULL in one-BWT mode), eb_flags_words() words each, for the reduction. */

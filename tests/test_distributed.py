@@ -60,6 +60,18 @@ def test_two_rank_gather_reproduces_golden(tmp_path, name):
     assert out.read_bytes() == golden_bytes(case["snp"])
 
 
+@pytest.mark.parametrize("name", ["m1_default", "m3_het_default"])
+def test_eight_rank_gather_reproduces_golden(tmp_path, name):
+    """World size 8 (the node north_star names) over gloo: eight shards of the scan range, eight packed call sets gathered to
+    rank 0 in rank order, one running cluster_nr across them."""
+    import torch.multiprocessing as mp
+
+    case = [c for c in CASES if c["name"] == name][0]
+    out = tmp_path / "out.snp"
+    mp.spawn(_worker, args=(8, _free_port(), case, str(out)), nprocs=8, join=True)
+    assert out.read_bytes() == golden_bytes(case["snp"])
+
+
 def test_shard_ranges_tile_the_bwt():
     from ebwt2indel_amd import distributed as ebd
     for n in (0, 1, 63, 64, 65, 1000, 1_010_000, 7_550_000_000):

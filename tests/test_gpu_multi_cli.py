@@ -69,6 +69,20 @@ def test_cli_G1_host_exchange_single_rank(tmp_path, name, complement):
     assert "on 1 GPU(s) [host-memory exchange]" in r.stdout
 
 
+@pytest.mark.parametrize("name", ["m1_default", "m3_het_default"])
+def test_cli_G8_ranks_share_the_gpu_through_host_exchange(tmp_path, name):
+    """EIGHT ranks -- the node north_star names -- as eight host threads of one process on the one GPU: sharded traversal,
+    sharded scan, call sets gathered in rank order, the N = 1 .snp and counters."""
+    case = _case(name)
+    r, out = _run(tmp_path, case, 8, {"EB_MULTI_BACKEND": "host"})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert out.read_bytes() == golden_bytes(case["snp"])
+    assert "on 8 GPU(s) [host-memory exchange]" in r.stdout
+    one, out1 = _run(tmp_path, case, 1)
+    pick = lambda log: [l for l in log.splitlines() if l.startswith(("Processed", "Found", "Computed", "Analyzed", "Stored"))]
+    assert pick(r.stdout) == pick(one.stdout)
+
+
 def test_cli_G_needs_one_gpu_per_rank_and_reports_bad_input(tmp_path):
     import torch
     case = _case("m1_default")

@@ -173,6 +173,11 @@ NAV_MODES = {
     # one byte per position with plain stores (needs n spare bytes of HBM), or bit words with atomicOr when memory is short
     "classic_bytes": {"EB_NAV_COMPLEMENT": "0", "EB_NAV_BYTES": "1"},
     "classic_words": {"EB_NAV_COMPLEMENT": "0", "EB_NAV_BYTES": "0"},
+    # the round-2 node kernels (record load, wait, block loads, wait, compute) instead of the software-pipelined ones of round 3,
+    # and the drain's planner read back after every launch instead of once per group of eight
+    "round2_node_kernels": {"EB_NAV_PIPELINED": "0"},
+    "one_launch_per_readback": {"EB_NAV_GROUP": "1"},
+    "classic_words_round2_kernels": {"EB_NAV_COMPLEMENT": "0", "EB_NAV_BYTES": "0", "EB_NAV_PIPELINED": "0", "EB_NAV_GROUP": "3"},
 }
 
 
@@ -209,9 +214,10 @@ def test_flags_batch_size_does_not_change_result(oracle, monkeypatch):
     e = golden_bytes("dip.ebwt")
     g = api.DnaBwt(e)
     ref = api.Flags.build(g, None, 16, 30).export()
-    for batch, mode in (("64", "complement"), ("1000", "classic_bytes"), ("777", "classic_words"), ("300", "complement_one_stream")):
+    for batch, mode in (("64", "complement"), ("1000", "classic_bytes"), ("777", "classic_words"), ("300", "complement_one_stream"), ("200", "round2_node_kernels"),
+                        ("130", "one_launch_per_readback")):
         monkeypatch.setenv("EB_NAV_BATCH", batch)                 # tiny batches: many launches, depth-first order
-        for k in ("EB_NAV_COMPLEMENT", "EB_NAV_BYTES", "EB_NAV_CONCURRENT"):
+        for k in ("EB_NAV_COMPLEMENT", "EB_NAV_BYTES", "EB_NAV_CONCURRENT", "EB_NAV_PIPELINED", "EB_NAV_GROUP"):
             monkeypatch.delenv(k, raising=False)
         for k, v in NAV_MODES[mode].items():
             monkeypatch.setenv(k, v)

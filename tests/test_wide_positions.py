@@ -161,3 +161,28 @@ def test_wire_images_carry_begins_beyond_32_bits(maker):
     assert cluster_nr == 1 + len(cl) and events == 2 * len(cl)      # cluster_nr starts at 1 (ebwt2InDel.cpp:52)
     assert text.count(b"_type:_SNP_event:A/G") == 2 * len(cl)
     assert text == calls.format_snp(p, False)[0]
+
+
+def test_every_slot_once_check_by_power_sums():
+    """eb_nav_covers_every_slot_once: count, sum and sum of squares (mod 2^64) of the written LCP positions against the
+    closed forms for 1 .. n-1 -- also past 2^32 and at configs[4] size, where the products wrap many times."""
+    from ebwt2indel_amd import _lib
+    L = api.lib()
+    M = (1 << 64) - 1
+    for n in (2, 3, 1000, (1 << 32) + 12345, 7_550_000_000, 151_000_000_000, (1 << 40) - 1):
+        st = _lib.NavStats()
+        st.n = n
+        st.lcp_values = n
+        st.lcp_pos_sum = (n * (n - 1) // 2) & M
+        st.lcp_pos_sq_sum = ((n - 1) * n * (2 * n - 1) // 6) & M
+        assert L.eb_nav_covers_every_slot_once(st) == 1, n
+        # one slot written twice, another never: the count still says n
+        a, b = n // 3 + 1, n // 2 + 1
+        if a != b and b < n:
+            st.lcp_pos_sum = (st.lcp_pos_sum + a - b) & M
+            st.lcp_pos_sq_sum = (st.lcp_pos_sq_sum + a * a - b * b) & M
+            assert L.eb_nav_covers_every_slot_once(st) == 0, n
+        st.lcp_pos_sum = (n * (n - 1) // 2) & M
+        st.lcp_pos_sq_sum = ((n - 1) * n * (2 * n - 1) // 6) & M
+        st.lcp_values = n - 1
+        assert L.eb_nav_covers_every_slot_once(st) == 0, n
