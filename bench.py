@@ -238,9 +238,13 @@ def main():
         parts = ebd.gather_packed(calls.blob(), device=comm_dev) if use_dist else None
         return calls, parts
 
+    gathered_events = []   # device_gather: one event per step, "all ranks' images resident in rank 0's HBM"
+
     def resolve(pending):
         if device_gather:
             parts = pending.result()                                     # rank 0: records of all ranks in page-locked host memory
+            if pending.gathered is not None:
+                gathered_events.append(pending.gathered)
             return pending.keep.finish(), parts                          # releases the job's device image
         return pending
 
@@ -349,6 +353,7 @@ def main():
 
     if args.warmup > 0:
         run_steps(args.warmup)
+    gathered_events.clear()
     scan_ms, ext_ms, right_ms, tot_ms, ctx_ms, req_ext, req_right = [], [], [], [], [], [], []
     scan_launches = 1
 
@@ -373,6 +378,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
+    # The same steps under the other delivery contract: a step counts as delivered when every rank's records are
+    # resident in rank 0's HBM -- rank 0's PCIe download (35 MB per step at N = 8: ~0.65 ms, more than a rank's kernels) then runs
+    # under the following steps and is no longer in the step.  Cadence of the "gathered" events on rank 0's stream.
+    ms_per_step_hbm = None
+    if len(gathered_events) > 2:
+        ms_per_step_hbm = gathered_events[0].elapsed_time(gathered_events[-1]) / (len(gathered_events) - 1)
     # spread over the timed steps: intervals between consecutive completions (steps are pipelined, so a step's own duration is
     # not observable from outside; in steady state the interval IS the step time); the first interval holds the pipeline fill
     # (single intervals are no use: the hand-over thread often resolves two passes back to back; windows of four steps are)
@@ -381,6 +392,7 @@ def main():
     win = (td[W:] - td[:-W])[1:] / W * 1e3 if len(td) > W + 1 else np.diff(td) * 1e3
     step_spread = {"ms_per_step_min": round(float(win.min()), 4), "ms_per_step_median": round(float(np.median(win)), 4),
                    "ms_per_step_max": round(float(win.max()), 4), "window_steps": W,
+                   **({"windows": [round(float(v), 3) for v in win[::W]]} if os.environ.get("EB_BENCH_TRACE_WINDOWS") == "1" else {}),
                    "what": "time per step over sliding windows of `window_steps` consecutive step completions on this rank (the window holding the pipeline fill excluded)"} if len(win) else None
     value = (end - begin if args.rehearse_rank_of > 1 else n) * args.steps / elapsed
 
@@ -610,6 +622,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "step_spread": step_spread,
+            **({"ms_per_step_records_in_rank0_hbm": round(ms_per_step_hbm, 4),
+                "ms_per_step_note": "ms_per_step: records of all ranks in rank 0's HOST memory (the contract `value` is quoted on); ms_per_step_records_in_rank0_hbm: "
+                                    "the same steps counted as delivered once the gathered call sets are resident in rank 0's HBM (cadence of the end of the gather on "
+                                    "rank 0's stream; its PCIe download then overlaps the following steps)"} if ms_per_step_hbm is not None else {}),
             "config": {"workload": workload, "mode": 1, "options": "-L31 -R30 -k16 -g10 -v2 -m3 -c20 -q0",
                        # every path-selecting switch of the library / this script that is set in the environment (none: the defaults ran)
                        "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith(("EB_", "EBGEN_")) or k in ("GPU_MAX_HW_QUEUES", "HSA_ENABLE_IPC_MODE_LEGACY")},

@@ -410,8 +410,12 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
         // keep closing positions inside [begin,end) and below n (a run still open at n-1 is dropped, ebwt2InDel.cpp:1609-1655)
         uint64_t ends = ea;
         uint64_t base = w << 6;
-        if (base < p.begin) ends &= (p.begin - base >= 64) ? 0ull : (~0ull << (p.begin - base));
-        if (base + 64 > hi_pos) ends &= (hi_pos <= base) ? 0ull : (~0ull >> (base + 64 - hi_pos));
+        // (only the two waves whose 64 words hold an end of the scanned range need the masks: wave-uniform test on the wave's span)
+        const uint64_t span_lo = (w_lo + tile * 256 + (uint64_t)wave * 64) << 6;
+        if (span_lo < p.begin || span_lo + 4096 > hi_pos) {
+            if (base < p.begin) ends &= (p.begin - base >= 64) ? 0ull : (~0ull << (p.begin - base));
+            if (base + 64 > hi_pos) ends &= (hi_pos <= base) ? 0ull : (~0ull >> (base + 64 - hi_pos));
+        }
         n_runs += (uint64_t)__popcll(ends);
         if (EB_DBG(p) & 4u) continue;
         // ---- bit-parallel: which closing runs can hold two frequent letters at all.  Two letters with >= mcov rows each
@@ -487,6 +491,7 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
                 }
             }
             uint32_t nb32 = 0, n_short = 0;
+            const int32_t cstart = cprev; // the lengths of the runs walked below add up to the last prefix popcount minus this one
             if (EB_DBG(p) & 16u) rest = 0;
             // branch-free body: runs longer than 200 (and, in the two words that hold the ends of the scanned range, the
             // closing positions outside it) add to a sink slot of the histogram instead of skipping the add
@@ -505,7 +510,6 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
                         int32_t c = cbase + (int32_t)__popc(h & (low - 1u));
                         uint32_t len = (uint32_t)(c - cprev);
                         cprev = c;
-                        nb32 += len;
                         atomicAdd(&sh_hist[len < 201u ? len : 201u], 1u);
                         short_bits |= len < p.min_len ? low : 0u;
                     }
@@ -525,6 +529,7 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
                 n_short += (uint32_t)__popc(short_bits);
                 hot &= ~((uint64_t)short_bits << (32 * half));
             }
+            if (!edge) nb32 = (uint32_t)(cprev - cstart); // (the edge form counts only the runs that close inside the scanned range)
             n_bases += nb32;
             n_clusters += (uint64_t)__popcll(ends & rest) - n_short; // closing positions walked here, minus the short runs
         }
@@ -999,9 +1004,9 @@ struct DevMem { // per-call temporary from the caching scratch allocator
 
 unsigned grid_of(uint64_t threads) { return (unsigned)((threads + 255) / 256); }
 // persistent scan grid: 8 workgroups per CU, each striding over 256-word tiles
-unsigned scan_grid(uint64_t words) {
+unsigned scan_grid(uint64_t words, unsigned per_cu = 8) {
     uint64_t tiles = (words + 255) / 256;
-    const uint64_t cap = 256ull * 8;
+    const uint64_t cap = 256ull * per_cu;
     return (unsigned)(tiles < 1 ? 1 : (tiles > cap ? cap : tiles));
 }
 
@@ -1055,6 +1060,7 @@ struct eb_scan_job {
     // EB_SCAN_PIPELINED: the job's last part (finish_begin) is held back until the next _begin on the index, or until the
     // job is waited for / ended; rc_tail is what that part returned
     hipStream_t s_ext = nullptr, s_right = nullptr; // this job's pair of context streams
+    hipStream_t s_order = nullptr;                  // stream of the ordering step and the image layout (the preparation stream, or the scan's in overlap mode)
     uint32_t reruns = 0;            // scans run a second time (ordered hand-over spilled / survivor list too short)
     bool half = false;
     int rc_tail = EB_OK;
@@ -1254,9 +1260,8 @@ static int launch_contexts(eb_scan_job* job) {
 // list, launch the context kernels and the hand-over (launch_contexts).
 static int finish_begin(eb_scan_job* job) {
     eb_index* b1 = job->b1;
-    eb_scan_ctx* ctx = b1->scan_ctx;
     EB_HIP(hipSetDevice(b1->device));
-    const hipStream_t sP = ctx->prep;
+    const hipStream_t sP = job->s_order;
     const int S = job->S;
     const uint32_t lw = job->lw, rw = job->rw;
     uint64_t rec_total = 0, chain_total = 0;
@@ -1402,7 +1407,10 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
         EB_HIP(hipEventRecord(ctx->last_ext, ctx->ext));
         EB_HIP(hipEventRecord(ctx->last_right, ctx->right));
     }
-    const hipStream_t sA = b1->stream, sP = ctx->prep;
+    static const unsigned overlap_wgs = [] { const char* e = getenv("EB_SCAN_OVERLAP"); int v = e ? atoi(e) : 0; return (unsigned)(v < 0 ? 0 : (v > 8 ? 8 : v)); }();
+    // overlap mode: the ordering of the survivors follows the scan on ITS stream, so that it does not queue behind the previous
+    // job's context kernels (which own the preparation stream) -- the context kernels of this job do
+    const hipStream_t sA = b1->stream, sP = overlap_wgs ? sA : ctx->prep;
     uint64_t w_lo = begin >> 6, w_hi = (end + 63) >> 6;
     uint64_t w_total = w_hi > w_lo ? w_hi - w_lo : 0;
     // Measured at 7.55 G positions (EB_SCAN_SUBSHARDS=1/2/4/8): 6.5 / 6.1 / 6.4 / 11.0 ms per call -- the streaming scan and
@@ -1434,6 +1442,7 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
     job->S = S;
     job->s_ext = ctx->ext;
     job->s_right = ctx->right;
+    job->s_order = sP;
     const hipStream_t sC = job->s_right;
     {
         std::lock_guard<std::mutex> lk(ctx->pool_mu);
@@ -1479,13 +1488,24 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
     // reports (ScanCounters.spilled): that scan is then run again the unordered way, into one list that position buckets put
     // in order.  EB_SCAN_ORDERED=0: always the unordered way.
     const bool ordered_ok = !(getenv("EB_SCAN_ORDERED") && atoi(getenv("EB_SCAN_ORDERED")) == 0);
+    // static LDS of k_scan is ~17.3 KB; with a dynamic request that brings a workgroup to 160 KB / k (minus a little), k fit a CU
+    // (a workgroup may ask for 64 KB at most: k = 1 and 2 both end at two per CU)
+    unsigned scan_dyn_lds = 0;
+    if (overlap_wgs) {
+        unsigned total = (160u * 1024u) / overlap_wgs - 256u;
+        if (total > 64u * 1024u) total = 64u * 1024u;
+        scan_dyn_lds = total - 18u * 1024u;
+    }
     auto launch_scan = [&](SubShard& x, bool ordered) -> int {
         ScanParams q = p;
         q.begin = x.begin;
         q.end = x.end;
         int r;
         x.ordered = ordered && x.w_count != 0;
-        const unsigned grid = scan_grid(x.w_count);
+        // EB_SCAN_OVERLAP=k (experiment, round 3): the scan holds at most k workgroups per CU -- its grid is 256 k workgroups and a
+        // dynamic LDS request of 160 KB / k keeps a k+1-th from fitting -- and does not wait for the previous job's context
+        // kernels: the VALU-bound scan and the memory-bound context kernels then share every CU instead of taking turns.
+        const unsigned grid = scan_grid(x.w_count, overlap_wgs ? overlap_wgs : 8);
         if (x.ordered) {
             const uint64_t tiles = (x.w_count + 255) / 256;
             q.ordered = 1;
@@ -1502,7 +1522,7 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
         EB_HIP(hipEventRecord(x.e[E_SCAN0], sA));
         if (x.w_count) {
             if ((r = x.part.alloc((size_t)grid * EB_SCAN_PARTIAL * 8)) != EB_OK) return r;
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, sA, x1, x2, df, q, x.w_lo, x.w_count, x.surv.as<Survivor>(), x.cap,
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), scan_dyn_lds, sA, x1, x2, df, q, x.w_lo, x.w_count, x.surv.as<Survivor>(), x.cap,
                                x.cnt.as<ScanCounters>(), x.part.as<unsigned long long>(), x.slots.as<Survivor>(), x.bcount.as<uint32_t>());
             hipLaunchKernelGGL(k_scan_reduce, dim3(EB_SCAN_PARTIAL), dim3(256), 0, sA, x.part.as<unsigned long long>(), grid, x.cnt.as<ScanCounters>(), x.ordered ? 1 : 0);
         }
@@ -1520,7 +1540,7 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
     // loads that leave the memory system room, and the scan -> counters on the host -> ordering kernels -> lists chain
     // of the next job is mostly waiting; there the next scan starts at once (EB_SCAN_AFTER_CONTEXTS=1: always wait).
     static const bool always_wait = getenv("EB_SCAN_AFTER_CONTEXTS") && atoi(getenv("EB_SCAN_AFTER_CONTEXTS")) == 1;
-    if (always_wait || !ctx->last_small) {
+    if (always_wait || (!ctx->last_small && !overlap_wgs)) {
         EB_HIP(hipStreamWaitEvent(sA, ctx->last_ext, 0));
         EB_HIP(hipStreamWaitEvent(sA, ctx->last_right, 0));
     }

@@ -49,8 +49,9 @@ class _DeviceBytes:
 class PendingGather:
     """A gather in flight (gather_device_async): result() waits for it and returns what gather_packed returns."""
 
-    def __init__(self, event, views, keep):
+    def __init__(self, event, views, keep, gathered=None):
         self._event, self._views, self.keep = event, views, keep
+        self.gathered = gathered   # timing event: every rank's image is resident in the root's HBM (before the root's PCIe download)
 
     def result(self):
         if self._event is not None:
@@ -88,6 +89,8 @@ def gather_device_async(ptr: int, length: int, device, group=None, dst: int = 0,
     outs = [buf["recv"][r * cap:(r + 1) * cap] for r in range(world)] if rank == dst else None
     work = dist.gather(send, outs, dst=dst, group=group, async_op=True)
     work.wait()                                           # orders the current stream behind the collective, not the host
+    gathered = torch.cuda.Event(enable_timing=True)
+    gathered.record(torch.cuda.current_stream(dev))
     views = None
     if rank == dst:
         host = buf["host"]
@@ -97,7 +100,7 @@ def gather_device_async(ptr: int, length: int, device, group=None, dst: int = 0,
         views = [memoryview(base[r * cap: r * cap + sizes[r]]) for r in range(world)]
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(dev))
-    return PendingGather(ev, views, keep)
+    return PendingGather(ev, views, keep, gathered)
 
 
 def gather_device(ptr: int, length: int, device, group=None, dst: int = 0) -> Optional[List[memoryview]]:

@@ -86,7 +86,13 @@ typedef struct {
     uint64_t F[4];      /* F_A,F_C,F_G,F_T (dna_bwt.hpp:51-60) */
     uint8_t bad_sym;
     uint64_t bad_pos;
+    /* select directory (select_fast below): block of every ORC_SEL_SAMPLE-th occurrence of each letter; built on first use */
+    uint64_t* sel_dir[4];
+    uint64_t sel_len[4];
+    int sel_ready;
 } oindex;
+
+void orc_index_build_select(oindex* x); /* called by every constructor: the scans that use it may run on many threads */
 
 static inline int sym_code(uint8_t c, uint8_t term) {
     if (c == term) return 4;
@@ -96,6 +102,7 @@ static inline int sym_code(uint8_t c, uint8_t term) {
 
 void orc_index_free(oindex* x) {
     if (!x) return;
+    for (int c = 0; c < 4; ++c) free(x->sel_dir[c]);
     free(x->blk);
     free(x->super);
     free(x);
@@ -142,6 +149,7 @@ oindex* orc_index_from_buffer(const uint8_t* ascii, uint64_t n, uint8_t term) {
     x->F[1] = x->F[0] + tot[0];
     x->F[2] = x->F[1] + tot[1];
     x->F[3] = x->F[2] + tot[2];
+    orc_index_build_select(x);
     return x;
 }
 
@@ -215,6 +223,7 @@ oindex* orc_index_from_buffer_mt(const uint8_t* ascii, uint64_t n, uint8_t term,
     x->F[1] = x->F[0] + abs4[0];
     x->F[2] = x->F[1] + abs4[1];
     x->F[3] = x->F[2] + abs4[2];
+    orc_index_build_select(x);
     return x;
 }
 /* whole-index comparison for the test of the threaded builder */
@@ -286,6 +295,77 @@ static uint64_t select1(const oindex* x, uint64_t i, uint8_t c) {
     return lo;
 }
 
+/* select(i,c) again, with the SAME unique answer -- max{p : rank(p,c) <= i}, the position of the i-th (0-based) c -- but
+ * without the ~33 cache-missing rank queries of the bisection over [0,n): a directory (block of every 256th occurrence of
+ * each letter) brackets the answer to a few neighbouring blocks, the block counters (rank at block starts, no popcounts)
+ * pick the block, a bit loop picks the position.  The reference's algorithm is select1 above; this exists because phase 4
+ * of the two-sample modes calls select ~30 times for nearly EVERY cluster, which at 7.55-15.1 G positions made a whole-range
+ * oracle pass outlast a 20-minute GPU-box call (round 3; scripts/fullsize_check.py).  Held to select1 by orc_select_check
+ * (tests/test_oracle_golden.py) and, through FL, by every golden .snp. */
+#define ORC_SEL_SAMPLE 256u
+static inline uint64_t block_start_rank(const oindex* x, uint64_t b, int k) { return x->super[b >> 25].v[k] + x->blk[b].cnt[k]; }
+void orc_index_build_select(oindex* x) {
+    if (x->sel_ready || getenv("ORC_REFERENCE_SELECT")) return; /* ORC_REFERENCE_SELECT=1: FL by the reference's bisection (timing / cross-checks) */
+    uint64_t tot[4];
+    {   /* occurrences of each letter in the whole string = rank4(n) */
+        rank4_t r = rank4(x, x->n);
+        for (int k = 0; k < 4; ++k) tot[k] = r.v[k];
+    }
+    for (int k = 0; k < 4; ++k) {
+        x->sel_len[k] = tot[k] / ORC_SEL_SAMPLE + 2;
+        x->sel_dir[k] = (uint64_t*)malloc(x->sel_len[k] * sizeof(uint64_t));
+        uint64_t next = 0, m = 0; /* next sampled occurrence number, entries written */
+        for (uint64_t b = 0; b < x->nblocks && m < x->sel_len[k]; ++b) {
+            /* occurrences before block b+1 */
+            const uint64_t after = b + 1 < x->nblocks ? block_start_rank(x, b + 1, k) : tot[k];
+            while (m < x->sel_len[k] && next < after) { x->sel_dir[k][m++] = b; next += ORC_SEL_SAMPLE; }
+        }
+        while (m < x->sel_len[k]) x->sel_dir[k][m++] = x->nblocks - 1;
+    }
+    __atomic_store_n(&x->sel_ready, 1, __ATOMIC_RELEASE);
+}
+static uint64_t select_fast(const oindex* x, uint64_t i, uint8_t c) {
+    const int k = sym_code(c, 0);
+    if (k < 0 || k > 3 || c == x->term || !__atomic_load_n(&x->sel_ready, __ATOMIC_ACQUIRE)) return select1(x, i, c);
+    const uint64_t m = i / ORC_SEL_SAMPLE;
+    if (m + 1 >= x->sel_len[k]) return select1(x, i, c);
+    uint64_t lo = x->sel_dir[k][m], hi = x->sel_dir[k][m + 1]; /* the block of the answer lies in [lo, hi] */
+    if (!(block_start_rank(x, lo, k) <= i)) return select1(x, i, c);
+    /* last block whose start rank is <= i */
+    while (hi > lo) {
+        uint64_t mid = (lo + hi + 1) / 2;
+        if (block_start_rank(x, mid, k) <= i) lo = mid; else hi = mid - 1;
+    }
+    const oblock* q = &x->blk[lo];
+    uint64_t need = i - block_start_rank(x, lo, k); /* occurrences to skip inside the block */
+    for (int w = 0; w < 2; ++w) {
+        uint64_t msk = ~q->b2[w] & ((k & 2) ? q->b1[w] : ~q->b1[w]) & ((k & 1) ? q->b0[w] : ~q->b0[w]);
+        const uint64_t have = (uint64_t)__builtin_popcountll(msk);
+        if (need >= have) { need -= have; continue; }
+        while (need--) msk &= msk - 1;
+        const uint64_t pos = lo * 128 + (uint64_t)w * 64 + (uint64_t)__builtin_ctzll(msk);
+        return pos < x->n ? pos : select1(x, i, c);
+    }
+    return select1(x, i, c); /* fewer than i+1 occurrences in the string: whatever the bisection says */
+}
+/* checker: m pseudo-random (i, c) queries, both ways; returns the number of disagreements */
+uint64_t orc_select_check(oindex* x, uint64_t m, uint64_t seed) {
+    orc_index_build_select(x);
+    rank4_t tot = rank4(x, x->n);
+    uint64_t s = seed * 0x9E3779B97F4A7C15ull + 1, bad = 0;
+    static const char sym[4] = {'A', 'C', 'G', 'T'};
+    for (uint64_t q = 0; q < m; ++q) {
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        const int k = (int)(s & 3);
+        if (tot.v[k] == 0) continue;
+        /* mostly uniform; every 16th query at the very first / last occurrences */
+        uint64_t i = (s >> 8) % tot.v[k];
+        if ((q & 15) == 0) i = (q & 16) ? tot.v[k] - 1 - (i % (tot.v[k] < 300 ? tot.v[k] : 300)) : i % (tot.v[k] < 300 ? tot.v[k] : 300);
+        if (select_fast(x, i, (uint8_t)sym[k]) != select1(x, i, (uint8_t)sym[k])) ++bad;
+    }
+    return bad;
+}
+
 /* F(i): dna_bwt.hpp:100-110 */
 static inline uint8_t F_sym(const oindex* x, uint64_t i) {
     return i < x->F[0] ? x->term : i < x->F[1] ? 'A' : i < x->F[2] ? 'C' : i < x->F[3] ? 'G' : 'T';
@@ -294,7 +374,7 @@ static inline uint8_t F_sym(const oindex* x, uint64_t i) {
 static inline uint64_t FL(const oindex* x, uint64_t i) {
     uint8_t c = F_sym(x, i);
     uint64_t r = i < x->F[0] ? i : i < x->F[1] ? i - x->F[0] : i < x->F[2] ? i - x->F[1] : i < x->F[3] ? i - x->F[2] : i - x->F[3];
-    return select1(x, r, c);
+    return select_fast(x, r, c); /* == select1(x, r, c), see select_fast */
 }
 
 typedef struct { range_t c[4]; } prange_t; /* p_range, include.hpp:540-547 */
@@ -1150,7 +1230,11 @@ static void scan(orun* r, int mode, uint64_t sb, uint64_t se) {
     /* shard entry: a run that is open at sb closes inside this shard, so rewind to its first position */
     uint64_t start = sb;
     while (start > 0 && bit_get(f->thrK, start - 1) && !bit_get(f->minima, start - 1)) --start;
-    if (mode == 2) for (uint64_t i = 0; i < start; ++i) { int d = bit_get(f->da, i); i0 += !d; i1 += d; }
+    if (mode == 2) { /* rows of each collection before `start` (ebwt2InDel.cpp:1431-1432 counted one by one from 0): popcount of DA[0, start) */
+        for (uint64_t w = 0; w < (start >> 6); ++w) i1 += (uint64_t)__builtin_popcountll(f->da[w]);
+        if (start & 63) i1 += (uint64_t)__builtin_popcountll(f->da[start >> 6] & ((1ull << (start & 63)) - 1ull));
+        i0 = start - i1;
+    }
     for (uint64_t i = start; i < se; ++i) {
         if (bit_get(f->thrK, i) && !bit_get(f->minima, i)) {
             if (open) ++len;

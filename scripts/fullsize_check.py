@@ -18,7 +18,8 @@ against the reference binary and, past 2^32, by tests/test_gpu_superblocks.py --
 
     gpurun --timeout 1200 -- 'python scripts/fullsize_check.py config2 all     > gpurun_out/fs2.log 2>&1'
     gpurun --timeout 1200 -- 'python scripts/fullsize_check.py config4 traversal > gpurun_out/fs4t.log 2>&1'
-    gpurun --timeout 1200 -- 'python scripts/fullsize_check.py config4 phase4    > gpurun_out/fs4p.log 2>&1'
+    gpurun --timeout 1200 -- 'python scripts/fullsize_check.py config4 phase4a   > gpurun_out/fs4a.log 2>&1'   # [0, cut)
+    gpurun --timeout 1200 -- 'python scripts/fullsize_check.py config4 phase4b   > gpurun_out/fs4b.log 2>&1'   # [cut, n); "phase4": the whole range in one call (config3)
     python scripts/fullsize_check.py config4 merge      # gpurun_out/r03_fullsize_config4_*.json -> profiles/r03_fullsize_config4.json
     (also: python scripts/fullsize_check.py 50000000 x10 -- the replicated input towards configs[4], as in round 2)
 """
@@ -115,31 +116,58 @@ def part_traversal(inp, res, orc, po, idx):
                 "oracle_traversal_seconds": round(hb_t.seconds, 1)}
 
 
-def part_phase4(inp, res, orc, po, idx, of=None):
-    """The oracle's phase 4 over the WHOLE range, sharded over the host threads; on the GPU's vectors unless the oracle's own
-    (`of`, from part_traversal in the same process) are at hand."""
+def neutral_cut(vec, n):
+    """A position c near n/2 that no cluster straddles (flag[c-1] == 0, flag = thrK & ~minima): the oracle gives a cluster to the
+    piece that holds its BEGIN, the product to the piece that holds its closing position -- at such a c both agree, so the
+    two halves of a range cut there can be compared piece by piece."""
+    c = n // 2
+    flag = vec[0] & ~vec[2]
+    while c < n and (int(flag[(c - 1) >> 6]) >> ((c - 1) & 63)) & 1:
+        c += 1
+    return int(c)
+
+
+def part_phase4(inp, res, orc, po, idx, of=None, half=None):
+    """The oracle's phase 4 over the WHOLE range (half = None) or over one of its two halves ("a": [0, c), "b": [c, n), c a
+    cut no cluster straddles -- for inputs whose whole-range pass outlasts a GPU-box call), sharded over the host threads; on
+    the GPU's vectors unless the oracle's own (`of`, from part_traversal in the same process) are at hand."""
     rec = {}
+    lo, hi = 0, inp.n
     if of is None:
         got_sha, vec = res.vector_shas()
         rec["phase4_ran_on_gpu_vectors_sha256"] = got_sha
+        if half is not None:
+            c = neutral_cut(vec, inp.n)
+            lo, hi = (0, c) if half == "a" else (c, inp.n)
         with Heartbeat("oracle flags imported from the GPU's vectors"):
             of = _oracle.OracleFlags(orc, idx[0], idx[1] if inp.mode == 2 else None, po.K, po.k_right, vectors=vec)
         del vec
-    n = inp.n
     shards = THREADS * 16
-    cuts = [ebd.shard_range(n, i, shards) for i in range(shards)]
+    cuts = [tuple(lo + v for v in ebd.shard_range(hi - lo, i, shards)) for i in range(shards)]
     done = [0]
 
     def one(be):
         r = of.scan(po, be[0], be[1])
         done[0] += 1
         return r["text"], r["cluster_nr"] - 1, r["events"], r["stats"]
-    with Heartbeat(f"oracle phase 4, whole range, {shards} shards on {THREADS} threads") as hb, ThreadPoolExecutor(THREADS) as ex:
+    with Heartbeat(f"oracle phase 4, [{lo}, {hi}), {shards} shards on {THREADS} threads") as hb, ThreadPoolExecutor(THREADS) as ex:
         parts = list(ex.map(one, cuts))
     want = fs.renumber([p[0] for p in parts], [p[1] for p in parts])
     orc_sha = hashlib.sha256(want).hexdigest()
     stats = {k: int(sum(p[3][k] for p in parts)) for k in ("runs_closed", "clusters", "bases_in_runs")}
     log(f"oracle: {want.count(b'>')} records, {sum(p[1] for p in parts)} cluster numbers, sha256 {orc_sha}; {stats}")
+    if half is not None:
+        # the product on the same half, numbered from 1 like the oracle's piece; and: the whole-run text is the two halves renumbered
+        pa = fs.piece(inp, res, 0, lo if half == "b" else hi)
+        pb = fs.piece(inp, res, lo if half == "b" else hi, inp.n)
+        mine = pa if half == "a" else pb
+        assert mine["text"] == want, f"GPU .snp of half {half} differs from the oracle's"
+        assert (mine["runs_closed"], mine["clusters"], mine["bases_in_runs"]) == (stats["runs_closed"], stats["clusters"], stats["bases_in_runs"]), "scan counters differ"
+        assert fs.renumber([pa["text"], pb["text"]], [pa["cluster_numbers"], pb["cluster_numbers"]]) == res.text, "the whole-run .snp is not its two halves renumbered"
+        rec.update({"cut": int(lo if half == "b" else hi), "gpu_snp_sha256": res.snp_sha256, "snp_records": int(res.snp_records), "cluster_numbers": int(res.cluster_nr - 1),
+                    f"half_{half}": {"range": [int(lo), int(hi)], "oracle_snp_sha256": orc_sha, "identical_to_gpu": True, "snp_records": int(want.count(b">")),
+                                     "cluster_numbers": int(sum(p[1] for p in parts)), "scan_counters": stats, "oracle_phase4_seconds": round(hb.seconds, 1), "oracle_shards": shards}})
+        return rec
     st = res.calls.stats
     assert (int(st.runs_closed), int(st.clusters), int(st.bases_in_runs)) == (stats["runs_closed"], stats["clusters"], stats["bases_in_runs"]), "scan counters differ"
     assert res.text == want, "GPU .snp differs from the oracle's whole-range .snp"
@@ -166,6 +194,8 @@ def main_config():
         out.update(rec)
     if PART in ("phase4", "all"):
         out.update(part_phase4(inp, res, orc, po, idx, of))
+    if PART in ("phase4a", "phase4b"):
+        out.update(part_phase4(inp, res, orc, po, idx, None, half=PART[-1]))
     with open(out_path(NAME, PART), "w") as f:
         json.dump(out, f, indent=1)
     log(json.dumps(out))
@@ -175,6 +205,22 @@ def merge():
     """gpurun_out/r03_fullsize_<name>_{all | traversal + phase4}.json -> profiles/r03_fullsize_<name>.json"""
     if os.path.exists(out_path(NAME, "all")):
         m = json.load(open(out_path(NAME, "all")))
+    elif os.path.exists(out_path(NAME, "phase4a")):
+        t, pa, pb = (json.load(open(out_path(NAME, k))) for k in ("traversal", "phase4a", "phase4b"))
+        assert t["input"] == pa["input"] == pb["input"], "the parts ran on different inputs"
+        assert pa["phase4_ran_on_gpu_vectors_sha256"] == pb["phase4_ran_on_gpu_vectors_sha256"] == t["oracle_vector_sha256"], "phase 4 ran on vectors the oracle's traversal did not produce"
+        assert pa["cut"] == pb["cut"] and pa["gpu_snp_sha256"] == pb["gpu_snp_sha256"]
+        m = dict(t)
+        m["gpu_seconds"] = pb["gpu_seconds"]
+        m.update({k: pb[k] for k in ("cut", "snp_records", "cluster_numbers")})
+        m["half_a"], m["half_b"] = pa["half_a"], pb["half_b"]
+        # each half of the product's .snp equals the oracle's half, and the product's whole-run text is its two halves renumbered
+        # (both asserted at record time): the product's whole-run SHA-256 IS the oracle's
+        m["oracle_snp_sha256"] = pb["gpu_snp_sha256"]
+        m["scan_counters"] = {k: pa["half_a"]["scan_counters"][k] + pb["half_b"]["scan_counters"][k] for k in pa["half_a"]["scan_counters"]}
+        m["identical"] = True
+        m["parts"] = ("traversal, phase 4 of [0, cut) and phase 4 of [cut, n) in three GPU-box calls (each inside the 20-minute cap); no cluster straddles the cut; "
+                      "phase 4 ran on the GPU's vectors, SHA-256 equal to the oracle's own")
     else:
         t, p4 = json.load(open(out_path(NAME, "traversal"))), json.load(open(out_path(NAME, "phase4")))
         assert t["input"] == p4["input"], "the two parts ran on different inputs"

@@ -3,12 +3,12 @@
 # Writes under gpurun_out/prof_<tag>/; scripts/pmc_summary.py turns the counter CSVs into profiles/<tag>_pmc_traffic.json.
 # Counter passes are separate runs with --kernel-trace only (no other trace domains), one counter group per pass.
 set -e -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-B="python3 $ROOT/bench.py --cpu-sample-reads 0"
+B="python3 $ROOT/bench.py --cpu-sample-reads 0 --cpu-dram-reads 0"
 timeout -k 10 280 rocprofv3 --kernel-trace --stats -d "$OUT/np" -o np --output-format csv -- $B --no-pipeline > "$OUT/np.json" 2> "$OUT/np.err"
 timeout -k 10 280 rocprofv3 --kernel-trace --stats -d "$OUT/pl" -o pl --output-format csv -- $B > "$OUT/pl.json" 2> "$OUT/pl.err"
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/fetch" -o fetch --output-format csv -- $B --no-pipeline --steps 5 --warmup 1 > "$OUT/fetch.json" 2> "$OUT/fetch.err"

@@ -145,3 +145,13 @@ def renumber(parts, used):
         out.append(t)
         off += u
     return b"".join(out)
+
+
+def piece(inp: "Inputs", res: "Result", begin: int, end: int):
+    """The product's phase 4 over closing positions [begin, end), its clusters numbered from 1."""
+    from ebwt2indel_amd import api
+    b2 = inp.bwts[1] if inp.mode == 2 else None
+    c = api.scan_clusters(inp.bwts[0], res.flags, res.params, bwt2=b2, begin=begin, end=end)
+    text, cluster_nr, _ = c.format_snp(res.params, inp.mode != 1)
+    st = c.stats
+    return dict(text=text, cluster_numbers=cluster_nr - 1, runs_closed=int(st.runs_closed), clusters=int(st.clusters), bases_in_runs=int(st.bases_in_runs))

@@ -111,6 +111,8 @@ class Oracle:
                                C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(u64), C.POINTER(u64), vp]
         L.orc_free.argtypes = [vp]
         L.orc_last_hist.argtypes = [vp]
+        L.orc_select_check.restype = u64
+        L.orc_select_check.argtypes = [vp, u64, u64]
         L.orc_rank_bench.restype = C.c_double
         L.orc_rank_bench.argtypes = [vp, u64, u64, C.POINTER(u64)]
 
@@ -254,7 +256,7 @@ class OracleFlags:
         return dict(zip(("leaves", "nodes", "lcp_values", "da_values", "minima", "max_stack"), (int(x) for x in c)))
 
     def scan(self, params, begin, end, cluster_nr=1, capture=False):
-        """Phase 4 over clusters starting in [begin,end).  Returns dict(text, cluster_nr, events, stats[, clusters, left, right])."""
+        """Phase 4 over clusters whose CLOSING position lies in [begin,end) (the product's ownership rule: a run open at `begin` is rewound to its first row, a run still open at `end` is left to the next shard).  Returns dict(text, cluster_nr, events, stats[, clusters, left, right])."""
         L = self.o.lib
         cn, ev, ln = C.c_uint64(cluster_nr), C.c_uint64(0), C.c_uint64(0)
         recs, chains, left, right = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()

@@ -41,3 +41,12 @@ def test_full_size_config_equals_the_oracle_record(name):
     assert res.cluster_nr - 1 == want["cluster_numbers"]
     st, sc = res.calls.stats, want["scan_counters"]
     assert (int(st.runs_closed), int(st.clusters), int(st.bases_in_runs)) == (sc["runs_closed"], sc["clusters"], sc["bases_in_runs"])
+    if "half_a" in want:
+        # the oracle walked this input's phase 4 in two GPU-box calls, [0, cut) and [cut, n), cut where no cluster straddles it:
+        # each half of the product's output against the oracle's, and the whole-run text = the halves with a running cluster_nr
+        import hashlib
+        halves = [fs.piece(inp, res, 0, want["cut"]), fs.piece(inp, res, want["cut"], inp.n)]
+        for got, key in zip(halves, ("half_a", "half_b")):
+            assert hashlib.sha256(got["text"]).hexdigest() == want[key]["oracle_snp_sha256"], key
+            assert got["cluster_numbers"] == want[key]["cluster_numbers"], key
+        assert fs.renumber([h["text"] for h in halves], [h["cluster_numbers"] for h in halves]) == res.text
