@@ -344,6 +344,10 @@ def main():
             log("[bench] host trace, ms since the first begin: hand-overs   " + " ".join(f"{(a - z) * 1e3:.2f}-{(b - z) * 1e3:.2f}" for a, b in t_collect)
                 + f"; all done {(time.perf_counter() - z) * 1e3:.2f}")
         if trace and len(t_begin) > 8 and rank == 0:
+            bd = np.array([y - x for x, y in t_begin]) * 1e3
+            cd = np.array([y - x for x, y in t_collect]) * 1e3
+            log("[bench] host trace: begin calls longer than twice the median (step: ms): " + ", ".join(f"{i}: {v:.2f}" for i, v in enumerate(bd) if v > 2 * np.median(bd))
+                + f" (median {np.median(bd):.2f}); hand-overs: " + ", ".join(f"{i}: {v:.2f}" for i, v in enumerate(cd) if v > 2 * np.median(cd)) + f" (median {np.median(cd):.2f})")
             b = np.array(t_begin[4:]) * 1e6
             c = np.array(t_collect[4:]) * 1e6
             log(f"[bench] host trace, us: begin call {np.mean(b[:, 1] - b[:, 0]):.0f}, between begin calls {np.mean(b[1:, 0] - b[:-1, 1]):.0f}, "

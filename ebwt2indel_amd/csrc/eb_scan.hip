@@ -182,7 +182,7 @@ __device__ __forceinline__ RunGeom run_geometry(const eb_dev_flags& f, uint64_t 
 // A queued run is a (word, bit) pair; its lane reloads the two flag words and planes (cache hits: just streamed).
 // Runs longer than the two words (and the two-BWT mode, whose symbols live in other coordinates) take the memory path.
 // Persistent grid; statistics leave as one row per workgroup.
-template <int MODE>
+template <int MODE, bool PREFETCH> // PREFETCH: the loads of tile it+1 are issued before tile it is worked on (see the main loop)
 __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, ScanParams p, uint64_t w_lo,
                                              uint64_t w_count, Survivor* __restrict__ surv, uint64_t surv_cap,
                                              ScanCounters* __restrict__ cnt, unsigned long long* __restrict__ partial,
@@ -389,13 +389,22 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
     uint32_t trips = 0;
     const uint64_t T = p.tiles_per_wg;
     const uint64_t iters = ordered ? T : (tiles > blockIdx.x ? (tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0);
-    // (Round 3 measured a software pipeline over the tiles -- the loads of tile it+1 issued before tile it is worked on, 12 more
-    // registers, 6 instead of 7 waves per SIMD: 1.144 against 1.090 ms on the same box.  The kernel is not short of bytes in
-    // flight: its ~480 vector instructions per 64-position word are what it waits for)
+    // PREFETCH: a software pipeline over the tiles -- the loads of tile it+1 are issued before tile it is worked on (12 more
+    // registers).  With the chip to itself (8 workgroups per CU) the kernel is not short of bytes in flight -- its ~480 vector
+    // instructions per 64-position word are what it waits for -- and the pipeline LOSES: 1.144 against 1.090 ms on the same box
+    // (round 3).  It is for the scan that shares the CUs with the context kernels at 3-4 workgroups per CU (EB_SCAN_OVERLAP),
+    // where half the waves must cover the same memory latency.
+    auto tile_of = [&](uint64_t it) -> uint64_t {
+        return it < iters ? (ordered ? (uint64_t)blockIdx.x * T + it : (uint64_t)blockIdx.x + it * gridDim.x) : tiles; // tiles: nothing to load
+    };
+    TileData nxt;
+    if (PREFETCH) nxt = load_tile(tile_of(0));
     for (uint64_t it = 0; it < iters; ++it) {
-        const uint64_t tile = ordered ? (uint64_t)blockIdx.x * T + it : (uint64_t)blockIdx.x + it * gridDim.x;
+        const uint64_t tile = tile_of(it);
         if (ordered) cur_batch = (uint64_t)blockIdx.x * ((T + EB_BATCH_TILES - 1) / EB_BATCH_TILES) + it / EB_BATCH_TILES;
-        TileData td = load_tile(tile);
+        TileData td;
+        if (PREFETCH) { td = nxt; nxt = load_tile(tile_of(it + 1)); }
+        else td = load_tile(tile);
         uint64_t t = tile * 256 + threadIdx.x;
         bool active = t < w_count;
         uint64_t w = w_lo + (active ? t : 0);
@@ -1228,6 +1237,13 @@ static int launch_contexts(eb_scan_job* job) {
         EB_HIP(hipMemcpyAsync(job->h_bad + 1 + 2 * k, x.cnt.as<ScanCounters>()->req_sum, 16, hipMemcpyDeviceToHost, sD));
     }
     if (!device_only) {
+        if ((options & EB_SCAN_PIPELINED) && ns) { // several call sets of this size will be alive at once: pin their blobs now, not in mid-pipeline
+            const uint64_t need = eb_calls_blob_size(ns, n_chains, prm->k_left, prm->k_right);
+            if (need > ctx->pinned_reserved) {
+                eb_pinned_reserve(need + need / 16, 8);
+                ctx->pinned_reserved = need + need / 16;
+            }
+        }
         calls = eb_calls_alloc(ns, n_chains, prm->k_left, prm->k_right, ns != 0);
         if (!calls) return EB_ERR_NOMEM;
         if (job->has_blob && ns) {
@@ -1407,7 +1423,24 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
         EB_HIP(hipEventRecord(ctx->last_ext, ctx->ext));
         EB_HIP(hipEventRecord(ctx->last_right, ctx->right));
     }
-    static const unsigned overlap_wgs = [] { const char* e = getenv("EB_SCAN_OVERLAP"); int v = e ? atoi(e) : 0; return (unsigned)(v < 0 ? 0 : (v > 8 ? 8 : v)); }();
+    // THE SCAN BESIDE THE PREVIOUS JOB'S CONTEXT KERNELS (round 3).  The scan is bound by vector instructions (~480 per 64-position
+    // word), the context kernels by the fabric's rate of random 128-byte lines with next to no arithmetic: run one after the
+    // other they add up (1.05 + 2.07 ms at 7.55 G positions), run side by side on the same CUs they do not.  Round 2 tried it with
+    // the scan's persistent grid of 8 workgroups per CU and lost (4.4 against 3.9 ms): whichever kernel arrives first owns every
+    // wave slot and the other starves.  What works is a PARTITION of each CU: the scan holds overlap_wgs workgroups per CU (its
+    // grid is 256 x overlap_wgs, and a dynamic LDS request of 160 KB / overlap_wgs keeps one more from fitting), issues the loads
+    // of its next tile before it works on the current one (k_scan<.., true>: half the waves must cover the same latency), and
+    // the context kernels -- no LDS, 16 waves per CU left -- keep the memory system busy.  Steady state at 7.55 G positions:
+    // 2.85 ms per pass against 3.27 on the same box (profiles/r03_overlap_ab.txt).
+    // Applied when the caller keeps jobs coming (EB_SCAN_PIPELINED) and the previous job's context kernels are still running;
+    // a job with nothing to share the chip with gets the full-width scan.  EB_SCAN_OVERLAP=0: never; =k: always, k per CU.
+    const unsigned overlap_wgs = [&]() -> unsigned {
+        const char* e = getenv("EB_SCAN_OVERLAP");
+        const int v = e ? atoi(e) : -1;
+        if (v >= 0) return (unsigned)(v > 8 ? 8 : v);
+        if (!(options & EB_SCAN_PIPELINED) || ctx->last_small) return 0u;
+        return hipEventQuery(ctx->last_right) == hipErrorNotReady ? 4u : 0u;
+    }();
     // overlap mode: the ordering of the survivors follows the scan on ITS stream, so that it does not queue behind the previous
     // job's context kernels (which own the preparation stream) -- the context kernels of this job do
     const hipStream_t sA = b1->stream, sP = overlap_wgs ? sA : ctx->prep;
@@ -1481,7 +1514,10 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
     job->ev_begin = ev_begin;
     job->ev_end = ev_end;
     int rc;
-    auto kern = p.mode == 1 ? k_scan<1> : (p.mode == 2 ? k_scan<2> : k_scan<3>);
+    const int scan_prefetch = getenv("EB_SCAN_PREFETCH") ? atoi(getenv("EB_SCAN_PREFETCH")) : -1; // -1: with EB_SCAN_OVERLAP only
+    const bool prefetch = scan_prefetch < 0 ? overlap_wgs != 0 : scan_prefetch != 0;
+    auto kern = prefetch ? (p.mode == 1 ? k_scan<1, true> : (p.mode == 2 ? k_scan<2, true> : k_scan<3, true>))
+                         : (p.mode == 1 ? k_scan<1, false> : (p.mode == 2 ? k_scan<2, false> : k_scan<3, false>));
     static const int early_lanes = getenv("EB_RIGHT_LANES_EARLY") && atoi(getenv("EB_RIGHT_LANES_EARLY")) == 4 ? 4 : 1; // the early walk of a small call set
     auto kern_right = p.mode == 2 ? (early_lanes == 4 ? k_right<true, 4> : k_right<true, 1>) : (early_lanes == 4 ? k_right<false, 4> : k_right<false, 1>);
     // The scan hands its survivors over in BWT-ordered batches (ScanParams.ordered) unless a batch overflows, which it
@@ -1502,9 +1538,7 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
         q.end = x.end;
         int r;
         x.ordered = ordered && x.w_count != 0;
-        // EB_SCAN_OVERLAP=k (experiment, round 3): the scan holds at most k workgroups per CU -- its grid is 256 k workgroups and a
-        // dynamic LDS request of 160 KB / k keeps a k+1-th from fitting -- and does not wait for the previous job's context
-        // kernels: the VALU-bound scan and the memory-bound context kernels then share every CU instead of taking turns.
+        // (overlap_wgs != 0: the scan that shares every CU with the previous job's context kernels, see above)
         const unsigned grid = scan_grid(x.w_count, overlap_wgs ? overlap_wgs : 8);
         if (x.ordered) {
             const uint64_t tiles = (x.w_count + 255) / 256;

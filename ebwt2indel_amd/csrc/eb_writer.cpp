@@ -279,10 +279,33 @@ void* pinned_get(uint64_t size, uint64_t* got) {
 }
 void pinned_put(void* p, uint64_t cap) {
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    if (g_pool.size() < 8) { g_pool.emplace_back(p, cap); return; }
+    if (g_pool.size() < 16) { g_pool.emplace_back(p, cap); return; }
     (void)hipHostFree(p);
 }
 uint64_t align8(uint64_t v) { return (v + 7) & ~7ull; }
+}  // namespace
+
+// A caller that keeps phase-4 jobs coming (EB_SCAN_PIPELINED) has several call sets alive at once -- begun, being handed over,
+// being read -- and each needs a page-locked blob; pinning one takes ~15-20 ms per 64 MB, which must not land in the middle of
+// the pipeline (round 3: one begin call of 17.8 ms among 2.9 ms ones whenever the number of live call sets reached a new
+// maximum).  Makes sure `count` blobs of at least `size` bytes are in the pool.
+void eb_pinned_reserve(uint64_t size, int count) {
+    std::vector<std::pair<void*, uint64_t>> fresh;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (const auto& e : g_pool)
+            if (e.second >= size && e.second <= 2 * size + (1u << 20)) --count;
+    }
+    for (; count > 0; --count) {
+        void* p = nullptr;
+        const uint64_t cap = size + size / 4 + 4096;
+        if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) break;
+        fresh.emplace_back(p, cap);
+    }
+    for (const auto& e : fresh) pinned_put(e.first, e.second);
+}
+
+namespace {
 
 void bind_sections(eb_calls* c) {
     uint8_t* q = c->blob + sizeof(eb_calls_header);

@@ -678,14 +678,19 @@ _STRESS = {
 }
 
 
+@pytest.mark.parametrize("scan_form", ["default", "overlap3_prefetch", "prefetch_only"])
 @pytest.mark.parametrize("mode", [1, 2, 3])
 @pytest.mark.parametrize("name", sorted(_STRESS))
-def test_scan_on_adversarial_flag_patterns(oracle, name, mode):
+def test_scan_on_adversarial_flag_patterns(oracle, monkeypatch, name, mode, scan_form):
     """Phase 4 on inputs the navigation would never produce: a random symbol string (every cluster mixes letters, so all of
     them reach the queues, the analysis and the survivor staging overflow) under flag patterns that pin the corner
     cases of the run logic -- runs ending on word boundaries, spanning exactly two words, spanning hundreds, nine
     clusters in one word.  The scan only reads these vectors (ebwt2InDel.cpp:1609-1655); records, counters and
     CLUST_SIZES must equal the oracle's, whole range and cut at odd positions."""
+    if scan_form == "overlap3_prefetch":       # the scan that shares the CUs with the context kernels: 3 workgroups per CU, tile loads one tile ahead
+        monkeypatch.setenv("EB_SCAN_OVERLAP", "3")
+    elif scan_form == "prefetch_only":
+        monkeypatch.setenv("EB_SCAN_PREFETCH", "1")
     n, p_term, pattern = _STRESS[name]
     rng = _rng(sum(name.encode()) * 7 + mode)
     sym = rng.choice(np.frombuffer(b"ACGT#", dtype=np.uint8), size=n, p=[(1 - p_term) / 4] * 4 + [p_term])
