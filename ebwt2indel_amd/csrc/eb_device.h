@@ -16,9 +16,10 @@
 
 #define EB_BLOCK_SYMS 128u
 #define EB_SUPER_SHIFT 32 /* 2^32 symbols per superblock (dna_string.hpp:36) */
-#ifndef EB_SEL_SHIFT
-#define EB_SEL_SHIFT 7    /* select directory samples every 128th occurrence of a letter */
-#endif
+/* The select directory samples every 2^sel_shift-th occurrence of a letter (eb_dev_index::sel_shift, chosen when the index is
+ * built: 5 up to 2^35 symbols -- n/8 bytes of directory, 1.24 block probes per FL -- 7 beyond -- n/32 bytes, 1.52 probes). */
+#define EB_SEL_SHIFT_DENSE 5
+#define EB_SEL_SHIFT_SPARSE 7
 
 struct eb_dev_index {
     const uint4* chunks;    // 4 * n_blocks chunks
@@ -27,9 +28,10 @@ struct eb_dev_index {
     uint64_t n_blocks;      // ceil((n+1)/128)
     uint64_t F[4];          // F_A,F_C,F_G,F_T
     const uint4* xy;         // code planes x,y of every 64 positions {x lo, x hi, y lo, y hi}: the scan's 2-bit view (may be null)
-    const uint32_t* sel_dir; // select directory: block of every EB_SEL_SAMPLE-th occurrence of each letter
+    const uint32_t* sel_dir; // select directory: block of every 2^sel_shift-th occurrence of each letter
     uint64_t sel_off[4];     // first directory entry of each letter
     uint32_t term;          // ASCII terminator
+    uint32_t sel_shift;     // log2 of the select directory's sampling distance
 };
 
 struct eb_dev_flags {
@@ -195,9 +197,10 @@ __device__ __forceinline__ uint64_t eb_block_count(const eb_dev_index& x, uint64
 // context_roofline is built from these counts).
 __device__ __forceinline__ uint64_t eb_select(const eb_dev_index& x, uint64_t r, int c, uint32_t& probes) {
     const uint32_t* dir = x.sel_dir + (c == 0 ? x.sel_off[0] : c == 1 ? x.sel_off[1] : c == 2 ? x.sel_off[2] : x.sel_off[3]);
-    uint64_t m = r >> EB_SEL_SHIFT;
+    const uint32_t sh = x.sel_shift;
+    uint64_t m = r >> sh;
     uint64_t lo = dir[m], hi = dir[m + 1]; // the answer lies in a block of [lo, hi]
-    uint64_t g = lo + (((r - (m << EB_SEL_SHIFT)) * (hi - lo + 1)) >> EB_SEL_SHIFT);
+    uint64_t g = lo + (((r - (m << sh)) * (hi - lo + 1)) >> sh);
     if (g > hi) g = hi;
     ++probes;
     for (;;) {
@@ -241,9 +244,10 @@ __device__ __forceinline__ uint64_t eb_select(const eb_dev_index& x, uint64_t r,
 // lane, and a wave holds 16 walks instead of 64, so fewer lanes wait for the walk that needs a third probe.
 __device__ __forceinline__ uint64_t eb_select_quad(const eb_dev_index& x, uint64_t r, int c, uint32_t j, uint32_t qbase, uint32_t& probes) {
     const uint32_t* dir = x.sel_dir + (c == 0 ? x.sel_off[0] : c == 1 ? x.sel_off[1] : c == 2 ? x.sel_off[2] : x.sel_off[3]);
-    uint64_t m = r >> EB_SEL_SHIFT;
+    const uint32_t sh = x.sel_shift;
+    uint64_t m = r >> sh;
     uint64_t lo = dir[m], hi = dir[m + 1]; // same address in all four lanes: one request
-    uint64_t g = lo + (((r - (m << EB_SEL_SHIFT)) * (hi - lo + 1)) >> EB_SEL_SHIFT);
+    uint64_t g = lo + (((r - (m << sh)) * (hi - lo + 1)) >> sh);
     if (g > hi) g = hi;
     ++probes;
     for (;;) {

@@ -207,8 +207,8 @@ __global__ void __launch_bounds__(TILE_BLOCKS) k_write_counters(uint4* __restric
     }
 }
 
-// Select directory: for each letter, the block that holds its (m * 1024)-th occurrence.  A block holds at most
-// 128 occurrences, so at most one sample per letter falls into it.
+// Select directory: for each letter, the block that holds its (m * 2^sel_shift)-th occurrence (a block holds at most 128
+// occurrences: up to four samples per letter fall into it at the dense sampling).
 __global__ void __launch_bounds__(256) k_select_dir(eb_dev_index x, uint32_t* __restrict__ dir) {
     uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= x.n_blocks) return;
@@ -216,8 +216,8 @@ __global__ void __launch_bounds__(256) k_select_dir(eb_dev_index x, uint32_t* __
     for (int c = 0; c < 4; ++c) {
         uint64_t before = eb_block_count(x, b, c);
         uint64_t in_block = (p >> (8 * c)) & 0xFFu;
-        // samples m * 2^EB_SEL_SHIFT that fall on an occurrence inside this block
-        for (uint64_t m = (before + (1ull << EB_SEL_SHIFT) - 1) >> EB_SEL_SHIFT; (m << EB_SEL_SHIFT) < before + in_block; ++m)
+        // samples m * 2^sel_shift that fall on an occurrence inside this block
+        for (uint64_t m = (before + (1ull << x.sel_shift) - 1) >> x.sel_shift; (m << x.sel_shift) < before + in_block; ++m)
             dir[x.sel_off[c] + m] = (uint32_t)b;
     }
 }
@@ -335,10 +335,15 @@ static int finish_index(eb_index* h, unsigned long long* d_bad, const uint8_t* d
     EB_HIP(hipFree(d_tmp));
     // select directory (eb_select): samples beyond a letter's last occurrence point at the last block
     if (h->n_blocks > 0xFFFFFFFFull) { eb_set_error("BWT too large for the 32-bit select directory"); return EB_ERR_ARG; }
+    // Sampling distance of the directory: the right-context walk reads one directory entry and then 1.24 (every 32nd occurrence)
+    // or 1.52 (every 128th) blocks per FL step; the dense form costs n/8 instead of n/32 bytes, which the largest inputs
+    // (BASELINE configs[4]: 151 G symbols, 277 of 309 GB of HBM in use) cannot spare.  EB_SEL_SHIFT=5..10 overrides.
+    h->sel_shift = h->n <= (1ull << 35) ? EB_SEL_SHIFT_DENSE : EB_SEL_SHIFT_SPARSE;
+    if (const char* e = getenv("EB_SEL_SHIFT")) { int v = atoi(e); if (v >= 5 && v <= 10) h->sel_shift = (uint32_t)v; }
     uint64_t sel_entries = 0;
     for (int c = 0; c < 4; ++c) {
         h->sel_off[c] = sel_entries;
-        sel_entries += (tot[c] >> EB_SEL_SHIFT) + 3;
+        sel_entries += (tot[c] >> h->sel_shift) + 3;
     }
     EB_HIP(hipMalloc(&h->d_sel_dir, sel_entries * sizeof(uint32_t)));
     h->device_bytes += sel_entries * sizeof(uint32_t);

@@ -47,6 +47,7 @@ struct eb_index {
     uint64_t n = 0, n_blocks = 0, n_super = 0;
     uint64_t F[4] = {0, 0, 0, 0};
     uint8_t term = '#';
+    uint32_t sel_shift = EB_SEL_SHIFT_SPARSE; // log2 of the select directory's sampling distance
     uint64_t device_bytes = 0;
     eb_scan_ctx* scan_ctx = nullptr;
     eb_dev_index dev() const {
@@ -60,6 +61,7 @@ struct eb_index {
         d.sel_dir = d_sel_dir;
         for (int i = 0; i < 4; ++i) d.sel_off[i] = sel_off[i];
         d.term = term;
+        d.sel_shift = sel_shift;
         return d;
     }
 };

@@ -136,6 +136,21 @@ def test_fl_is_inverse_of_lf(dip):
     assert np.array_equal(back, pos)
 
 
+@pytest.mark.parametrize("shift", ["5", "7", "10"])
+@pytest.mark.parametrize("name", ["dip.ebwt", "edge.ebwt", "het_m.ebwt"])
+def test_fl_under_every_select_sampling(oracle, monkeypatch, name, shift):
+    """The select directory samples every 32nd occurrence of a letter up to 2^35 symbols and every 128th beyond
+    (EB_SEL_SHIFT overrides): FL, and a whole run's .snp through the right-context walk, must not depend on it."""
+    monkeypatch.setenv("EB_SEL_SHIFT", shift)
+    e = golden_bytes(name)
+    g, o = api.DnaBwt(e), oracle.index(e)
+    pos = _rng(int(shift)).integers(g.F_arr[0], len(e), size=30_000, dtype=np.uint64)
+    assert np.array_equal(g.FL(pos), o.fl(pos))
+    if name == "dip.ebwt":
+        want, _ = oracle.run(e)
+        assert api.run_one_dataset(e) == want
+
+
 def test_lf_node(dip):
     e, g, o = dip
     r = _rng(6)
