@@ -373,6 +373,8 @@ def main():
         req_right.append(int(st.requests_right))
 
     sync()
+    if os.environ.get("EB_BENCH_TRACE") == "1":
+        log("[bench] timed region starts")
     t0 = time.perf_counter()
     calls, parts = run_steps(args.steps, record)
     sync()
@@ -382,6 +384,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
+    if os.environ.get("EB_BENCH_TRACE") == "1" and rank == 0:
+        log("[bench] per pass, ms (HIP events): scan " + " ".join(f"{v:.2f}" for v in scan_ms) + " | extend " + " ".join(f"{v:.2f}" for v in ext_ms)
+            + " | right " + " ".join(f"{v:.2f}" for v in right_ms) + " | begin..end " + " ".join(f"{v:.2f}" for v in tot_ms))
     # The same steps under the other delivery contract: a step counts as delivered when every rank's records are
     # resident in rank 0's HBM -- rank 0's PCIe download (35 MB per step at N = 8: ~0.65 ms, more than a rank's kernels) then runs
     # under the following steps and is no longer in the step.  Cadence of the "gathered" events on rank 0's stream.
@@ -617,7 +622,8 @@ def main():
     # profile was taken on the same launch size.  GB/s, the unit of `achieved`.
     traffic = ctx_traffic = rank_traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as fh:
+        pmc_path = next(q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_traffic.json") for r in (3, 2)) if os.path.exists(q))
+        with open(pmc_path) as fh:
             pmc = json.load(fh)
         same = abs(pmc["workload_positions"] - positions_per_launch) <= 0.01 * positions_per_launch
         if same and scan_avg_ms > 0:

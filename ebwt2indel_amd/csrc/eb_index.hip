@@ -89,6 +89,7 @@ void* eb_scratch_get(int device, size_t bytes, size_t* capacity) {
         eb_scratch_release(device); // give cached blocks back and retry once
         if (hipMalloc(&p, cap) != hipSuccess) return nullptr;
     }
+    if (getenv("EB_ALLOC_TRACE")) fprintf(stderr, "[scratch] hipMalloc of %.1f MB (no cached block fits)\n", cap / 1e6);
     *capacity = cap;
     return p;
 }
@@ -96,7 +97,7 @@ void* eb_scratch_get(int device, size_t bytes, size_t* capacity) {
 void eb_scratch_put(int device, void* p, size_t capacity) {
     if (!p) return;
     std::lock_guard<std::mutex> lk(g_scratch_mu);
-    if (g_scratch.size() < 64) { g_scratch.push_back({device, p, capacity}); return; }
+    if (g_scratch.size() < 512) { g_scratch.push_back({device, p, capacity}); return; }
     (void)hipFree(p);
 }
 

@@ -32,6 +32,7 @@ struct eb_scan_ctx {
     std::mutex half_mu;                          // half_job and the jobs' `half` flags
     struct eb_scan_job* half_job = nullptr;      // EB_SCAN_PIPELINED: the job whose last part is held back until the next _begin
     std::mutex pool_mu;                          // events / h_bad_pool: a job may be ended on one host thread while the next is begun on another
+    uint64_t scratch_reserved = 0;               // call-set size (clusters) a ring of device-scratch sets was reserved for (likewise)
     uint64_t pinned_reserved = 0;                // largest call-set size a ring of page-locked blobs was reserved for (EB_SCAN_PIPELINED callers)
 };
 void eb_scan_ctx_destroy(eb_scan_ctx* c);
@@ -132,7 +133,7 @@ struct eb_calls {
 };
 uint64_t eb_calls_blob_size(uint64_t count, uint64_t n_chains, int32_t k_left, int32_t k_right);
 // makes sure the pool of page-locked blobs holds `count` of at least `size` bytes (eb_writer.cpp)
-void eb_pinned_reserve(uint64_t size, int count);
+void eb_pinned_reserve(uint64_t size, int count, const void* d_warm, uint64_t warm_bytes);
 // allocates the blob (zeroed), fills the header and the section pointers; nullptr on failure (error set)
 eb_calls* eb_calls_alloc(uint64_t count, uint64_t n_chains, int32_t k_left, int32_t k_right, bool pinned);
 

@@ -18,6 +18,8 @@
 
 #include <stdlib.h>
 
+#include <chrono>
+
 #include "eb_internal.h"
 
 namespace {
@@ -1148,6 +1150,7 @@ void eb_scan_ctx_destroy(eb_scan_ctx* c) {
 }
 
 static int wire_enqueue(eb_scan_job* job, hipStream_t st, unsigned long long* h_bad, int version);
+static void begin_trace_at(const char* what); // EB_BEGIN_TRACE (see BeginTrace)
 
 // Part two of a phase-4 job: the context kernels, the hand-over of the call set (host blob or device image, wire image)
 // and the end event.  (Round 2 tried holding this part back until the NEXT job on the index had enqueued its scan, so that
@@ -1205,6 +1208,7 @@ static int launch_contexts(eb_scan_job* job) {
         EB_HIP(hipEventRecord(ctx->last_right, sC));
         EB_HIP(hipGetLastError());
     }
+    begin_trace_at("context-kernels");
     const uint64_t ns = job->ns, n_chains = job->n_chains;
     struct { int32_t k_left, k_right; } prm_{job->k_left, job->k_right};
     auto* prm = &prm_;
@@ -1236,16 +1240,36 @@ static int launch_contexts(eb_scan_job* job) {
         hipLaunchKernelGGL(k_req_sum, dim3(1), dim3(EB_REQ_SLOTS), 0, sD, x.cnt.as<ScanCounters>());
         EB_HIP(hipMemcpyAsync(job->h_bad + 1 + 2 * k, x.cnt.as<ScanCounters>()->req_sum, 16, hipMemcpyDeviceToHost, sD));
     }
+    if ((options & EB_SCAN_PIPELINED) && ns && job->sh.size() && ns > ctx->scratch_reserved + ctx->scratch_reserved / 8) {
+        // Several jobs of this size will be alive at once (begun, context kernels running, being handed over, being read) and each
+        // holds its own set of device temporaries.  The cache grows by one set whenever the number of live jobs reaches a new
+        // maximum -- a dozen hipMallocs, 16-19 ms, in the middle of the pipeline (round 3: one begin call of 19 ms among 2.9 ms
+        // ones, at a different step of every run).  A pipelining caller pays for a ring of sets once, with its first call set.
+        std::vector<std::pair<void*, size_t>> held;
+        for (int copy = 0; copy < 5; ++copy)
+            for (SubShard& x : job->sh)
+                for (DevMem* m : {&x.cnt, &x.part, &x.surv, &x.sorted, &x.bcnt, &x.boff, &x.tmp, &x.nch, &x.choff, &x.chains, &x.recs, &x.crec, &x.left, &x.right, &x.blob,
+                                  &x.rt_rec, &x.rt_right, &x.slots, &x.bcount}) {
+                    if (!m->p) continue;
+                    size_t cap = 0;
+                    void* q = eb_scratch_get(b1->device, m->cap - m->cap / 16, &cap); // a block of this job's class (a cached one of that class does as well)
+                    if (q) held.emplace_back(q, cap);
+                }
+        for (const auto& h : held) eb_scratch_put(b1->device, h.first, h.second);
+        ctx->scratch_reserved = ns;
+    }
     if (!device_only) {
         if ((options & EB_SCAN_PIPELINED) && ns) { // several call sets of this size will be alive at once: pin their blobs now, not in mid-pipeline
             const uint64_t need = eb_calls_blob_size(ns, n_chains, prm->k_left, prm->k_right);
             if (need > ctx->pinned_reserved) {
-                eb_pinned_reserve(need + need / 16, 8);
+                eb_pinned_reserve(need + need / 16, 8, job->has_blob ? sh[0].blob.p : nullptr, job->has_blob ? job->blob_bytes : 0);
                 ctx->pinned_reserved = need + need / 16;
             }
         }
+        begin_trace_at("reserves");
         calls = eb_calls_alloc(ns, n_chains, prm->k_left, prm->k_right, ns != 0);
         if (!calls) return EB_ERR_NOMEM;
+        begin_trace_at("host-blob");
         if (job->has_blob && ns) {
             EB_HIP(hipMemcpyAsync(calls->blob, sh[0].blob.p, job->blob_bytes, hipMemcpyDeviceToHost, sD));
         } else {
@@ -1288,6 +1312,7 @@ static int finish_begin(eb_scan_job* job) {
         x.chain_base = chain_total;
         if (x.ns_raw == 0) continue;
         EB_HIP(hipEventSynchronize(x.e[E_PREP_CNT]));
+        begin_trace_at("ordering-counts");
         x.ns = x.h_last[0];
         x.n_chains = x.h_last[1];
         if (x.ns == 0) continue;
@@ -1330,6 +1355,7 @@ static int finish_begin(eb_scan_job* job) {
     }
     job->ns = rec_total;
     job->n_chains = chain_total;
+    begin_trace_at("image-laid-out");
     return launch_contexts(job);
 }
 
@@ -1356,9 +1382,29 @@ static int ensure_begun(eb_scan_job* job) { // every entry point that takes a jo
     return job->rc_tail;
 }
 
+namespace {
+// EB_BEGIN_TRACE=<ms>: host-side timeline of every _begin call that takes longer than <ms> (stderr)
+struct BeginTrace {
+    double limit_ms = 0, t0 = 0;
+    char line[512];
+    size_t len = 0;
+    static double now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    BeginTrace() { if (const char* e = getenv("EB_BEGIN_TRACE")) { limit_ms = atof(e); t0 = now(); } line[0] = 0; }
+    void at(const char* what) {
+        if (limit_ms <= 0 || len > sizeof line - 48) return;
+        len += (size_t)snprintf(line + len, sizeof line - len, " %s %.2f", what, now() - t0);
+    }
+    ~BeginTrace() { if (limit_ms > 0 && now() - t0 > limit_ms) fprintf(stderr, "[begin] %.2f ms:%s\n", now() - t0, line); }
+};
+thread_local BeginTrace* g_begin_trace = nullptr;
+}  // namespace
+static void begin_trace_at(const char* what) { if (g_begin_trace) g_begin_trace->at(what); }
+
 extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f, uint64_t begin, uint64_t end, const eb_params* prm,
                                          uint32_t options, eb_scan_job** out_job) {
     if (!b1 || !f || !prm || !out_job) { eb_set_error("null argument"); return EB_ERR_ARG; }
+    BeginTrace bt;
+    struct TraceScope { TraceScope(BeginTrace* b) { g_begin_trace = b; } ~TraceScope() { g_begin_trace = nullptr; } } trace_scope(&bt);
     *out_job = nullptr;
     const uint64_t n = b1->n + (b2 ? b2->n : 0);
     if (f->n != n) { eb_set_error("flag vectors cover %llu positions, BWT has %llu", (unsigned long long)f->n, (unsigned long long)n); return EB_ERR_ARG; }
@@ -1606,7 +1652,9 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
     job->rw = rw;
     // EB_SCAN_PIPELINED: the previous job's last part goes out now, behind this job's scan: the host's wait for that job's
     // ordering counts and the wait for this scan below overlap instead of adding up
+    bt.at("scan-enqueued");
     if ((rc = finish_pending(ctx)) != EB_OK) return rc;
+    bt.at("pending-out");
     ScanCounters c;
     memset(&c, 0, sizeof c);
     bool small = true;
@@ -1615,6 +1663,7 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
         if (S == 1) x.h_last = reinterpret_cast<uint32_t*>(job->h_bad + 40); // the job's own pinned words: a held-back tail reads them later
         for (;;) {
             EB_HIP(hipEventSynchronize(x.e[E_SCAN_DONE]));
+            bt.at("scan-done");
             if (x.ordered) {
                 if (!x.h_cnt->spilled) break;
                 if (getenv("EB_SCAN_TRACE")) fprintf(stderr, "[scan] a batch of the ordered hand-over overflowed: scanning again unordered\n");
@@ -1718,6 +1767,7 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
         EB_HIP(hipEventRecord(x.e[E_PREP_CNT], sP));
         EB_HIP(hipGetLastError());
     }
+    bt.at("ordering-enqueued");
     job->c = c;
     ctx->last_small = small;
     // Last part: the call set's image, the chain list, the context kernels and the hand-over.  It needs the ordering
@@ -1729,6 +1779,7 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
         ctx->half_job = job;
     } else if ((rc = finish_begin(job)) != EB_OK)
         return rc;
+    bt.at("contexts-enqueued");
     *out_job = job;
     job = nullptr;
     return EB_OK;

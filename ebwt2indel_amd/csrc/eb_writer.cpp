@@ -274,6 +274,7 @@ void* pinned_get(uint64_t size, uint64_t* got) {
     void* p = nullptr;
     uint64_t cap = size + size / 4 + 4096;
     if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+    if (getenv("EB_ALLOC_TRACE")) fprintf(stderr, "[calls] pinned a new blob of %.1f MB (none of that size in the pool)\n", cap / 1e6);
     *got = cap;
     return p;
 }
@@ -286,10 +287,13 @@ uint64_t align8(uint64_t v) { return (v + 7) & ~7ull; }
 }  // namespace
 
 // A caller that keeps phase-4 jobs coming (EB_SCAN_PIPELINED) has several call sets alive at once -- begun, being handed over,
-// being read -- and each needs a page-locked blob; pinning one takes ~15-20 ms per 64 MB, which must not land in the middle of
-// the pipeline (round 3: one begin call of 17.8 ms among 2.9 ms ones whenever the number of live call sets reached a new
-// maximum).  Makes sure `count` blobs of at least `size` bytes are in the pool.
-void eb_pinned_reserve(uint64_t size, int count) {
+// being read -- and each needs a page-locked blob.  Pinning one takes ~6 ms per 80 MB; and the first time a device-to-host copy is
+// issued while another one is still running, the host sits 12-28 ms inside hipMemcpyAsync (EB_BEGIN_TRACE, round 3: one begin
+// call of 19-30 ms among 2.9 ms ones, at a different step of every run, not under the profiler where copies are kernels): the
+// runtime opens a further copy-engine queue on first need.  Neither may land in the middle of the pipeline: makes sure `count`
+// blobs of at least `size` bytes are in the pool, and runs throw-away copies from `d_warm` into the new ones, four at a time on
+// four streams, so that the queues a pipelined caller will need exist before its second call.
+void eb_pinned_reserve(uint64_t size, int count, const void* d_warm, uint64_t warm_bytes) {
     std::vector<std::pair<void*, uint64_t>> fresh;
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
@@ -301,6 +305,16 @@ void eb_pinned_reserve(uint64_t size, int count) {
         const uint64_t cap = size + size / 4 + 4096;
         if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) break;
         fresh.emplace_back(p, cap);
+    }
+    if (d_warm && warm_bytes && !fresh.empty()) {
+        hipStream_t st[4] = {nullptr, nullptr, nullptr, nullptr};
+        bool ok = true;
+        for (auto& s : st) ok = ok && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess;
+        if (ok)
+            for (size_t i = 0; i < fresh.size(); ++i)
+                (void)hipMemcpyAsync(fresh[i].first, d_warm, warm_bytes < fresh[i].second ? warm_bytes : fresh[i].second, hipMemcpyDeviceToHost, st[i % 4]);
+        for (auto& s : st)
+            if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
     }
     for (const auto& e : fresh) pinned_put(e.first, e.second);
 }

@@ -9,7 +9,8 @@ src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 # run on the GPU box by scripts/profile_round.sh (the per-dispatch counter tables are too large to travel back):
 # the summary goes next to them, under gpurun_out/, and is copied to profiles/ by hand
 dst_dir = sys.argv[2] if len(sys.argv) > 2 else os.path.join(root, "profiles")
-KERNELS = {"k_scan<1>": r"k_scan<1>", "k_extend": r"k_extend", "k_right": r"k_right", "k_nodes<1>": r"k_nodes<1>", "k_nodes1p": r"k_nodes1p",
+KERNELS = {"k_scan<1>": r"k_scan<1",   # k_scan<1, false> / <1, true> since round 3 (second parameter: tile loads one tile ahead)
+            "k_extend": r"k_extend", "k_right": r"k_right", "k_nodes<1>": r"k_nodes<1>", "k_nodes1p": r"k_nodes1p",
            "k_leaves<1>": r"k_leaves<1>", "k_rank4_batch": r"k_rank4_batch", "k_long_runs": r"k_long_runs"}
 
 
@@ -86,7 +87,7 @@ sizes = {}
 for kern in ("k_scan<1>", "k_extend", "k_right"):
     e = {}
     for cn in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"):
-        v = one("rdreq_bench", cn, kern)
+        v = one("rdreq_bench", cn, KERNELS.get(kern, kern))
         if v:
             e[cn] = sum(v) / len(v)
     if e:
