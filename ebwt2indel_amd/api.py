@@ -293,7 +293,8 @@ class Calls:
         cn, ev = C.c_uint64(cluster_nr), C.c_uint64(events)
         txt, ln = C.c_void_p(), C.c_uint64(0)
         _check(lib().eb_format_snp(self._h, C.byref(params), int(two_samples), C.byref(cn), C.byref(ev), C.byref(txt), C.byref(ln)))
-        out = C.string_at(txt, ln.value)
+        # (ctypes.string_at takes the length as a C int: the text of a 151 G-position call set is past 2 GB)
+        out = bytes((C.c_char * ln.value).from_address(txt.value)) if ln.value else b""
         lib().eb_free(txt)
         return out, cn.value, ev.value
 

@@ -182,6 +182,7 @@ def two_samples(genome_len: int, n_reads_each: int, read_len: int, seed: int, he
 # --------------------------------------------------------------------------- GPU generator (benchmark scale)
 
 _GEN_SRC = os.path.join(_HERE, "tools", "ebwt_gen.hip")
+_GEN_SLABS_SRC = os.path.join(_HERE, "tools", "ebwt_gen_slabs.hip")   # the slab-by-slab generator (inputs whose keys do not fit one GPU at once)
 _GEN_SO = os.path.join(_BUILD, "libebwt_gen.so")
 _gen = None
 
@@ -189,9 +190,9 @@ _gen = None
 def build_gpu_tool(force: bool = False) -> str:
     """Compile the GPU eBWT generator (hipcc, gfx950)."""
     os.makedirs(_BUILD, exist_ok=True)
-    if force or not os.path.exists(_GEN_SO) or os.path.getmtime(_GEN_SO) < os.path.getmtime(_GEN_SRC):
+    if force or not os.path.exists(_GEN_SO) or os.path.getmtime(_GEN_SO) < max(os.path.getmtime(_GEN_SRC), os.path.getmtime(_GEN_SLABS_SRC)):
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC",
-                               "-Wl,-rpath,/opt/rocm/lib", "-o", _GEN_SO, _GEN_SRC])
+                               "-Wl,-rpath,/opt/rocm/lib", "-o", _GEN_SO, _GEN_SRC, _GEN_SLABS_SRC])
     return _GEN_SO
 
 
@@ -213,6 +214,17 @@ def _gpu_tool():
         _gen.ebgen_build.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint8,
                                      ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
                                      ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double)]
+        _gen.ebgen_slabs_last_error.restype = ctypes.c_char_p
+        _gen.ebgen_build_slabbed.restype = ctypes.c_int
+        _gen.ebgen_build_slabbed.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint32,
+                                             ctypes.c_uint8, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
+                                             ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double),
+                                             ctypes.POINTER(ctypes.c_uint64), ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p,
+                                             ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
+        _gen.ebgen_synth_diploid.restype = ctypes.c_int
+        _gen.ebgen_synth_diploid.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint32,
+                                             ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_void_p),
+                                             ctypes.POINTER(ctypes.c_uint64)]
     return _gen
 
 
@@ -289,6 +301,89 @@ def build_ebwt_gpu(text: np.ndarray, starts: np.ndarray, read_len: int, term: in
     if rc != 0:
         raise RuntimeError(f"ebgen_build failed ({rc}): {g.ebgen_last_error().decode()}")
     return DeviceEbwt(d_bwt.value, d_da.value if want_da else None, n.value, list(tm))
+
+
+class DeviceSample:
+    """A diploid sample made on the GPU (ebgen_synth_diploid): text = haplotype 1, byte 1, haplotype 2, byte 2; free() releases it."""
+
+    def __init__(self, text_ptr, text_len, starts_ptr, n_reads, read_len, genome_len, hap2_len):
+        self.text_ptr, self.text_len, self.starts_ptr, self.n_reads, self.read_len = text_ptr, text_len, starts_ptr, n_reads, read_len
+        self.genome_len, self.hap2_len = genome_len, hap2_len
+
+    def text_to_host(self):
+        out = np.empty(self.text_len, dtype=np.uint8)
+        _hip_copy_to_host(out, self.text_ptr, self.text_len)
+        return out
+
+    def starts_to_host(self):
+        out = np.empty(self.n_reads, dtype=np.uint64)
+        _hip_copy_to_host(out, self.starts_ptr, self.n_reads * 8)
+        return out
+
+    def free(self):
+        g = _gpu_tool()
+        for a in ("text_ptr", "starts_ptr"):
+            if getattr(self, a):
+                g.ebgen_free(getattr(self, a))
+                setattr(self, a, None)
+
+
+def synth_diploid_gpu(genome_len: int, n_reads: int, read_len: int, seed: int, snp_every: int = 500, indel_every: int = 2000, max_indel: int = 3,
+                      device: int = 0) -> DeviceSample:
+    """The recipe of diploid_sample() evaluated on the GPU with a counter-based generator (5 Gb genomes in a second; another
+    random stream than the host recipe's, so the two do not produce the same sample)."""
+    g = _gpu_tool()
+    d_text, d_starts, m, h2 = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_uint64(0), ctypes.c_uint64(0)
+    rc = g.ebgen_synth_diploid(genome_len, seed, snp_every, indel_every, max_indel, n_reads, read_len, device, ctypes.byref(d_text), ctypes.byref(m),
+                               ctypes.byref(d_starts), ctypes.byref(h2))
+    if rc != 0:
+        raise RuntimeError(f"ebgen_synth_diploid failed ({rc}): {g.ebgen_slabs_last_error().decode()}")
+    return DeviceSample(d_text.value, m.value, d_starts.value, n_reads, read_len, genome_len, h2.value)
+
+
+def build_ebwt_gpu_slabbed(text, starts, read_len: int, term: int = 35, n_first: Optional[int] = None, want_da: bool = False, device: int = 0,
+                           prefix_len: int = -1, group_len: int = -1, n_reads: Optional[int] = None, text_len: Optional[int] = None,
+                           lcp_truth: Optional[Tuple[int, int]] = None) -> DeviceEbwt:
+    """Like build_ebwt_gpu, through the slab-by-slab generator (tools/ebwt_gen_slabs.hip): nothing of the size of the output but
+    the output itself is resident, and the text may have 2^32 symbols or more.  `text` / `starts`: numpy arrays, or device
+    pointers (int) with text_len / n_reads.  The returned object carries .info = (P, Pg, max rows of a group, max keys of a slab).
+    lcp_truth = (K, k_right): the generator also states the collection's LCP bit vectors by their DEFINITION (common prefixes of
+    adjacent read suffixes, from the text's suffix order) -- .truth = device pointers of thrK, thrR, minima ((n + 63) // 64 + 1 words
+    each, release with free_truth()), .unknown = rows whose minimum bit it leaves undecided (the edges of slabs and short blocks)."""
+    g = _gpu_tool()
+    text_dev, starts_dev = isinstance(text, int), isinstance(starts, int)
+    if not text_dev:
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        text_len = len(text)
+    if not starts_dev:
+        starts = np.ascontiguousarray(starts, dtype=np.uint64)
+        n_reads = len(starts)
+    d_bwt, d_da, n = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_uint64(0)
+    tm = (ctypes.c_double * 5)()
+    info = (ctypes.c_uint64 * 4)()
+    truth = (ctypes.c_void_p * 3)()
+    unknown = np.zeros(3 * (4 ** 6 + 4 ** 6 // 3 + 2) if lcp_truth else 1, dtype=np.uint64)
+    n_unknown = ctypes.c_uint64(0)
+    rc = g.ebgen_build_slabbed(ctypes.c_void_p(text) if text_dev else text.ctypes.data, text_len, int(text_dev),
+                               ctypes.c_void_p(starts) if starts_dev else starts.ctypes.data, n_reads, int(starts_dev), read_len, term,
+                               n_reads if n_first is None else n_first, prefix_len, group_len, device, ctypes.byref(d_bwt),
+                               ctypes.byref(d_da) if want_da else None, ctypes.byref(n), tm, info,
+                               lcp_truth[0] if lcp_truth else 0, lcp_truth[1] if lcp_truth else 0, truth if lcp_truth else None,
+                               unknown.ctypes.data, len(unknown), ctypes.byref(n_unknown))
+    if rc != 0:
+        raise RuntimeError(f"ebgen_build_slabbed failed ({rc}): {g.ebgen_slabs_last_error().decode()}")
+    out = DeviceEbwt(d_bwt.value, d_da.value if want_da else None, n.value, list(tm))
+    out.info = tuple(int(v) for v in info)
+    out.truth = [truth[i] for i in range(3)] if lcp_truth else None
+    out.unknown = np.unique(unknown[:n_unknown.value]) if lcp_truth else None
+
+    def free_truth():
+        for ptr in out.truth or []:
+            if ptr:
+                g.ebgen_free(ctypes.c_void_p(ptr))
+        out.truth = None
+    out.free_truth = free_truth
+    return out
 
 
 def replicated_ebwt_gpu(n_reads: int, read_len: int, coverage: float, copies: int, seed: int, device: int = 0):
