@@ -226,6 +226,76 @@ oindex* orc_index_from_buffer_mt(const uint8_t* ascii, uint64_t n, uint8_t term,
     orc_index_build_select(x);
     return x;
 }
+/* The same index fed in PIECES (checker for inputs whose ASCII form does not fit the host next to the index: BASELINE
+ * configs[4], 151 G symbols, comes off the GPU a few GB at a time).  begin -> append (pieces start on a multiple of 128, any
+ * order, each position once; packed by `threads` threads, every block keeping its OWN letter counts for the moment) ->
+ * finish (own counts -> counts before the block inside its superblock, superblock table, F, select directory).
+ * Bit-identical to orc_index_from_buffer's (tests/test_oracle_threads.py). */
+oindex* orc_index_stream_begin(uint64_t n, uint8_t term) {
+    oindex* x = (oindex*)calloc(1, sizeof *x);
+    x->n = n;
+    x->term = term;
+    x->nblocks = (n + 1 + 127) / 128;
+    x->nsuper = (n + 1 + 0xFFFFFFFFull) >> 32;
+    x->blk = (oblock*)aligned_alloc(64, x->nblocks * sizeof(oblock));
+    x->super = (rank4_t*)calloc(x->nsuper, sizeof(rank4_t));
+    x->bad_pos = UINT64_MAX;
+    if (!x->blk || !x->super) { orc_index_free(x); return NULL; }
+    return x;
+}
+int orc_index_stream_append(oindex* x, uint64_t pos, const uint8_t* ascii, uint64_t len, int threads) {
+    if (!x || (pos & 127) || pos + len > x->n || ((len & 127) && pos + len != x->n)) return -1;
+    const uint64_t n = x->n, b0 = pos >> 7, b1 = (pos + len + 127) >> 7;
+    uint64_t bad_pos = x->bad_pos;
+#pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : 1)
+    for (long long bb = (long long)b0; bb < (long long)b1; ++bb) {
+        const uint64_t b = (uint64_t)bb, base = b * 128;
+        oblock* k = &x->blk[b];
+        memset(k, 0, sizeof *k);
+        for (uint64_t j = 0; j < 128 && base + j < n && base + j < pos + len; ++j) {
+            int code = sym_code(ascii[base + j - pos], x->term);
+            if (code < 0) {
+                uint64_t seen = __atomic_load_n(&bad_pos, __ATOMIC_RELAXED);
+                while (base + j < seen && !__atomic_compare_exchange_n(&bad_pos, &seen, base + j, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+                continue;
+            }
+            uint64_t m = 1ull << (j & 63);
+            if (code & 1) k->b0[j >> 6] |= m;
+            if (code & 2) k->b1[j >> 6] |= m;
+            if (code & 4) k->b2[j >> 6] |= m;
+            if (code < 4) k->cnt[code]++;
+        }
+    }
+    if (bad_pos < x->bad_pos) { x->bad_pos = bad_pos; x->bad_sym = ascii[bad_pos - pos]; }
+    return 0;
+}
+int orc_index_stream_finish(oindex* x, int threads) {
+    if (!x) return -1;
+    if (x->bad_pos != UINT64_MAX) { x->n = UINT64_MAX; return -3; }
+    x->bad_pos = 0;
+    /* the last block(s) behind the text (nblocks covers n + 1 positions) were never appended when n is a multiple of 128 */
+    if (((x->n + 127) >> 7) < x->nblocks) memset(&x->blk[(x->n + 127) >> 7], 0, (x->nblocks - ((x->n + 127) >> 7)) * sizeof(oblock));
+    uint64_t* tot = (uint64_t*)calloc(x->nsuper * 4, 8);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads > 0 ? threads : 1)
+    for (long long s = 0; s < (long long)x->nsuper; ++s) {
+        uint64_t b1 = ((uint64_t)s + 1) << 25;
+        if (b1 > x->nblocks) b1 = x->nblocks;
+        uint64_t rel[4] = {0, 0, 0, 0};
+        for (uint64_t b = (uint64_t)s << 25; b < b1; ++b)
+            for (int q = 0; q < 4; ++q) { uint32_t own = x->blk[b].cnt[q]; x->blk[b].cnt[q] = (uint32_t)rel[q]; rel[q] += own; }
+        for (int q = 0; q < 4; ++q) tot[4 * s + q] = rel[q];
+    }
+    uint64_t abs4[4] = {0, 0, 0, 0};
+    for (uint64_t s = 0; s < x->nsuper; ++s)
+        for (int q = 0; q < 4; ++q) { x->super[s].v[q] = abs4[q]; abs4[q] += tot[4 * s + q]; }
+    free(tot);
+    x->F[0] = x->n - (abs4[0] + abs4[1] + abs4[2] + abs4[3]);
+    x->F[1] = x->F[0] + abs4[0];
+    x->F[2] = x->F[1] + abs4[1];
+    x->F[3] = x->F[2] + abs4[2];
+    orc_index_build_select(x);
+    return 0;
+}
 /* whole-index comparison for the test of the threaded builder */
 int orc_index_equal(const oindex* a, const oindex* b) {
     return a->n == b->n && a->nblocks == b->nblocks && a->nsuper == b->nsuper && !memcmp(a->F, b->F, sizeof a->F) &&

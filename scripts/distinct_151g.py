@@ -12,7 +12,9 @@ No CPU checker fits the box at this size (host-memory cap, DESIGN.md section 4);
     bit vectors themselves against an INDEPENDENT statement of them: the generator knows the suffix order of the text, so it writes
     thrK / thrR / minima from the definition (common prefixes of adjacent read suffixes; held to the CPU oracle on small inputs in
     tests/test_gpu_generator.py) and the traversal's vectors must equal them bit for bit over all 151 G positions;
-  * phase 4: the whole-range call set equals the concatenation of 8 shards' call sets (the N = 8 ownership rule);
+  * phase 4: identical to the CPU ORACLE's on windows around every superblock boundary, both ends and random places (records with
+    their contexts, text) -- the oracle's index is streamed off the GPU in pieces (orc_index_stream_*), its bit vectors are the
+    ones just verified; and the whole-range call set equals the concatenation of 8 shards' call sets (the N = 8 ownership rule);
   * every called SNP against the TRUTH the sample was made from is out of scope here (post-processing); the record count is
     compared with 20 x config 2's.
 
@@ -32,12 +34,17 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import torch  # noqa: E402
 
+from concurrent.futures import ThreadPoolExecutor  # noqa: E402
+
 from ebwt2indel_amd import api, sim  # noqa: E402
 from ebwt2indel_amd import distributed as ebd  # noqa: E402
+from tests import _oracle  # noqa: E402  (the checker; this script is test tooling, not product)
 
 READS = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000_000
 READ_LEN, COVERAGE, SEED = 150, 30.0, 1
 DECODE = 200_000          # reads spelled back through the index
+THREADS = min(64, os.cpu_count() or 8)
+WINDOW = 1 << 21          # positions per oracle window of phase 4
 T0 = time.time()
 
 
@@ -126,6 +133,22 @@ def main():
     log(f"F = symbol counts ({terms} terminators); parallel_rank = prefix counts of the ASCII symbols at {checked} positions around {len(edges)} superblock boundaries; "
         f"operator[] at {len(acc)} random positions ({time.time() - t0:.1f}s)")
     res.update(rank_positions_checked_against_definition=int(checked), access_positions_checked=int(len(acc)))
+    # ---- the CPU oracle's index of the same eBWT, fed in pieces (the ASCII form would not fit the host beside it)
+    t0 = time.time()
+    orc = _oracle.Oracle()
+    oidx = _oracle.OracleIndex.stream(orc, n)
+    piece = 1 << 30
+    buf = np.empty(piece, dtype=np.uint8)
+    for x in range(0, n, piece):
+        ln = min(piece, n - x)
+        sim._hip_copy_to_host(buf[:ln], dev.ptr + x, ln)
+        oidx.append(x, buf[:ln], threads=THREADS)
+    del buf
+    oidx.finish(threads=THREADS)
+    assert oidx.ok and [int(v) for v in oidx.F()] == [int(v) for v in F]
+    probe = rng.integers(0, n + 1, size=100_000, dtype=np.uint64)
+    assert np.array_equal(oidx.rank4(probe), bwt.parallel_rank(probe))
+    log(f"oracle index streamed off the GPU and built on {THREADS} host threads in {time.time() - t0:.1f}s; F and {len(probe)} random parallel_rank queries equal the GPU's")
     del ascii_t
     dev.free()
     torch.cuda.empty_cache()
@@ -187,13 +210,42 @@ def main():
     mask_b = ~(np.uint64(1) << (unknown & np.uint64(63)))
     mine = minima[:words]
     undecided_set = int(((mine[mask_w] >> (unknown & np.uint64(63))) & np.uint64(1)).sum())
+    uw = np.unique(mask_w)
+    saved = mine[uw].copy()
     np.bitwise_and.at(mine, mask_w, mask_b)
     assert np.array_equal(mine, truth[2]), "minima differ from the local minima of the LCP by definition"
+    mine[uw] = saved                                                    # the traversal's own bits again: the oracle windows below use them
     ones = [int(sum(int(np.bitwise_count(v[i:i + (1 << 27)]).sum(dtype=np.uint64)) for i in range(0, len(v), 1 << 27))) for v in (truth[0], truth[1])]
     log(f"thrK ({ones[0]} ones), thrR ({ones[1]} ones) equal LCP >= {p.K} / >= {p.k_right} BY DEFINITION bit for bit over all {n} positions; minima equal the LCP's local minima "
         f"at all but the {len(unknown)} undecided rows ({undecided_set} of them set by the traversal) ({time.time() - t0:.1f}s)")
     res.update(thrK_thrR_equal_definition=True, minima_equal_definition_except_rows=int(len(unknown)), thrK_ones=ones[0], thrR_ones=ones[1])
-    del thrK, thrR, minima, mine, truth
+    del mine, truth
+
+    # ---- phase 4 against the CPU oracle on windows: its scan + cluster analysis + context extension (the reference's algorithm) over
+    # its own index, with the bit vectors just verified
+    t0 = time.time()
+    of = _oracle.OracleFlags(orc, oidx, vectors=(thrK, thrR, minima))
+    del thrK, thrR, minima
+    po = _oracle.Params.from_args()
+    wrng = np.random.Generator(np.random.PCG64(7))
+    centres = [k << 32 for k in range(1, int(n >> 32) + 1)] + [WINDOW // 2, n - WINDOW // 2] + [int(v) for v in wrng.integers(WINDOW, n - WINDOW, size=12)]
+    windows = sorted({(max(0, (c - WINDOW // 2) // 64 * 64), min(n, (c - WINDOW // 2) // 64 * 64 + WINDOW)) for c in centres})
+    with ThreadPoolExecutor(min(THREADS, len(windows))) as ex:
+        wants = list(ex.map(lambda be: of.scan(po, be[0], be[1], capture=True), windows))
+    recs = 0
+    for (wb, we), want_w in zip(windows, wants):
+        c = api.scan_clusters(bwt, flags, p, begin=wb, end=we)
+        cl, chains, left, right = c.arrays()
+        assert len(c) == want_w["count"], (wb, we, len(c), want_w["count"])
+        assert np.array_equal(cl, want_w["clusters"]) and np.array_equal(chains, want_w["chains"]), (wb, we)
+        assert np.array_equal(left, want_w["left"]) and np.array_equal(right, want_w["right"]), (wb, we)
+        t, _, _ = c.format_snp(p, False)
+        assert t == want_w["text"], (wb, we)
+        recs += t.count(b">")
+    log(f"phase 4 on {len(windows)} windows of {WINDOW} positions (every superblock boundary, both ends, 12 random places) identical to the CPU oracle's: "
+        f"{sum(w['count'] for w in wants)} clusters with their contexts, {recs} records ({time.time() - t0:.1f}s)")
+    res.update(phase4_oracle_windows=len(windows), window_positions=WINDOW, window_clusters=int(sum(w["count"] for w in wants)), window_records=int(recs), oracle_threads=THREADS)
+    del of, oidx, wants
 
     # ---- phase 4: whole range vs 8 shards
     t0 = time.time()
@@ -218,8 +270,9 @@ def main():
         res.update(snp_records_over_config2=round(ev_whole / base["snp_records"], 3))
     res["checks"] = ("reads spelled back through the index, rank = prefix counts of the ASCII symbols around every superblock boundary, operator[], F = symbol counts, "
                      "FL/LF round trips, every LCP slot written once (count + power sums), 8 shards == whole")
-    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", f"distinct_reads_{READS}.json"), "w") as f:
+    out = os.environ.get("EB_DISTINCT_OUT") or os.path.join(ROOT, "gpurun_out", f"distinct_reads_{READS}.json")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    with open(out, "w") as f:
         json.dump(res, f, indent=1)
     log(json.dumps(res))
 

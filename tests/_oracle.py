@@ -92,6 +92,10 @@ class Oracle:
         L.orc_index_from_buffer_mt.restype = vp
         L.orc_index_from_buffer_mt.argtypes = [vp, u64, u8, C.c_int]
         L.orc_index_equal.argtypes = [vp, vp]
+        L.orc_index_stream_begin.restype = vp
+        L.orc_index_stream_begin.argtypes = [u64, u8]
+        L.orc_index_stream_append.argtypes = [vp, u64, vp, u64, C.c_int]
+        L.orc_index_stream_finish.argtypes = [vp, C.c_int]
         L.orc_navigate_two.restype = vp
         L.orc_navigate_two.argtypes = [vp, vp, C.c_int, C.c_int]
         L.orc_navigate_two_mt.restype = vp
@@ -151,6 +155,26 @@ class OracleIndex:
         self.ok = bool(orc.lib.orc_index_ok(self.h))
         self.n = len(self.buf)
         self.term = term
+
+    @classmethod
+    def stream(cls, orc, n, term=35):
+        """An index fed in pieces (orc_index_stream_*): append(pos, piece) for every piece, then finish(threads).  For inputs whose
+        ASCII form does not fit the host beside the index (151 G symbols come off the GPU a few GB at a time)."""
+        self = cls.__new__(cls)
+        self.o, self.buf, self.n, self.term, self.ok = orc, None, n, term, False
+        self.h = orc.lib.orc_index_stream_begin(n, term)
+        assert self.h, "out of host memory for the oracle index"
+        return self
+
+    def append(self, pos, piece, threads=1):
+        piece = _u8(piece)
+        rc = self.o.lib.orc_index_stream_append(self.h, pos, piece.ctypes.data, len(piece), threads)
+        assert rc == 0, f"piece [{pos}, {pos + len(piece)}) refused: pieces start on multiples of 128 and only the last may end elsewhere"
+
+    def finish(self, threads=1):
+        self.o.lib.orc_index_stream_finish(self.h, threads)
+        self.ok = bool(self.o.lib.orc_index_ok(self.h))
+        return self
 
     def __del__(self):
         try:

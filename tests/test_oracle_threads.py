@@ -85,3 +85,29 @@ def test_sharded_scan_renumbered_equals_the_reference_snp(oracle, name, shards):
         parts = list(ex.map(lambda be: fl.scan(p, be[0], be[1]), cuts))
     text = fs.renumber([r["text"] for r in parts], [r["cluster_nr"] - 1 for r in parts])
     assert text == golden_bytes(case["snp"])
+
+
+@pytest.mark.parametrize("n,piece", [(128 * 1000, 128 * 77), (128 * 1000 + 55, 128 * 300), (999, 128), (1 << 22, 1 << 20), ((1 << 25) * 3 + 17, (1 << 25) + 128)])
+def test_streamed_index_equals_the_one_built_from_a_buffer(oracle, n, piece):
+    """orc_index_stream_*: the index fed in pieces (how the 151 G-symbol eBWT of BASELINE configs[4] reaches the oracle: it comes off
+    the GPU a few GB at a time and would not fit the host beside the index): bit-identical, whatever the order of the pieces, n a
+    multiple of the block size or not; a bad symbol is reported with its position."""
+    rng = np.random.Generator(np.random.PCG64(n))
+    e = np.frombuffer(b"ACGT#", dtype=np.uint8)[rng.integers(0, 5, size=n)]
+    want = oracle.index(e)
+    x = _oracle.OracleIndex.stream(oracle, n)
+    cuts = list(range(0, n, piece))
+    for pos in reversed(cuts):
+        x.append(pos, e[pos:pos + piece], threads=3)
+    x.finish(threads=3)
+    assert x.ok and oracle.lib.orc_index_equal(want.h, x.h)
+    pos = rng.integers(0, n + 1, size=5000, dtype=np.uint64)
+    assert np.array_equal(x.rank4(pos), want.rank4(pos))
+    if n > 5000:
+        e = e.copy()
+        e[4321] = ord("N")
+        y = _oracle.OracleIndex.stream(oracle, n)
+        for pos in cuts:
+            y.append(pos, e[pos:pos + piece], threads=2)
+        y.finish(threads=2)
+        assert not y.ok and y.bad() == (ord("N"), 4321)
