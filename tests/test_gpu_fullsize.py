@@ -50,3 +50,22 @@ def test_full_size_config_equals_the_oracle_record(name):
             assert hashlib.sha256(got["text"]).hexdigest() == want[key]["oracle_snp_sha256"], key
             assert got["cluster_numbers"] == want[key]["cluster_numbers"], key
         assert fs.renumber([h["text"] for h in halves], [h["cluster_numbers"] for h in halves]) == res.text
+
+
+def test_slabbed_generator_reproduces_the_recorded_config2_input():
+    """The slab-by-slab generator (tools/ebwt_gen_slabs.hip, what builds the 151 G-position input of configs[4]) at 7.55 G positions: the
+    bench's reads through it give the very bytes the one-pass generator gave -- the input whose SHA-256 the oracle record holds."""
+    from ebwt2indel_amd import sim
+    want = _expected("config2")["input"]
+    reads = want["reads_per_collection"]
+    glen = int(reads * fs.READ_LEN / 30.0)
+    g = sim.random_genome(glen, 1)
+    h2 = sim.mutate_haplotype(g, 1)
+    text, offs = sim.haplotype_text([g, h2])
+    starts = sim.sample_read_starts([g, h2], offs, reads, fs.READ_LEN, 1)
+    del g, h2
+    dev = sim.build_ebwt_gpu_slabbed(text, starts, fs.READ_LEN)
+    host, _ = dev.to_host()
+    dev.free()
+    assert [len(host)] == want["n"]
+    assert fs.sha256(host) == want["ebwt_sha256"][0]
