@@ -153,7 +153,7 @@ def main():
 
     # ---------------- synthetic workload (SURVEY.md 8d recipe), identical on every rank:
     # random genome, second haplotype with a SNP / 500 bp and a 1-3 bp indel / 2 kb, error-free reads alternating
-    # between the haplotypes.  The eBWT is built on this rank's GPU (ebwt2indel_amd/tools/ebwt_gen.hip) and never
+    # between the haplotypes.  The eBWT is built on this rank's GPU (ebwt2indel_amd/tools/ebwt_gen_slabs.hip) and never
     # leaves HBM: generator output -> eb_index_create_from_device.
     genome_len = int(args.reads * args.read_len / args.coverage)
     threads = max(1, (os.cpu_count() or 8) // max(1, world))
@@ -165,7 +165,10 @@ def main():
     del g, h2
     t_host = time.time() - t0
     t0 = time.time()
-    dev_ebwt = sim.build_ebwt_gpu(text, starts, args.read_len, device=local)
+    # (the slab-by-slab generator since round 3: 1.2 s instead of 6 s at this size and a tenth of the temporaries; the same bytes --
+    # tests/test_gpu_fullsize.py holds both generators to the recorded SHA-256 of this input; EB_BENCH_ONE_PASS_GENERATOR=1: the old one)
+    build = sim.build_ebwt_gpu if os.environ.get("EB_BENCH_ONE_PASS_GENERATOR") == "1" else sim.build_ebwt_gpu_slabbed
+    dev_ebwt = build(text, starts, args.read_len, device=local)
     n = dev_ebwt.n
     t_gen = time.time() - t0
     del text, starts

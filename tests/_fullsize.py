@@ -76,7 +76,7 @@ class Inputs:
         with ThreadPoolExecutor(2) as ex:            # the host copies are hashed while the GPU goes on
             for starts, n_first, want_da in groups:
                 t0 = time.time()
-                dev = sim.build_ebwt_gpu(text, starts, READ_LEN, n_first=n_first, want_da=want_da)
+                dev = sim.build_ebwt_gpu_slabbed(text, starts, READ_LEN, n_first=n_first, want_da=want_da)   # same bytes as the one-pass generator the records were made with (input SHA-256 below)
                 t_gen += time.time() - t0
                 host, da = dev.to_host()
                 shas.append(ex.submit(sha256, host))
