@@ -9,7 +9,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ARGS = ["--reads", "300000", "--steps", "2", "--warmup", "1", "--rank-queries", "1048576"]
+ARGS = ["--reads", "300000", "--steps", "2", "--warmup", "1", "--rank-queries", "1048576", "--cpu-dram-reads", "0"]
 
 
 def _last_json(out: str):
@@ -19,7 +19,8 @@ def _last_json(out: str):
 
 
 def test_bench_contract_single_gpu():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-sample-reads", "20000"] + ARGS,
+    # (the DRAM-resident leg of the CPU baseline at a size that keeps the test short; the other tests here skip it)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-sample-reads", "20000"] + ARGS[:-1] + ["300000"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
@@ -30,6 +31,7 @@ def test_bench_contract_single_gpu():
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["peak"] == 8000.0
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["snp_identical_to_gpu"]
+    assert d["cpu_baseline"]["dram_resident"]["snp_identical_to_gpu"]
     assert d["snp_records"] > 1000
     pytest.single_gpu_sha = d["snp_sha256"]
 
