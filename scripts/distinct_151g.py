@@ -204,8 +204,11 @@ def main():
     # ---- the traversal's bit vectors against the generator's statement of them
     t0 = time.time()
     thrK, thrR, minima, _ = flags.export()
+    ones = [int(sum(int(np.bitwise_count(v[i:i + (1 << 27)]).sum(dtype=np.uint64)) for i in range(0, len(v), 1 << 27))) for v in (truth[0], truth[1])]
     assert np.array_equal(thrK[:words], truth[0]), "thrK differs from LCP >= K by definition"
+    truth[0] = None                                                      # (host memory: each statement is dropped once it has been compared)
     assert np.array_equal(thrR[:words], truth[1]), "thrR differs from LCP >= k_right by definition"
+    truth[1] = None
     mask_w = (unknown >> np.uint64(6)).astype(np.int64)
     mask_b = ~(np.uint64(1) << (unknown & np.uint64(63)))
     mine = minima[:words]
@@ -215,7 +218,6 @@ def main():
     np.bitwise_and.at(mine, mask_w, mask_b)
     assert np.array_equal(mine, truth[2]), "minima differ from the local minima of the LCP by definition"
     mine[uw] = saved                                                    # the traversal's own bits again: the oracle windows below use them
-    ones = [int(sum(int(np.bitwise_count(v[i:i + (1 << 27)]).sum(dtype=np.uint64)) for i in range(0, len(v), 1 << 27))) for v in (truth[0], truth[1])]
     log(f"thrK ({ones[0]} ones), thrR ({ones[1]} ones) equal LCP >= {p.K} / >= {p.k_right} BY DEFINITION bit for bit over all {n} positions; minima equal the LCP's local minima "
         f"at all but the {len(unknown)} undecided rows ({undecided_set} of them set by the traversal) ({time.time() - t0:.1f}s)")
     res.update(thrK_thrR_equal_definition=True, minima_equal_definition_except_rows=int(len(unknown)), thrK_ones=ones[0], thrR_ones=ones[1])
