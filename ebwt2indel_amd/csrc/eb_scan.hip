@@ -1196,11 +1196,16 @@ static int launch_contexts(eb_scan_job* job) {
             // A large call set keeps the memory system busy with either kernel alone, so nothing is lost by running the
             // right-context walk BEHIND the left-context extension -- and it can then skip the clusters whose chains came
             // out too short to ever print (see the gate in k_right): straight into the image, one request in nine saved.
+            // A small call set (up to 524288 clusters: a rank's share) walks every cluster: its records then equal the reference's
+            // cluster for cluster, which is what the window checks against the oracle compare (gated: 0.47 instead of 0.48 ms per pass
+            // at 98 k clusters, 0.84 / 0.86 at 197 k, 1.52 / 1.60 at 395 k; not waiting for the extension: no gain).
+            const uint64_t gate_min = getenv("EB_RIGHT_GATE_MIN") ? strtoull(getenv("EB_RIGHT_GATE_MIN"), nullptr, 10) : 524288; // tests: the gate on small call sets
+            const bool gated = x.ns_raw > gate_min;
             EB_HIP(hipStreamWaitEvent(sC, x.e[E_EXT_DONE], 0));
             EB_HIP(hipEventRecord(x.e[E_RIGHT0], sC));
             hipLaunchKernelGGL(kern_right, dim3(grid_of(x.ns * (uint64_t)right_lanes)), dim3(256), 0, sC, x1, x2, df, p, x.sorted.as<Survivor>(), x.d_ns,
                                x.choff.as<uint32_t>(), (uint32_t)x.chain_base, x.d_recs, x.d_right, rw, x.cnt.as<ScanCounters>()->req_right,
-                               (const eb_chain*)x.d_crec);
+                               gated ? (const eb_chain*)x.d_crec : (const eb_chain*)nullptr);
         } else
             hipLaunchKernelGGL(k_right_finish, dim3(grid_of(x.ns)), dim3(256), 0, sC, x.rt_rec.as<eb_cluster>(), x.rt_right.as<uint64_t>(), x.choff.as<uint32_t>(),
                            (uint32_t)x.chain_base, x.ns, rw, x.d_recs, x.d_right);
@@ -1495,8 +1500,9 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
     // Measured at 7.55 G positions (EB_SCAN_SUBSHARDS=1/2/4/8): 6.5 / 6.1 / 6.4 / 11.0 ms per call -- the streaming scan and
     // the random-access chains compete for the same memory request rate, so overlap buys little and slows each kernel.
     // Default: one shard (kernels run alone, cleanest timings); the knob stays for experiments.
-    uint64_t right_early_max = 524288; // see the launch of k_right below; EB_RIGHT_EARLY_MAX overrides (experiments)
+    uint64_t right_early_max = 0; // the early right-context walk of rounds 1-2 (see the launch of k_right below): off since round 3; EB_RIGHT_EARLY_MAX=<clusters> brings it back
     if (const char* e = getenv("EB_RIGHT_EARLY_MAX")) right_early_max = strtoull(e, nullptr, 10);
+    const uint64_t small_set_max = 524288; // call sets up to this size: every cluster gets its right context, the job's last part may be held back
     int S = 1;
     if (const char* e = getenv("EB_SCAN_SUBSHARDS")) { int v = atoi(e); if (v >= 1 && v <= 16) S = v; }
     if ((uint64_t)S > w_total) S = w_total ? (int)w_total : 1;
@@ -1657,7 +1663,7 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
     bt.at("pending-out");
     ScanCounters c;
     memset(&c, 0, sizeof c);
-    bool small = true;
+    bool small = true, defer = true; // small: every sub-shard walks early; defer: every sub-shard's call set is a small one
     for (int k = 0; k < S; ++k) {
         SubShard& x = sh[(size_t)k];
         if (S == 1) x.h_last = reinterpret_cast<uint32_t*>(job->h_bad + 40); // the job's own pinned words: a held-back tail reads them later
@@ -1740,13 +1746,15 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
                            x.sorted.as<Survivor>());
         hipLaunchKernelGGL(k_bucket_fix, dim3(grid_of(n_buckets)), dim3(256), 0, sP, d_boff, n_buckets, x.sorted.as<Survivor>());
         }
-        // The right-context walk needs nothing else.  For a small call set (a rank's slice of a multi-GPU job) it starts
-        // now, under the rest of the preparation and the host round trip (per step: 0.78 -> 0.69 ms at 98 k clusters,
-        // 1.32 -> 1.24 at 197 k, 2.30 -> 2.16 at 395 k, no difference at 793 k); a
-        // large one saturates the memory system at once and the small kernels that follow here crawl (1.2 ms instead
-        // of 0.1 at 790 k clusters), so there it starts with k_extend as before.
+        // The right-context walk needs nothing else.  Rounds 1-2 started it NOW for a small call set (a rank's slice of a multi-GPU
+        // job), one lane per cluster into temporaries, under the rest of the preparation and the host round trip (per step then:
+        // 0.78 -> 0.69 ms at 98 k clusters, 1.32 -> 1.24 at 197 k, 2.30 -> 2.16 at 395 k, no difference at 793 k).  Round 3 measured
+        // it again with what the late walk has gained since -- a quad per cluster, straight into the image, the next scan beside it
+        // at 4 workgroups per CU: a rank's share of 1/2, 1/4, 1/8, 1/16 takes 1.79 / 0.93 / 0.57 / 0.40 ms per pass with the early walk
+        // and 1.60 / 0.86 / 0.48 / 0.32 without (profiles/r03_rank_share_rehearsal.txt).  Off by default (right_early_max = 0).
         x.right_early = x.ns_raw <= right_early_max;
         small = small && x.right_early;
+        defer = defer && x.ns_raw <= small_set_max;
         const unsigned right_grid = grid_of(x.ns_raw * (uint64_t)early_lanes);
         if (x.right_early) {
             if ((rc = x.rt_rec.alloc(x.ns_raw * sizeof(eb_cluster))) != EB_OK || (rc = x.rt_right.alloc(x.ns_raw * (size_t)rw * 8)) != EB_OK) return rc;
@@ -1773,7 +1781,7 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
     // Last part: the call set's image, the chain list, the context kernels and the hand-over.  It needs the ordering
     // step's counts on the host.  A pipelining caller (EB_SCAN_PIPELINED, one shard, small call set) gets the job back
     // now; the part goes out with the next _begin on this index, or when the job is waited for / ended.
-    if ((options & EB_SCAN_PIPELINED) && S == 1 && small) {
+    if ((options & EB_SCAN_PIPELINED) && S == 1 && (small || defer)) {
         std::lock_guard<std::mutex> lk(ctx->half_mu);
         job->half = true;
         ctx->half_job = job;

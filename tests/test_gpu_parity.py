@@ -342,12 +342,16 @@ def test_snp_byte_identical_to_reference(case):
 
 @pytest.mark.parametrize("case", [c for c in CASES if c["name"] in ("m1_default", "m1_edge_m2", "m2_het_default", "m2_edge_default",
                                                                       "m3_het_default", "m3_edge_default")], ids=lambda c: c["name"])
-@pytest.mark.parametrize("early_max", [None, "0"], ids=["walks_early", "walks_late"])
+@pytest.mark.parametrize("early_max", [None, "524288", "0"], ids=["walks_late_every_cluster", "walks_early", "walks_late_gated"])
 def test_cluster_records_match_oracle(oracle, monkeypatch, case, early_max):
-    """Record-level parity of phase 4 (clusters, supports, contexts, counters), whole range and sharded -- with the
-    context walks launched early into temporaries (small call sets) and late, straight into the image (large ones)."""
+    """Record-level parity of phase 4 (clusters, supports, contexts, counters), whole range and sharded -- with the right-context
+    walk behind the extension for every cluster (small call sets, the default since round 3), launched early into temporaries
+    (the small call sets of rounds 1-2, EB_RIGHT_EARLY_MAX) and behind the extension for the clusters that can print only (large
+    call sets; forced on these small ones by EB_RIGHT_GATE_MIN=0)."""
     if early_max is not None:
         monkeypatch.setenv("EB_RIGHT_EARLY_MAX", early_max)
+    if early_max == "0":
+        monkeypatch.setenv("EB_RIGHT_GATE_MIN", "0")
     p, e1, e2, da = _flag_case(oracle, case)
     pp = api.make_params(case["args"])
     o1 = oracle.index(e1, p.term)
@@ -653,9 +657,11 @@ def test_sub_shards_give_the_same_call_set(oracle, monkeypatch, case, subshards)
     if da is not None:
         gf.set_da(da)
     n = g1.n + (g2.n if g2 is not None else 0)
-    for early in (None, "0"):
+    for early in (None, "524288", "0"):         # the walk: late for every cluster (default), early (rounds 1-2), late and gated (large call sets)
         if early is not None:
             monkeypatch.setenv("EB_RIGHT_EARLY_MAX", early)
+        if early == "0":
+            monkeypatch.setenv("EB_RIGHT_GATE_MIN", "0")
         for b, e in ((0, n), (n // 5 + 3, n - n // 7)):
             monkeypatch.delenv("EB_SCAN_SUBSHARDS", raising=False)
             plain = api.scan_clusters(g1, gf, pp, bwt2=g2, begin=b, end=e)
