@@ -8,10 +8,10 @@ n_reads = int(sys.argv[1]); L = 150
 glen = int(n_reads * L / 30)
 g = sim.random_genome(glen, 1); h2 = sim.mutate_haplotype(g, 1)
 text, offs = sim.haplotype_text([g, h2]); starts = sim.sample_read_starts([g, h2], offs, n_reads, L, 1)
-dev = sim.build_ebwt_gpu(text, starts, L)
+dev = sim.build_ebwt_gpu_slabbed(text, starts, L)
 bwt = api.DnaBwt(None, device_ptr=dev.ptr, n=dev.n); dev.free()
 n = bwt.n
-m = 16 << 20
+m = int(sys.argv[2]) if len(sys.argv) > 2 else 16 << 20
 gen = torch.Generator(device="cuda"); gen.manual_seed(1)
 b0 = torch.randint(0, n - 64, (m,), dtype=torch.int64, device="cuda", generator=gen)
 off = torch.tensor([0, 5, 11, 17, 23, 30], dtype=torch.int64, device="cuda")
