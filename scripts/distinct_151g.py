@@ -12,8 +12,8 @@ No CPU checker fits the box at this size (host-memory cap, DESIGN.md section 4);
     bit vectors themselves against an INDEPENDENT statement of them: the generator knows the suffix order of the text, so it writes
     thrK / thrR / minima from the definition (common prefixes of adjacent read suffixes; held to the CPU oracle on small inputs in
     tests/test_gpu_generator.py) and the traversal's vectors must equal them bit for bit over all 151 G positions;
-  * phase 4: identical to the CPU ORACLE's on windows around every superblock boundary, both ends and random places (records with
-    their contexts, text) -- the oracle's index is streamed off the GPU in pieces (orc_index_stream_*), its bit vectors are the
+  * phase 4: the whole-range .snp BYTE-IDENTICAL to the CPU ORACLE's whole-range pass (sharded over the host threads, a minute), and
+    identical on windows around every superblock boundary, both ends and random places record by record (contexts, text) -- the oracle's index is streamed off the GPU in pieces (orc_index_stream_*), its bit vectors are the
     ones just verified; and the whole-range call set equals the concatenation of 8 shards' call sets (the N = 8 ownership rule);
   * every called SNP against the TRUTH the sample was made from is out of scope here (post-processing); the record count is
     compared with 20 x config 2's.
@@ -247,7 +247,20 @@ def main():
     log(f"phase 4 on {len(windows)} windows of {WINDOW} positions (every superblock boundary, both ends, 12 random places) identical to the CPU oracle's: "
         f"{sum(w['count'] for w in wants)} clusters with their contexts, {recs} records ({time.time() - t0:.1f}s)")
     res.update(phase4_oracle_windows=len(windows), window_positions=WINDOW, window_clusters=int(sum(w["count"] for w in wants)), window_records=int(recs), oracle_threads=THREADS)
-    del of, oidx, wants
+    del wants
+    # ---- ... and over the WHOLE range: the oracle's phase 4 sharded over the host threads (every shard numbering its clusters from 1, the
+    # texts renumbered into one run, tests/_fullsize.py::renumber) -> the .snp the product's whole-range pass must equal byte for byte
+    t0 = time.time()
+    from tests import _fullsize as fsz
+    n_shards = THREADS * 8
+    cuts = [ebd.shard_range(n, i, n_shards) for i in range(n_shards)]
+    with ThreadPoolExecutor(THREADS) as ex:
+        oparts = list(ex.map(lambda be: of.scan(po, be[0], be[1]), cuts))
+    oracle_text = fsz.renumber([r["text"] for r in oparts], [r["cluster_nr"] - 1 for r in oparts])
+    oracle_sha = hashlib.sha256(oracle_text).hexdigest()
+    log(f"oracle phase 4 over the whole range ({n_shards} shards on {THREADS} threads): {oracle_text.count(b'>')} records, sha256 {oracle_sha} ({time.time() - t0:.1f}s)")
+    res.update(oracle_snp_sha256=oracle_sha, oracle_phase4_seconds=round(time.time() - t0, 1))
+    del of, oidx, oparts
 
     # ---- phase 4: whole range vs 8 shards
     t0 = time.time()
@@ -266,7 +279,9 @@ def main():
         parts.append(t)
     assert b"".join(parts) == whole and cn == cn_whole and ev == ev_whole
     sha = hashlib.sha256(whole).hexdigest()
-    log(f"8 shards (the N = 8 ownership rule) concatenate to the whole-range .snp: {ev} records, sha256 {sha}")
+    assert whole == oracle_text, "the whole-range .snp differs from the CPU oracle's"
+    res.update(snp_equals_oracle_whole_range=True)
+    log(f"the whole-range .snp equals the CPU oracle's byte for byte, and 8 shards (the N = 8 ownership rule) concatenate to it: {ev} records, sha256 {sha}")
     res.update(snp_sha256=sha, shards8_equal_whole=True)
     if base:
         res.update(snp_records_over_config2=round(ev_whole / base["snp_records"], 3))

@@ -8,7 +8,8 @@ generator, then index -> traversal -> phase 4, every stage against a checker --
   traversal   every LCP slot written once; thrK / thrR = LCP >= K / k_right BY DEFINITION over all 151 G positions, minima = the
               LCP's local minima (the generator's own statement of the vectors, held to the oracle on small inputs in
               test_gpu_generator.py);
-  phase 4     = the CPU oracle's on 49 windows of 2 M positions (every superblock boundary, both ends, random places); the
+  phase 4     the whole-range .snp BYTE-IDENTICAL to the CPU oracle's whole-range pass (512 shards on the host threads, ~95 s) and, record
+              by record with contexts, on 49 windows of 2 M positions (every superblock boundary, both ends, random places); the
               whole-range .snp = 8 shards' (the N = 8 ownership rule).
 The script asserts all of that; here its figures are also held to the record of the builder's run (profiles/)."""
 import json
@@ -37,7 +38,8 @@ def test_config5_one_billion_distinct_reads_whole_pipeline(tmp_path):
     assert r.returncode == 0, tail
     with open(out) as f:
         got = json.load(f)
-    for k in ("n", "text_symbols", "nodes", "leaves", "minima", "thrK_ones", "thrR_ones", "clusters_analysed", "call_set", "snp_records", "snp_sha256",
+    for k in ("n", "text_symbols", "nodes", "leaves", "minima", "thrK_ones", "thrR_ones", "clusters_analysed", "call_set", "snp_records", "snp_sha256", "oracle_snp_sha256",
               "phase4_oracle_windows", "window_clusters", "window_records", "reads_spelled_back", "rank_positions_checked_against_definition"):
         assert got[k] == want[k], (k, got[k], want[k])
-    assert got["n"] == 151_000_000_000 and got["every_lcp_slot_written_once"] and got["thrK_thrR_equal_definition"] and got["shards8_equal_whole"]
+    assert got["n"] == 151_000_000_000 and got["every_lcp_slot_written_once"] and got["thrK_thrR_equal_definition"] and got["shards8_equal_whole"] and got["snp_equals_oracle_whole_range"]
+    assert got["snp_sha256"] == got["oracle_snp_sha256"]
