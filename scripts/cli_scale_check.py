@@ -6,7 +6,7 @@ n_reads = int(sys.argv[1]); L = 150
 glen = int(n_reads * L / 30)
 g = sim.random_genome(glen, 1); h2 = sim.mutate_haplotype(g, 1)
 text, offs = sim.haplotype_text([g, h2]); starts = sim.sample_read_starts([g, h2], offs, n_reads, L, 1)
-dev = sim.build_ebwt_gpu(text, starts, L)
+dev = sim.build_ebwt_gpu_slabbed(text, starts, L)
 ebwt, _ = dev.to_host(); dev.free()
 path = "/tmp/scale.ebwt"; ebwt.tofile(path)
 p = api.make_params()
