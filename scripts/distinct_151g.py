@@ -1,298 +1,13 @@
-"""BASELINE configs[4] with DISTINCT reads on one MI355X: 1 G x 150 bp reads of a 5 Gb diploid genome = 151 G BWT positions.
-
-Round 2 could only replicate the 7.55 G sample twenty times (same suffix tree, 20 x fewer nodes than a real input of this
-size).  The slab-by-slab generator (ebwt2indel_amd/tools/ebwt_gen_slabs.hip) builds the real thing: the sample is made on
-the device (10 G symbols of text, past 2^32), its eBWT slab by slab into 151 GB of HBM, then index -> traversal -> phase 4.
-No CPU checker fits the box at this size (host-memory cap); what is checked without one:
-  * the eBWT IS the eBWT of these reads: the terminator rows 0 .. reads-1 are walked backwards with access + LF(range, c) --
-    read_len steps through the index -- and must spell the reads the text holds, then reach a terminator;
-  * parallel_rank against the DEFINITION (prefix counts of the ASCII symbols, on the device) around every superblock
-    boundary, operator[] against the ASCII symbols, F against the symbol counts, FL/LF round trips;
-  * traversal: every LCP slot written exactly once (count and power sums), leaves + nodes in proportion to config 2's -- and the
-    bit vectors themselves against an INDEPENDENT statement of them: the generator knows the suffix order of the text, so it writes
-    thrK / thrR / minima from the definition (common prefixes of adjacent read suffixes; held to the CPU oracle on small inputs in
-    tests/test_gpu_generator.py) and the traversal's vectors must equal them bit for bit over all 151 G positions;
-  * phase 4: the whole-range .snp BYTE-IDENTICAL to the CPU ORACLE's whole-range pass (sharded over the host threads, a minute), and
-    identical on windows around every superblock boundary, both ends and random places record by record (contexts, text) -- the oracle's index is streamed off the GPU in pieces (orc_index_stream_*), its bit vectors are the
-    ones just verified; and the whole-range call set equals the concatenation of 8 shards' call sets (the N = 8 ownership rule);
-  * every called SNP against the TRUTH the sample was made from is out of scope here (post-processing); the record count is
-    compared with 20 x config 2's.
+"""BASELINE configs[4] with DISTINCT reads on one MI355X -- launcher.  The run itself (generator -> index -> traversal -> phase 4, every
+stage against a checker, the CPU oracle among them) is test tooling and lives in tests/config5_distinct_reads.py; this file only starts it:
 
     gpurun --timeout 1200 -- 'python scripts/distinct_151g.py > gpurun_out/distinct151.log 2>&1'
     (python scripts/distinct_151g.py 50000000 for a rehearsal at config 2's size)
 """
-import hashlib
-import json
 import os
+import runpy
 import sys
-import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-import torch  # noqa: E402
-
-from concurrent.futures import ThreadPoolExecutor  # noqa: E402
-
-from ebwt2indel_amd import api, sim  # noqa: E402
-from ebwt2indel_amd import distributed as ebd  # noqa: E402
-from tests import _oracle  # noqa: E402  (the checker; this script is test tooling, not product)
-
-READS = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000_000
-READ_LEN, COVERAGE, SEED = 150, 30.0, 1
-DECODE = 200_000          # reads spelled back through the index
-THREADS = min(64, os.cpu_count() or 8)
-WINDOW = 1 << 21          # positions per oracle window of phase 4
-T0 = time.time()
-
-
-def log(*a):
-    print(f"{time.time() - T0:7.1f}s", *a, flush=True)
-
-
-def hbm():
-    free_b, total_b = torch.cuda.mem_get_info(0)
-    return f"HBM in use {(total_b - free_b) / 1e9:.1f} of {total_b / 1e9:.1f} GB"
-
-
-class _Bytes:
-    def __init__(self, ptr, n, typestr="|u1"):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 3, "strides": None}
-
-
-def main():
-    res = {"what": f"BASELINE configs[4] with DISTINCT reads on ONE MI355X: {READS} x {READ_LEN} bp reads, {COVERAGE:.0f}x diploid genome, whole pipeline HBM-resident"}
-    genome_len = int(READS * READ_LEN / COVERAGE)
-    t0 = time.time()
-    s = sim.synth_diploid_gpu(genome_len, READS, READ_LEN, SEED)
-    log(f"sample made on the device in {time.time() - t0:.2f}s: genome {genome_len}, text {s.text_len} symbols ({s.text_len / (1 << 32):.2f} x 2^32); {hbm()}")
-    t0 = time.time()
-    p = api.make_params()
-    dev = sim.build_ebwt_gpu_slabbed(s.text_ptr, s.starts_ptr, READ_LEN, n_reads=READS, text_len=s.text_len, lcp_truth=(p.K, p.k_right))
-    t_gen = time.time() - t0
-    n = dev.n
-    P, Pg, max_group, max_keys = dev.info
-    log(f"eBWT of {n} positions ({n / (1 << 32):.2f} superblocks) in {t_gen:.1f}s: slabs of {P} symbols ({4 ** P}), groups of {Pg}; largest group {max_group} text "
-        f"positions, largest slab {max_keys} keys; pack+histograms {dev.timings[0]:.1f}s, sorted starts {dev.timings[1]:.1f}s, short blocks {dev.timings[2]:.1f}s, "
-        f"suffix sorting {dev.timings[3]:.1f}s, keys+sort+emit {dev.timings[4]:.1f}s; {hbm()}")
-    res.update(n=int(n), superblocks=n / (1 << 32), text_symbols=int(s.text_len), generator_seconds=round(t_gen, 1), slab_prefix=P, group_prefix=Pg,
-               generator_timings=[round(float(v), 2) for v in dev.timings])
-    # the generator's statement of the LCP bit vectors (definition, from the text's suffix order) goes to host memory: HBM is needed
-    t0 = time.time()
-    words = (n + 63) // 64
-    truth = []
-    for ptr in dev.truth:
-        a = np.empty(words + 1, dtype=np.uint64)
-        sim._hip_copy_to_host(a, ptr, (words + 1) * 8)
-        truth.append(a[:words])
-    unknown = dev.unknown
-    dev.free_truth()
-    log(f"LCP bit vectors by definition (thrK, thrR, minima; {3 * words * 8 / 1e9:.1f} GB) copied to the host in {time.time() - t0:.1f}s; minima undecided at {len(unknown)} rows "
-        f"(edges of slabs and short blocks); {hbm()}")
-    ascii_t = torch.as_tensor(_Bytes(dev.ptr, n), device="cuda:0")
-    t0 = time.time()
-    bwt = api.DnaBwt(None, device_ptr=dev.ptr, n=n)
-    t_index = time.time() - t0
-    log(f"index: {t_index:.2f}s, {bwt.device_bytes / 1e9:.1f} GB; {hbm()}")
-    res.update(index_seconds=round(t_index, 2), index_device_bytes=int(bwt.device_bytes))
-
-    # ---- F against the symbol counts; rank against the definition around every superblock boundary
-    letters = [ord(c) for c in "ACGT"]
-    edges = [int(k) << 32 for k in range(1, int(n >> 32) + 1)]
-    cuts = sorted(set([0] + [e - 300 for e in edges] + [n]))
-    counts_before = {0: np.zeros(4, dtype=np.int64)}
-    run = np.zeros(4, dtype=np.int64)
-    CH = 1 << 30
-    t0 = time.time()
-    for a, b in zip(cuts[:-1], cuts[1:]):
-        for x in range(a, b, CH):
-            seg = ascii_t[x:min(b, x + CH)]
-            run += np.array([int((seg == c).sum()) for c in letters], dtype=np.int64)
-        counts_before[b] = run.copy()
-    total = counts_before[n]
-    terms = n - int(total.sum())
-    assert terms == READS, (terms, READS)
-    F = np.array(bwt.F_arr, dtype=np.int64)
-    assert F[0] == READS and np.array_equal(np.diff(np.append(F, n)), total), (F, total)
-    checked = 0
-    for e in edges:
-        a = e - 300
-        seg = ascii_t[a:min(n, e + 300)]
-        pos = np.arange(a, a + len(seg) + 1, dtype=np.uint64)
-        want = np.zeros((len(pos), 4), dtype=np.uint64)
-        for k, c in enumerate(letters):
-            want[1:, k] = torch.cumsum((seg == c).to(torch.int64), 0).cpu().numpy().astype(np.uint64)
-        want += counts_before[a].astype(np.uint64)[None, :]
-        assert np.array_equal(bwt.parallel_rank(pos), want), f"parallel_rank differs from the definition around {e}"
-        checked += len(pos)
-    rng = np.random.Generator(np.random.PCG64(3))
-    acc = rng.integers(0, n, size=2_000_000, dtype=np.uint64)
-    assert np.array_equal(bwt[acc], ascii_t[torch.from_numpy(acc.astype(np.int64)).cuda()].cpu().numpy())
-    log(f"F = symbol counts ({terms} terminators); parallel_rank = prefix counts of the ASCII symbols at {checked} positions around {len(edges)} superblock boundaries; "
-        f"operator[] at {len(acc)} random positions ({time.time() - t0:.1f}s)")
-    res.update(rank_positions_checked_against_definition=int(checked), access_positions_checked=int(len(acc)))
-    # ---- the CPU oracle's index of the same eBWT, fed in pieces (the ASCII form would not fit the host beside it)
-    t0 = time.time()
-    orc = _oracle.Oracle()
-    oidx = _oracle.OracleIndex.stream(orc, n)
-    piece = 1 << 30
-    buf = np.empty(piece, dtype=np.uint8)
-    for x in range(0, n, piece):
-        ln = min(piece, n - x)
-        sim._hip_copy_to_host(buf[:ln], dev.ptr + x, ln)
-        oidx.append(x, buf[:ln], threads=THREADS)
-    del buf
-    oidx.finish(threads=THREADS)
-    assert oidx.ok and [int(v) for v in oidx.F()] == [int(v) for v in F]
-    probe = rng.integers(0, n + 1, size=100_000, dtype=np.uint64)
-    assert np.array_equal(oidx.rank4(probe), bwt.parallel_rank(probe))
-    log(f"oracle index streamed off the GPU and built on {THREADS} host threads in {time.time() - t0:.1f}s; F and {len(probe)} random parallel_rank queries equal the GPU's")
-    del ascii_t
-    dev.free()
-    torch.cuda.empty_cache()
-
-    # ---- the eBWT spells the reads: backward walk from the terminator rows
-    t0 = time.time()
-    text_t = torch.as_tensor(_Bytes(s.text_ptr, s.text_len), device="cuda:0")
-    starts_t = torch.as_tensor(_Bytes(s.starts_ptr, READS, "<i8"), device="cuda:0")
-    pick = np.unique(np.concatenate([rng.integers(0, READS, size=DECODE, dtype=np.int64), np.array([0, 1, READS - 2, READS - 1])]))
-    st = starts_t[torch.from_numpy(pick).cuda()]
-    want_reads = text_t[st[:, None] + torch.arange(READ_LEN, device="cuda:0")[None, :]].cpu().numpy()
-    rows = pick.astype(np.uint64)
-    got = np.zeros((len(pick), READ_LEN), dtype=np.uint8)
-    for k in range(READ_LEN):
-        c = bwt[rows]
-        got[:, READ_LEN - 1 - k] = c
-        assert not (c == bwt.term).any(), f"a terminator after {k} steps"
-        rows = bwt.LF(np.stack([rows, rows + np.uint64(1)], axis=1), c)[:, 0].copy()
-    assert (bwt[rows] == bwt.term).all(), "the walk does not end at a terminator"
-    assert np.array_equal(got, want_reads), "the eBWT does not spell the reads"
-    # FL is the inverse of LF
-    r2 = rng.integers(int(F[0]), n, size=200_000, dtype=np.uint64)
-    fl = bwt.FL(r2)
-    back = bwt.LF(np.stack([fl, fl + np.uint64(1)], axis=1), bwt[fl])[:, 0]
-    assert np.array_equal(back, r2)
-    log(f"{len(pick)} reads spelled back through access + LF ({READ_LEN} steps each) equal the text's; {len(r2)} FL/LF round trips ({time.time() - t0:.1f}s)")
-    res.update(reads_spelled_back=int(len(pick)), fl_lf_round_trips=int(len(r2)))
-    del text_t, starts_t, st
-    s.free()
-    torch.cuda.empty_cache()
-
-    # ---- phases 2-3
-    t0 = time.time()
-    flags = api.navigate_one_bwt(bwt, p)
-    t_nav = time.time() - t0
-    ns = flags.stats
-    log(f"phases 2-3: wall {t_nav:.2f}s, traversals {ns.seconds_traversal:.2f}s: {ns.nodes} nodes, {ns.leaves} leaves, {ns.minima} minima, lcp_values {ns.lcp_values}; {hbm()}")
-    assert ns.lcp_values == n
-    assert api.lib().eb_nav_covers_every_slot_once(ns) == 1, "an LCP slot was written twice or never"
-    base = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r03_fullsize_config2.json")) as fh:
-            base = json.load(fh)
-    except OSError:
-        pass
-    res.update(phases23_wall_seconds=round(t_nav, 2), traversal_seconds=round(float(ns.seconds_traversal), 2), nodes=int(ns.nodes), leaves=int(ns.leaves),
-               minima=int(ns.minima), every_lcp_slot_written_once=True)
-    if base:
-        scale = READS / base["input"]["reads_per_collection"]
-        res.update(nodes_over_config2=round(ns.nodes / base["counters"]["nodes"], 3), leaves_over_config2=round(ns.leaves / base["counters"]["leaves"], 3), reads_over_config2=scale)
-        log(f"against config 2 ({base['counters']['nodes']} nodes, {base['counters']['leaves']} leaves) at {scale:.0f} x the reads: nodes x {res['nodes_over_config2']}, leaves x {res['leaves_over_config2']}")
-
-    # ---- the traversal's bit vectors against the generator's statement of them
-    t0 = time.time()
-    thrK, thrR, minima, _ = flags.export()
-    ones = [int(sum(int(np.bitwise_count(v[i:i + (1 << 27)]).sum(dtype=np.uint64)) for i in range(0, len(v), 1 << 27))) for v in (truth[0], truth[1])]
-    assert np.array_equal(thrK[:words], truth[0]), "thrK differs from LCP >= K by definition"
-    truth[0] = None                                                      # (host memory: each statement is dropped once it has been compared)
-    assert np.array_equal(thrR[:words], truth[1]), "thrR differs from LCP >= k_right by definition"
-    truth[1] = None
-    mask_w = (unknown >> np.uint64(6)).astype(np.int64)
-    mask_b = ~(np.uint64(1) << (unknown & np.uint64(63)))
-    mine = minima[:words]
-    undecided_set = int(((mine[mask_w] >> (unknown & np.uint64(63))) & np.uint64(1)).sum())
-    uw = np.unique(mask_w)
-    saved = mine[uw].copy()
-    np.bitwise_and.at(mine, mask_w, mask_b)
-    assert np.array_equal(mine, truth[2]), "minima differ from the local minima of the LCP by definition"
-    mine[uw] = saved                                                    # the traversal's own bits again: the oracle windows below use them
-    log(f"thrK ({ones[0]} ones), thrR ({ones[1]} ones) equal LCP >= {p.K} / >= {p.k_right} BY DEFINITION bit for bit over all {n} positions; minima equal the LCP's local minima "
-        f"at all but the {len(unknown)} undecided rows ({undecided_set} of them set by the traversal) ({time.time() - t0:.1f}s)")
-    res.update(thrK_thrR_equal_definition=True, minima_equal_definition_except_rows=int(len(unknown)), thrK_ones=ones[0], thrR_ones=ones[1])
-    del mine, truth
-
-    # ---- phase 4 against the CPU oracle on windows: its scan + cluster analysis + context extension (the reference's algorithm) over
-    # its own index, with the bit vectors just verified
-    t0 = time.time()
-    of = _oracle.OracleFlags(orc, oidx, vectors=(thrK, thrR, minima))
-    del thrK, thrR, minima
-    po = _oracle.Params.from_args()
-    wrng = np.random.Generator(np.random.PCG64(7))
-    centres = [k << 32 for k in range(1, int(n >> 32) + 1)] + [WINDOW // 2, n - WINDOW // 2] + [int(v) for v in wrng.integers(WINDOW, n - WINDOW, size=12)]
-    windows = sorted({(max(0, (c - WINDOW // 2) // 64 * 64), min(n, (c - WINDOW // 2) // 64 * 64 + WINDOW)) for c in centres})
-    with ThreadPoolExecutor(min(THREADS, len(windows))) as ex:
-        wants = list(ex.map(lambda be: of.scan(po, be[0], be[1], capture=True), windows))
-    recs = 0
-    for (wb, we), want_w in zip(windows, wants):
-        c = api.scan_clusters(bwt, flags, p, begin=wb, end=we)
-        cl, chains, left, right = c.arrays()
-        assert len(c) == want_w["count"], (wb, we, len(c), want_w["count"])
-        assert np.array_equal(cl, want_w["clusters"]) and np.array_equal(chains, want_w["chains"]), (wb, we)
-        assert np.array_equal(left, want_w["left"]) and np.array_equal(right, want_w["right"]), (wb, we)
-        t, _, _ = c.format_snp(p, False)
-        assert t == want_w["text"], (wb, we)
-        recs += t.count(b">")
-    log(f"phase 4 on {len(windows)} windows of {WINDOW} positions (every superblock boundary, both ends, 12 random places) identical to the CPU oracle's: "
-        f"{sum(w['count'] for w in wants)} clusters with their contexts, {recs} records ({time.time() - t0:.1f}s)")
-    res.update(phase4_oracle_windows=len(windows), window_positions=WINDOW, window_clusters=int(sum(w["count"] for w in wants)), window_records=int(recs), oracle_threads=THREADS)
-    del wants
-    # ---- ... and over the WHOLE range: the oracle's phase 4 sharded over the host threads (every shard numbering its clusters from 1, the
-    # texts renumbered into one run, tests/_fullsize.py::renumber) -> the .snp the product's whole-range pass must equal byte for byte
-    t0 = time.time()
-    from tests import _fullsize as fsz
-    n_shards = THREADS * 8
-    cuts = [ebd.shard_range(n, i, n_shards) for i in range(n_shards)]
-    with ThreadPoolExecutor(THREADS) as ex:
-        oparts = list(ex.map(lambda be: of.scan(po, be[0], be[1]), cuts))
-    oracle_text = fsz.renumber([r["text"] for r in oparts], [r["cluster_nr"] - 1 for r in oparts])
-    oracle_sha = hashlib.sha256(oracle_text).hexdigest()
-    log(f"oracle phase 4 over the whole range ({n_shards} shards on {THREADS} threads): {oracle_text.count(b'>')} records, sha256 {oracle_sha} ({time.time() - t0:.1f}s)")
-    res.update(oracle_snp_sha256=oracle_sha, oracle_phase4_seconds=round(time.time() - t0, 1))
-    del of, oidx, oparts
-
-    # ---- phase 4: whole range vs 8 shards
-    t0 = time.time()
-    calls = api.scan_clusters(bwt, flags, p)
-    stt = calls.stats
-    whole, cn_whole, ev_whole = calls.format_snp(p, False)
-    log(f"phase 4, whole BWT: {time.time() - t0:.2f}s wall (scan {stt.ms_scan:.1f} ms, extend {stt.ms_extend:.1f}, right {stt.ms_right:.1f}); {stt.clusters} clusters analysed, "
-        f"{len(calls)} in the call set, {ev_whole} records; {hbm()}")
-    res.update(phase4_scan_ms=round(float(stt.ms_scan), 1), phase4_extend_ms=round(float(stt.ms_extend), 1), phase4_right_ms=round(float(stt.ms_right), 1),
-               clusters_analysed=int(stt.clusters), call_set=int(len(calls)), snp_records=int(ev_whole), scan_reruns=int(stt.scan_reruns))
-    del calls
-    parts, cn, ev = [], 1, 0
-    for rk in range(8):
-        b, e = ebd.shard_range(n, rk, 8)
-        t, cn, ev = api.scan_clusters(bwt, flags, p, begin=b, end=e).format_snp(p, False, cn, ev)
-        parts.append(t)
-    assert b"".join(parts) == whole and cn == cn_whole and ev == ev_whole
-    sha = hashlib.sha256(whole).hexdigest()
-    assert whole == oracle_text, "the whole-range .snp differs from the CPU oracle's"
-    res.update(snp_equals_oracle_whole_range=True)
-    log(f"the whole-range .snp equals the CPU oracle's byte for byte, and 8 shards (the N = 8 ownership rule) concatenate to it: {ev} records, sha256 {sha}")
-    res.update(snp_sha256=sha, shards8_equal_whole=True)
-    if base:
-        res.update(snp_records_over_config2=round(ev_whole / base["snp_records"], 3))
-    res["checks"] = ("reads spelled back through the index, rank = prefix counts of the ASCII symbols around every superblock boundary, operator[], F = symbol counts, "
-                     "FL/LF round trips, every LCP slot written once (count + power sums), 8 shards == whole")
-    out = os.environ.get("EB_DISTINCT_OUT") or os.path.join(ROOT, "gpurun_out", f"distinct_reads_{READS}.json")
-    os.makedirs(os.path.dirname(out), exist_ok=True)
-    with open(out, "w") as f:
-        json.dump(res, f, indent=1)
-    log(json.dumps(res))
-
-
-if __name__ == "__main__":
-    main()
+runpy.run_module("tests.config5_distinct_reads", run_name="__main__")

@@ -1,6 +1,6 @@
 """BASELINE configs[4] -- mode 1, 1 G x 150 bp DISTINCT reads, 151 G BWT positions, HBM-resident -- on the one GPU of the test box.
 
-Runs scripts/distinct_151g.py in a process of its own (it needs 250 of the 288 GB of HBM and ~190 GB of host memory, so it runs
+Runs tests/config5_distinct_reads.py in a process of its own (it needs 250 of the 288 GB of HBM and ~190 GB of host memory, so it runs
 FIRST, before this process holds anything on the device): the sample is made on the device, its eBWT by the slab-by-slab
 generator, then index -> traversal -> phase 4, every stage against a checker --
   index       F and 100 k parallel_rank queries = the CPU oracle's (its index streamed off the GPU in pieces); parallel_rank =
@@ -33,7 +33,7 @@ def test_config5_one_billion_distinct_reads_whole_pipeline(tmp_path):
         want = json.load(f)
     out = tmp_path / "distinct.json"
     env = dict(os.environ, EB_DISTINCT_OUT=str(out))
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "distinct_151g.py")], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1100)
+    r = subprocess.run([sys.executable, "-m", "tests.config5_distinct_reads"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1100)
     tail = r.stdout.decode(errors="replace")[-3000:]
     assert r.returncode == 0, tail
     with open(out) as f:
