@@ -47,6 +47,7 @@ READ_LEN, COVERAGE, SEED = 150, 30.0, 1
 DECODE = 200_000          # reads spelled back through the index
 THREADS = min(64, os.cpu_count() or 8)
 WINDOW = 1 << 21          # positions per oracle window of phase 4
+ORACLE = os.environ.get("EB_DISTINCT_NO_ORACLE") != "1"   # =1: the product's run and the definition checks only (profiling runs)
 T0 = time.time()
 
 
@@ -135,22 +136,23 @@ def main():
     log(f"F = symbol counts ({terms} terminators); parallel_rank = prefix counts of the ASCII symbols at {checked} positions around {len(edges)} superblock boundaries; "
         f"operator[] at {len(acc)} random positions ({time.time() - t0:.1f}s)")
     res.update(rank_positions_checked_against_definition=int(checked), access_positions_checked=int(len(acc)))
-    # ---- the CPU oracle's index of the same eBWT, fed in pieces (the ASCII form would not fit the host beside it)
-    t0 = time.time()
-    orc = _oracle.Oracle()
-    oidx = _oracle.OracleIndex.stream(orc, n)
-    piece = 1 << 30
-    buf = np.empty(piece, dtype=np.uint8)
-    for x in range(0, n, piece):
-        ln = min(piece, n - x)
-        sim._hip_copy_to_host(buf[:ln], dev.ptr + x, ln)
-        oidx.append(x, buf[:ln], threads=THREADS)
-    del buf
-    oidx.finish(threads=THREADS)
-    assert oidx.ok and [int(v) for v in oidx.F()] == [int(v) for v in F]
-    probe = rng.integers(0, n + 1, size=100_000, dtype=np.uint64)
-    assert np.array_equal(oidx.rank4(probe), bwt.parallel_rank(probe))
-    log(f"oracle index streamed off the GPU and built on {THREADS} host threads in {time.time() - t0:.1f}s; F and {len(probe)} random parallel_rank queries equal the GPU's")
+    if ORACLE:
+        # ---- the CPU oracle's index of the same eBWT, fed in pieces (the ASCII form would not fit the host beside it)
+        t0 = time.time()
+        orc = _oracle.Oracle()
+        oidx = _oracle.OracleIndex.stream(orc, n)
+        piece = 1 << 30
+        buf = np.empty(piece, dtype=np.uint8)
+        for x in range(0, n, piece):
+            ln = min(piece, n - x)
+            sim._hip_copy_to_host(buf[:ln], dev.ptr + x, ln)
+            oidx.append(x, buf[:ln], threads=THREADS)
+        del buf
+        oidx.finish(threads=THREADS)
+        assert oidx.ok and [int(v) for v in oidx.F()] == [int(v) for v in F]
+        probe = rng.integers(0, n + 1, size=100_000, dtype=np.uint64)
+        assert np.array_equal(oidx.rank4(probe), bwt.parallel_rank(probe))
+        log(f"oracle index streamed off the GPU and built on {THREADS} host threads in {time.time() - t0:.1f}s; F and {len(probe)} random parallel_rank queries equal the GPU's")
     del ascii_t
     dev.free()
     torch.cuda.empty_cache()
@@ -225,44 +227,47 @@ def main():
     res.update(thrK_thrR_equal_definition=True, minima_equal_definition_except_rows=int(len(unknown)), thrK_ones=ones[0], thrR_ones=ones[1])
     del mine, truth
 
-    # ---- phase 4 against the CPU oracle on windows: its scan + cluster analysis + context extension (the reference's algorithm) over
-    # its own index, with the bit vectors just verified
-    t0 = time.time()
-    of = _oracle.OracleFlags(orc, oidx, vectors=(thrK, thrR, minima))
-    del thrK, thrR, minima
-    po = _oracle.Params.from_args()
-    wrng = np.random.Generator(np.random.PCG64(7))
-    centres = [k << 32 for k in range(1, int(n >> 32) + 1)] + [WINDOW // 2, n - WINDOW // 2] + [int(v) for v in wrng.integers(WINDOW, n - WINDOW, size=12)]
-    windows = sorted({(max(0, (c - WINDOW // 2) // 64 * 64), min(n, (c - WINDOW // 2) // 64 * 64 + WINDOW)) for c in centres})
-    with ThreadPoolExecutor(min(THREADS, len(windows))) as ex:
-        wants = list(ex.map(lambda be: of.scan(po, be[0], be[1], capture=True), windows))
-    recs = 0
-    for (wb, we), want_w in zip(windows, wants):
-        c = api.scan_clusters(bwt, flags, p, begin=wb, end=we)
-        cl, chains, left, right = c.arrays()
-        assert len(c) == want_w["count"], (wb, we, len(c), want_w["count"])
-        assert np.array_equal(cl, want_w["clusters"]) and np.array_equal(chains, want_w["chains"]), (wb, we)
-        assert np.array_equal(left, want_w["left"]) and np.array_equal(right, want_w["right"]), (wb, we)
-        t, _, _ = c.format_snp(p, False)
-        assert t == want_w["text"], (wb, we)
-        recs += t.count(b">")
-    log(f"phase 4 on {len(windows)} windows of {WINDOW} positions (every superblock boundary, both ends, 12 random places) identical to the CPU oracle's: "
-        f"{sum(w['count'] for w in wants)} clusters with their contexts, {recs} records ({time.time() - t0:.1f}s)")
-    res.update(phase4_oracle_windows=len(windows), window_positions=WINDOW, window_clusters=int(sum(w["count"] for w in wants)), window_records=int(recs), oracle_threads=THREADS)
-    del wants
-    # ---- ... and over the WHOLE range: the oracle's phase 4 sharded over the host threads (every shard numbering its clusters from 1, the
-    # texts renumbered into one run, tests/_fullsize.py::renumber) -> the .snp the product's whole-range pass must equal byte for byte
-    t0 = time.time()
-    from tests import _fullsize as fsz
-    n_shards = THREADS * 8
-    cuts = [ebd.shard_range(n, i, n_shards) for i in range(n_shards)]
-    with ThreadPoolExecutor(THREADS) as ex:
-        oparts = list(ex.map(lambda be: of.scan(po, be[0], be[1]), cuts))
-    oracle_text = fsz.renumber([r["text"] for r in oparts], [r["cluster_nr"] - 1 for r in oparts])
-    oracle_sha = hashlib.sha256(oracle_text).hexdigest()
-    log(f"oracle phase 4 over the whole range ({n_shards} shards on {THREADS} threads): {oracle_text.count(b'>')} records, sha256 {oracle_sha} ({time.time() - t0:.1f}s)")
-    res.update(oracle_snp_sha256=oracle_sha, oracle_phase4_seconds=round(time.time() - t0, 1))
-    del of, oidx, oparts
+    if ORACLE:
+        # ---- phase 4 against the CPU oracle on windows: its scan + cluster analysis + context extension (the reference's algorithm) over
+        # its own index, with the bit vectors just verified
+        t0 = time.time()
+        of = _oracle.OracleFlags(orc, oidx, vectors=(thrK, thrR, minima))
+        del thrK, thrR, minima
+        po = _oracle.Params.from_args()
+        wrng = np.random.Generator(np.random.PCG64(7))
+        centres = [k << 32 for k in range(1, int(n >> 32) + 1)] + [WINDOW // 2, n - WINDOW // 2] + [int(v) for v in wrng.integers(WINDOW, n - WINDOW, size=12)]
+        windows = sorted({(max(0, (c - WINDOW // 2) // 64 * 64), min(n, (c - WINDOW // 2) // 64 * 64 + WINDOW)) for c in centres})
+        with ThreadPoolExecutor(min(THREADS, len(windows))) as ex:
+            wants = list(ex.map(lambda be: of.scan(po, be[0], be[1], capture=True), windows))
+        recs = 0
+        for (wb, we), want_w in zip(windows, wants):
+            c = api.scan_clusters(bwt, flags, p, begin=wb, end=we)
+            cl, chains, left, right = c.arrays()
+            assert len(c) == want_w["count"], (wb, we, len(c), want_w["count"])
+            assert np.array_equal(cl, want_w["clusters"]) and np.array_equal(chains, want_w["chains"]), (wb, we)
+            assert np.array_equal(left, want_w["left"]) and np.array_equal(right, want_w["right"]), (wb, we)
+            t, _, _ = c.format_snp(p, False)
+            assert t == want_w["text"], (wb, we)
+            recs += t.count(b">")
+        log(f"phase 4 on {len(windows)} windows of {WINDOW} positions (every superblock boundary, both ends, 12 random places) identical to the CPU oracle's: "
+            f"{sum(w['count'] for w in wants)} clusters with their contexts, {recs} records ({time.time() - t0:.1f}s)")
+        res.update(phase4_oracle_windows=len(windows), window_positions=WINDOW, window_clusters=int(sum(w["count"] for w in wants)), window_records=int(recs), oracle_threads=THREADS)
+        del wants
+        # ---- ... and over the WHOLE range: the oracle's phase 4 sharded over the host threads (every shard numbering its clusters from 1, the
+        # texts renumbered into one run, tests/_fullsize.py::renumber) -> the .snp the product's whole-range pass must equal byte for byte
+        t0 = time.time()
+        from tests import _fullsize as fsz
+        n_shards = THREADS * 8
+        cuts = [ebd.shard_range(n, i, n_shards) for i in range(n_shards)]
+        with ThreadPoolExecutor(THREADS) as ex:
+            oparts = list(ex.map(lambda be: of.scan(po, be[0], be[1]), cuts))
+        oracle_text = fsz.renumber([r["text"] for r in oparts], [r["cluster_nr"] - 1 for r in oparts])
+        oracle_sha = hashlib.sha256(oracle_text).hexdigest()
+        log(f"oracle phase 4 over the whole range ({n_shards} shards on {THREADS} threads): {oracle_text.count(b'>')} records, sha256 {oracle_sha} ({time.time() - t0:.1f}s)")
+        res.update(oracle_snp_sha256=oracle_sha, oracle_phase4_seconds=round(time.time() - t0, 1))
+        del of, oidx, oparts
+    else:
+        del thrK, thrR, minima
 
     # ---- phase 4: whole range vs 8 shards
     t0 = time.time()
@@ -281,9 +286,10 @@ def main():
         parts.append(t)
     assert b"".join(parts) == whole and cn == cn_whole and ev == ev_whole
     sha = hashlib.sha256(whole).hexdigest()
-    assert whole == oracle_text, "the whole-range .snp differs from the CPU oracle's"
-    res.update(snp_equals_oracle_whole_range=True)
-    log(f"the whole-range .snp equals the CPU oracle's byte for byte, and 8 shards (the N = 8 ownership rule) concatenate to it: {ev} records, sha256 {sha}")
+    if ORACLE:
+        assert whole == oracle_text, "the whole-range .snp differs from the CPU oracle's"
+        res.update(snp_equals_oracle_whole_range=True)
+    log((f"the whole-range .snp equals the CPU oracle's byte for byte, and " if ORACLE else "(no oracle in this run) ") + f"8 shards (the N = 8 ownership rule) concatenate to the whole-range .snp: {ev} records, sha256 {sha}")
     res.update(snp_sha256=sha, shards8_equal_whole=True)
     if base:
         res.update(snp_records_over_config2=round(ev_whole / base["snp_records"], 3))
