@@ -264,7 +264,10 @@ void eb_scan_clusters_cancel(eb_scan_job* job);
  * (a rank's share of a multi-GPU run; one sub-shard) _begin then returns after ONE host wait -- the scan's -- and holds
  * the job's last part (image layout, chain list, context kernels, hand-over; it needs the ordering step's counts on
  * the host) back until the next _begin on the index, which sends it out behind its own scan, so that the two waits of
- * consecutive jobs overlap; _wait / _end / the device-image accessors send it out themselves if it is still pending. */
+ * consecutive jobs overlap; _wait / _end / the device-image accessors send it out themselves if it is still pending.
+ * Whatever the size of the call set: while the previous job's context kernels are still running, the scan of this job
+ * shares every CU with them instead of waiting for them (round 3), and the library reserves, with the caller's first call
+ * set, what several live jobs need -- page-locked blobs, device temporaries, copy-engine queues (+0.14 s on that call). */
 #define EB_SCAN_PIPELINED 4u
 int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f, uint64_t begin, uint64_t end, const eb_params* p,
                               uint32_t options, eb_scan_job** job);
