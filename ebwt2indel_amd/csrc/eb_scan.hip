@@ -201,12 +201,16 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
     if (threadIdx.x == 0) s_count = 0;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const unsigned long long lanes_below = (1ull << lane) - 1ull;
+    // ones of a ballot mask in the lanes below this one
+    auto ones_below = [](unsigned long long m) -> uint32_t {
+        return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    };
     const uint64_t hi_pos = p.end < p.n ? p.end : p.n;
     // scan planes in the coordinates the flags live in: the index's own (modes 1, 3) or the two BWTs merged by the DA (mode 2)
     const uint4* __restrict__ xy = MODE == 2 ? f.mxy : x1.xy;
     const uint64_t n_bwt_words = MODE == 2 ? f.words : (x1.n_blocks << 1); // 64-symbol words backed by the planes
-    uint64_t n_runs = 0, n_clusters = 0, n_bases = 0, n_surv = 0;
+    uint32_t n_runs32 = 0, n_clusters32 = 0, n_surv32 = 0; // per lane: bounded by the positions a lane streams (64 per tile)
+    uint64_t n_bases = 0;
     uint64_t cur_batch = 0;                           // ordered mode: the batch of the tile at hand (wave-uniform)
     uint32_t hot_n = 0, todo_n = 0;                   // queue fill, the same in every lane of the wave
     const uint64_t tiles = (w_count + 255) / 256;
@@ -265,7 +269,7 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
             const uint32_t pos = atomicAdd(&bcount[cur_batch], 1u);
             if (pos < EB_BATCH_SLOTS) slots[cur_batch * EB_BATCH_SLOTS + pos] = s;
             else cnt->spilled = 1ull;
-            ++n_surv;
+            ++n_surv32;
         } else if (keep) {
             // LDS staging (no per-survivor global atomic on the one list cursor); a full buffer spills straight to the list
             uint32_t slot = atomicAdd(&s_count, 1u);
@@ -282,7 +286,7 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
     // flow), so the fill counters live in registers; LDS operations of one wave complete in order.
     auto todo_push = [&](bool have, unsigned long long entry) {
         unsigned long long m = __ballot(have);
-        if (have) q_todo[wave][todo_n + (uint32_t)__popcll(m & lanes_below)] = entry;
+        if (have) q_todo[wave][todo_n + ones_below(m)] = entry;
         todo_n += (uint32_t)__popcll(m);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -336,7 +340,7 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
     };
     auto hot_push = [&](bool have, unsigned long long entry) {
         unsigned long long m = __ballot(have);
-        if (have) q_hot[wave][hot_n + (uint32_t)__popcll(m & lanes_below)] = entry;
+        if (have) q_hot[wave][hot_n + ones_below(m)] = entry;
         hot_n += (uint32_t)__popcll(m);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -427,7 +431,7 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
             if (base < p.begin) ends &= (p.begin - base >= 64) ? 0ull : (~0ull << (p.begin - base));
             if (base + 64 > hi_pos) ends &= (hi_pos <= base) ? 0ull : (~0ull >> (base + 64 - hi_pos));
         }
-        n_runs += (uint64_t)__popcll(ends);
+        n_runs32 += (uint32_t)__popcll(ends);
         if (EB_DBG(p) & 4u) continue;
         // ---- bit-parallel: which closing runs can hold two frequent letters at all.  Two letters with >= mcov rows each
         // (:961; the two-sample modes need two distinct frequent letters to print anything, see analyse()) mean that at
@@ -495,7 +499,7 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
                         uint64_t len = base + bit - g.b;
                         n_bases += len;
                         if (len <= 200 && !(EB_DBG(p) & 1u)) atomicAdd(&sh_hist[len], 1u);
-                        if (len >= p.min_len) ++n_clusters;
+                        if (len >= p.min_len) ++n_clusters32;
                         else hot &= ~(1ull << bit);
                     }
                     cprev = (int32_t)bit; // all rows below `bit` are flagged
@@ -542,7 +546,7 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
             }
             if (!edge) nb32 = (uint32_t)(cprev - cstart); // (the edge form counts only the runs that close inside the scanned range)
             n_bases += nb32;
-            n_clusters += (uint64_t)__popcll(ends & rest) - n_short; // closing positions walked here, minus the short runs
+            n_clusters32 += (uint32_t)__popcll(ends & rest) - n_short; // closing positions walked here, minus the short runs
         }
         // ---- hand the clusters that may matter to the queues, one per lane and round
         if (EB_DBG(p) & 8u) hot = 0;
@@ -575,6 +579,7 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
     }
     // Statistics leave the kernel as one row of plain stores per workgroup (k_scan_reduce adds the rows up): thousands of
     // waves hammering three counters in one cache line with atomics cost ~0.25 ms per launch, whatever the range size.
+    uint64_t n_runs = n_runs32, n_clusters = n_clusters32, n_surv = n_surv32;
     for (int o = 32; o > 0; o >>= 1) {
         n_runs += __shfl_xor((unsigned long long)n_runs, o);
         n_clusters += __shfl_xor((unsigned long long)n_clusters, o);
