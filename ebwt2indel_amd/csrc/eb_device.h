@@ -129,6 +129,72 @@ __device__ __forceinline__ rank4_t eb_rank4(const eb_dev_index& x, uint64_t i) {
     return r;
 }
 
+// ---- quad-local data movement with DPP (quad_perm) instead of __shfl / __shfl_xor: those compile to ds_bpermute_b32 -- an
+// LDS round trip of ~100 cycles on the path of every dependent step -- whereas a quad permutation is a modifier of the vector
+// instruction that consumes the value (v_add_u32_dpp, v_max_u32_dpp, v_or_b32_dpp).  All four lanes of a quad must be active.
+#define EB_QUAD_XOR1 0xB1 /* quad_perm:[1,0,3,2] */
+#define EB_QUAD_XOR2 0x4E /* quad_perm:[2,3,0,1] */
+template <int CTRL>
+__device__ __forceinline__ uint32_t eb_quad_perm(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+__device__ __forceinline__ uint32_t eb_quad_sum(uint32_t v) {
+    v += eb_quad_perm<EB_QUAD_XOR1>(v);
+    v += eb_quad_perm<EB_QUAD_XOR2>(v);
+    return v;
+}
+__device__ __forceinline__ uint32_t eb_quad_max(uint32_t v) {
+    uint32_t o = eb_quad_perm<EB_QUAD_XOR1>(v);
+    v = o > v ? o : v;
+    o = eb_quad_perm<EB_QUAD_XOR2>(v);
+    return o > v ? o : v;
+}
+__device__ __forceinline__ uint64_t eb_quad_max64(uint64_t v) {
+    uint64_t o = ((uint64_t)eb_quad_perm<EB_QUAD_XOR1>((uint32_t)(v >> 32)) << 32) | eb_quad_perm<EB_QUAD_XOR1>((uint32_t)v);
+    v = o > v ? o : v;
+    o = ((uint64_t)eb_quad_perm<EB_QUAD_XOR2>((uint32_t)(v >> 32)) << 32) | eb_quad_perm<EB_QUAD_XOR2>((uint32_t)v);
+    return o > v ? o : v;
+}
+__device__ __forceinline__ uint32_t eb_quad_or(uint32_t v) {
+    v |= eb_quad_perm<EB_QUAD_XOR1>(v);
+    v |= eb_quad_perm<EB_QUAD_XOR2>(v);
+    return v;
+}
+// the value of the ONE lane of the quad whose `mine` is set, in all four
+__device__ __forceinline__ uint64_t eb_quad_pick64(uint64_t v, bool mine) {
+    const uint32_t lo = eb_quad_or(mine ? (uint32_t)v : 0u), hi = eb_quad_or(mine ? (uint32_t)(v >> 32) : 0u);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint32_t eb_quad_pick32(uint32_t v, bool mine) { return eb_quad_or(mine ? v : 0u); }
+
+// Letter j's count before the superblock of position i, with the last answer kept: consecutive queries of a walk nearly always
+// stay in one superblock (2^32 symbols), and the table read is a global load on the path of every step otherwise.
+struct eb_super_cache {
+    uint32_t hi;   // superblock of `val` (0xFFFFFFFF: none yet)
+    uint64_t val;
+};
+__device__ __forceinline__ uint64_t eb_super_cached(const eb_dev_index& x, eb_super_cache& sc, uint64_t i, uint32_t j) {
+    const uint32_t hi = (uint32_t)(i >> EB_SUPER_SHIFT);
+    if (hi != sc.hi) {
+        sc.hi = hi;
+        sc.val = x.super[((uint64_t)hi << 2) + j];
+    }
+    return sc.val;
+}
+
+// rank of letter j at both ends of [lo, hi] by one quad, as eb_rank4_quad_pair, with the quad sums through DPP and the
+// superblock counts through the cache; sh8 = 8 * j.
+__device__ __forceinline__ void eb_rank4_quad_pair_dpp(const eb_dev_index& x, eb_super_cache& sc, uint64_t lo, uint64_t hi, uint32_t j, uint32_t sh8,
+                                                       uint64_t& a, uint64_t& b) {
+    uint4 c = eb_load_chunk(x.chunks + ((lo >> 7) << 2) + j);
+    uint4 d = c;
+    if ((hi >> 7) != (lo >> 7)) d = eb_load_chunk(x.chunks + ((hi >> 7) << 2) + j); // uniform inside the quad
+    const uint32_t p = eb_quad_sum(eb_chunk_counts(c, eb_prefix_mask32((uint32_t)(lo & 127u), j)));
+    const uint32_t q = eb_quad_sum(eb_chunk_counts(d, eb_prefix_mask32((uint32_t)(hi & 127u), j)));
+    a = eb_super_cached(x, sc, lo, j) + ((uint64_t)c.w + ((p >> sh8) & 0xFFu));
+    b = eb_super_cached(x, sc, hi, j) + ((uint64_t)d.w + ((q >> sh8) & 0xFFu));
+}
+
 // parallel_rank by FOUR adjacent lanes (lane&3 = j): each loads chunk j; returns the rank of letter j.
 // All four lanes of the quad must be active and pass the same i.
 __device__ __forceinline__ uint64_t eb_rank4_quad(const eb_dev_index& x, uint64_t i, uint32_t j) {

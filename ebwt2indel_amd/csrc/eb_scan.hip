@@ -817,7 +817,6 @@ __global__ void __launch_bounds__(256) k_extend(eb_dev_index x1, eb_dev_index x2
                                                const uint64_t* __restrict__ chains, uint64_t n_chains, eb_chain* __restrict__ crec,
                                                uint64_t* __restrict__ left, uint32_t left_words, unsigned long long* __restrict__ req_slots) {
     const uint32_t j = threadIdx.x & 3u;
-    const uint32_t qbase = (threadIdx.x & 63u) & ~3u; // first lane of this quad inside the wave
     uint64_t ch = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
     uint32_t n_req = 0; // 64-byte block requests issued by this quad (counted by its lane 0)
     if (ch < n_chains) { // uniform inside a quad
@@ -833,32 +832,41 @@ __global__ void __launch_bounds__(256) k_extend(eb_dev_index x1, eb_dev_index x2
     uint64_t L, R;
     if (TWO) { L = side ? s.b1 : s.b0; R = side ? s.e1 : s.e0; } else { L = s.b; R = s.e; }
     uint64_t* out = left + ch * (uint64_t)left_words;
+    // Every lane keeps what belongs to its letter j: F[j], and the rank of j at both ends of the range.  The quad sums of the
+    // packed counts, the arg-max and the hand-over of the winner's range go through DPP (quad permutations on the consuming
+    // instruction) -- with __shfl they were fourteen ds_bpermute round trips per step, five of them one after the other.
+    const uint32_t sh8 = 8u * j;
+    const uint64_t Fj = pick4(x.F, j);
+    eb_super_cache sc = {0xFFFFFFFFu, 0};
     // LF(range, c)
     uint64_t a, bq;
-    eb_rank4_quad_pair(x, L, R, j, a, bq);
+    eb_rank4_quad_pair_dpp(x, sc, L, R, j, sh8, a, bq);
     n_req += 1u + ((R >> 7) != (L >> 7));
-    uint64_t Fc = pick4(x.F, c);
-    L = Fc + __shfl((unsigned long long)a, qbase + c);
-    R = Fc + __shfl((unsigned long long)bq, qbase + c);
+    L = eb_quad_pick64(Fj + a, j == c);
+    R = eb_quad_pick64(Fj + bq, j == c);
     uint32_t support = (uint32_t)(R - L);
     uint32_t have = 1;
     uint64_t word = c; // base 0 = the frequent symbol itself
     while (have < (uint32_t)p.k_left) {
-        eb_rank4_quad_pair(x, L, R, j, a, bq);
+        eb_rank4_quad_pair_dpp(x, sc, L, R, j, sh8, a, bq);
         n_req += 1u + ((R >> 7) != (L >> 7));
-        uint64_t len = bq - a;
-        // arg-max over the quad, ties to the smaller letter (stable descending sort, ebwt2InDel.cpp:252-255)
-        uint64_t bl = len;
-        uint32_t bj = j;
-        for (int o = 1; o <= 2; o <<= 1) {
-            uint64_t ol = __shfl_xor((unsigned long long)bl, o);
-            uint32_t oj = (uint32_t)__shfl_xor((int)bj, o);
-            if (ol > bl || (ol == bl && oj < bj)) { bl = ol; bj = oj; }
+        const uint64_t len = bq - a;
+        // arg-max over the quad, ties to the smaller letter (stable descending sort, ebwt2InDel.cpp:252-255): the maximum of
+        // len << 2 | (3 - j); 32-bit keys unless some range of the wave is 2^30 rows or longer (wave-uniform choice)
+        uint32_t bj;
+        uint64_t bl;
+        if (__ballot((len >> 30) != 0ull) == 0ull) {
+            const uint32_t key = eb_quad_max(((uint32_t)len << 2) | (3u - j));
+            bj = 3u - (key & 3u);
+            bl = key >> 2;
+        } else {
+            const uint64_t key = eb_quad_max64((len << 2) | (uint64_t)(3u - j));
+            bj = 3u - ((uint32_t)key & 3u);
+            bl = key >> 2;
         }
         if (bl == 0) break; // consensus_letter returns 0 (:257)
-        uint64_t Fb = pick4(x.F, bj);
-        L = Fb + __shfl((unsigned long long)a, qbase + bj);
-        R = Fb + __shfl((unsigned long long)bq, qbase + bj);
+        L = eb_quad_pick64(Fj + a, j == bj);
+        R = L + bl;
         word |= (uint64_t)bj << (2u * (have & 31u));
         ++have;
         if ((have & 31u) == 0) { // 32 bases collected
