@@ -101,8 +101,10 @@ struct rank4_t {
 
 __device__ __forceinline__ uint32_t eb_prefix_mask32(uint32_t o, uint32_t j) {
     // mask of the symbols of chunk j that lie before in-block offset o (0..127)
-    uint32_t w = o >> 5;
-    return j < w ? 0xFFFFFFFFu : (j == w ? ((1u << (o & 31u)) - 1u) : 0u);
+    // the low min(max(o - 32 j, 0), 32) bits: a clamp, a 64-bit shift (32 must give all ones) and a decrement of its low half
+    int t = (int)o - (int)(32u * j);
+    t = t < 0 ? 0 : (t > 32 ? 32 : t);
+    return (uint32_t)(1ull << t) - 1u;
 }
 
 // Packed per-letter popcounts (A | C<<8 | G<<16 | T<<24) of the symbols selected by `mask`.
@@ -200,8 +202,7 @@ __device__ __forceinline__ void eb_rank4_quad_pair_dpp(const eb_dev_index& x, eb
 __device__ __forceinline__ uint64_t eb_rank4_quad(const eb_dev_index& x, uint64_t i, uint32_t j) {
     uint4 c = eb_load_chunk(x.chunks + ((i >> 7) << 2) + j);
     uint32_t p = eb_chunk_counts(c, eb_prefix_mask32((uint32_t)(i & 127u), j));
-    p += (uint32_t)__shfl_xor((int)p, 1);
-    p += (uint32_t)__shfl_xor((int)p, 2);
+    p = eb_quad_sum(p);
     return x.super[((i >> EB_SUPER_SHIFT) << 2) + j] + c.w + ((p >> (8u * j)) & 0xFFu);
 }
 
@@ -209,8 +210,7 @@ __device__ __forceinline__ uint64_t eb_rank4_quad(const eb_dev_index& x, uint64_
 __device__ __forceinline__ uint4 eb_rank4_quad_load(const eb_dev_index& x, uint64_t i, uint32_t j) { return eb_load_chunk(x.chunks + ((i >> 7) << 2) + j); }
 __device__ __forceinline__ uint64_t eb_rank4_quad_finish(const eb_dev_index& x, uint4 c, uint64_t i, uint32_t j) {
     uint32_t p = eb_chunk_counts(c, eb_prefix_mask32((uint32_t)(i & 127u), j));
-    p += (uint32_t)__shfl_xor((int)p, 1);
-    p += (uint32_t)__shfl_xor((int)p, 2);
+    p = eb_quad_sum(p);
     return x.super[((i >> EB_SUPER_SHIFT) << 2) + j] + c.w + ((p >> (8u * j)) & 0xFFu);
 }
 
@@ -222,10 +222,8 @@ __device__ __forceinline__ void eb_rank4_quad_pair(const eb_dev_index& x, uint64
     if ((hi >> 7) != (lo >> 7)) d = eb_load_chunk(x.chunks + ((hi >> 7) << 2) + j); // uniform inside the quad
     uint32_t p = eb_chunk_counts(c, eb_prefix_mask32((uint32_t)(lo & 127u), j));
     uint32_t q = eb_chunk_counts(d, eb_prefix_mask32((uint32_t)(hi & 127u), j));
-    p += (uint32_t)__shfl_xor((int)p, 1);
-    q += (uint32_t)__shfl_xor((int)q, 1);
-    p += (uint32_t)__shfl_xor((int)p, 2);
-    q += (uint32_t)__shfl_xor((int)q, 2);
+    p = eb_quad_sum(p);
+    q = eb_quad_sum(q);
     a = x.super[((lo >> EB_SUPER_SHIFT) << 2) + j] + c.w + ((p >> (8u * j)) & 0xFFu);
     b = x.super[((hi >> EB_SUPER_SHIFT) << 2) + j] + d.w + ((q >> (8u * j)) & 0xFFu);
 }

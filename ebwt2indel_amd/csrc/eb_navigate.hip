@@ -521,8 +521,7 @@ __global__ void __launch_bounds__(256) k_nodes1p(eb_dev_index x1, eb_dev_flags f
         for (int k = 0; k < 6; ++k) {
             const uint64_t i = Nc.b[k];
             uint32_t pc = eb_chunk_counts(cc[k], eb_prefix_mask32((uint32_t)(i & 127u), j));
-            pc += (uint32_t)__shfl_xor((int)pc, 1);
-            pc += (uint32_t)__shfl_xor((int)pc, 2);
+            pc = eb_quad_sum(pc);
             uint64_t sup;
             if constexpr (SUPER_LDS) sup = s_super[((i >> EB_SUPER_SHIFT) << 2) + j];
             else sup = x1.super[((i >> EB_SUPER_SHIFT) << 2) + j];
@@ -677,10 +676,8 @@ __global__ void __launch_bounds__(256) k_nodes2p(eb_dev_index x1, eb_dev_index x
             const uint64_t ia = Nc.a[k], ib = Nc.b[k];
             uint32_t pa = eb_chunk_counts(cur_a, eb_prefix_mask32((uint32_t)(ia & 127u), j));
             uint32_t pb = eb_chunk_counts(cur_b, eb_prefix_mask32((uint32_t)(ib & 127u), j));
-            pa += (uint32_t)__shfl_xor((int)pa, 1);
-            pb += (uint32_t)__shfl_xor((int)pb, 1);
-            pa += (uint32_t)__shfl_xor((int)pa, 2);
-            pb += (uint32_t)__shfl_xor((int)pb, 2);
+            pa = eb_quad_sum(pa);
+            pb = eb_quad_sum(pb);
             uint64_t sa, sb;
             if constexpr (SUPER_LDS) { sa = s_super[0][((ia >> EB_SUPER_SHIFT) << 2) + j]; sb = s_super[1][((ib >> EB_SUPER_SHIFT) << 2) + j]; }
             else { sa = x1.super[((ia >> EB_SUPER_SHIFT) << 2) + j]; sb = x2.super[((ib >> EB_SUPER_SHIFT) << 2) + j]; }

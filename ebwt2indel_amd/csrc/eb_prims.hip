@@ -29,10 +29,8 @@ __global__ void __launch_bounds__(256) k_rank4_batch(eb_dev_index x, const uint6
         uint4 c1 = eb_load_chunk(x.chunks + ((i1 >> 7) << 2) + j);
         uint32_t p0 = eb_chunk_counts(c0, eb_prefix_mask32((uint32_t)(i0 & 127u), j));
         uint32_t p1 = eb_chunk_counts(c1, eb_prefix_mask32((uint32_t)(i1 & 127u), j));
-        p0 += (uint32_t)__shfl_xor((int)p0, 1);
-        p1 += (uint32_t)__shfl_xor((int)p1, 1);
-        p0 += (uint32_t)__shfl_xor((int)p0, 2);
-        p1 += (uint32_t)__shfl_xor((int)p1, 2);
+        p0 = eb_quad_sum(p0);
+        p1 = eb_quad_sum(p1);
         out4[q * 4 + j] = x.super[((i0 >> EB_SUPER_SHIFT) << 2) + j] + c0.w + ((p0 >> (8u * j)) & 0xFFu);
         if (has1) out4[q1 * 4 + j] = x.super[((i1 >> EB_SUPER_SHIFT) << 2) + j] + c1.w + ((p1 >> (8u * j)) & 0xFFu);
     }

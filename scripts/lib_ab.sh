@@ -9,7 +9,7 @@ for rep in $(seq 1 ${REPS:-2}); do
     EB_LIB_PATH=$ROOT/ebwt2indel_amd/$lib/libebwt2indel.so timeout -k 10 200 $B 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('$lib', 'ms_per_step', d['ms_per_step'], 'min/median/max', d['step_spread']['ms_per_step_min'], d['step_spread']['ms_per_step_median'], d['step_spread']['ms_per_step_max'], 'scan', d['phase4_device_ms']['scan'], 'scan alone', d['roofline']['alone']['avg_launch_ms'], 'ctx', d['phase4_device_ms']['context_span'], 'snp', d['snp_verified'] is not None, flush=True)
+print('$lib', 'ms_per_step', d['ms_per_step'], 'min/median/max', d['step_spread']['ms_per_step_min'], d['step_spread']['ms_per_step_median'], d['step_spread']['ms_per_step_max'], 'scan', d['phase4_device_ms']['scan'], 'scan alone', d['roofline']['alone']['avg_launch_ms'], 'ctx', d['phase4_device_ms']['context_span'], 'alone: extend', d['phase4_device_ms']['alone']['extend_ms'], 'right', d['phase4_device_ms']['alone']['right_ms'], 'span', d['phase4_device_ms']['alone']['context_span_ms'], 'nav s', d['phases23_gpu']['seconds'], 'leaves', d['phases23_gpu']['seconds_leaves'], 'snp', d['snp_verified'] is not None, flush=True)
 " || exit 1
   done
 done
