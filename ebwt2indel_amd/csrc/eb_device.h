@@ -32,6 +32,7 @@ struct eb_dev_index {
     uint64_t sel_off[4];     // first directory entry of each letter
     uint32_t term;          // ASCII terminator
     uint32_t sel_shift;     // log2 of the select directory's sampling distance
+    uint32_t sel_blk_bits;  // low bits of a directory entry that hold the block (32: nothing else in the entry), see eb_select_guess
 };
 
 struct eb_dev_flags {
@@ -250,6 +251,42 @@ __device__ __forceinline__ uint64_t eb_block_count(const eb_dev_index& x, uint64
     return x.super[((b >> 25) << 2) + c] + w[3];
 }
 
+// A directory entry holds the block of a sampled occurrence in its low sel_blk_bits bits and, in the bits an index of this size
+// leaves free, how many occurrences of the letter precede the sample INSIDE that block (0..127, in units of 2^os so that it
+// fits: os = 7 - (32 - sel_blk_bits)).  With that the block of the r-th occurrence is known before any block is read, in the
+// usual case: if the next sample (2^sel_shift occurrences on) sits in block hi with o' occurrences of its block before it,
+// the last o' occurrences before that sample lie in hi, all earlier ones before hi -- so with hi = lo + 1 (consecutive samples
+// are about a block apart at the dense sampling) the answer is exact up to the rounding of o'.  Round 3's directory held the
+// blocks only and guessed by interpolation: right three times out of four (1.24 probes per select); every wrong guess costs a
+// wave of 16 walks a second pass through the probe body and a second random line.  Returns a block in [lo, hi].
+// (Written without early exits, as one 32-bit select: the first form -- `return hi;` from inside nested divergent ifs of a function
+// returning uint64_t -- came out of hipcc 7.2 with the high half of the result left holding a temporary in the lanes that took
+// that exit, i.e. a block index beyond 2^32 and a memory fault; found in the disassembly of k_right, round 3.)
+__device__ __forceinline__ uint32_t eb_select_guess(const eb_dev_index& x, const uint32_t* __restrict__ dir, uint64_t r) {
+    const uint32_t sh = x.sel_shift, bb = x.sel_blk_bits; // (wave-uniform)
+    const uint64_t m = r >> sh;
+    const uint32_t e0 = dir[m], e1 = dir[m + 1]; // (same line nearly always)
+    const uint32_t frac = (uint32_t)r & ((1u << sh) - 1u);
+    const bool ord = bb < 32u; // entries carry ordinals (up to 2^29 blocks)
+    uint32_t lo = e0, hi = e1, o1 = 0;
+    if (ord) {
+        const uint32_t bmask = (1u << bb) - 1u;
+        lo = e0 & bmask;
+        hi = e1 & bmask;
+        o1 = (e1 >> bb) << (bb - 25u); // occurrences in block hi before the next sample, rounded down to the stored unit
+    }
+    const uint32_t span = hi - lo;
+    // with ordinals: the last o' occurrences before the next sample lie in hi, every earlier one before hi (samples beyond the
+    // letter's last occurrence point at the last block with o' = 0)
+    const bool at_hi = ord && (span == 0u || frac + o1 >= (1u << sh));
+    // otherwise spread the guess over the blocks that can hold the answer: lo .. hi - 1 with ordinals, lo .. hi without
+    const uint32_t sp0 = ord ? span : (span < 0xFFFFFFFFu ? span + 1u : span);
+    const uint32_t sp = sp0 < 0xFFFFFFu ? sp0 : 0xFFFFFFu; // 24 bits x sh <= 7 bits: the product fits (a wider sh only blurs the guess)
+    uint32_t gi = (frac * sp) >> sh;                         // < sp, were it not for a product that overflows with sh > 8
+    gi = gi < sp ? gi : sp - 1u;
+    return at_hi ? hi : lo + gi;
+}
+
 // select (dna_string.hpp:182-188,254-272): position of the r-th (0-based) letter c.  The reference
 // bisects [0,n) with ~log2(n) full rank queries (33 at n = 7.55 G).  Here a directory (block of every
 // 128th occurrence of each letter, n/32 bytes in all) brackets the answer to a handful of blocks; letters are locally
@@ -261,11 +298,7 @@ __device__ __forceinline__ uint64_t eb_block_count(const eb_dev_index& x, uint64
 // context_roofline is built from these counts).
 __device__ __forceinline__ uint64_t eb_select(const eb_dev_index& x, uint64_t r, int c, uint32_t& probes) {
     const uint32_t* dir = x.sel_dir + (c == 0 ? x.sel_off[0] : c == 1 ? x.sel_off[1] : c == 2 ? x.sel_off[2] : x.sel_off[3]);
-    const uint32_t sh = x.sel_shift;
-    uint64_t m = r >> sh;
-    uint64_t lo = dir[m], hi = dir[m + 1]; // the answer lies in a block of [lo, hi]
-    uint64_t g = lo + (((r - (m << sh)) * (hi - lo + 1)) >> sh);
-    if (g > hi) g = hi;
+    uint64_t g = (uint64_t)eb_select_guess(x, dir, r); // the answer lies in a block between the two samples around r
     ++probes;
     for (;;) {
         ++probes;
@@ -308,11 +341,7 @@ __device__ __forceinline__ uint64_t eb_select(const eb_dev_index& x, uint64_t r,
 // lane, and a wave holds 16 walks instead of 64, so fewer lanes wait for the walk that needs a third probe.
 __device__ __forceinline__ uint64_t eb_select_quad(const eb_dev_index& x, uint64_t r, int c, uint32_t j, uint32_t qbase, uint32_t& probes) {
     const uint32_t* dir = x.sel_dir + (c == 0 ? x.sel_off[0] : c == 1 ? x.sel_off[1] : c == 2 ? x.sel_off[2] : x.sel_off[3]);
-    const uint32_t sh = x.sel_shift;
-    uint64_t m = r >> sh;
-    uint64_t lo = dir[m], hi = dir[m + 1]; // same address in all four lanes: one request
-    uint64_t g = lo + (((r - (m << sh)) * (hi - lo + 1)) >> sh);
-    if (g > hi) g = hi;
+    uint64_t g = (uint64_t)eb_select_guess(x, dir, r); // same addresses in all four lanes: one request
     ++probes;
     for (;;) {
         ++probes;

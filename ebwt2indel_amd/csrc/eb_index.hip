@@ -218,8 +218,13 @@ __global__ void __launch_bounds__(256) k_select_dir(eb_dev_index x, uint32_t* __
         uint64_t before = eb_block_count(x, b, c);
         uint64_t in_block = (p >> (8 * c)) & 0xFFu;
         // samples m * 2^sel_shift that fall on an occurrence inside this block
-        for (uint64_t m = (before + (1ull << x.sel_shift) - 1) >> x.sel_shift; (m << x.sel_shift) < before + in_block; ++m)
-            dir[x.sel_off[c] + m] = (uint32_t)b;
+        // (with the sample's ordinal inside the block in the entry's free bits, eb_select_guess)
+        const uint32_t bb = x.sel_blk_bits, os = bb < 32u ? 7u - (32u - bb) : 0u;
+        for (uint64_t m = (before + (1ull << x.sel_shift) - 1) >> x.sel_shift; (m << x.sel_shift) < before + in_block; ++m) {
+            uint32_t e = (uint32_t)b;
+            if (bb < 32u) e |= (((uint32_t)((m << x.sel_shift) - before)) >> os) << bb;
+            dir[x.sel_off[c] + m] = e;
+        }
     }
 }
 __global__ void __launch_bounds__(256) k_fill_u32(uint32_t* __restrict__ p, uint64_t n, uint32_t v) {
@@ -341,6 +346,13 @@ static int finish_index(eb_index* h, unsigned long long* d_bad, const uint8_t* d
     // (BASELINE configs[4]: 151 G symbols, 277 of 309 GB of HBM in use) cannot spare.  EB_SEL_SHIFT=5..10 overrides.
     h->sel_shift = h->n <= (1ull << 35) ? EB_SEL_SHIFT_DENSE : EB_SEL_SHIFT_SPARSE;
     if (const char* e = getenv("EB_SEL_SHIFT")) { int v = atoi(e); if (v >= 5 && v <= 10) h->sel_shift = (uint32_t)v; }
+    // bits of an entry the block index leaves free carry the sample's ordinal inside its block (at least three, else none)
+    {
+        uint32_t bb = 1;
+        while (bb < 32u && (h->n_blocks >> bb) != 0) ++bb;
+        h->sel_blk_bits = bb <= 29u ? (bb < 25u ? 25u : bb) : 32u;
+        if (const char* e = getenv("EB_SEL_ORDINALS")) { if (atoi(e) == 0) h->sel_blk_bits = 32; }
+    }
     uint64_t sel_entries = 0;
     for (int c = 0; c < 4; ++c) {
         h->sel_off[c] = sel_entries;

@@ -49,6 +49,7 @@ struct eb_index {
     uint64_t F[4] = {0, 0, 0, 0};
     uint8_t term = '#';
     uint32_t sel_shift = EB_SEL_SHIFT_SPARSE; // log2 of the select directory's sampling distance
+    uint32_t sel_blk_bits = 32;               // block bits of a directory entry (eb_select_guess)
     uint64_t device_bytes = 0;
     eb_scan_ctx* scan_ctx = nullptr;
     eb_dev_index dev() const {
@@ -63,6 +64,7 @@ struct eb_index {
         for (int i = 0; i < 4; ++i) d.sel_off[i] = sel_off[i];
         d.term = term;
         d.sel_shift = sel_shift;
+        d.sel_blk_bits = sel_blk_bits;
         return d;
     }
 };

@@ -947,6 +947,7 @@ __global__ void __launch_bounds__(256) k_right(eb_dev_index x1, eb_dev_index x2,
             row = second ? i1 : pos - i1;
             if (second) {
                 x.chunks = x2.chunks; x.super = x2.super; x.sel_dir = x2.sel_dir;
+                x.sel_shift = x2.sel_shift; x.sel_blk_bits = x2.sel_blk_bits; // (the two indexes may differ in size: their directories are read their own way)
                 for (int k = 0; k < 4; ++k) { x.F[k] = x2.F[k]; x.sel_off[k] = x2.sel_off[k]; }
             }
         }
