@@ -268,12 +268,13 @@ __device__ __forceinline__ uint32_t eb_select_guess(const eb_dev_index& x, const
     const uint32_t e0 = dir[m], e1 = dir[m + 1]; // (same line nearly always)
     const uint32_t frac = (uint32_t)r & ((1u << sh) - 1u);
     const bool ord = bb < 32u; // entries carry ordinals (up to 2^29 blocks)
-    uint32_t lo = e0, hi = e1, o1 = 0;
+    uint32_t lo = e0, hi = e1, o0 = 0, o1 = 0;
     if (ord) {
         const uint32_t bmask = (1u << bb) - 1u;
         lo = e0 & bmask;
         hi = e1 & bmask;
-        o1 = (e1 >> bb) << (bb - 25u); // occurrences in block hi before the next sample, rounded down to the stored unit
+        o0 = (e0 >> bb) << (bb - 25u); // occurrences in block lo before this sample, rounded down to the stored unit
+        o1 = (e1 >> bb) << (bb - 25u); // occurrences in block hi before the next sample
     }
     const uint32_t span = hi - lo;
     // with ordinals: the last o' occurrences before the next sample lie in hi, every earlier one before hi (samples beyond the
@@ -284,6 +285,10 @@ __device__ __forceinline__ uint32_t eb_select_guess(const eb_dev_index& x, const
     const uint32_t sp = sp0 < 0xFFFFFFu ? sp0 : 0xFFFFFFu; // 24 bits x sh <= 7 bits: the product fits (a wider sh only blurs the guess)
     uint32_t gi = (frac * sp) >> sh;                         // < sp, were it not for a product that overflows with sh > 8
     gi = gi < sp ? gi : sp - 1u;
+    // two blocks before hi (one select in twelve at the dense sampling): they share the 2^sh - o' + o occurrences from the start of
+    // lo to the next sample's block about evenly, and the answer is number o + frac of those -- in lo + 1 iff past the middle
+    // (CPU model of the whole rule on read-like letter frequencies: 98 % of first probes right, 95.5 % without this line)
+    if (ord && span == 2u) gi = 2u * frac + o0 + o1 >= (1u << sh) ? 1u : 0u;
     return at_hi ? hi : lo + gi;
 }
 
