@@ -17,7 +17,8 @@
 #define EB_BLOCK_SYMS 128u
 #define EB_SUPER_SHIFT 32 /* 2^32 symbols per superblock (dna_string.hpp:36) */
 /* The select directory samples every 2^sel_shift-th occurrence of a letter (eb_dev_index::sel_shift, chosen when the index is
- * built: 5 up to 2^35 symbols -- n/8 bytes of directory, 1.24 block probes per FL -- 7 beyond -- n/32 bytes, 1.52 probes). */
+ * built: 5 up to 2^35 symbols -- n/8 bytes of directory, 1.24 block probes per FL by interpolation, ~1.03 with the ordinals of
+ * eb_select_guess -- 7 beyond -- n/32 bytes, 1.52 probes). */
 #define EB_SEL_SHIFT_DENSE 5
 #define EB_SEL_SHIFT_SPARSE 7
 
@@ -298,7 +299,7 @@ __device__ __forceinline__ uint32_t eb_select_guess(const eb_dev_index& x, const
 // uniform, so an interpolated guess usually lands on the right block at once.  Each probe loads the WHOLE 64-byte block (one line): its
 // counter says how many c precede it, its planes how many it holds, so the block that contains the answer is
 // recognised without probing its neighbour, and the in-block select needs no further memory access.
-// Same unique answer as the reference's bisection in ~2.3 dependent 64-byte reads.
+// Same unique answer as the reference's bisection in ~2 dependent reads (directory line, block).
 // `probes` counts the memory requests issued: 1 for the directory pair + 1 per 64-byte block probed (bench.py's
 // context_roofline is built from these counts).
 __device__ __forceinline__ uint64_t eb_select(const eb_dev_index& x, uint64_t r, int c, uint32_t& probes) {
