@@ -351,7 +351,12 @@ static int finish_index(eb_index* h, unsigned long long* d_bad, const uint8_t* d
         uint32_t bb = 1;
         while (bb < 32u && (h->n_blocks >> bb) != 0) ++bb;
         h->sel_blk_bits = bb <= 29u ? (bb < 25u ? 25u : bb) : 32u;
-        if (const char* e = getenv("EB_SEL_ORDINALS")) { if (atoi(e) == 0) h->sel_blk_bits = 32; }
+        // EB_SEL_BLK_BITS=32: plain entries (round 3's interpolation); 25..29: ordinals in coarser units than the index needs
+        // (what a larger index would use: tests run the layouts of 2^32 .. 2^36 symbols on small inputs)
+        if (const char* e = getenv("EB_SEL_BLK_BITS")) {
+            const int v = atoi(e);
+            if (v == 32 || (v >= 25 && v <= 29 && (uint32_t)v >= bb)) h->sel_blk_bits = (uint32_t)v;
+        }
     }
     uint64_t sel_entries = 0;
     for (int c = 0; c < 4; ++c) {

@@ -151,6 +151,22 @@ def test_fl_under_every_select_sampling(oracle, monkeypatch, name, shift):
         assert api.run_one_dataset(e) == want
 
 
+@pytest.mark.parametrize("shift,bits", [("5", "29"), ("7", "29"), ("7", "27"), ("5", "32"), ("10", "26")])
+def test_fl_under_every_directory_entry_layout(oracle, monkeypatch, shift, bits):
+    """A select-directory entry keeps the block of its sample in its low bits and the sample's ordinal inside that block in
+    the bits an index of that size leaves free, in units of 1 (up to 2^32 symbols) to 16 (up to 2^36), none beyond
+    (eb_select_guess); EB_SEL_BLK_BITS puts the layouts of the large indexes on a small one.  FL, and a whole run's .snp
+    through the right-context walk, must not depend on the layout: the guess only chooses where the probes start."""
+    monkeypatch.setenv("EB_SEL_SHIFT", shift)
+    monkeypatch.setenv("EB_SEL_BLK_BITS", bits)
+    e = golden_bytes("dip.ebwt")
+    g, o = api.DnaBwt(e), oracle.index(e)
+    pos = _rng(int(shift) * 37 + int(bits)).integers(g.F_arr[0], len(e), size=30_000, dtype=np.uint64)
+    assert np.array_equal(g.FL(pos), o.fl(pos))
+    want, _ = oracle.run(e)
+    assert api.run_one_dataset(e) == want
+
+
 def test_lf_node(dip):
     e, g, o = dip
     r = _rng(6)
