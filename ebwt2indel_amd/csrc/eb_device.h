@@ -305,6 +305,7 @@ __device__ __forceinline__ uint32_t eb_select_guess(const eb_dev_index& x, const
 __device__ __forceinline__ uint64_t eb_select(const eb_dev_index& x, uint64_t r, int c, uint32_t& probes) {
     const uint32_t* dir = x.sel_dir + (c == 0 ? x.sel_off[0] : c == 1 ? x.sel_off[1] : c == 2 ? x.sel_off[2] : x.sel_off[3]);
     uint64_t g = (uint64_t)eb_select_guess(x, dir, r); // the answer lies in a block between the two samples around r
+    if (g >= x.n_blocks) g = x.n_blocks - 1; // (never, by construction of the directory: a wrong guess may cost probes, it must not cost a fault)
     ++probes;
     for (;;) {
         ++probes;
@@ -348,6 +349,7 @@ __device__ __forceinline__ uint64_t eb_select(const eb_dev_index& x, uint64_t r,
 __device__ __forceinline__ uint64_t eb_select_quad(const eb_dev_index& x, uint64_t r, int c, uint32_t j, uint32_t qbase, uint32_t& probes) {
     const uint32_t* dir = x.sel_dir + (c == 0 ? x.sel_off[0] : c == 1 ? x.sel_off[1] : c == 2 ? x.sel_off[2] : x.sel_off[3]);
     uint64_t g = (uint64_t)eb_select_guess(x, dir, r); // same addresses in all four lanes: one request
+    if (g >= x.n_blocks) g = x.n_blocks - 1; // (never, by construction of the directory: a wrong guess may cost probes, it must not cost a fault)
     ++probes;
     for (;;) {
         ++probes;
