@@ -294,9 +294,9 @@ __device__ __forceinline__ uint32_t eb_select_guess(const eb_dev_index& x, const
 }
 
 // select (dna_string.hpp:182-188,254-272): position of the r-th (0-based) letter c.  The reference
-// bisects [0,n) with ~log2(n) full rank queries (33 at n = 7.55 G).  Here a directory (block of every
-// 128th occurrence of each letter, n/32 bytes in all) brackets the answer to a handful of blocks; letters are locally
-// uniform, so an interpolated guess usually lands on the right block at once.  Each probe loads the WHOLE 64-byte block (one line): its
+// bisects [0,n) with ~log2(n) full rank queries (33 at n = 7.55 G).  Here a directory (block of every 2^sel_shift-th
+// occurrence of each letter: every 32nd up to 2^35 symbols, n/8 bytes in all; every 128th beyond) brackets the answer to a
+// block or two, and eb_select_guess names the right one nearly always.  Each probe loads the WHOLE 64-byte block (one line): its
 // counter says how many c precede it, its planes how many it holds, so the block that contains the answer is
 // recognised without probing its neighbour, and the in-block select needs no further memory access.
 // Same unique answer as the reference's bisection in ~2 dependent reads (directory line, block).

@@ -828,7 +828,7 @@ __global__ void __launch_bounds__(256) k_extend(eb_dev_index x1, eb_dev_index x2
     // the index of this chain: a by-value pick of the few fields used (a reference chosen at run time between two kernel
     // arguments would put both structs into scratch memory, on the path of every dependent step)
     eb_dev_index x = x1;
-    if (TWO && side == 1) { x.chunks = x2.chunks; x.super = x2.super; for (int k = 0; k < 4; ++k) x.F[k] = x2.F[k]; }
+    if (TWO && side == 1) { x.chunks = x2.chunks; x.super = x2.super; x.n = x2.n; x.n_blocks = x2.n_blocks; for (int k = 0; k < 4; ++k) x.F[k] = x2.F[k]; }
     uint64_t L, R;
     if (TWO) { L = side ? s.b1 : s.b0; R = side ? s.e1 : s.e0; } else { L = s.b; R = s.e; }
     uint64_t* out = left + ch * (uint64_t)left_words;
@@ -947,6 +947,7 @@ __global__ void __launch_bounds__(256) k_right(eb_dev_index x1, eb_dev_index x2,
             row = second ? i1 : pos - i1;
             if (second) {
                 x.chunks = x2.chunks; x.super = x2.super; x.sel_dir = x2.sel_dir;
+                x.n = x2.n; x.n_blocks = x2.n_blocks; // (the select's guess is clamped to the index it walks in)
                 x.sel_shift = x2.sel_shift; x.sel_blk_bits = x2.sel_blk_bits; // (the two indexes may differ in size: their directories are read their own way)
                 for (int k = 0; k < 4; ++k) { x.F[k] = x2.F[k]; x.sel_off[k] = x2.sel_off[k]; }
             }
@@ -1011,6 +1012,7 @@ __global__ void __launch_bounds__(256) k_right_finish(const eb_cluster* __restri
     for (uint32_t k = 0; k < right_words; ++k) right[i * (uint64_t)right_words + k] = tmp_right[i * (uint64_t)right_words + k];
 }
 
+#define EB_PINNED_RING_BYTES (2ull << 30) /* most host memory a pipelining caller's ring of eight page-locked blobs may take */
 #define EB_JOB_PINNED_BYTES (512 + 16 * (sizeof(ScanCounters) + 64)) /* page-locked words of one job (<= 16 sub-shards) */
 struct DevMem { // per-call temporary from the caching scratch allocator
     void* p = nullptr;
@@ -1158,7 +1160,6 @@ void eb_scan_ctx_destroy(eb_scan_ctx* c) {
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     if (c->last_ext) (void)hipEventDestroy(c->last_ext);
     if (c->last_right) (void)hipEventDestroy(c->last_right);
-    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     for (unsigned long long* p : c->h_bad_pool) (void)hipHostFree(p);
     delete c;
 }
@@ -1264,24 +1265,36 @@ static int launch_contexts(eb_scan_job* job) {
         // holds its own set of device temporaries.  The cache grows by one set whenever the number of live jobs reaches a new
         // maximum -- a dozen hipMallocs, 16-19 ms, in the middle of the pipeline (round 3: one begin call of 19 ms among 2.9 ms
         // ones, at a different step of every run).  A pipelining caller pays for a ring of sets once, with its first call set.
+        // Bounded: the ring may take an eighth of the HBM that is free right now, no more (a call set of tens of millions of
+        // clusters on a device the index nearly fills reserves nothing and pays the mallocs as its pipeline fills), and a failed
+        // allocation ends the reservation (eb_scratch_get empties the whole cache before it gives up).
+        size_t set_bytes = 0, free_b = 0, total_b = 0;
+        for (SubShard& x : job->sh)
+            for (DevMem* m : {&x.cnt, &x.part, &x.surv, &x.sorted, &x.bcnt, &x.boff, &x.tmp, &x.nch, &x.choff, &x.chains, &x.recs, &x.crec, &x.left, &x.right, &x.blob,
+                              &x.rt_rec, &x.rt_right, &x.slots, &x.bcount})
+                if (m->p) set_bytes += m->cap;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
         std::vector<std::pair<void*, size_t>> held;
-        for (int copy = 0; copy < 5; ++copy)
+        bool failed = 5 * set_bytes > free_b / 8;
+        for (int copy = 0; copy < 5 && !failed; ++copy)
             for (SubShard& x : job->sh)
                 for (DevMem* m : {&x.cnt, &x.part, &x.surv, &x.sorted, &x.bcnt, &x.boff, &x.tmp, &x.nch, &x.choff, &x.chains, &x.recs, &x.crec, &x.left, &x.right, &x.blob,
                                   &x.rt_rec, &x.rt_right, &x.slots, &x.bcount}) {
-                    if (!m->p) continue;
+                    if (!m->p || failed) continue;
                     size_t cap = 0;
                     void* q = eb_scratch_get(b1->device, m->cap - m->cap / 16, &cap); // a block of this job's class (a cached one of that class does as well)
                     if (q) held.emplace_back(q, cap);
+                    else failed = true;
                 }
         for (const auto& h : held) eb_scratch_put(b1->device, h.first, h.second);
-        ctx->scratch_reserved = ns;
+        ctx->scratch_reserved = ns; // (also after a refusal: asked once per call-set size, not once per job)
     }
     if (!device_only) {
         if ((options & EB_SCAN_PIPELINED) && ns) { // several call sets of this size will be alive at once: pin their blobs now, not in mid-pipeline
             const uint64_t need = eb_calls_blob_size(ns, n_chains, prm->k_left, prm->k_right);
-            if (need > ctx->pinned_reserved) {
-                eb_pinned_reserve(need + need / 16, 8, job->has_blob ? sh[0].blob.p : nullptr, job->has_blob ? job->blob_bytes : 0);
+            if (need > ctx->pinned_reserved) { // (at most EB_PINNED_RING_BYTES page-locked in all: larger call sets pin their blobs one by one)
+                if (8 * (need + need / 16) <= EB_PINNED_RING_BYTES)
+                    eb_pinned_reserve(need + need / 16, 8, job->has_blob ? sh[0].blob.p : nullptr, job->has_blob ? job->blob_bytes : 0);
                 ctx->pinned_reserved = need + need / 16;
             }
         }

@@ -153,12 +153,19 @@ class _DeviceWords:
 
 
 _NAV_COUNTERS = ("leaves", "nodes", "lcp_values", "da_values", "minima", "rank_queries", "batches")
-_NAV_SUMS = ("lcp_pos_sum", "lcp_pos_sq_sum")      # modulo 2^64: they travel as int64 and wrap the same way
+_NAV_SUMS = ("lcp_pos_sum", "lcp_pos_sq_sum")      # modulo 2^64: they travel as four 16-bit limbs each, so that no
+                                                   # backend ever adds two int64 values that overflow (signed overflow is
+                                                   # undefined on the gloo path and unspecified for RCCL)
 
 
-def _signed(v: int) -> int:
+def _limbs(v: int) -> List[int]:
     v &= (1 << 64) - 1
-    return v - (1 << 64) if v >= (1 << 63) else v
+    return [(v >> (16 * k)) & 0xFFFF for k in range(4)]
+
+
+def _from_limbs(l) -> int:
+    """Sum over the ranks of each limb (< world * 2^16, exact in int64) -> the sum of the values modulo 2^64."""
+    return sum(int(x) << (16 * k) for k, x in enumerate(l)) & ((1 << 64) - 1)
 
 
 def navigate_sharded(bwt1, params, bwt2=None, group=None, device=None):
@@ -208,12 +215,15 @@ def navigate_sharded(bwt1, params, bwt2=None, group=None, device=None):
                            f"sum of the ranks' ones {ones.tolist()}; order thrK, thrR, minima, da)")
     if dev.type == "cuda":
         fl.finalize()
-    cnt = torch.tensor([int(getattr(st, k)) for k in _NAV_COUNTERS] + [_signed(int(getattr(st, k))) for k in _NAV_SUMS], dtype=torch.int64, device=dev)
+    cnt = torch.tensor([int(getattr(st, k)) for k in _NAV_COUNTERS] + [x for k in _NAV_SUMS for x in _limbs(int(getattr(st, k)))], dtype=torch.int64, device=dev)
     sec = torch.tensor([st.seconds_leaves, st.seconds_nodes, st.seconds_traversal], dtype=torch.float64, device=dev)
     dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
     dist.all_reduce(sec, op=dist.ReduceOp.MAX, group=group)
-    for k, v in zip(_NAV_COUNTERS + _NAV_SUMS, cnt.tolist()):
-        setattr(st, k, int(v) & ((1 << 64) - 1))
+    cnt = cnt.tolist()
+    for k, v in zip(_NAV_COUNTERS, cnt):
+        setattr(st, k, int(v))
+    for i, k in enumerate(_NAV_SUMS):
+        setattr(st, k, _from_limbs(cnt[len(_NAV_COUNTERS) + 4 * i: len(_NAV_COUNTERS) + 4 * i + 4]))
     if st.n > 0 and not api.lib().eb_nav_covers_every_slot_once(st):
         # the shards collected the complement of the LCP thresholds, which is exact only if every position has one writer
         raise RuntimeError(f"sharded traversal wrote {st.lcp_values} of {st.n} LCP slots (or some of them twice): the input is not the eBWT of a read collection "

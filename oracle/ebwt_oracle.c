@@ -436,6 +436,28 @@ uint64_t orc_select_check(oindex* x, uint64_t m, uint64_t seed) {
     return bad;
 }
 
+/* checker at scale (advisor, round 3): the whole-range records of 7.55 G ... 151 G positions lean on select_fast alone, and its
+ * 64-bit arithmetic matters exactly where superblock counters change.  For every superblock boundary B = k * 2^32 < n and every
+ * letter, the `per_side` occurrences before and after rank(B, c) -- i.e. the last ones of superblock k-1 and the first of k --
+ * are selected both ways.  *checked receives the number of queries; returns the number of disagreements. */
+uint64_t orc_select_check_boundaries(oindex* x, uint64_t per_side, uint64_t* checked) {
+    orc_index_build_select(x);
+    rank4_t tot = rank4(x, x->n);
+    static const char sym[4] = {'A', 'C', 'G', 'T'};
+    uint64_t bad = 0, done = 0;
+    for (uint64_t B = 1ull << 32; B < x->n; B += 1ull << 32) {
+        rank4_t at = rank4(x, B);
+        for (int k = 0; k < 4; ++k) {
+            if (tot.v[k] == 0) continue;
+            uint64_t lo = at.v[k] > per_side ? at.v[k] - per_side : 0, hi = at.v[k] + per_side < tot.v[k] ? at.v[k] + per_side : tot.v[k];
+            for (uint64_t i = lo; i < hi; ++i, ++done)
+                if (select_fast(x, i, (uint8_t)sym[k]) != select1(x, i, (uint8_t)sym[k])) ++bad;
+        }
+    }
+    if (checked) *checked = done;
+    return bad;
+}
+
 /* F(i): dna_bwt.hpp:100-110 */
 static inline uint8_t F_sym(const oindex* x, uint64_t i) {
     return i < x->F[0] ? x->term : i < x->F[1] ? 'A' : i < x->F[2] ? 'C' : i < x->F[3] ? 'G' : 'T';

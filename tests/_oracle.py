@@ -117,6 +117,8 @@ class Oracle:
         L.orc_last_hist.argtypes = [vp]
         L.orc_select_check.restype = u64
         L.orc_select_check.argtypes = [vp, u64, u64]
+        L.orc_select_check_boundaries.restype = u64
+        L.orc_select_check_boundaries.argtypes = [vp, u64, C.POINTER(u64)]
         L.orc_rank_bench.restype = C.c_double
         L.orc_rank_bench.argtypes = [vp, u64, u64, C.POINTER(u64)]
 

@@ -153,6 +153,15 @@ def main():
         probe = rng.integers(0, n + 1, size=100_000, dtype=np.uint64)
         assert np.array_equal(oidx.rank4(probe), bwt.parallel_rank(probe))
         log(f"oracle index streamed off the GPU and built on {THREADS} host threads in {time.time() - t0:.1f}s; F and {len(probe)} random parallel_rank queries equal the GPU's")
+        # the oracle's directory select against the reference's bisection on both sides of all superblock boundaries (advisor, round 3:
+        # at this size phase 4's whole-range record leans on the directory form alone)
+        import ctypes
+        t0 = time.time()
+        cnt = ctypes.c_uint64(0)
+        bad = int(orc.lib.orc_select_check_boundaries(oidx.h, 1000, ctypes.byref(cnt))) + int(orc.lib.orc_select_check(oidx.h, 100_000, 17))
+        assert bad == 0, f"oracle select_fast differs from the bisection on {bad} queries"
+        log(f"oracle select: directory form == bisection on {cnt.value} occurrences around the superblock boundaries and 100000 random ones ({time.time() - t0:.1f}s)")
+        res.update(oracle_select_vs_bisection={"boundary_queries": int(cnt.value), "random_queries": 100_000, "mismatches": 0})
     del ascii_t
     dev.free()
     torch.cuda.empty_cache()

@@ -91,6 +91,23 @@ def oracle_indexes(orc, inp):
     return idx
 
 
+def select_boundary_check(orc, idx, per_side=2000):
+    """The oracle's directory select against the reference's bisection where 64-bit counts matter: the occurrences on both sides
+    of every superblock boundary of every index, plus random ones (advisor, round 3).  Returns what goes into the record."""
+    import ctypes
+    checked, bad, rnd = 0, 0, 0
+    with Heartbeat("oracle select: directory form against the reference's bisection around every superblock boundary"):
+        for i in idx:
+            c = ctypes.c_uint64(0)
+            bad += int(orc.lib.orc_select_check_boundaries(i.h, per_side, ctypes.byref(c)))
+            checked += int(c.value)
+            bad += int(orc.lib.orc_select_check(i.h, 200_000, 17))
+            rnd += 200_000
+    assert bad == 0, f"oracle select_fast differs from the bisection on {bad} queries"
+    log(f"oracle select: {checked} queries around superblock boundaries + {rnd} random ones, directory form == bisection")
+    return {"oracle_select_vs_bisection": {"boundary_queries": checked, "random_queries": rnd, "mismatches": 0}}
+
+
 def part_traversal(inp, res, orc, po, idx):
     """The oracle's own traversal against the GPU's: counters and every bit vector (SHA-256 + word for word)."""
     with Heartbeat(f"oracle traversal (phases 2-3), {THREADS} threads") as hb_t:
@@ -189,6 +206,12 @@ def main_config():
     idx = oracle_indexes(orc, inp)
     inp.hosts = []          # the oracle indexes hold what they need
     of = None
+    out.update(select_boundary_check(orc, idx))
+    if PART == "select":    # only that: the oracle's select at this size (seconds), written beside the round-3 record
+        with open(os.path.join(ROOT, "gpurun_out", f"r04_oracle_select_{NAME}.json"), "w") as f:
+            json.dump({k: out[k] for k in ("what", "input", "oracle_threads", "oracle_select_vs_bisection")}, f, indent=1)
+        log(json.dumps(out["oracle_select_vs_bisection"]))
+        return
     if PART in ("traversal", "all"):
         of, rec = part_traversal(inp, res, orc, po, idx)
         out.update(rec)

@@ -153,6 +153,16 @@ def test_lf_and_fl_straddling_2p32(big, oracle_big):
     assert np.array_equal(g.FL(some), oracle_big.fl(some))               # and the reference's bisection agrees
 
 
+def test_oracle_directory_select_equals_bisection_around_2p32(oracle, oracle_big):
+    """The checker's own select (directory form, what the full-size records run on) against the reference's bisection
+    (dna_string.hpp:254-272) for the occurrences on both sides of the superblock boundary, and at random."""
+    import ctypes
+    cnt = ctypes.c_uint64(0)
+    assert oracle.lib.orc_select_check_boundaries(oracle_big.h, 3000, ctypes.byref(cnt)) == 0
+    assert cnt.value == 4 * 6000
+    assert oracle.lib.orc_select_check(oracle_big.h, 100_000, 23) == 0
+
+
 def test_lf_node_boundaries_past_2p32(big, oracle_big):
     g = big["bwt"]
     rng = np.random.Generator(np.random.PCG64(3))
