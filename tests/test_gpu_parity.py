@@ -481,6 +481,32 @@ def test_medium_modes23(oracle):
     assert np.array_equal(da_bits, (da == ord("1")).astype(np.uint8))
 
 
+@pytest.mark.parametrize("n0,n1", [(8_000, 24_000), (24_000, 8_000)], ids=["second_3x_larger", "second_3x_smaller"])
+def test_two_bwts_of_different_sizes_walk_each_in_its_own_index(oracle, n0, n1):
+    """Mode 2 with collections of different sizes (advisor, round 3): a right-context walk in the second BWT must take that
+    index's size for the clamp of its select guess -- with the first one's, a larger second index had its correct guesses
+    pulled back (dozens of dependent block probes per FL step instead of about one, all counted in requests_right), a
+    smaller one was left unguarded.  Same .snp as the oracle, and about two memory requests per FL step (directory + block)."""
+    g = sim.random_genome(40_000, 77)
+    h2 = sim.mutate_haplotype(g, 77)
+    r0, r1 = sim.sample_reads([g], n0, 100, 77), sim.sample_reads([g, h2], n1, 100, 78)
+    a, b = sim.build_ebwt(r0), sim.build_ebwt(r1)
+    p = _oracle.Params.from_args([])
+    want, _ = oracle.run(a, bwt2=b, params=p)
+    assert want.count(b">") > 20
+    pp = api.make_params()
+    b1, b2 = api.DnaBwt(a), api.DnaBwt(b)
+    fl = api.navigate_two_bwts(b1, b2, pp)
+    calls = api.scan_clusters(b1, fl, pp, bwt2=b2)
+    assert calls.format_snp(pp, True)[0] == want
+    cl = np.frombuffer(calls.arrays()[0].tobytes(), dtype=np.dtype([("begin", "<u8"), ("end", "<u8"), ("first_chain", "<u4"), ("n_slots", "<u2"),
+                                                                     ("right_found", "<u2"), ("right_len", "<u4"), ("reserved", "<u4")]))
+    steps = int(cl["right_len"].sum())
+    assert steps > 1000
+    per_step = calls.stats.requests_right / steps
+    assert per_step < 2.6, f"{per_step:.2f} memory requests per FL step: the select's guess is being pulled off its block"
+
+
 def test_properties_at_larger_size():
     """Size-independent properties on an input too large for per-query oracle checks in the default run:
     rank is monotone, rank(n) sums to n - #TERM, LF intervals tile the F column, every LCP slot is written."""
