@@ -368,6 +368,34 @@ def main():
                 f"{np.mean(wait_us[-len(c):]) if wait_us else 0:.0f}), period {np.mean(np.diff(c[:, 0])):.0f}")
         return last
 
+    # ---------------- the FL table (round 4): an index that is scanned again and again keeps one 16-byte chunk per 16 occurrences
+    # of a letter, so that a step of the right-context walk is one 16-byte read (ebwt2indel.h, eb_index_build_psi).  Phase 4 builds
+    # it by itself with the third job on an index -- a one-shot run of the tool never pays for it -- so the first two passes below run
+    # without it and are reported as such; then it is built here, timed.  It is part of the resident index the timed region runs on,
+    # like the select directory and the scan planes.  EB_PSI=0: no table (the round-3 walk).
+    fl_table = None
+    if rank == 0 or use_dist:
+        st0 = None
+        for _ in range(2):
+            st0 = api.scan_clusters(bwt, flags, p, begin=begin, end=end).stats
+        before = {"scan_ms": round(st0.ms_scan / max(1, int(st0.scan_launches)), 4), "extend_ms": round(st0.ms_extend, 4), "right_ms": round(st0.ms_right, 4),
+                  "context_span_ms": round(st0.ms_context, 4), "requests_right": int(st0.requests_right), "pass_ms_first_launch_to_records_on_host": round(st0.ms_total, 4),
+                  "what": "the second pass on the index, run by itself: no table yet (what a one-shot run of the tool gets)"}
+        t1 = time.perf_counter()
+        if os.environ.get("EB_PSI") != "0":
+            try:
+                bwt.build_psi()
+            except Exception as e:      # refused (memory, size): the directory select serves
+                log(f"[bench] FL table not built: {e}")
+        t_psi = time.perf_counter() - t1
+        have, psi_bytes, psi_void = bwt.psi()
+        fl_table = {"present": have, "bytes": int(psi_bytes), "void_chunks": int(psi_void), "build_ms": round(t_psi * 1e3, 2) if have else None,
+                    "pass_before_it": before,
+                    "what": "FL table of a repeatedly scanned index: one 16-byte chunk per 16 occurrences of a letter (38-bit position, 15-bit bitmap of the occurrences that do not sit right behind their predecessor, their distances in 75 bits); "
+                            "FL = one 16-byte read by one lane instead of a directory read + a block probe by four; built once, outside the timed region"}
+        if rank == 0:
+            log(f"[bench] FL table: {fl_table['present']}, {psi_bytes/1e9:.2f} GB, {psi_void} void chunks, built in {t_psi*1e3:.1f} ms")
+
     if args.warmup > 0:
         run_steps(args.warmup)
     gathered_events.clear()
@@ -653,6 +681,10 @@ def main():
     except Exception:
         pass
 
+    # algorithmic bytes the context kernels ask for: a 64-byte block per k_extend request; per k_right request a 16-byte chunk of the
+    # FL table, or 64 bytes (directory line / block) without it
+    right_bytes = 16 if (fl_table and fl_table["present"]) else 64
+    ctx_bytes = float(np.mean(req_ext)) * 64 + float(np.mean(req_right)) * right_bytes
     if rank == 0:
         line = {
             **({"rehearsal": f"ONE rank's share of a {args.rehearse_rank_of}-GPU run on one GPU (positions [{begin}, {end}), collectives with a single rank): "
@@ -686,20 +718,21 @@ def main():
             # the kernels that dominate the step: k_extend, then k_right (a large call set runs them one behind the other; a small one
             # side by side on two streams), dependent random reads.  Requests
             # are counted on the device where they are issued (eb_scan_stats.requests_*), 64 bytes each, over first start .. last end.
-            "context_roofline": {"bound": "hbm", "achieved": round((np.mean(req_ext) + np.mean(req_right)) * 64 / (max(np.mean(ctx_ms), 1e-9) * 1e-3) / 1e9, 2),
+            "context_roofline": {"bound": "hbm", "achieved": round(ctx_bytes / (max(np.mean(ctx_ms), 1e-9) * 1e-3) / 1e9, 2),
                                  "peak": 8000.0, "unit": "GB/s",
-                                 "frac": round((np.mean(req_ext) + np.mean(req_right)) * 64 / (max(np.mean(ctx_ms), 1e-9) * 1e-3) / 1e9 / 8000.0, 5),
+                                 "frac": round(ctx_bytes / (max(np.mean(ctx_ms), 1e-9) * 1e-3) / 1e9 / 8000.0, 5),
                                  "traffic": ctx_traffic, "kernel": "k_extend, then k_right", "ms": round(float(np.mean(ctx_ms)), 4),
                                  "requests_extend": int(np.mean(req_ext)), "requests_right": int(np.mean(req_right)),
-                                 "bytes_per_request": 64, "requests_per_s": round((np.mean(req_ext) + np.mean(req_right)) / (max(np.mean(ctx_ms), 1e-9) * 1e-3), 1),
+                                 "bytes_per_request": {"k_extend": 64, "k_right": right_bytes}, "requests_per_s": round((np.mean(req_ext) + np.mean(req_right)) / (max(np.mean(ctx_ms), 1e-9) * 1e-3), 1),
                                  "what": "rank 0's shard, timed region (the next pass's scan shares the chip while these run); k_extend: one request per 64-byte block of a rank "
-                                         "pair (1-2 per LF step); k_right: one per select-directory read + one per block probed; the chip serves ~47 G independent random 64-byte "
+                                         "pair (1-2 per LF step); k_right: one per FL-table chunk (without the table: one per select-directory read + one per block probed); the chip serves ~47 G independent random 64-byte "
                                          "reads per second, each as a 128-byte line (profiles/r02_rank_probe.txt, r02_rank_probe_cache_policy.txt, r02_pmc_traffic.json)",
                                  **({"alone": {"ms": alone["context_span_ms"],
-                                               "achieved": round((np.mean(req_ext) + np.mean(req_right)) * 64 / (alone["context_span_ms"] * 1e-3) / 1e9, 2),
-                                               "frac": round((np.mean(req_ext) + np.mean(req_right)) * 64 / (alone["context_span_ms"] * 1e-3) / 1e9 / 8000.0, 5),
+                                               "achieved": round(ctx_bytes / (alone["context_span_ms"] * 1e-3) / 1e9, 2),
+                                               "frac": round(ctx_bytes / (alone["context_span_ms"] * 1e-3) / 1e9 / 8000.0, 5),
                                                "requests_per_s": round((np.mean(req_ext) + np.mean(req_right)) / (alone["context_span_ms"] * 1e-3), 1)}} if alone else {})},
             "rank_roofline": rank_info,
+            "fl_table": fl_table,
             "cpu_baseline": cpu,
             "phase4_device_ms": {"scan": round(scan_sum_ms, 4), "extend": round(float(np.mean(ext_ms)), 4),
                                  "right": round(float(np.mean(right_ms)), 4), "context_span": round(float(np.mean(ctx_ms)), 4),

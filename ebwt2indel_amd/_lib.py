@@ -60,7 +60,7 @@ class CallsView(C.Structure):
 ABI_SYMBOLS = [
     "eb_params_init", "eb_params_resolve", "eb_last_error", "eb_device_count",
     "eb_index_create", "eb_index_create_from_file", "eb_index_create_from_device", "eb_index_destroy", "eb_index_bad_symbol",
-    "eb_index_info", "eb_rank4_batch", "eb_access_batch", "eb_lf_range_batch", "eb_lf_range_sym_batch", "eb_fl_batch",
+    "eb_index_info", "eb_index_build_psi", "eb_index_has_psi", "eb_rank4_batch", "eb_access_batch", "eb_lf_range_batch", "eb_lf_range_sym_batch", "eb_fl_batch",
     "eb_lf_node_batch", "eb_rank4_batch_device", "eb_flags_build", "eb_nav_covers_every_slot_once", "eb_flags_build_shard", "eb_flags_device_vectors", "eb_flags_popcounts", "eb_flags_finalize", "eb_flags_set_da", "eb_flags_words", "eb_flags_has_da",
     "eb_flags_export", "eb_flags_import", "eb_flags_import_shard_sum", "eb_flags_destroy", "eb_scan_clusters", "eb_scan_clusters_begin", "eb_scan_clusters_end",
     "eb_scan_clusters_cancel", "eb_scan_clusters_begin_ex", "eb_scan_job_wait", "eb_scan_job_device_blob", "eb_scan_job_device_wire", "eb_calls_get", "eb_calls_free",
@@ -106,6 +106,8 @@ def load():
     L.eb_index_destroy.restype = None
     L.eb_index_bad_symbol.argtypes = [P(u8), P(u64)]
     L.eb_index_info.argtypes = [vp, P(IndexInfo)]
+    L.eb_index_build_psi.argtypes = [vp]
+    L.eb_index_has_psi.argtypes = [vp, P(u64), P(u64)]
     for f in ("eb_rank4_batch", "eb_access_batch", "eb_lf_range_batch", "eb_fl_batch", "eb_lf_node_batch"):
         getattr(L, f).argtypes = [vp, vp, u64, vp]
     L.eb_lf_range_sym_batch.argtypes = [vp, vp, vp, u64, vp]

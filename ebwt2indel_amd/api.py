@@ -100,6 +100,16 @@ class DnaBwt:
     def size(self) -> int:
         return self.n
 
+    def build_psi(self):
+        """FL table for an index that is scanned repeatedly (eb_index_build_psi): FL becomes one 16-byte read."""
+        _check(lib().eb_index_build_psi(self._h))
+
+    def psi(self):
+        """(present, bytes, void chunks) of the FL table."""
+        b, v = C.c_uint64(0), C.c_uint64(0)
+        have = lib().eb_index_has_psi(self._h, C.byref(b), C.byref(v))
+        return bool(have), b.value, v.value
+
     # ---- dna_string / dna_bwt primitives, batched
     def parallel_rank(self, pos) -> np.ndarray:
         pos = np.ascontiguousarray(pos, dtype=np.uint64)

@@ -34,6 +34,8 @@ struct eb_dev_index {
     uint32_t term;          // ASCII terminator
     uint32_t sel_shift;     // log2 of the select directory's sampling distance
     uint32_t sel_blk_bits;  // low bits of a directory entry that hold the block (32: nothing else in the entry), see eb_select_guess
+    const uint4* psi;        // FL table (eb_psi_lookup): one 16-byte chunk per 16 occurrences of a letter, or null
+    uint64_t psi_off[4];     // first chunk of each letter
 };
 
 struct eb_dev_flags {
@@ -380,12 +382,62 @@ __device__ __forceinline__ uint64_t eb_F_of(const eb_dev_index& x, int letter) {
     return letter == 0 ? x.F[0] : letter == 1 ? x.F[1] : letter == 2 ? x.F[2] : x.F[3];
 }
 
+// ---- FL table ("psi", round 4).  An index that is scanned again and again (eb_index_build_psi; phase 4 builds it by itself with
+// the third job on an index) keeps, for every letter c and every 16 consecutive occurrences of c, ONE 16-byte chunk that spells
+// their positions out, so that select(r, c) is one 16-byte load by one lane and a few dozen integer instructions -- no directory,
+// no block, no probe loop: a right-context walk (k_right x FL, dna_bwt.hpp:115-133) moves ONE line per step instead of 2.1.
+// In the BWT of a read collection a letter comes in runs (~coverage rows long): 93 % of the occurrences of a letter sit right
+// behind the previous one, the others a jump of some tens or hundreds of rows on.  Chunk = 128 bits:
+//   bits   0..37   position of the chunk's first occurrence
+//   bits  38..52   bit k-1 set iff occurrence k (1..15) does NOT sit right behind occurrence k-1 (a "jump")
+//   bits  53..127  the jumps' lengths (rows skipped), in order, W bits each: W = min(15, 75 / jumps) -- few long jumps or many
+//                  short ones (a heterozygous column alternates letters), eb_psi_width
+// position(k) = first + k + the first popcount(bitmap & low k bits) jump lengths.  A chunk whose jumps do not fit (0.1 % on
+// 30x read data) is VOID -- all ones; no position of an index this table is built for, n < 2^38 - 1, looks like that -- and the
+// directory select answers.  n bytes in all (the index itself is n/2).
+#define EB_PSI_SHIFT 4u
+#define EB_PSI_MAX_N ((1ull << 38) - 2ull)
+#define EB_PSI_MAX_JUMP 32767u
+__device__ __forceinline__ uint4 eb_psi_void() { return make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu); }
+// width of a jump field in a chunk with nj (1..15) jumps: min(15, 75 / nj), as a table of nibbles
+__host__ __device__ __forceinline__ uint32_t eb_psi_width(uint32_t nj) { return (uint32_t)((0x55566789ACFFFFF0ull >> (4u * nj)) & 15u); }
+// W bits at bit offset `off` (38 <= off, off + W <= 128) of the chunk
+__device__ __forceinline__ uint32_t eb_psi_bits(uint4 v, uint32_t off, uint32_t W) {
+    const uint32_t idx = off >> 5, bit = off & 31u;
+    const uint32_t lo = idx == 1u ? v.y : idx == 2u ? v.z : v.w, hi = idx == 1u ? v.z : idx == 2u ? v.w : 0u;
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> bit) & ((1u << W) - 1u);
+}
+// position of the r-th (0-based) letter c, from its chunk; false: the chunk is void
+__device__ __forceinline__ bool eb_psi_lookup(const eb_dev_index& x, uint64_t r, int c, uint64_t& pos) {
+    const uint64_t off = c == 0 ? x.psi_off[0] : c == 1 ? x.psi_off[1] : c == 2 ? x.psi_off[2] : x.psi_off[3];
+    const uint4 v = eb_load_chunk_select(x.psi + off + (r >> EB_PSI_SHIFT));
+    if (v.x == 0xFFFFFFFFu && (v.y & 63u) == 63u) return false;
+    const uint32_t k = (uint32_t)r & 15u;
+    const uint32_t bitmap = (v.y >> 6) & 0x7FFFu;
+    const uint32_t W = eb_psi_width((uint32_t)__popc(bitmap));
+    const uint32_t j = (uint32_t)__popc(bitmap & ((1u << k) - 1u)); // jumps on the way from the first occurrence to this one
+    uint32_t skipped = 0;
+    for (uint32_t t = 0; t < j; ++t) skipped += eb_psi_bits(v, 53u + t * W, W);
+    pos = (((uint64_t)(v.y & 63u) << 32) | v.x) + k + skipped;
+    return true;
+}
+
 // FL(i) (dna_bwt.hpp:115-133); i must not be a TERM row.
 __device__ __forceinline__ uint64_t eb_FL(const eb_dev_index& x, uint64_t i, int letter) {
-    return eb_select(x, i - eb_F_of(x, letter), letter);
+    const uint64_t r = i - eb_F_of(x, letter);
+    uint64_t pos;
+    if (x.psi && eb_psi_lookup(x, r, letter, pos)) return pos;
+    return eb_select(x, r, letter);
 }
+// `probes`: memory requests issued (one per table chunk; directory read + blocks probed otherwise)
 __device__ __forceinline__ uint64_t eb_FL(const eb_dev_index& x, uint64_t i, int letter, uint32_t& probes) {
-    return eb_select(x, i - eb_F_of(x, letter), letter, probes);
+    const uint64_t r = i - eb_F_of(x, letter);
+    uint64_t pos;
+    if (x.psi) {
+        ++probes;
+        if (eb_psi_lookup(x, r, letter, pos)) return pos;
+    }
+    return eb_select(x, r, letter, probes);
 }
 
 __device__ __forceinline__ bool eb_bit(const uint64_t* b, uint64_t i) { return (b[i >> 6] >> (i & 63u)) & 1ull; }

@@ -240,7 +240,154 @@ __global__ void __launch_bounds__(256) k_scan_planes(const uint4* __restrict__ c
     }
 }
 
+// FL table (eb_psi_lookup in eb_device.h): one thread per chunk = 16 consecutive occurrences of one letter.  The first is
+// found by the directory select; the fifteen that follow by walking the letter's bit mask forward through the blocks (threads
+// of neighbouring chunks read neighbouring blocks, so the BWT is streamed once per letter).  tot[c] = occurrences of letter c.
+__global__ void __launch_bounds__(256) k_build_psi(eb_dev_index x, uint4* __restrict__ psi, uint64_t tot0, uint64_t tot1, uint64_t tot2, uint64_t tot3,
+                                                  uint64_t n_chunks, unsigned long long* __restrict__ n_void) {
+    uint32_t voids = 0;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_chunks; t += (uint64_t)gridDim.x * blockDim.x) {
+        const int c = t >= x.psi_off[3] ? 3 : t >= x.psi_off[2] ? 2 : t >= x.psi_off[1] ? 1 : 0;
+        const uint64_t tot = c == 0 ? tot0 : c == 1 ? tot1 : c == 2 ? tot2 : tot3;
+        const uint64_t off = c == 0 ? x.psi_off[0] : c == 1 ? x.psi_off[1] : c == 2 ? x.psi_off[2] : x.psi_off[3];
+        const uint64_t r0 = (t - off) << EB_PSI_SHIFT;
+        if (r0 >= tot) { psi[t] = make_uint4(0, 0, 0, 0); continue; } // the spare chunk behind a letter's last one: never read
+        const uint64_t p0 = eb_select(x, r0, c);
+        uint64_t g = p0 >> 7;
+        auto letter_masks = [&](uint64_t blk, uint64_t& lo, uint64_t& hi) {
+            const uint4* b = x.chunks + (blk << 2);
+            const uint4 ch0 = b[0], ch1 = b[1], ch2 = b[2], ch3 = b[3];
+            const uint32_t m0 = ~ch0.z & ((c & 2) ? ch0.y : ~ch0.y) & ((c & 1) ? ch0.x : ~ch0.x);
+            const uint32_t m1 = ~ch1.z & ((c & 2) ? ch1.y : ~ch1.y) & ((c & 1) ? ch1.x : ~ch1.x);
+            const uint32_t m2 = ~ch2.z & ((c & 2) ? ch2.y : ~ch2.y) & ((c & 1) ? ch2.x : ~ch2.x);
+            const uint32_t m3 = ~ch3.z & ((c & 2) ? ch3.y : ~ch3.y) & ((c & 1) ? ch3.x : ~ch3.x);
+            lo = (uint64_t)m0 | ((uint64_t)m1 << 32);
+            hi = (uint64_t)m2 | ((uint64_t)m3 << 32);
+        };
+        uint64_t lo, hi;
+        letter_masks(g, lo, hi);
+        { // drop the occurrences up to and including p0
+            const uint32_t o = (uint32_t)(p0 & 127u);
+            if (o < 63u) lo &= ~0ull << (o + 1u);
+            else { lo = 0; if (o >= 64u) hi = o < 127u ? hi & (~0ull << (o - 63u)) : 0ull; }
+        }
+        uint32_t jump[15];   // rows skipped in front of occurrence k + 1 (0: it sits right behind its predecessor)
+        uint32_t bitmap = 0, nj = 0, widest = 0;
+        bool ok = true;
+        uint64_t prev = p0;
+        const uint64_t left = tot - r0 - 1; // occurrences behind the first
+        const uint32_t want = left < 15 ? (uint32_t)left : 15u;
+#pragma unroll
+        for (uint32_t k = 0; k < 15; ++k) jump[k] = 0;
+        for (uint32_t k = 1; k <= want && ok; ++k) {
+            while (!(lo | hi)) {
+                if (++g >= x.n_blocks || ((g << 7) - prev) > (uint64_t)EB_PSI_MAX_JUMP + 1u) { ok = false; break; } // (a longer jump does not fit anyway)
+                letter_masks(g, lo, hi);
+            }
+            if (!ok) break;
+            uint64_t q;
+            if (lo) { q = (g << 7) + (uint32_t)__ffsll((long long)lo) - 1u; lo &= lo - 1; }
+            else { q = (g << 7) + 64u + (uint32_t)__ffsll((long long)hi) - 1u; hi &= hi - 1; }
+            const uint64_t skipped = q - prev - 1;
+            if (skipped > EB_PSI_MAX_JUMP) { ok = false; break; }
+            if (skipped) {
+                bitmap |= 1u << (k - 1);
+                // (the jumps are kept in a register array indexed by compile-time constants only: nj-th slot by a select chain)
+#pragma unroll
+                for (uint32_t t = 0; t < 15; ++t) if (t == nj) jump[t] = (uint32_t)skipped;
+                ++nj;
+                widest = skipped > widest ? (uint32_t)skipped : widest;
+            }
+            prev = q;
+        }
+        const uint32_t W = nj ? eb_psi_width(nj) : 0u;
+        if (!ok || (nj && (widest >> W) != 0u)) { psi[t] = eb_psi_void(); ++voids; continue; }
+        // 128 bits: position (38) | bitmap (15) | nj fields of W bits
+        uint64_t w_lo = (p0 & ((1ull << 38) - 1ull)) | ((uint64_t)bitmap << 38), w_hi = 0; // bits 0..52 used
+        uint32_t at = 53;
+#pragma unroll
+        for (uint32_t t2 = 0; t2 < 15; ++t2) {
+            if (t2 < nj) {
+                const uint64_t v = jump[t2];
+                if (at < 64u) { w_lo |= v << at; if (at + W > 64u) w_hi |= v >> (64u - at); }
+                else w_hi |= v << (at - 64u);
+                at += W;
+            }
+        }
+        psi[t] = make_uint4((uint32_t)w_lo, (uint32_t)(w_lo >> 32), (uint32_t)w_hi, (uint32_t)(w_hi >> 32));
+    }
+    if (voids) atomicAdd(n_void, (unsigned long long)voids);
+}
+
 // ------------------------------------------------------------------ host side
+
+// FL table: see eb_psi_lookup (eb_device.h).  n bytes of HBM; refused (EB_ERR_STATE / EB_ERR_NOMEM, the index works on without it)
+// beyond 2^38 - 2 symbols or when the device cannot spare the memory.
+extern "C" int eb_index_build_psi(eb_index* h) {
+    if (!h) { eb_set_error("null argument"); return EB_ERR_ARG; }
+    if (h->d_psi) return EB_OK;
+    h->psi_tried = true;
+    if (h->n > EB_PSI_MAX_N) { eb_set_error("the FL table holds 38-bit positions: %llu symbols are too many", (unsigned long long)h->n); return EB_ERR_STATE; }
+    if (h->n == 0) { eb_set_error("empty index"); return EB_ERR_STATE; }
+    EB_HIP(hipSetDevice(h->device));
+    const uint64_t tot[4] = {h->F[1] - h->F[0], h->F[2] - h->F[1], h->F[3] - h->F[2], h->n - h->F[3]};
+    uint64_t off[4], n_chunks = 0;
+    for (int c = 0; c < 4; ++c) { off[c] = n_chunks; n_chunks += ((tot[c] + 15) >> EB_PSI_SHIFT) + 1; }
+    const size_t bytes = n_chunks * sizeof(uint4);
+    size_t free_b = 0, total_b = 0;
+    EB_HIP(hipMemGetInfo(&free_b, &total_b));
+    // leave room for what phase 4 itself allocates (call-set images, scratch): the table may take at most half of what is free
+    if (bytes > free_b / 2) { eb_set_error("FL table of %zu bytes refused: %zu bytes of HBM free", bytes, free_b); return EB_ERR_NOMEM; }
+    uint4* d = nullptr;
+    unsigned long long* d_void = nullptr;
+    hipError_t e = hipMalloc(&d, bytes);
+    if (e == hipSuccess) e = hipMalloc(&d_void, sizeof(unsigned long long));
+    if (e != hipSuccess) { if (d) (void)hipFree(d); eb_set_error("FL table allocation failed (%zu bytes): %s", bytes, hipGetErrorString(e)); return EB_ERR_NOMEM; }
+    EB_HIP(hipMemsetAsync(d_void, 0, sizeof(unsigned long long), h->stream));
+    eb_dev_index x = h->dev();
+    x.psi = nullptr; // (the kernel's own select goes through the directory)
+    for (int c = 0; c < 4; ++c) x.psi_off[c] = off[c];
+    const unsigned grid = (unsigned)((n_chunks + 255) / 256 < 65536u * 16u ? (n_chunks + 255) / 256 : 65536u * 16u);
+    hipLaunchKernelGGL(k_build_psi, dim3(grid), dim3(256), 0, h->stream, x, d, tot[0], tot[1], tot[2], tot[3], n_chunks, d_void);
+    unsigned long long voids = 0;
+    e = hipMemcpyAsync(&voids, d_void, sizeof voids, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    (void)hipFree(d_void);
+    if (e != hipSuccess) { (void)hipFree(d); eb_set_error("FL table build failed: %s", hipGetErrorString(e)); return EB_ERR_DEVICE; }
+    // a BWT in which a letter is absent from 64 rows in a row every few chunks gains nothing from the table: give the memory back
+    if (voids > n_chunks / 4) { (void)hipFree(d); eb_set_error("FL table dropped: %llu of %llu chunks void (gaps of 64 rows or more)", voids, (unsigned long long)n_chunks); return EB_ERR_STATE; }
+    for (int c = 0; c < 4; ++c) h->psi_off[c] = off[c];
+    h->d_psi = d;
+    h->device_bytes += bytes;
+    h->psi_void_chunks = voids;
+    return EB_OK;
+}
+
+extern "C" int eb_index_has_psi(const eb_index* h, uint64_t* bytes, uint64_t* void_chunks) {
+    if (!h) return 0;
+    if (bytes) {
+        uint64_t n_chunks = 0;
+        const uint64_t tot[4] = {h->F[1] - h->F[0], h->F[2] - h->F[1], h->F[3] - h->F[2], h->n - h->F[3]};
+        for (int c = 0; c < 4; ++c) n_chunks += ((tot[c] + 15) >> EB_PSI_SHIFT) + 1;
+        *bytes = h->d_psi ? n_chunks * sizeof(uint4) : 0;
+    }
+    if (void_chunks) *void_chunks = h->d_psi ? h->psi_void_chunks : 0;
+    return h->d_psi != nullptr;
+}
+
+// Phase 4 calls this once per job begun on the index.  A caller that is on its third job will likely begin a fourth: the
+// table costs about as much as five passes of the walk it speeds up (and n bytes), so a one-shot run never builds it.
+// EB_PSI=0: never; EB_PSI=1: with the first job.
+void eb_index_note_phase4_job(eb_index* h) {
+    ++h->phase4_jobs;
+    if (h->d_psi || h->psi_tried) return;
+    const int mode = getenv("EB_PSI") ? atoi(getenv("EB_PSI")) : -1; // (read per job: tests switch it inside one process)
+    if (mode == 0) return;
+    if (mode == 1 || h->phase4_jobs >= 3) {
+        if (eb_index_build_psi(h) != EB_OK && getenv("EB_ALLOC_TRACE")) fprintf(stderr, "[index] %s\n", eb_last_error());
+    }
+}
 
 int eb_index_scan_planes(eb_index* h) {
     if (h->d_xy) return EB_OK;
@@ -511,6 +658,7 @@ extern "C" void eb_index_destroy(eb_index* h) {
     if (h->d_super) (void)hipFree(h->d_super);
     if (h->d_sel_dir) (void)hipFree(h->d_sel_dir);
     if (h->d_xy) (void)hipFree(h->d_xy);
+    if (h->d_psi) (void)hipFree(h->d_psi);
     eb_scan_ctx_destroy(h->scan_ctx);
     eb_scratch_release(h->device);
     if (h->stream) (void)hipStreamDestroy(h->stream);

@@ -49,6 +49,11 @@ struct eb_index {
     uint8_t term = '#';
     uint32_t sel_shift = EB_SEL_SHIFT_SPARSE; // log2 of the select directory's sampling distance
     uint32_t sel_blk_bits = 32;               // block bits of a directory entry (eb_select_guess)
+    uint4* d_psi = nullptr;                   // FL table (eb_index_build_psi), or null
+    uint64_t psi_off[4] = {0, 0, 0, 0};
+    uint32_t phase4_jobs = 0;                 // phase-4 jobs begun on this index (the third one builds the FL table)
+    bool psi_tried = false;                   // a build was attempted (and failed or was refused): not again
+    uint64_t psi_void_chunks = 0;             // chunks of the table that fall back to the directory select
     uint64_t device_bytes = 0;
     eb_scan_ctx* scan_ctx = nullptr;
     eb_dev_index dev() const {
@@ -64,6 +69,8 @@ struct eb_index {
         d.term = term;
         d.sel_shift = sel_shift;
         d.sel_blk_bits = sel_blk_bits;
+        d.psi = d_psi;
+        for (int i = 0; i < 4; ++i) d.psi_off[i] = psi_off[i];
         return d;
     }
 };
@@ -153,6 +160,8 @@ int eb_flags_build_da_rank(eb_flags* f);
 int eb_flags_derive(eb_flags* f);
 // builds the scan planes of an index if absent (eb_index.hip)
 int eb_index_scan_planes(eb_index* h);
+// phase 4 counts its jobs per index and builds the FL table when a caller keeps scanning (eb_index.hip)
+void eb_index_note_phase4_job(eb_index* h);
 int eb_flags_alloc(uint64_t n, int device, bool with_da, eb_flags** out);
 
 // Caching device-scratch allocator (eb_index.hip).  hipMalloc / hipFree cost 0.1-1 ms each and hipFree synchronises

@@ -949,7 +949,8 @@ __global__ void __launch_bounds__(256) k_right(eb_dev_index x1, eb_dev_index x2,
                 x.chunks = x2.chunks; x.super = x2.super; x.sel_dir = x2.sel_dir;
                 x.n = x2.n; x.n_blocks = x2.n_blocks; // (the select's guess is clamped to the index it walks in)
                 x.sel_shift = x2.sel_shift; x.sel_blk_bits = x2.sel_blk_bits; // (the two indexes may differ in size: their directories are read their own way)
-                for (int k = 0; k < 4; ++k) { x.F[k] = x2.F[k]; x.sel_off[k] = x2.sel_off[k]; }
+                x.psi = x2.psi;
+                for (int k = 0; k < 4; ++k) { x.F[k] = x2.F[k]; x.sel_off[k] = x2.sel_off[k]; x.psi_off[k] = x2.psi_off[k]; }
             }
         }
         uint64_t* out = right + i * (uint64_t)right_words;
@@ -1187,7 +1188,10 @@ static int launch_contexts(eb_scan_job* job) {
     std::vector<SubShard>& sh = job->sh;
     auto kern_extend = p.mode == 2 ? k_extend<true> : k_extend<false>;
     // the late walk of a large call set: a quad per cluster (EB_RIGHT_LANES=1: one lane, the form the early walk keeps)
-    static const int right_lanes = getenv("EB_RIGHT_LANES") && atoi(getenv("EB_RIGHT_LANES")) == 1 ? 1 : 4;
+    // With the FL table (eb_psi_lookup) a step is one 16-byte read by one lane: one lane per cluster, 64 walks per wave.
+    static const int right_lanes_env = getenv("EB_RIGHT_LANES") ? atoi(getenv("EB_RIGHT_LANES")) : 0;
+    const bool have_psi = x1.psi && (p.mode != 2 || x2.psi);
+    const int right_lanes = right_lanes_env == 1 || right_lanes_env == 4 ? right_lanes_env : (have_psi ? 1 : 4);
     auto kern_right = p.mode == 2 ? (right_lanes == 4 ? k_right<true, 4> : k_right<true, 1>) : (right_lanes == 4 ? k_right<false, 4> : k_right<false, 1>);
     int rc;
     for (int k = 0; k < S; ++k) {
@@ -1467,6 +1471,10 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
         EB_HIP(hipStreamSynchronize(f->stream));
         EB_HIP(hipGetLastError());
     }
+
+    // a caller that keeps scanning an index gets the FL table for its right-context walks (third job; eb_index.hip)
+    eb_index_note_phase4_job(b1);
+    if (b2) eb_index_note_phase4_job(b2);
 
     ScanParams p;
     p.mode = b2 ? 2 : (f->d_da ? 3 : 1);

@@ -87,6 +87,16 @@ typedef struct {
 } eb_index_info_t;
 int eb_index_info(const eb_index* h, eb_index_info_t* info);
 
+/* FL table for indexes that are scanned repeatedly (no reference counterpart: dna_bwt::FL, dna_bwt.hpp:115-133, bisects with
+ * rank every time).  One 16-byte chunk per 16 occurrences of a letter spells their positions out, so that FL -- the step of the
+ * right-context walk extract_dna, ebwt2InDel.cpp:325-342 -- is one 16-byte read instead of a directory read plus a block probe.
+ * Costs n bytes of HBM and about the time of five phase-4 walks to build; results are those of select either way.  Phase 4
+ * builds it by itself when a THIRD job is begun on an index (EB_PSI=0: never, EB_PSI=1: with the first); this call builds it now.
+ * EB_ERR_STATE beyond 2^38 - 2 symbols, EB_ERR_NOMEM if the device cannot spare the memory: the index works on without it. */
+int eb_index_build_psi(eb_index* h);
+/* 1 iff the table exists; *bytes its size, *void_chunks the chunks that fall back to the directory (a gap of 64 rows or more). */
+int eb_index_has_psi(const eb_index* h, uint64_t* bytes, uint64_t* void_chunks);
+
 /* ------------------------------------------------------------------ rank / LF primitives
  * Host-buffer batches.  m queries in, results out; positions are 0 <= i <= n. */
 /* dna_string::parallel_rank (dna_string.hpp:140-152): out4[4q..4q+3] = #A,#C,#G,#T in [0,pos[q]). */

@@ -167,6 +167,75 @@ def test_fl_under_every_directory_entry_layout(oracle, monkeypatch, shift, bits)
     assert api.run_one_dataset(e) == want
 
 
+def _gappy_bwt(seed, n=300_000):
+    """A legal input whose letters come in long stretches: many occurrences lie 64 rows or more behind their predecessor
+    (void chunks of the FL table), others a row apart, with terminators sprinkled in."""
+    r = _rng(seed)
+    out = np.empty(n, dtype=np.uint8)
+    i = 0
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+    while i < n:
+        kind = r.integers(0, 3)
+        ln = int(r.integers(1, 400)) if kind == 0 else int(r.integers(1, 70))
+        ln = min(ln, n - i)
+        if kind == 2:
+            out[i:i + ln] = letters[r.integers(0, 4, size=ln)]
+        else:
+            out[i:i + ln] = letters[r.integers(0, 4)]
+        i += ln
+    # a letter that shows up once every 600 rows (fifteen long jumps in one chunk), and one that stays away for 40 000 rows
+    out[100_000:130_000] = ord("C")
+    out[100_000:130_000:600] = ord("A")
+    out[150_000:190_000][out[150_000:190_000] == ord("G")] = ord("T")
+    out[r.integers(0, n, size=n // 150)] = 35
+    return out.tobytes()
+
+
+@pytest.mark.parametrize("name", ["dip.ebwt", "edge.ebwt", "het_m.ebwt", "n128_t36.ebwt", "tiny.ebwt", "gappy"])
+def test_fl_through_the_fl_table(oracle, name):
+    """FL with the table of repeatedly scanned indexes (eb_index_build_psi: one 16-byte chunk per 16 occurrences of a letter) equals
+    FL through the select directory and the oracle's bisection (dna_string.hpp:254-272) -- at EVERY non-terminator row, so every
+    chunk, every bitmap, every jump field and every void chunk (jumps that do not fit: the directory answers) is read."""
+    term = 36 if name == "n128_t36.ebwt" else 35
+    e = _gappy_bwt(11) if name == "gappy" else golden_bytes(name)
+    g, o = api.DnaBwt(e, term=term), oracle.index(e, term)
+    rows = np.arange(g.F_arr[0], len(e), dtype=np.uint64)
+    plain = g.FL(rows)
+    assert g.psi() == (False, 0, 0)
+    g.build_psi()
+    have, nbytes, voids = g.psi()
+    assert have and nbytes >= len(e) - g.F_arr[0]
+    assert voids >= 2 if name == "gappy" else voids * 50 * 16 < len(e)      # (read data: ~0.1 % of the chunks)
+    assert np.array_equal(g.FL(rows), plain)
+    some = rows[:: max(1, len(rows) // 50_000)]
+    assert np.array_equal(plain[:: max(1, len(rows) // 50_000)], o.fl(some))
+    g.build_psi()                                                     # idempotent
+    assert g.psi() == (have, nbytes, voids)
+
+
+def test_third_job_on_an_index_builds_the_fl_table(monkeypatch, dip):
+    """A caller that keeps scanning an index gets the FL table with its third job (a one-shot run never pays for it); the call
+    set does not depend on it, the right-context walk then issues about one memory request per FL step instead of two."""
+    monkeypatch.delenv("EB_PSI", raising=False)
+    e, _, _ = dip
+    g = api.DnaBwt(e)
+    p = api.make_params()
+    fl = api.navigate_one_bwt(g, p)
+    blobs, reqs = [], []
+    for k in range(4):
+        assert g.psi()[0] == (k >= 3)
+        calls = api.scan_clusters(g, fl, p)
+        blobs.append(bytes(calls.blob()))
+        reqs.append(calls.stats.requests_right)
+    assert blobs[1:] == blobs[:1] * 3
+    assert reqs[0] == reqs[1] and reqs[2] == reqs[3] and reqs[2] < 0.6 * reqs[0]
+    monkeypatch.setenv("EB_PSI", "0")
+    g2 = api.DnaBwt(e)
+    for k in range(4):
+        assert bytes(api.scan_clusters(g2, fl, p).blob()) == blobs[0]
+    assert not g2.psi()[0]
+
+
 def test_lf_node(dip):
     e, g, o = dip
     r = _rng(6)
@@ -358,12 +427,15 @@ def test_snp_byte_identical_to_reference(case):
 
 @pytest.mark.parametrize("case", [c for c in CASES if c["name"] in ("m1_default", "m1_edge_m2", "m2_het_default", "m2_edge_default",
                                                                       "m3_het_default", "m3_edge_default")], ids=lambda c: c["name"])
-@pytest.mark.parametrize("early_max", [None, "524288", "0"], ids=["walks_late_every_cluster", "walks_early", "walks_late_gated"])
-def test_cluster_records_match_oracle(oracle, monkeypatch, case, early_max):
+@pytest.mark.parametrize("early_max,psi", [(None, "0"), ("524288", "0"), ("0", "0"), (None, "1"), ("524288", "1"), ("0", "1")],
+                         ids=["walks_late_every_cluster", "walks_early", "walks_late_gated", "fl_table_every_cluster", "fl_table_walks_early", "fl_table_gated"])
+def test_cluster_records_match_oracle(oracle, monkeypatch, case, early_max, psi):
     """Record-level parity of phase 4 (clusters, supports, contexts, counters), whole range and sharded -- with the right-context
     walk behind the extension for every cluster (small call sets, the default since round 3), launched early into temporaries
     (the small call sets of rounds 1-2, EB_RIGHT_EARLY_MAX) and behind the extension for the clusters that can print only (large
-    call sets; forced on these small ones by EB_RIGHT_GATE_MIN=0)."""
+    call sets; forced on these small ones by EB_RIGHT_GATE_MIN=0) -- each through the directory select (EB_PSI=0) and through the
+    FL table of repeatedly scanned indexes (round 4, EB_PSI=1: built with the first job instead of the third)."""
+    monkeypatch.setenv("EB_PSI", psi)
     if early_max is not None:
         monkeypatch.setenv("EB_RIGHT_EARLY_MAX", early_max)
     if early_max == "0":
@@ -414,6 +486,7 @@ def test_cluster_records_match_oracle(oracle, monkeypatch, case, early_max):
         # the same shards as jobs of a pipelining caller (EB_SCAN_PIPELINED), all begun before the first is ended
         jobs = [api.scan_clusters_begin(g1, gf, pp, bwt2=g2, begin=b, end=e, pipelined=True) for b, e in zip(cuts[:-1], cuts[1:])]
         assert [bytes(j.finish().blob()) for j in jobs] == plain
+    assert g1.psi()[0] == (psi == "1") and (g2 is None or g2.psi()[0] == (psi == "1"))
     if early_max == "0" and case["name"] in ("m1_default", "m2_het_default", "m3_het_default"):
         assert skipped > 0                                           # the gate is exercised, not just present
 
@@ -481,12 +554,14 @@ def test_medium_modes23(oracle):
     assert np.array_equal(da_bits, (da == ord("1")).astype(np.uint8))
 
 
+@pytest.mark.parametrize("psi", ["0", "1"], ids=["directory_select", "fl_table"])
 @pytest.mark.parametrize("n0,n1", [(8_000, 24_000), (24_000, 8_000)], ids=["second_3x_larger", "second_3x_smaller"])
-def test_two_bwts_of_different_sizes_walk_each_in_its_own_index(oracle, n0, n1):
+def test_two_bwts_of_different_sizes_walk_each_in_its_own_index(oracle, monkeypatch, n0, n1, psi):
     """Mode 2 with collections of different sizes (advisor, round 3): a right-context walk in the second BWT must take that
     index's size for the clamp of its select guess -- with the first one's, a larger second index had its correct guesses
     pulled back (dozens of dependent block probes per FL step instead of about one, all counted in requests_right), a
     smaller one was left unguarded.  Same .snp as the oracle, and about two memory requests per FL step (directory + block)."""
+    monkeypatch.setenv("EB_PSI", psi)      # "1": each index also brings its own FL table (built with the first job)
     g = sim.random_genome(40_000, 77)
     h2 = sim.mutate_haplotype(g, 77)
     r0, r1 = sim.sample_reads([g], n0, 100, 77), sim.sample_reads([g, h2], n1, 100, 78)
@@ -504,7 +579,7 @@ def test_two_bwts_of_different_sizes_walk_each_in_its_own_index(oracle, n0, n1):
     steps = int(cl["right_len"].sum())
     assert steps > 1000
     per_step = calls.stats.requests_right / steps
-    assert per_step < 2.6, f"{per_step:.2f} memory requests per FL step: the select's guess is being pulled off its block"
+    assert per_step < (2.6 if psi == "0" else 1.1), f"{per_step:.2f} memory requests per FL step: the select's guess is being pulled off its block"
 
 
 def test_properties_at_larger_size():

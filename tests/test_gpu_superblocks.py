@@ -151,6 +151,10 @@ def test_lf_and_fl_straddling_2p32(big, oracle_big):
     assert np.array_equal(rj[np.arange(len(rows)), c], rows - F[c])
     some = rows[:: 97]
     assert np.array_equal(g.FL(some), oracle_big.fl(some))               # and the reference's bisection agrees
+    # the same rows through the FL table (38-bit positions: bits 32..37 travel in the chunk's spare bits)
+    assert not g.psi()[0]
+    g.build_psi()
+    assert g.psi()[0] and np.array_equal(g.FL(rows), j)
 
 
 def test_oracle_directory_select_equals_bisection_around_2p32(oracle, oracle_big):
