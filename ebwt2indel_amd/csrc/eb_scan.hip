@@ -1201,6 +1201,8 @@ static int launch_contexts(eb_scan_job* job) {
         // Small call set: the two context kernels are independent chains of dependent loads, one stream each (the walk
         // was launched with the ordering step).  Large call set: the walk runs BEHIND the extension, so both simply follow
         // the ordering step on its stream -- a hand-over between streams costs 15-25 us of idle device each time.
+        // (Round 4, with the FL table: the walk of pass i on its own stream beside the extension of pass i+1 -- own streams for a
+        // pipelining caller's large call sets too -- 2.50-2.61 against 2.20-2.31 ms per step: not kept, profiles/r04_overlap_ab.txt.)
         const bool own_streams = right_early || S > 1; // (sub-shards overlap one shard's ordering with the previous one's kernels)
         const hipStream_t sB = own_streams ? job->s_ext : ctx->prep, sC = own_streams ? job->s_right : ctx->prep;
         EB_HIP(hipStreamWaitEvent(sB, x.e[E_PREP_DONE], 0));
@@ -1525,7 +1527,10 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
         const int v = e ? atoi(e) : -1;
         if (v >= 0) return (unsigned)(v > 8 ? 8 : v);
         if (!(options & EB_SCAN_PIPELINED) || ctx->last_small) return 0u;
-        return hipEventQuery(ctx->last_right) == hipErrorNotReady ? 4u : 0u;
+        // (4 per CU in round 3, when the walk took as long as the extension; with the FL table the context kernels are the shorter
+        // side and the scan gets every slot it can use: 2.60 / 2.46 / 2.36 / 2.22 ms per step for 4 / 5 / 6 / 8, profiles/r04_overlap_ab.txt)
+        const unsigned share = (b1->d_psi && (!b2 || b2->d_psi)) ? 8u : 4u;
+        return hipEventQuery(ctx->last_right) == hipErrorNotReady ? share : 0u;
     }();
     // overlap mode: the ordering of the survivors follows the scan on ITS stream, so that it does not queue behind the previous
     // job's context kernels (which own the preparation stream) -- the context kernels of this job do
