@@ -893,6 +893,97 @@ __global__ void __launch_bounds__(256) k_extend(eb_dev_index x1, eb_dev_index x2
     count_requests(req_slots, j == 0 ? n_req : 0u);
 }
 
+// The same chains, ONE lane per chain (round 4).  The quad form above spends ~113 vector instructions per LF step and wave on 16
+// chains -- every lane runs the whole instruction stream on a quarter of the block -- and beside the scan the pass is short of
+// vector issue as much as of memory lines.  Here a lane loads the whole 64-byte block (four 16-byte loads from one line: one
+// fabric request all the same) and counts all four letters at both ends of its range: ~170 instructions per step and wave for
+// 64 chains.  Same results by construction (the counts are those of eb_rank4).
+template <bool TWO>
+__global__ void __launch_bounds__(256) k_extend1(eb_dev_index x1, eb_dev_index x2, ScanParams p, const Survivor* __restrict__ surv,
+                                                const uint64_t* __restrict__ chains, uint64_t n_chains, eb_chain* __restrict__ crec,
+                                                uint64_t* __restrict__ left, uint32_t left_words, unsigned long long* __restrict__ req_slots) {
+    const uint64_t ch = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n_req = 0;
+    if (ch < n_chains) {
+        const uint64_t item = chains[ch];
+        const uint64_t i = item >> 3;
+        const uint32_t sidx = (uint32_t)(item & 7u);
+        const Survivor s = surv[i];
+        const uint32_t side = sidx >> 2, c = sidx & 3u;
+        eb_dev_index x = x1; // by value, see k_extend
+        if (TWO && side == 1) { x.chunks = x2.chunks; x.super = x2.super; x.n = x2.n; x.n_blocks = x2.n_blocks; for (int k = 0; k < 4; ++k) x.F[k] = x2.F[k]; }
+        uint64_t L, R;
+        if (TWO) { L = side ? s.b1 : s.b0; R = side ? s.e1 : s.e0; } else { L = s.b; R = s.e; }
+        uint64_t* out = left + ch * (uint64_t)left_words;
+        // packed per-letter counts (A | C << 8 | G << 16 | T << 24; at most 128 each) of the symbols before in-block offset o
+        auto counts = [](const uint4& c0, const uint4& c1, const uint4& c2, const uint4& c3, uint32_t o) -> uint32_t {
+            return eb_chunk_counts(c0, eb_prefix_mask32(o, 0)) + eb_chunk_counts(c1, eb_prefix_mask32(o, 1)) + eb_chunk_counts(c2, eb_prefix_mask32(o, 2)) +
+                   eb_chunk_counts(c3, eb_prefix_mask32(o, 3));
+        };
+        auto letter_w = [](const uint4& c0, const uint4& c1, const uint4& c2, const uint4& c3, uint32_t j) -> uint32_t {
+            return j == 0 ? c0.w : j == 1 ? c1.w : j == 2 ? c2.w : c3.w;
+        };
+        // one LF(range) (dna_bwt.hpp:138-166): a[j], b[j] = rank of letter j at L and R, without F
+        auto ranks = [&](uint64_t lo, uint64_t hi, uint64_t* a, uint64_t* b) {
+            const uint4* bl = x.chunks + ((lo >> 7) << 2);
+            const uint4 c0 = eb_load_chunk(bl), c1 = eb_load_chunk(bl + 1), c2 = eb_load_chunk(bl + 2), c3 = eb_load_chunk(bl + 3);
+            uint4 d0 = c0, d1 = c1, d2 = c2, d3 = c3;
+            const bool two = (hi >> 7) != (lo >> 7);
+            if (two) {
+                const uint4* br = x.chunks + ((hi >> 7) << 2);
+                d0 = eb_load_chunk(br); d1 = eb_load_chunk(br + 1); d2 = eb_load_chunk(br + 2); d3 = eb_load_chunk(br + 3);
+            }
+            n_req += 1u + (two ? 1u : 0u);
+            const uint32_t pl = counts(c0, c1, c2, c3, (uint32_t)(lo & 127u)), pr = counts(d0, d1, d2, d3, (uint32_t)(hi & 127u));
+            const uint64_t* sl = x.super + ((lo >> EB_SUPER_SHIFT) << 2);
+            const uint64_t* sr = x.super + ((hi >> EB_SUPER_SHIFT) << 2);
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                a[j] = sl[j] + letter_w(c0, c1, c2, c3, j) + ((pl >> (8u * j)) & 0xFFu);
+                b[j] = sr[j] + letter_w(d0, d1, d2, d3, j) + ((pr >> (8u * j)) & 0xFFu);
+            }
+        };
+        uint64_t a[4], b[4];
+        ranks(L, R, a, b);
+        // LF(range, c)
+        L = pick4(x.F, c) + (c == 0 ? a[0] : c == 1 ? a[1] : c == 2 ? a[2] : a[3]);
+        R = pick4(x.F, c) + (c == 0 ? b[0] : c == 1 ? b[1] : c == 2 ? b[2] : b[3]);
+        const uint32_t support = (uint32_t)(R - L);
+        uint32_t have = 1;
+        uint64_t word = c; // base 0 = the frequent symbol itself
+        while (have < (uint32_t)p.k_left) {
+            ranks(L, R, a, b);
+            // largest sub-range, ties to the smaller letter (stable descending sort, ebwt2InDel.cpp:252-255)
+            uint64_t bl = b[0] - a[0];
+            uint32_t bj = 0;
+#pragma unroll
+            for (uint32_t j = 1; j < 4; ++j) {
+                const uint64_t len = b[j] - a[j];
+                if (len > bl) { bl = len; bj = j; }
+            }
+            if (bl == 0) break; // consensus_letter returns 0 (:257)
+            L = pick4(x.F, bj) + (bj == 0 ? a[0] : bj == 1 ? a[1] : bj == 2 ? a[2] : a[3]);
+            R = L + bl;
+            word |= (uint64_t)bj << (2u * (have & 31u));
+            ++have;
+            if ((have & 31u) == 0) { out[(have >> 5) - 1] = word; word = 0; }
+        }
+        if (have == (uint32_t)p.k_left) {
+            if (have & 31u) out[have >> 5] = word;
+        } else {
+            for (uint32_t wi = 0; wi < (have >> 5); ++wi) out[wi] = 0; // a context shorter than k_left is dropped by the writer (:317): blank
+        }
+        eb_chain k;
+        k.side = (uint8_t)side;
+        k.sym = (uint8_t)"ACGT"[c];
+        k.reserved = 0;
+        k.len = have;
+        k.support = support;
+        crec[ch] = k;
+    }
+    count_requests(req_slots, n_req);
+}
+
 // One lane per cluster: record header + right context (extract_dna, ebwt2InDel.cpp:325-342) at the first
 // cluster position whose LCP >= k_right (:979-988; two BWTs :896-912); bases packed 2 bits each in text order.
 // It needs nothing but the survivors in BWT order, so it is launched as soon as they are -- before the host knows their
@@ -1186,7 +1277,10 @@ static int launch_contexts(eb_scan_job* job) {
     const int S = job->S;
     const uint32_t options = job->options;
     std::vector<SubShard>& sh = job->sh;
-    auto kern_extend = p.mode == 2 ? k_extend<true> : k_extend<false>;
+    // one lane per chain (k_extend1) since round 4: 0.98 -> 0.80 ms alone at 7.55 G positions, 1.42 -> 0.87 beside the scan
+    // (profiles/r04_extend_ab.txt); EB_EXTEND_LANES=4: a quad per chain (k_extend), kept under test
+    const int extend_lanes = getenv("EB_EXTEND_LANES") && atoi(getenv("EB_EXTEND_LANES")) == 4 ? 4 : 1;
+    auto kern_extend = extend_lanes == 1 ? (p.mode == 2 ? k_extend1<true> : k_extend1<false>) : (p.mode == 2 ? k_extend<true> : k_extend<false>);
     // the late walk of a large call set: a quad per cluster (EB_RIGHT_LANES=1: one lane, the form the early walk keeps)
     // With the FL table (eb_psi_lookup) a step is one 16-byte read by one lane: one lane per cluster, 64 walks per wave.
     static const int right_lanes_env = getenv("EB_RIGHT_LANES") ? atoi(getenv("EB_RIGHT_LANES")) : 0;
@@ -1208,7 +1302,7 @@ static int launch_contexts(eb_scan_job* job) {
         EB_HIP(hipStreamWaitEvent(sB, x.e[E_PREP_DONE], 0));
         EB_HIP(hipEventRecord(x.e[E_EXT0], sB));
         if (x.n_chains)
-            hipLaunchKernelGGL(kern_extend, dim3(grid_of(x.n_chains * 4)), dim3(256), 0, sB, x1, x2, p, x.sorted.as<Survivor>(), x.chains.as<uint64_t>(), x.n_chains,
+            hipLaunchKernelGGL(kern_extend, dim3(grid_of(x.n_chains * (uint64_t)extend_lanes)), dim3(256), 0, sB, x1, x2, p, x.sorted.as<Survivor>(), x.chains.as<uint64_t>(), x.n_chains,
                                x.d_crec, x.d_left, lw, x.cnt.as<ScanCounters>()->req_ext);
         EB_HIP(hipEventRecord(x.e[E_EXT_DONE], sB));
         EB_HIP(hipEventRecord(ctx->last_ext, sB));

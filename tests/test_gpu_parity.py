@@ -491,6 +491,26 @@ def test_cluster_records_match_oracle(oracle, monkeypatch, case, early_max, psi)
         assert skipped > 0                                           # the gate is exercised, not just present
 
 
+@pytest.mark.parametrize("case", [c for c in CASES if c["name"] in ("m1_default", "m1_edge_m2", "m2_het_default", "m3_het_default", "m3_edge_default")], ids=lambda c: c["name"])
+def test_extension_by_one_lane_per_chain_gives_the_same_call_set(monkeypatch, case):
+    """k_extend1 (one lane per left-context chain, the whole 64-byte block per lane) against k_extend (a quad per chain): the
+    same call-set image byte for byte, the same number of block requests, and the reference-written .snp."""
+    p = api.make_params(case["args"])
+    inp = case["inputs"]
+    g1 = api.DnaBwt(golden_bytes(inp["bwt1"]), term=p.term)
+    g2 = api.DnaBwt(golden_bytes(inp["bwt2"]), term=p.term) if case["mode"] == 2 else None
+    fl = api.navigate_two_bwts(g1, g2, p) if g2 is not None else api.navigate_one_bwt(g1, p)
+    if case["mode"] == 3:
+        fl.set_da(golden_bytes(inp["da"]))
+    out = {}
+    for lanes in ("4", "1"):
+        monkeypatch.setenv("EB_EXTEND_LANES", lanes)
+        calls = api.scan_clusters(g1, fl, p, bwt2=g2)
+        out[lanes] = (bytes(calls.blob()), calls.stats.requests_extend, calls.format_snp(p, case["mode"] != 1)[0])
+    assert out["1"] == out["4"]
+    assert out["1"][2] == golden_bytes(case["snp"])
+
+
 def test_cluster_histogram_matches_oracle_counts(oracle):
     e = golden_bytes("dip.ebwt")
     g = api.DnaBwt(e)
