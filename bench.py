@@ -663,7 +663,7 @@ def main():
     # profile was taken on the same launch size.  GB/s, the unit of `achieved`.
     traffic = ctx_traffic = rank_traffic = None
     try:
-        pmc_path = next(q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_traffic.json") for r in (3, 2)) if os.path.exists(q))
+        pmc_path = next(q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_traffic.json") for r in (4, 3, 2)) if os.path.exists(q))
         with open(pmc_path) as fh:
             pmc = json.load(fh)
         same = abs(pmc["workload_positions"] - positions_per_launch) <= 0.01 * positions_per_launch
