@@ -80,6 +80,8 @@ __host__ __device__ __forceinline__ void unpack_rec(const Leaf1& p, Leaf1& l) { 
 struct NavCounters {
     unsigned long long pushed;     // children appended by the current launch
     unsigned long long pad0[7];    // keep the hot word on its own 64-byte line
+    unsigned long long taken;      // k_nodes1c: input records handed out so far by the current launch (reset with `pushed`)
+    unsigned long long pad1[7];
     unsigned long long leaves, nodes, lcp_values, da_values, minima, ranks, pos_sum, pos_sq_sum;
 };
 
@@ -111,7 +113,8 @@ struct NavLaunch {
     void* out;         // children are appended here through NavCounters::pushed ...
     uint64_t out_cap;  // ... up to this many
     int32_t write;     // 0: expand only (the shared top of the tree on shards other than 0): no bit writes, no statistics
-    int32_t pad;
+    int32_t follow;    // k_nodes1c: 1 = a node's first kept child is expanded by the same quad instead of being pushed (0 while a
+                       // sharded traversal still walks level by level towards its cut)
 };
 
 // Power sums of the LCP positions written, modulo 2^64 (eb_nav_stats.lcp_pos_sum / lcp_pos_sq_sum).  The count alone
@@ -545,6 +548,223 @@ __global__ void __launch_bounds__(256) k_nodes1p(eb_dev_index x1, eb_dev_flags f
     flush_stats(stat_rows, st);
 }
 
+// ---- phase 3, one BWT, CHAINS FOLLOWED IN REGISTERS (round 4).  The suffix tree of a read collection is mostly unary under Weiner
+// links: W is right-maximal because some read ends behind it ('#') while the others go on with one letter, and the same holds for
+// cW, c'cW, ... until the reads run out -- ~135 nodes in a row whose only kept child is the next one (6.1 G nodes, ~50 M such
+// chains at 7.55 G positions).  k_nodes1p sends every one of them through the stack: 32 bytes written, 32 read, packed, staged,
+// unpacked.  Here a quad KEEPS the first kept child of its node -- lane jc's six boundaries are spread over the quad by DPP -- and
+// expands it in its next turn; only the other kept children (one node in a hundred has any) go to the stack, and a quad takes a
+// new record from the launch's input only when its chain ends.  A quad runs TWO chains alternately, so that the block loads of
+// one are in flight while the other computes (the distance k_nodes1p keeps between its stages A and D), plus one input record
+// fetched ahead.  Input records are handed out through a cursor (NavCounters::taken): a wave takes a chunk with one atomic, its
+// quads take records from the chunk as their chains end.  Same bits, same counters: every node is still expanded exactly once.
+// A launch may now push more than four records per input record; the planner's room rule no longer bounds that, so an overflow
+// (never seen: the whole traversal pushes fewer records than ONE stack holds) ends the traversal with an error and the caller
+// walks again with k_nodes1p (flags_build_chains).
+template <bool SUPER_LDS>
+__global__ void __launch_bounds__(256) k_nodes1c(eb_dev_index x1, eb_dev_flags f, uint64_t* __restrict__ kr, NavParams p, const NavLaunch* __restrict__ la,
+                                                NavCounters* cnt, unsigned long long* __restrict__ stat_rows) {
+    using Rec = Node1P;
+    // Pushes are rare here (one node in a hundred has a second kept child), so the staging buffer is small -- the 48 KB of k_nodes1p
+    // would keep the leaf traversal, which runs side by side, off the CUs for the whole of these long launches -- and a record that
+    // finds it full (the bushy top of the tree) goes straight to the stack with an atomic of its own.
+    constexpr int STAGE = 256;
+    __shared__ uint4 s_buf[STAGE * (sizeof(Rec) / 16)];
+    __shared__ uint32_t s_count;
+    __shared__ unsigned long long s_base;
+    __shared__ unsigned long long s_super[EB_NAV_SUPER_LDS * 4];
+    __shared__ int s_alive;
+    const Rec* __restrict__ in = static_cast<const Rec*>(la->in);
+    Rec* out = static_cast<Rec*>(la->out);
+    const uint64_t count = la->count, out_cap = la->out_cap;
+    p.write = la->write;
+    const bool follow = la->follow != 0;
+    if ((uint64_t)blockIdx.x * 64 >= count) return; // the grid is sized for a full batch: nothing for this workgroup (uniform)
+    Stager<Rec, STAGE> stage{s_buf, &s_count, &s_base};
+    if (SUPER_LDS) {
+        const uint64_t n_super = (x1.n >> EB_SUPER_SHIFT) + 1;
+        for (uint32_t k = threadIdx.x; k < n_super * 4; k += blockDim.x) s_super[k] = x1.super[k];
+    }
+    if (threadIdx.x == 0) { s_count = 0; s_alive = 0; }
+    __syncthreads();
+    const uint32_t j = threadIdx.x & 3u, lane = threadIdx.x & 63u;
+    uint64_t n_node = 0, n_lcp = 0, n_rank = 0, n_min = 0, n_s1 = 0, n_s2 = 0;
+    const uint64_t Fj = pick4(x1.F, j);
+    // records per chunk a wave takes from the cursor: 16 (one per quad) for small launches, up to 256
+    const uint64_t waves = (count + 15) / 16 < (uint64_t)gridDim.x * 4 ? (count + 15) / 16 : (uint64_t)gridDim.x * 4;
+    uint64_t chunk = count / (waves * 4);
+    chunk = chunk < 16 ? 16 : (chunk > 256 ? 256 : chunk);
+    uint64_t w_next = 0, w_end = 0; // this wave's chunk (wave-uniform)
+    bool dry = false;               // the input is used up (wave-uniform)
+
+    // border bits of a node (update_lcp_threshold include.hpp:826-860, update_lcp_minima ebwt2InDel.cpp:357-391), as in k_nodes1p
+    auto mark = [&](const Node1& N) {
+        uint64_t lo = 0, hi = 0;
+        for (int k = 0; k < 4; ++k) if (j == (uint32_t)k) { lo = N.b[k]; hi = N.b[k + 1]; }
+        if (hi > lo && hi != N.b[5]) {
+            const bool setK = ((int64_t)N.depth >= p.K) != (p.below != 0), setR = ((int64_t)N.depth >= p.k_right) != (p.below != 0);
+            if (p.lcpb) {
+                uint8_t v = (uint8_t)((setK ? 1 : 0) | (setR ? 2 : 0));
+                if (v && !(EB_NDBG(p) & 1u)) p.lcpb[hi] = v;
+            } else {
+                if (setK) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * (hi >> 6)), 1ull << (hi & 63u));
+                if (setR) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * (hi >> 6) + 1), 1ull << (hi & 63u));
+            }
+            ++n_lcp;
+            n_s1 += hi;
+            n_s2 += hi * hi;
+        }
+        if (j >= 1 && hi - lo >= 2 && hi < N.b[5] - 1) {
+            if (!(EB_NDBG(p) & 2u)) eb_bit_set_atomic(f.minima, hi);
+            ++n_min;
+        }
+    };
+    // Hands input records to the quads that ask for one (`want`, the same in the four lanes of a quad): idx = the record's index,
+    // want stays set where the input ran out.  Wave-uniform control flow; one returning atomic per chunk.
+    auto take = [&](bool& want, uint64_t& idx) {
+        for (;;) {
+            const unsigned long long m = __ballot(want && j == 0);
+            if (!m || dry) break;
+            if (w_next == w_end) {
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(&cnt->taken, (unsigned long long)chunk);
+                base = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+                w_next = base < count ? base : count;
+                w_end = base + chunk < count ? base + chunk : count;
+                if (w_next == w_end) { dry = true; break; }
+            }
+            const uint64_t avail = w_end - w_next;
+            const uint32_t rank = (uint32_t)__popcll(m & ((1ull << (lane & ~3u)) - 1ull)); // askers in the quads below this one
+            if (want && rank < avail) { idx = w_next + rank; want = false; }
+            const uint64_t asked = (uint64_t)__popcll(m);
+            w_next += asked < avail ? asked : avail;
+        }
+    };
+
+    // ---- two chains per quad + one record fetched ahead
+    Node1 N0, N1;
+    uint4 c0[6], c1[6];
+    bool act0 = false, act1 = false, have_spare = false;
+    Rec spare;
+    spare.w[0] = spare.w[1] = spare.w[2] = spare.w[3] = 0;
+    auto start = [&](Node1& N, uint4 (&c)[6], bool& act) {
+        bool want = true;
+        uint64_t idx = 0;
+        take(want, idx);
+        act = !want;
+        Rec r;
+        r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0;
+        if (act) r = eb_load_global(in + idx);
+        unpack_rec(r, N);
+        if (act && p.write) mark(N);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) c[k] = eb_rank4_quad_load(x1, N.b[k], j);
+    };
+    start(N0, c0, act0);
+    start(N1, c1, act1);
+    {
+        bool want = true;
+        uint64_t idx = 0;
+        take(want, idx);
+        have_spare = !want;
+        if (have_spare) spare = eb_load_global(in + idx);
+    }
+    // one turn of a chain = ranks and children of its node (LF(sa_node) dna_bwt.hpp:323-356, next_nodes :381-404), then its next
+    // node: the kept child, or the record fetched ahead.  Six turns (three per chain) between two flushes of the staging buffer.
+    for (;;) {
+        const bool wave_alive = __ballot(act0 || act1 || have_spare) != 0ull;
+        if (wave_alive) {
+#pragma unroll
+            for (int rep = 0; rep < 3; ++rep) {
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
+                    Node1& N = sl ? N1 : N0;
+                    uint4 (&c)[6] = sl ? c1 : c0;
+                    bool& act = sl ? act1 : act0;
+                    Node1 child;
+                    child.pad = 0;
+                    int kids = 0;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        const uint64_t i = N.b[k];
+                        uint32_t pc = eb_chunk_counts(c[k], eb_prefix_mask32((uint32_t)(i & 127u), j));
+                        pc = eb_quad_sum(pc);
+                        uint64_t sup;
+                        if constexpr (SUPER_LDS) sup = s_super[((i >> EB_SUPER_SHIFT) << 2) + j];
+                        else sup = x1.super[((i >> EB_SUPER_SHIFT) << 2) + j];
+                        child.b[k] = Fj + sup + c[k].w + ((pc >> (8u * j)) & 0xFFu);
+                    }
+                    for (int k = 0; k < 5; ++k) kids += child.b[k + 1] > child.b[k];
+                    child.depth = N.depth + 1;
+                    const bool keep = act && kids >= 2; // number_of_children (include.hpp:760-768)
+                    if (act && p.write && j == 0) {
+                        ++n_node;
+                        n_rank += 1;
+                        for (int k = 1; k < 6; ++k) n_rank += N.b[k] != N.b[k - 1]; // the reference shares the query of equal neighbours
+                    }
+                    // the quad goes on with its first kept child; the others travel through the stack
+                    const uint32_t km = eb_quad_or(keep ? (1u << j) : 0u);
+                    const uint32_t jc = follow && km ? (uint32_t)__ffs((int)km) - 1u : 4u;
+                    {
+                        const bool px = keep && j != jc;
+                        const unsigned long long pm = __ballot(px);
+                        if (pm) { // (uniform; most turns nobody pushes and the record is not even packed)
+                            const Rec rec = pack_rec(child);
+                            uint32_t wbase = 0;
+                            if (lane == 0) wbase = atomicAdd(&s_count, (uint32_t)__popcll(pm));
+                            wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+                            if (px) {
+                                const uint32_t slot = wbase + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
+                                const uint4* src = reinterpret_cast<const uint4*>(&rec);
+                                if (slot < (uint32_t)STAGE) {
+                                    for (int q = 0; q < (int)(sizeof(Rec) / 16); ++q) s_buf[slot * (sizeof(Rec) / 16) + q] = src[q];
+                                } else {
+                                    const unsigned long long g = atomicAdd(&cnt->pushed, 1ull);
+                                    if (g < out_cap)
+                                        for (int q = 0; q < (int)(sizeof(Rec) / 16); ++q) eb_store_global(reinterpret_cast<uint4*>(out) + g * (sizeof(Rec) / 16) + q, src[q]);
+                                }
+                            }
+                        }
+                    }
+                    bool want = false;
+                    if (jc < 4u) {
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) N.b[k] = eb_quad_pick64(child.b[k], j == jc);
+                        N.depth = child.depth;
+                    } else {
+                        // the chain ended (or the slot was idle): on with the record fetched ahead, and another one is asked for
+                        act = have_spare;
+                        if (have_spare) { unpack_rec(spare, N); want = true; }
+                        have_spare = false;
+                    }
+                    uint64_t idx = 0;
+                    bool asked = want;
+                    take(want, idx);
+                    if (asked && !want) { spare = eb_load_global(in + idx); have_spare = true; }
+                    // the new node of this chain: its border bits, its block loads (consumed in this chain's next turn)
+                    if (act && p.write) mark(N);
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) c[k] = eb_rank4_quad_load(x1, act ? N.b[k] : 0ull, j);
+                }
+            }
+        }
+        // six turns add at most 6 x 256 records: the staging buffer is emptied here, and the workgroup goes on while any of its waves does
+        __syncthreads();
+        if (threadIdx.x == 0 && s_count > (uint32_t)STAGE) s_count = STAGE; // (the excess went straight to the stack)
+        stage.flush(out, out_cap, &cnt->pushed);
+        const bool still = __ballot(act0 || act1 || have_spare) != 0ull;
+        if (threadIdx.x == 0) s_alive = 0;
+        __syncthreads();
+        if (lane == 0 && still) s_alive = 1;
+        __syncthreads();
+        const int go_on = s_alive;
+        __syncthreads(); // (nobody resets the flag before everybody has read it)
+        if (!go_on) break;
+    }
+    const uint64_t st[EB_NAV_STATS] = {0, n_node, n_lcp, 0, n_min, n_rank, n_s1, n_s2};
+    flush_stats(stat_rows, st);
+}
+
 // ---- phase 3, two BWTs, software-pipelined the same way (k_nodes1p).  A merged node is two sa_nodes (12 boundaries); as in
 // k_nodes<2, 1> a block is loaded ONCE for the boundaries of a node that share it (they are sorted and a few dozen rows apart):
 // which boundaries issue a load is decided in stage A and kept as a 12-bit mask for stage D.
@@ -833,6 +1053,7 @@ struct DrainState {
 __device__ __forceinline__ void drain_account(DrainState* st, NavCounters* cnt) {
     const unsigned long long pushed = cnt->pushed;
     cnt->pushed = 0;
+    cnt->taken = 0;
     if (st->last == DRAIN_EXPAND) {
         const uint32_t src = st->last_src, dst = 1u - src;
         if (pushed > st->last_room) st->error = DRAIN_ERR_OVERFLOW;
@@ -881,6 +1102,7 @@ __global__ void k_drain_plan(DrainState* st, NavCounters* cnt) {
     st->expand.out = reinterpret_cast<void*>(st->stack[dst] + st->top[dst] * ib);
     st->expand.out_cap = room;
     st->expand.write = (st->n_shards == 1 || st->split_done || st->shard == 0) ? 1 : 0;
+    st->expand.follow = (st->n_shards == 1 || st->split_done) ? 1 : 0;
     st->last = DRAIN_EXPAND;
     st->last_src = src;
     st->last_base = base;
@@ -1075,7 +1297,7 @@ int eb_flags_derive(eb_flags* f) {
 // derive: finish the vectors (inversion of the complement form, fused flag word, DA ranks) -- eb_flags_build; false: leave them in
 // the form the traversal collected them in, for a caller that still has to combine shards (eb_flags_build_shard)
 static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_right, uint32_t shard, uint32_t n_shards, eb_flags** out,
-                            eb_nav_stats* stats, bool complement, bool derive) {
+                            eb_nav_stats* stats, bool complement, bool derive, bool chains) {
     if (!b1 || !out) { eb_set_error("null argument"); return EB_ERR_ARG; }
     if (n_shards == 0 || shard >= n_shards) { eb_set_error("shard %u of %u", shard, n_shards); return EB_ERR_ARG; }
     if (K < 0 || K > 65534 || k_right < 0 || k_right > 65534) { eb_set_error("K and k_right must be below 65535"); return EB_ERR_ARG; }
@@ -1237,7 +1459,9 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
             Node1 root{{0, b1->F[0], b1->F[1], b1->F[2], b1->F[3], b1->n}, 0, 0};
             if ((r = d.push_host(pack_rec(root))) != EB_OK) return r;
             r = d.run<-1>(dc, nb.state, nb.h_state, [&](const NavLaunch* la, unsigned grid) {
-                if (pipelined_nodes && (b1->n >> EB_SUPER_SHIFT) + 1 <= EB_NAV_SUPER_LDS) hipLaunchKernelGGL((k_nodes1p<true>), dim3(grid), dim3(256), 0, sx, x1, df, d_kr, p, la, dc, rows);
+                if (pipelined_nodes && chains && (b1->n >> EB_SUPER_SHIFT) + 1 <= EB_NAV_SUPER_LDS) hipLaunchKernelGGL((k_nodes1c<true>), dim3(grid), dim3(256), 0, sx, x1, df, d_kr, p, la, dc, rows);
+                else if (pipelined_nodes && chains) hipLaunchKernelGGL((k_nodes1c<false>), dim3(grid), dim3(256), 0, sx, x1, df, d_kr, p, la, dc, rows);
+                else if (pipelined_nodes && (b1->n >> EB_SUPER_SHIFT) + 1 <= EB_NAV_SUPER_LDS) hipLaunchKernelGGL((k_nodes1p<true>), dim3(grid), dim3(256), 0, sx, x1, df, d_kr, p, la, dc, rows);
                 else if (pipelined_nodes) hipLaunchKernelGGL((k_nodes1p<false>), dim3(grid), dim3(256), 0, sx, x1, df, d_kr, p, la, dc, rows);
                 else hipLaunchKernelGGL((k_nodes<1, EB_NODES_PER_QUAD>), dim3(grid), dim3(256), 0, sx, x1, x2, df, d_kr, p, la, dc, rows);
             });
@@ -1353,11 +1577,24 @@ extern "C" int eb_nav_covers_every_slot_once(const eb_nav_stats* s) {
     return s->lcp_values == s->n && (s->n == 0 || (s->lcp_pos_sum == eb_tri(s->n) && s->lcp_pos_sq_sum == eb_sq(s->n)));
 }
 
+// One-BWT node traversal with chains followed in registers (k_nodes1c; EB_NAV_CHAINS=0: k_nodes1p).  A launch of k_nodes1c may
+// push more records than the planner left room for (it never has: see the kernel); the traversal then ends with an error and is
+// walked again the round-3 way.
+static int flags_build_chains(eb_index* b1, eb_index* b2, int32_t K, int32_t k_right, uint32_t shard, uint32_t n_shards, eb_flags** out,
+                              eb_nav_stats* stats, bool complement, bool derive) {
+    const uint64_t mode = env_u64("EB_NAV_CHAINS", 1); // 2 (tests): the first walk's result is thrown away as if it had overflowed
+    const bool chains = mode != 0;
+    int rc = flags_build_impl(b1, b2, K, k_right, shard, n_shards, out, stats, complement, derive, chains);
+    if (mode == 2 && rc == EB_OK) { eb_flags_destroy(*out); *out = nullptr; rc = EB_ERR_STATE; }
+    if (chains && (rc == EB_ERR_STATE || rc == EB_ERR_NOMEM)) rc = flags_build_impl(b1, b2, K, k_right, shard, n_shards, out, stats, complement, derive, false);
+    return rc;
+}
+
 extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_right, eb_flags** out, eb_nav_stats* stats) {
     if (!out) { eb_set_error("null argument"); return EB_ERR_ARG; }
     const bool complement = env_u64("EB_NAV_COMPLEMENT", 1) != 0;
     eb_nav_stats s;
-    int rc = flags_build_impl(b1, b2, K, k_right, 0, 1, out, &s, complement, true);
+    int rc = flags_build_chains(b1, b2, K, k_right, 0, 1, out, &s, complement, true);
     if (rc != EB_OK) return rc;
     if (complement && !eb_nav_covers_every_slot_once(&s)) {
         // Not every LCP slot was written exactly once: the input is not the eBWT of a read collection.  The reference leaves
@@ -1365,7 +1602,7 @@ extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_r
         // the reference's way (writers at or above the thresholds set their bits).
         eb_flags_destroy(*out);
         *out = nullptr;
-        rc = flags_build_impl(b1, b2, K, k_right, 0, 1, out, &s, false, true);
+        rc = flags_build_chains(b1, b2, K, k_right, 0, 1, out, &s, false, true);
         if (rc != EB_OK) return rc;
     }
     if (stats) *stats = s;
@@ -1379,7 +1616,7 @@ extern "C" int eb_flags_build_shard(eb_index* b1, eb_index* b2, int32_t K, int32
     // ALWAYS shard form, never derived -- also for n_shards == 1: the callers' next step (all-reduce + eb_flags_finalize, or
     // eb_flags_export + eb_flags_import_shard_sum) is the same for any number of shards, and a one-shard build that came
     // back finished would be inverted a second time on the host-exchange paths (round-2 advisor finding).
-    return flags_build_impl(b1, b2, K, k_right, shard, n_shards, out, stats, true, false);
+    return flags_build_chains(b1, b2, K, k_right, shard, n_shards, out, stats, true, false);
 }
 
 extern "C" int eb_flags_device_vectors(eb_flags* f, uint64_t* d_vectors[4], uint64_t* words) {

@@ -276,6 +276,11 @@ NAV_MODES = {
     # the round-2 node kernels (record load, wait, block loads, wait, compute) instead of the software-pipelined ones of round 3,
     # and the drain's planner read back after every launch instead of once per group of eight
     "round2_node_kernels": {"EB_NAV_PIPELINED": "0"},
+    # the round-3 one-BWT node kernel (every node through the stack) instead of the chain-following one of round 4; and the
+    # chain-following walk thrown away as if a launch had overflowed its stack (the caller then walks again the round-3 way)
+    "round3_node_kernel": {"EB_NAV_CHAINS": "0"},
+    "chains_overflow_walks_again": {"EB_NAV_CHAINS": "2"},
+    "chains_classic_words": {"EB_NAV_COMPLEMENT": "0", "EB_NAV_BYTES": "0", "EB_NAV_GROUP": "2"},
     "one_launch_per_readback": {"EB_NAV_GROUP": "1"},
     "classic_words_round2_kernels": {"EB_NAV_COMPLEMENT": "0", "EB_NAV_BYTES": "0", "EB_NAV_PIPELINED": "0", "EB_NAV_GROUP": "3"},
 }
@@ -315,9 +320,9 @@ def test_flags_batch_size_does_not_change_result(oracle, monkeypatch):
     g = api.DnaBwt(e)
     ref = api.Flags.build(g, None, 16, 30).export()
     for batch, mode in (("64", "complement"), ("1000", "classic_bytes"), ("777", "classic_words"), ("300", "complement_one_stream"), ("200", "round2_node_kernels"),
-                        ("130", "one_launch_per_readback")):
+                        ("130", "one_launch_per_readback"), ("64", "round3_node_kernel"), ("17", "complement")):
         monkeypatch.setenv("EB_NAV_BATCH", batch)                 # tiny batches: many launches, depth-first order
-        for k in ("EB_NAV_COMPLEMENT", "EB_NAV_BYTES", "EB_NAV_CONCURRENT", "EB_NAV_PIPELINED", "EB_NAV_GROUP"):
+        for k in ("EB_NAV_COMPLEMENT", "EB_NAV_BYTES", "EB_NAV_CONCURRENT", "EB_NAV_PIPELINED", "EB_NAV_GROUP", "EB_NAV_CHAINS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in NAV_MODES[mode].items():
             monkeypatch.setenv(k, v)
