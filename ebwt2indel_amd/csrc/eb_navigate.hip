@@ -765,6 +765,178 @@ __global__ void __launch_bounds__(256) k_nodes1c(eb_dev_index x1, eb_dev_flags f
     flush_stats(stat_rows, st);
 }
 
+// ---- phase 2, one BWT, chains followed in registers like k_nodes1c.  Two reads that end at the same place share every suffix, so
+// the leaves W#, cW#, c'cW#, ... form a chain as long as the reads (0.58 G leaves in ~4 M chains at 7.55 G positions, which
+// k_leaves walks in lock-step: a hundred launches of 4 M records at the end of the traversal).  A quad keeps the first kept child
+// leaf and expands it in its next turn; two chains per quad alternate, so that the two block loads of one are in flight while the
+// other computes (k_leaves waits for its record, then for its blocks: nothing overlaps), one input record is fetched ahead.
+__global__ void __launch_bounds__(256) k_leaves1c(eb_dev_index x1, eb_dev_flags f, uint64_t* __restrict__ kr, NavParams p, const NavLaunch* __restrict__ la,
+                                                 NavCounters* cnt, unsigned long long* __restrict__ stat_rows) {
+    using Rec = Leaf1;
+    constexpr int STAGE = 256;
+    __shared__ uint4 s_buf[STAGE * (sizeof(Rec) / 16)];
+    __shared__ uint32_t s_count;
+    __shared__ unsigned long long s_base;
+    __shared__ int s_alive;
+    const Rec* __restrict__ in = static_cast<const Rec*>(la->in);
+    Rec* out = static_cast<Rec*>(la->out);
+    const uint64_t count = la->count, out_cap = la->out_cap;
+    p.write = la->write;
+    const bool follow = la->follow != 0;
+    if ((uint64_t)blockIdx.x * 64 >= count) return; // the grid is sized for a full batch: nothing for this workgroup (uniform)
+    Stager<Rec, STAGE> stage{s_buf, &s_count, &s_base};
+    if (threadIdx.x == 0) { s_count = 0; s_alive = 0; }
+    __syncthreads();
+    const uint32_t j = threadIdx.x & 3u, lane = threadIdx.x & 63u;
+    uint64_t n_leaf = 0, n_lcp = 0, n_rank = 0, n_s1 = 0, n_s2 = 0;
+    const uint64_t Fj = pick4(x1.F, j);
+    const uint64_t waves = (count + 15) / 16 < (uint64_t)gridDim.x * 4 ? (count + 15) / 16 : (uint64_t)gridDim.x * 4;
+    uint64_t chunk = count / (waves * 4);
+    chunk = chunk < 16 ? 16 : (chunk > 256 ? 256 : chunk);
+    uint64_t w_next = 0, w_end = 0;
+    bool dry = false;
+    // LCP slots l+1 .. r-1 of a leaf (update_LCP_leaf, ebwt2InDel.cpp:344-355): the quad splits the touched words
+    auto mark = [&](uint64_t l, uint64_t r, uint64_t depth) {
+        if (r <= l + 1) return;
+        const uint64_t lo = l + 1, hi = r;
+        const bool setK = ((int64_t)depth >= p.K) != (p.below != 0), setR = ((int64_t)depth >= p.k_right) != (p.below != 0);
+        if ((setK || setR) && p.lcpb) {
+            const uint8_t v = (uint8_t)((setK ? 1 : 0) | (setR ? 2 : 0));
+            for (uint64_t i2 = lo + j; i2 < hi; i2 += 4) p.lcpb[i2] = v;
+        } else if (setK || setR) {
+            const uint64_t w0 = lo >> 6, w1 = (hi - 1) >> 6;
+            for (uint64_t w = w0 + j; w <= w1; w += 4) {
+                uint64_t m = ~0ull;
+                if (w == w0) m &= ~0ull << (lo & 63u);
+                if (w == w1) m &= ~0ull >> (63u - ((hi - 1) & 63u));
+                if (setK) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * w), m);
+                if (setR) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * w + 1), m);
+            }
+        }
+        if (j == 0) { n_lcp += hi - lo; n_s1 += eb_tri(hi) - eb_tri(lo); n_s2 += eb_sq(hi) - eb_sq(lo); }
+    };
+    auto take = [&](bool& want, uint64_t& idx) { // as in k_nodes1c
+        for (;;) {
+            const unsigned long long m = __ballot(want && j == 0);
+            if (!m || dry) break;
+            if (w_next == w_end) {
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(&cnt->taken, (unsigned long long)chunk);
+                base = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+                w_next = base < count ? base : count;
+                w_end = base + chunk < count ? base + chunk : count;
+                if (w_next == w_end) { dry = true; break; }
+            }
+            const uint64_t avail = w_end - w_next;
+            const uint32_t rank = (uint32_t)__popcll(m & ((1ull << (lane & ~3u)) - 1ull));
+            if (want && rank < avail) { idx = w_next + rank; want = false; }
+            const uint64_t asked = (uint64_t)__popcll(m);
+            w_next += asked < avail ? asked : avail;
+        }
+    };
+    struct Chain { uint64_t l, r, depth; uint4 cl, cr; bool act; };
+    Chain C0, C1;
+    bool have_spare = false;
+    Rec spare;
+    spare.l = spare.r = spare.depth = spare.pad = 0;
+    // a chain's new leaf: its LCP bits, its statistics, its two block loads (consumed in the chain's next turn)
+    auto arm = [&](Chain& C) {
+        if (C.act && p.write) {
+            mark(C.l, C.r, C.depth);
+            if (j == 0) { ++n_leaf; n_rank += C.r > C.l ? 2 : 1; }
+        }
+        C.cl = eb_rank4_quad_load(x1, C.act ? C.l : 0ull, j);
+        C.cr = eb_rank4_quad_load(x1, C.act ? (C.r > C.l ? C.r : C.l) : 0ull, j);
+    };
+    auto start = [&](Chain& C) {
+        bool want = true;
+        uint64_t idx = 0;
+        take(want, idx);
+        C.act = !want;
+        Rec r;
+        r.l = r.r = r.depth = r.pad = 0;
+        if (C.act) r = eb_load_global(in + idx);
+        C.l = r.l; C.r = r.r; C.depth = r.depth;
+        arm(C);
+    };
+    start(C0);
+    start(C1);
+    {
+        bool want = true;
+        uint64_t idx = 0;
+        take(want, idx);
+        have_spare = !want;
+        if (have_spare) spare = eb_load_global(in + idx);
+    }
+    for (;;) {
+        const bool wave_alive = __ballot(C0.act || C1.act || have_spare) != 0ull;
+        if (wave_alive) {
+#pragma unroll
+            for (int rep = 0; rep < 3; ++rep) {
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
+                    Chain& C = sl ? C1 : C0;
+                    // next_leaves (dna_bwt.hpp:358-379): the child obtained by prepending letter j
+                    const uint64_t a = eb_rank4_quad_finish(x1, C.cl, C.l, j), b = eb_rank4_quad_finish(x1, C.cr, C.r > C.l ? C.r : C.l, j);
+                    Rec child;
+                    child.l = Fj + a; child.r = Fj + b; child.depth = C.depth + 1; child.pad = 0;
+                    const bool keep = C.act && (b - a >= 2);
+                    const uint32_t km = eb_quad_or(keep ? (1u << j) : 0u);
+                    const uint32_t jc = follow && km ? (uint32_t)__ffs((int)km) - 1u : 4u;
+                    {
+                        const bool px = keep && j != jc;
+                        const unsigned long long pm = __ballot(px);
+                        if (pm) {
+                            uint32_t wbase = 0;
+                            if (lane == 0) wbase = atomicAdd(&s_count, (uint32_t)__popcll(pm));
+                            wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+                            if (px) {
+                                const uint32_t slot = wbase + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
+                                const uint4* src = reinterpret_cast<const uint4*>(&child);
+                                if (slot < (uint32_t)STAGE) {
+                                    for (int q = 0; q < (int)(sizeof(Rec) / 16); ++q) s_buf[slot * (sizeof(Rec) / 16) + q] = src[q];
+                                } else {
+                                    const unsigned long long g = atomicAdd(&cnt->pushed, 1ull);
+                                    if (g < out_cap)
+                                        for (int q = 0; q < (int)(sizeof(Rec) / 16); ++q) eb_store_global(reinterpret_cast<uint4*>(out) + g * (sizeof(Rec) / 16) + q, src[q]);
+                                }
+                            }
+                        }
+                    }
+                    bool want = false;
+                    if (jc < 4u) {
+                        C.l = eb_quad_pick64(child.l, j == jc);
+                        C.r = eb_quad_pick64(child.r, j == jc);
+                        C.depth = child.depth;
+                    } else {
+                        C.act = have_spare;
+                        if (have_spare) { C.l = spare.l; C.r = spare.r; C.depth = spare.depth; want = true; }
+                        have_spare = false;
+                    }
+                    uint64_t idx = 0;
+                    const bool asked = want;
+                    take(want, idx);
+                    if (asked && !want) { spare = eb_load_global(in + idx); have_spare = true; }
+                    arm(C);
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0 && s_count > (uint32_t)STAGE) s_count = STAGE; // (the excess went straight to the stack)
+        stage.flush(out, out_cap, &cnt->pushed);
+        const bool still = __ballot(C0.act || C1.act || have_spare) != 0ull;
+        if (threadIdx.x == 0) s_alive = 0;
+        __syncthreads();
+        if (lane == 0 && still) s_alive = 1;
+        __syncthreads();
+        const int go_on = s_alive;
+        __syncthreads();
+        if (!go_on) break;
+    }
+    const uint64_t st[EB_NAV_STATS] = {n_leaf, 0, n_lcp, 0, 0, n_rank, n_s1, n_s2};
+    flush_stats(stat_rows, st);
+}
+
 // ---- phase 3, two BWTs, software-pipelined the same way (k_nodes1p).  A merged node is two sa_nodes (12 boundaries); as in
 // k_nodes<2, 1> a block is loaded ONCE for the boundaries of a node that share it (they are sorted and a few dozen rows apart):
 // which boundaries issue a load is decided in stage A and kept as a 12-bit mask for stage D.
@@ -1428,7 +1600,8 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
             if ((r = d.init(arena, bytes, n, batch_max)) != EB_OK) return r;
             if ((r = d.push_host(Leaf1{0, b1->F[0], 0, 0})) != EB_OK) return r;
             r = d.run<-1>(dc, nb.state, nb.h_state, [&](const NavLaunch* la, unsigned grid) {
-                hipLaunchKernelGGL(k_leaves<1>, dim3(grid), dim3(256), 0, sx, x1, x2, df, d_kr, p, la, dc, rows);
+                if (chains) hipLaunchKernelGGL(k_leaves1c, dim3(grid), dim3(256), 0, sx, x1, df, d_kr, p, la, dc, rows);
+                else hipLaunchKernelGGL(k_leaves<1>, dim3(grid), dim3(256), 0, sx, x1, x2, df, d_kr, p, la, dc, rows);
             });
             launches_l = d.launches;
             return r;
