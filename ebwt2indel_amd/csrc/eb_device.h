@@ -243,6 +243,13 @@ __device__ __forceinline__ uint32_t eb_code_to_ascii(uint32_t code, uint32_t ter
     return code == 0 ? 'A' : code == 1 ? 'C' : code == 2 ? 'G' : code == 3 ? 'T' : term;
 }
 
+// a[c] for a run-time letter c of a four-entry table held in a by-value index struct, as four independent selects OR-ed together:
+// the chain  c == 0 ? a[0] : c == 1 ? a[1] : ...  is turned back into a dynamically indexed load by the compiler, and a struct
+// that is indexed dynamically lives in scratch memory (k_right<two BWTs, one lane>: 176 bytes per lane, round 4)
+__device__ __forceinline__ uint64_t eb_pick_letter(const uint64_t (&a)[4], int c) {
+    return (c == 0 ? a[0] : 0ull) | (c == 1 ? a[1] : 0ull) | (c == 2 ? a[2] : 0ull) | (c == 3 ? a[3] : 0ull);
+}
+
 // F(i) (dna_bwt.hpp:100-110) as a letter index: -1 for a TERM row.
 __device__ __forceinline__ int eb_F_letter(const eb_dev_index& x, uint64_t i) {
     return i < x.F[0] ? -1 : i < x.F[1] ? 0 : i < x.F[2] ? 1 : i < x.F[3] ? 2 : 3;
@@ -305,7 +312,7 @@ __device__ __forceinline__ uint32_t eb_select_guess(const eb_dev_index& x, const
 // `probes` counts the memory requests issued: 1 for the directory pair + 1 per 64-byte block probed (bench.py's
 // context_roofline is built from these counts).
 __device__ __forceinline__ uint64_t eb_select(const eb_dev_index& x, uint64_t r, int c, uint32_t& probes) {
-    const uint32_t* dir = x.sel_dir + (c == 0 ? x.sel_off[0] : c == 1 ? x.sel_off[1] : c == 2 ? x.sel_off[2] : x.sel_off[3]);
+    const uint32_t* dir = x.sel_dir + eb_pick_letter(x.sel_off, c);
     uint64_t g = (uint64_t)eb_select_guess(x, dir, r); // the answer lies in a block between the two samples around r
     if (g >= x.n_blocks) g = x.n_blocks - 1; // (never, by construction of the directory: a wrong guess may cost probes, it must not cost a fault)
     ++probes;
@@ -349,7 +356,7 @@ __device__ __forceinline__ uint64_t eb_select(const eb_dev_index& x, uint64_t r,
 // same r and c): each probe is one coalesced 64-byte request -- lane j loads chunk j -- instead of four 16-byte loads by one
 // lane, and a wave holds 16 walks instead of 64, so fewer lanes wait for the walk that needs a third probe.
 __device__ __forceinline__ uint64_t eb_select_quad(const eb_dev_index& x, uint64_t r, int c, uint32_t j, uint32_t qbase, uint32_t& probes) {
-    const uint32_t* dir = x.sel_dir + (c == 0 ? x.sel_off[0] : c == 1 ? x.sel_off[1] : c == 2 ? x.sel_off[2] : x.sel_off[3]);
+    const uint32_t* dir = x.sel_dir + eb_pick_letter(x.sel_off, c);
     uint64_t g = (uint64_t)eb_select_guess(x, dir, r); // same addresses in all four lanes: one request
     if (g >= x.n_blocks) g = x.n_blocks - 1; // (never, by construction of the directory: a wrong guess may cost probes, it must not cost a fault)
     ++probes;
@@ -379,7 +386,7 @@ __device__ __forceinline__ uint64_t eb_select_quad(const eb_dev_index& x, uint64
 
 // F[letter] by selects: a dynamic index into a kernel-argument array would send the whole struct to scratch memory
 __device__ __forceinline__ uint64_t eb_F_of(const eb_dev_index& x, int letter) {
-    return letter == 0 ? x.F[0] : letter == 1 ? x.F[1] : letter == 2 ? x.F[2] : x.F[3];
+    return eb_pick_letter(x.F, letter);
 }
 
 // ---- FL table ("psi", round 4).  An index that is scanned again and again (eb_index_build_psi; phase 4 builds it by itself with
@@ -409,8 +416,7 @@ __device__ __forceinline__ uint32_t eb_psi_bits(uint4 v, uint32_t off, uint32_t 
 }
 // position of the r-th (0-based) letter c, from its chunk; false: the chunk is void
 __device__ __forceinline__ bool eb_psi_lookup(const eb_dev_index& x, uint64_t r, int c, uint64_t& pos) {
-    const uint64_t off = c == 0 ? x.psi_off[0] : c == 1 ? x.psi_off[1] : c == 2 ? x.psi_off[2] : x.psi_off[3];
-    const uint4 v = eb_load_chunk_select(x.psi + off + (r >> EB_PSI_SHIFT));
+    const uint4 v = eb_load_chunk_select(x.psi + eb_pick_letter(x.psi_off, c) + (r >> EB_PSI_SHIFT));
     if (v.x == 0xFFFFFFFFu && (v.y & 63u) == 63u) return false;
     const uint32_t k = (uint32_t)r & 15u;
     const uint32_t bitmap = (v.y >> 6) & 0x7FFFu;

@@ -1092,6 +1092,237 @@ __global__ void __launch_bounds__(256) k_nodes2p(eb_dev_index x1, eb_dev_index x
     flush_stats(stat_rows, st);
 }
 
+// ---- phase 3, two BWTs, chains followed in registers (k_nodes1c for merged nodes).  ONE chain per quad (two, like k_nodes1c, need
+// 256 registers: one wave per SIMD) and one input record fetched ahead; the loads of a turn are covered by the other waves of the
+// SIMD.  The first kept child's twelve boundaries are spread over the quad by DPP, the other kept children go to the stack (small
+// staging buffer, excess straight to the stack).
+template <bool SUPER_LDS>
+__global__ void __launch_bounds__(256) k_nodes2c(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, uint64_t* __restrict__ kr, NavParams p,
+                                                const NavLaunch* __restrict__ la, NavCounters* cnt, unsigned long long* __restrict__ stat_rows) {
+    using Rec = Node2P;
+    constexpr int STAGE = 256;
+    __shared__ uint4 s_buf[STAGE * (sizeof(Rec) / 16)];
+    __shared__ uint32_t s_count;
+    __shared__ unsigned long long s_base;
+    __shared__ unsigned long long s_super[2][EB_NAV_SUPER_LDS * 4];
+    __shared__ int s_alive;
+    const Rec* __restrict__ in = static_cast<const Rec*>(la->in);
+    Rec* out = static_cast<Rec*>(la->out);
+    const uint64_t count = la->count, out_cap = la->out_cap;
+    p.write = la->write;
+    const bool follow = la->follow != 0;
+    if ((uint64_t)blockIdx.x * 64 >= count) return; // the grid is sized for a full batch: nothing for this workgroup (uniform)
+    Stager<Rec, STAGE> stage{s_buf, &s_count, &s_base};
+    if (SUPER_LDS) {
+        const uint64_t ns1 = (x1.n >> EB_SUPER_SHIFT) + 1, ns2 = (x2.n >> EB_SUPER_SHIFT) + 1;
+        for (uint32_t k = threadIdx.x; k < ns1 * 4; k += blockDim.x) s_super[0][k] = x1.super[k];
+        for (uint32_t k = threadIdx.x; k < ns2 * 4; k += blockDim.x) s_super[1][k] = x2.super[k];
+    }
+    if (threadIdx.x == 0) { s_count = 0; s_alive = 0; }
+    __syncthreads();
+    const uint32_t j = threadIdx.x & 3u, lane = threadIdx.x & 63u;
+    uint64_t n_node = 0, n_lcp = 0, n_da = 0, n_rank = 0, n_min = 0, n_s1 = 0, n_s2 = 0;
+    const uint64_t F1 = pick4(x1.F, j), F2 = pick4(x2.F, j);
+    const uint64_t waves = (count + 15) / 16 < (uint64_t)gridDim.x * 4 ? (count + 15) / 16 : (uint64_t)gridDim.x * 4;
+    uint64_t chunk = count / (waves * 4);
+    chunk = chunk < 16 ? 16 : (chunk > 256 ? 256 : chunk);
+    uint64_t w_next = 0, w_end = 0;
+    bool dry = false;
+
+    // border bits in merged coordinates (merge_nodes, include.hpp:476-490), DA slots of singleton leaves: as in k_nodes2p
+    auto mark = [&](const Node2& N) {
+        uint64_t lo = 0, hi = 0;
+        const uint64_t last = N.a[5] + N.b[5];
+        for (int k = 0; k < 4; ++k) if (j == (uint32_t)k) { lo = N.a[k] + N.b[k]; hi = N.a[k + 1] + N.b[k + 1]; }
+        if (hi > lo && hi != last) {
+            const bool setK = ((int64_t)N.depth >= p.K) != (p.below != 0), setR = ((int64_t)N.depth >= p.k_right) != (p.below != 0);
+            if (p.lcpb) {
+                uint8_t v = (uint8_t)((setK ? 1 : 0) | (setR ? 2 : 0));
+                if (v && !(EB_NDBG(p) & 1u)) p.lcpb[hi] = v;
+            } else {
+                if (setK) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * (hi >> 6)), 1ull << (hi & 63u));
+                if (setR) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * (hi >> 6) + 1), 1ull << (hi & 63u));
+            }
+            ++n_lcp;
+            n_s1 += hi;
+            n_s2 += hi * hi;
+        }
+        if (j >= 1 && hi - lo >= 2 && hi < last - 1) {
+            if (!(EB_NDBG(p) & 2u)) eb_bit_set_atomic(f.minima, hi);
+            ++n_min;
+        }
+        // leaves of merged size 1 were not visited in phase 2: write their DA slot now (find_leaves, ebwt2InDel.cpp:474-527)
+        for (int k = 0; k < 5; ++k) {
+            if ((uint32_t)(k & 3) != j || (k == 4 && j != 0)) continue;
+            uint64_t s1 = N.a[k + 1] - N.a[k], s2 = N.b[k + 1] - N.b[k];
+            if (s1 + s2 == 1) {
+                if (s2 && !(EB_NDBG(p) & 8u)) eb_bit_set_atomic(f.da, N.b[k] + N.a[k + 1]);
+                ++n_da;
+            }
+        }
+    };
+    // which boundaries start a new block (bit k: a[k], bit 6 + k: b[k]); the others reuse their left neighbour's
+    auto load_mask = [&](const Node2& N) -> uint32_t {
+        uint32_t m = 1u | (1u << 6);
+#pragma unroll
+        for (int k = 1; k < 6; ++k) {
+            m |= ((N.a[k] >> 7) != (N.a[k - 1] >> 7) ? 1u : 0u) << k;
+            m |= ((N.b[k] >> 7) != (N.b[k - 1] >> 7) ? 1u : 0u) << (6 + k);
+        }
+        return m;
+    };
+    auto take = [&](bool& want, uint64_t& idx) { // as in k_nodes1c
+        for (;;) {
+            const unsigned long long m = __ballot(want && j == 0);
+            if (!m || dry) break;
+            if (w_next == w_end) {
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(&cnt->taken, (unsigned long long)chunk);
+                base = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+                w_next = base < count ? base : count;
+                w_end = base + chunk < count ? base + chunk : count;
+                if (w_next == w_end) { dry = true; break; }
+            }
+            const uint64_t avail = w_end - w_next;
+            const uint32_t rank = (uint32_t)__popcll(m & ((1ull << (lane & ~3u)) - 1ull));
+            if (want && rank < avail) { idx = w_next + rank; want = false; }
+            const uint64_t asked = (uint64_t)__popcll(m);
+            w_next += asked < avail ? asked : avail;
+        }
+    };
+    Node2 N0;
+    uint4 a0[6], b0[6];
+    uint32_t m0 = 0;
+    bool act0 = false, have_spare = false;
+    Rec spare;
+    for (uint64_t& w : spare.w) w = 0;
+    // a chain's new node: its bits, its block loads (consumed in the chain's next turn)
+    auto arm = [&](Node2& N, uint4 (&ca)[6], uint4 (&cb)[6], uint32_t& m, bool act) {
+        if (act && p.write) mark(N);
+        m = load_mask(N);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            if ((m >> k) & 1u) ca[k] = eb_rank4_quad_load(x1, act ? N.a[k] : 0ull, j);
+            if ((m >> (6 + k)) & 1u) cb[k] = eb_rank4_quad_load(x2, act ? N.b[k] : 0ull, j);
+        }
+    };
+    auto start = [&](Node2& N, uint4 (&ca)[6], uint4 (&cb)[6], uint32_t& m, bool& act) {
+        bool want = true;
+        uint64_t idx = 0;
+        take(want, idx);
+        act = !want;
+        Rec r;
+        for (uint64_t& w : r.w) w = 0;
+        if (act) r = eb_load_global(in + idx);
+        unpack_rec(r, N);
+        arm(N, ca, cb, m, act);
+    };
+    start(N0, a0, b0, m0, act0);
+    {
+        bool want = true;
+        uint64_t idx = 0;
+        take(want, idx);
+        have_spare = !want;
+        if (have_spare) spare = eb_load_global(in + idx);
+    }
+    for (;;) {
+        const bool wave_alive = __ballot(act0 || have_spare) != 0ull;
+        if (wave_alive) {
+            for (int rep = 0; rep < 6; ++rep) {
+                {
+                    Node2& N = N0;
+                    uint4 (&ca)[6] = a0;
+                    uint4 (&cb)[6] = b0;
+                    uint32_t& mc = m0;
+                    bool& act = act0;
+                    // ranks and children (LF on both BWTs, next_nodes ebwt2InDel.cpp:529-553)
+                    Node2 child;
+                    child.pad[0] = child.pad[1] = child.pad[2] = 0;
+                    int kids = 0;
+                    uint4 cur_a = ca[0], cur_b = cb[0];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        if ((mc >> k) & 1u) cur_a = ca[k]; // else: the block of the boundary to the left
+                        if ((mc >> (6 + k)) & 1u) cur_b = cb[k];
+                        const uint64_t ia = N.a[k], ib = N.b[k];
+                        uint32_t pa = eb_chunk_counts(cur_a, eb_prefix_mask32((uint32_t)(ia & 127u), j));
+                        uint32_t pb = eb_chunk_counts(cur_b, eb_prefix_mask32((uint32_t)(ib & 127u), j));
+                        pa = eb_quad_sum(pa);
+                        pb = eb_quad_sum(pb);
+                        uint64_t sa, sb;
+                        if constexpr (SUPER_LDS) { sa = s_super[0][((ia >> EB_SUPER_SHIFT) << 2) + j]; sb = s_super[1][((ib >> EB_SUPER_SHIFT) << 2) + j]; }
+                        else { sa = x1.super[((ia >> EB_SUPER_SHIFT) << 2) + j]; sb = x2.super[((ib >> EB_SUPER_SHIFT) << 2) + j]; }
+                        child.a[k] = F1 + sa + cur_a.w + ((pa >> (8u * j)) & 0xFFu);
+                        child.b[k] = F2 + sb + cur_b.w + ((pb >> (8u * j)) & 0xFFu);
+                    }
+                    for (int k = 0; k < 5; ++k) kids += (child.a[k + 1] > child.a[k]) || (child.b[k + 1] > child.b[k]); // include.hpp:784-792
+                    child.depth = N.depth + 1;
+                    const bool keep = act && kids >= 2;
+                    if (act && p.write && j == 0) {
+                        ++n_node;
+                        n_rank += 2;
+                        for (int k = 1; k < 6; ++k) n_rank += (N.a[k] != N.a[k - 1]) + (N.b[k] != N.b[k - 1]);
+                    }
+                    const uint32_t km = eb_quad_or(keep ? (1u << j) : 0u);
+                    const uint32_t jc = follow && km ? (uint32_t)__ffs((int)km) - 1u : 4u;
+                    {
+                        const bool px = keep && j != jc;
+                        const unsigned long long pm = __ballot(px);
+                        if (pm) { // (uniform; most turns nobody pushes and the record is not even packed)
+                            const Rec rec = pack_rec(child);
+                            uint32_t wbase = 0;
+                            if (lane == 0) wbase = atomicAdd(&s_count, (uint32_t)__popcll(pm));
+                            wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+                            if (px) {
+                                const uint32_t slot = wbase + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
+                                const uint4* src = reinterpret_cast<const uint4*>(&rec);
+                                if (slot < (uint32_t)STAGE) {
+                                    for (int q = 0; q < (int)(sizeof(Rec) / 16); ++q) s_buf[slot * (sizeof(Rec) / 16) + q] = src[q];
+                                } else {
+                                    const unsigned long long g = atomicAdd(&cnt->pushed, 1ull);
+                                    if (g < out_cap)
+                                        for (int q = 0; q < (int)(sizeof(Rec) / 16); ++q) eb_store_global(reinterpret_cast<uint4*>(out) + g * (sizeof(Rec) / 16) + q, src[q]);
+                                }
+                            }
+                        }
+                    }
+                    bool want = false;
+                    if (jc < 4u) {
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) {
+                            N.a[k] = eb_quad_pick64(child.a[k], j == jc);
+                            N.b[k] = eb_quad_pick64(child.b[k], j == jc);
+                        }
+                        N.depth = child.depth;
+                    } else {
+                        act = have_spare;
+                        if (have_spare) { unpack_rec(spare, N); want = true; }
+                        have_spare = false;
+                    }
+                    uint64_t idx = 0;
+                    const bool asked = want;
+                    take(want, idx);
+                    if (asked && !want) { spare = eb_load_global(in + idx); have_spare = true; }
+                    arm(N, ca, cb, mc, act);
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0 && s_count > (uint32_t)STAGE) s_count = STAGE; // (the excess went straight to the stack)
+        stage.flush(out, out_cap, &cnt->pushed);
+        const bool still = __ballot(act0 || have_spare) != 0ull;
+        if (threadIdx.x == 0) s_alive = 0;
+        __syncthreads();
+        if (lane == 0 && still) s_alive = 1;
+        __syncthreads();
+        const int go_on = s_alive;
+        __syncthreads();
+        if (!go_on) break;
+    }
+    const uint64_t st[EB_NAV_STATS] = {0, n_node, n_lcp, n_da, n_min, n_rank, n_s1, n_s2};
+    flush_stats(stat_rows, st);
+}
+
 // Sharded traversal: at the first level wide enough, every shard keeps the records whose interval start
 // hashes to it -- content-addressed, so all shards agree whatever order their own launches left the level in.
 // W2 >= 0: a second word of the record is added to the key (packed two-BWT records: more of the two interval starts).
@@ -1649,7 +1880,9 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
         if ((r = d.push_host(pack_rec(root))) != EB_OK) return r;
         const bool super_fits = (b1->n >> EB_SUPER_SHIFT) + 1 <= EB_NAV_SUPER_LDS && (b2->n >> EB_SUPER_SHIFT) + 1 <= EB_NAV_SUPER_LDS;
         r = d.run<1>(dc, nb.state, nb.h_state, [&](const NavLaunch* la, unsigned grid) {
-            if (pipelined_nodes && super_fits) hipLaunchKernelGGL((k_nodes2p<true>), dim3(grid), dim3(256), 0, sx, x1, x2, df, d_kr, p, la, dc, rows);
+            if (pipelined_nodes && chains && super_fits) hipLaunchKernelGGL((k_nodes2c<true>), dim3(grid), dim3(256), 0, sx, x1, x2, df, d_kr, p, la, dc, rows);
+            else if (pipelined_nodes && chains) hipLaunchKernelGGL((k_nodes2c<false>), dim3(grid), dim3(256), 0, sx, x1, x2, df, d_kr, p, la, dc, rows);
+            else if (pipelined_nodes && super_fits) hipLaunchKernelGGL((k_nodes2p<true>), dim3(grid), dim3(256), 0, sx, x1, x2, df, d_kr, p, la, dc, rows);
             else if (pipelined_nodes) hipLaunchKernelGGL((k_nodes2p<false>), dim3(grid), dim3(256), 0, sx, x1, x2, df, d_kr, p, la, dc, rows);
             else hipLaunchKernelGGL((k_nodes<2, 1>), dim3(grid), dim3(256), 0, sx, x1, x2, df, d_kr, p, la, dc, rows);
         });

@@ -923,6 +923,8 @@ __global__ void __launch_bounds__(256) k_extend1(eb_dev_index x1, eb_dev_index x
         auto letter_w = [](const uint4& c0, const uint4& c1, const uint4& c2, const uint4& c3, uint32_t j) -> uint32_t {
             return j == 0 ? c0.w : j == 1 ? c1.w : j == 2 ? c2.w : c3.w;
         };
+        uint64_t sup[4] = {0, 0, 0, 0};
+        uint32_t sup_at = 0xFFFFFFFFu; // superblock whose counts `sup` holds
         // one LF(range) (dna_bwt.hpp:138-166): a[j], b[j] = rank of letter j at L and R, without F
         auto ranks = [&](uint64_t lo, uint64_t hi, uint64_t* a, uint64_t* b) {
             const uint4* bl = x.chunks + ((lo >> 7) << 2);
@@ -935,12 +937,19 @@ __global__ void __launch_bounds__(256) k_extend1(eb_dev_index x1, eb_dev_index x
             }
             n_req += 1u + (two ? 1u : 0u);
             const uint32_t pl = counts(c0, c1, c2, c3, (uint32_t)(lo & 127u)), pr = counts(d0, d1, d2, d3, (uint32_t)(hi & 127u));
-            const uint64_t* sl = x.super + ((lo >> EB_SUPER_SHIFT) << 2);
-            const uint64_t* sr = x.super + ((hi >> EB_SUPER_SHIFT) << 2);
+            // superblock counts: kept from the previous step (a walk nearly always stays inside one superblock of 2^32 symbols;
+            // eight table loads per step otherwise, on the path of every dependent step)
+            const uint32_t sbl = (uint32_t)(lo >> EB_SUPER_SHIFT), sbr = (uint32_t)(hi >> EB_SUPER_SHIFT);
+            if (sbl != sup_at) {
+                sup_at = sbl;
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) sup[j] = x.super[((uint64_t)sbl << 2) + j];
+            }
 #pragma unroll
             for (uint32_t j = 0; j < 4; ++j) {
-                a[j] = sl[j] + letter_w(c0, c1, c2, c3, j) + ((pl >> (8u * j)) & 0xFFu);
-                b[j] = sr[j] + letter_w(d0, d1, d2, d3, j) + ((pr >> (8u * j)) & 0xFFu);
+                const uint64_t sr = sbr == sbl ? sup[j] : x.super[((uint64_t)sbr << 2) + j];
+                a[j] = sup[j] + letter_w(c0, c1, c2, c3, j) + ((pl >> (8u * j)) & 0xFFu);
+                b[j] = sr + letter_w(d0, d1, d2, d3, j) + ((pr >> (8u * j)) & 0xFFu);
             }
         };
         uint64_t a[4], b[4];
@@ -1036,13 +1045,14 @@ __global__ void __launch_bounds__(256) k_right(eb_dev_index x1, eb_dev_index x2,
             const bool second = eb_bit(f.da, pos);
             uint64_t i1 = da_rank(f, pos);
             row = second ? i1 : pos - i1;
-            if (second) {
-                x.chunks = x2.chunks; x.super = x2.super; x.sel_dir = x2.sel_dir;
-                x.n = x2.n; x.n_blocks = x2.n_blocks; // (the select's guess is clamped to the index it walks in)
-                x.sel_shift = x2.sel_shift; x.sel_blk_bits = x2.sel_blk_bits; // (the two indexes may differ in size: their directories are read their own way)
-                x.psi = x2.psi;
-                for (int k = 0; k < 4; ++k) { x.F[k] = x2.F[k]; x.sel_off[k] = x2.sel_off[k]; x.psi_off[k] = x2.psi_off[k]; }
-            }
+            // every field the walk reads, picked one by one (a conditional copy of the arrays left the whole struct in scratch
+            // memory in the one-lane form: 176 bytes per lane and a dynamic index on the path of every step)
+            x.chunks = second ? x2.chunks : x1.chunks; x.super = second ? x2.super : x1.super; x.sel_dir = second ? x2.sel_dir : x1.sel_dir;
+            x.n = second ? x2.n : x1.n; x.n_blocks = second ? x2.n_blocks : x1.n_blocks; // (the select's guess is clamped to the index it walks in)
+            x.sel_shift = second ? x2.sel_shift : x1.sel_shift; x.sel_blk_bits = second ? x2.sel_blk_bits : x1.sel_blk_bits; // (the two indexes may differ in size)
+            x.psi = second ? x2.psi : x1.psi;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { x.F[k] = second ? x2.F[k] : x1.F[k]; x.sel_off[k] = second ? x2.sel_off[k] : x1.sel_off[k]; x.psi_off[k] = second ? x2.psi_off[k] : x1.psi_off[k]; }
         }
         uint64_t* out = right + i * (uint64_t)right_words;
         uint64_t word = 0;
@@ -1279,7 +1289,9 @@ static int launch_contexts(eb_scan_job* job) {
     std::vector<SubShard>& sh = job->sh;
     // one lane per chain (k_extend1) since round 4: 0.98 -> 0.80 ms alone at 7.55 G positions, 1.42 -> 0.87 beside the scan
     // (profiles/r04_extend_ab.txt); EB_EXTEND_LANES=4: a quad per chain (k_extend), kept under test
-    const int extend_lanes = getenv("EB_EXTEND_LANES") && atoi(getenv("EB_EXTEND_LANES")) == 4 ? 4 : 1;
+    // (two BWTs: the quad form -- with a lane's index chosen at run time the one-lane form loses, 1.49 against 0.96 ms at 2 x 3.8 G)
+    const int extend_env = getenv("EB_EXTEND_LANES") ? atoi(getenv("EB_EXTEND_LANES")) : 0;
+    const int extend_lanes = extend_env == 4 || extend_env == 1 ? extend_env : (p.mode == 2 ? 4 : 1);
     auto kern_extend = extend_lanes == 1 ? (p.mode == 2 ? k_extend1<true> : k_extend1<false>) : (p.mode == 2 ? k_extend<true> : k_extend<false>);
     // the late walk of a large call set: a quad per cluster (EB_RIGHT_LANES=1: one lane, the form the early walk keeps)
     // With the FL table (eb_psi_lookup) a step is one 16-byte read by one lane: one lane per cluster, 64 walks per wave.
