@@ -1121,7 +1121,8 @@ __global__ void __launch_bounds__(256) k_nodes2c(eb_dev_index x1, eb_dev_index x
     if (threadIdx.x == 0) { s_count = 0; s_alive = 0; }
     __syncthreads();
     const uint32_t j = threadIdx.x & 3u, lane = threadIdx.x & 63u;
-    uint64_t n_node = 0, n_lcp = 0, n_da = 0, n_rank = 0, n_min = 0, n_s1 = 0, n_s2 = 0;
+    uint32_t n_node = 0, n_lcp = 0, n_da = 0, n_rank = 0, n_min = 0; // per lane and launch: far below 2^32
+    uint64_t n_s1 = 0, n_s2 = 0;
     const uint64_t F1 = pick4(x1.F, j), F2 = pick4(x2.F, j);
     const uint64_t waves = (count + 15) / 16 < (uint64_t)gridDim.x * 4 ? (count + 15) / 16 : (uint64_t)gridDim.x * 4;
     uint64_t chunk = count / (waves * 4);
@@ -1194,8 +1195,7 @@ __global__ void __launch_bounds__(256) k_nodes2c(eb_dev_index x1, eb_dev_index x
     uint4 a0[6], b0[6];
     uint32_t m0 = 0;
     bool act0 = false, have_spare = false;
-    Rec spare;
-    for (uint64_t& w : spare.w) w = 0;
+    uint64_t spare = 0; // index of the input record reserved for this quad's next chain (loaded when the chain at hand ends: once in ~135 turns)
     // a chain's new node: its bits, its block loads (consumed in the chain's next turn)
     auto arm = [&](Node2& N, uint4 (&ca)[6], uint4 (&cb)[6], uint32_t& m, bool act) {
         if (act && p.write) mark(N);
@@ -1223,7 +1223,7 @@ __global__ void __launch_bounds__(256) k_nodes2c(eb_dev_index x1, eb_dev_index x
         uint64_t idx = 0;
         take(want, idx);
         have_spare = !want;
-        if (have_spare) spare = eb_load_global(in + idx);
+        spare = idx;
     }
     for (;;) {
         const bool wave_alive = __ballot(act0 || have_spare) != 0ull;
@@ -1296,13 +1296,13 @@ __global__ void __launch_bounds__(256) k_nodes2c(eb_dev_index x1, eb_dev_index x
                         N.depth = child.depth;
                     } else {
                         act = have_spare;
-                        if (have_spare) { unpack_rec(spare, N); want = true; }
+                        if (have_spare) { unpack_rec(eb_load_global(in + spare), N); want = true; }
                         have_spare = false;
                     }
                     uint64_t idx = 0;
                     const bool asked = want;
                     take(want, idx);
-                    if (asked && !want) { spare = eb_load_global(in + idx); have_spare = true; }
+                    if (asked && !want) { spare = idx; have_spare = true; }
                     arm(N, ca, cb, mc, act);
                 }
             }
