@@ -705,8 +705,8 @@ def main():
                          "frac": round(scan_gbs / 8000.0, 5), "traffic": traffic, "kernel": "k_scan",
                          "avg_launch_ms": round(scan_avg_ms, 4), "launches_per_step": scan_launches, "positions_per_launch": int(positions_per_launch),
                          "algorithmic_bytes_per_position": 0.75,
-                         "measured": "timed region" + ("" if args.no_pipeline else ": the launch shares every CU with the previous pass's context kernels (4 of 8 workgroup slots per CU), "
-                                                       "so it lasts longer than alone -- see `alone`"),
+                         "measured": "timed region" + ("" if args.no_pipeline else ": the launch shares every CU with the previous pass's context kernels (the scan holds 8 workgroup slots per CU "
+                                                       "with the FL table, 4 without), so it lasts longer than alone -- see `alone`"),
                          **({"alone": {"avg_launch_ms": alone["scan_ms"], "achieved": round(0.75 * positions_per_launch / (alone["scan_ms"] * 1e-3) / 1e9, 2),
                                        "frac": round(0.75 * positions_per_launch / (alone["scan_ms"] * 1e-3) / 1e9 / 8000.0, 5),
                                        "what": f"the same launch with the chip to itself: {alone['passes']} passes run one at a time after the timed region"}} if alone else {})},

@@ -1289,9 +1289,12 @@ static int launch_contexts(eb_scan_job* job) {
     std::vector<SubShard>& sh = job->sh;
     // one lane per chain (k_extend1) since round 4: 0.98 -> 0.80 ms alone at 7.55 G positions, 1.42 -> 0.87 beside the scan
     // (profiles/r04_extend_ab.txt); EB_EXTEND_LANES=4: a quad per chain (k_extend), kept under test
-    // (two BWTs: the quad form -- with a lane's index chosen at run time the one-lane form loses, 1.49 against 0.96 ms at 2 x 3.8 G)
+    // (two BWTs: the quad form -- with a lane's index chosen at run time the one-lane form loses, 1.49 against 0.96 ms at 2 x 3.8 G.
+    // Large indexes: the quad form too -- a lane's four 16-byte loads are four address translations where the quad's coalesced
+    // request is one, and once the index outgrows what the translation caches reach that is what counts: 0.72 / 0.82 ms (one lane /
+    // quad) at 7.55 G symbols, 1.92 / 1.82 at 15.1 G, 45 / 23 ms at 151 G; the superblock counts in LDS changed nothing there.)
     const int extend_env = getenv("EB_EXTEND_LANES") ? atoi(getenv("EB_EXTEND_LANES")) : 0;
-    const int extend_lanes = extend_env == 4 || extend_env == 1 ? extend_env : (p.mode == 2 ? 4 : 1);
+    const int extend_lanes = extend_env == 4 || extend_env == 1 ? extend_env : (p.mode == 2 || x1.n > (1ull << 33) ? 4 : 1);
     auto kern_extend = extend_lanes == 1 ? (p.mode == 2 ? k_extend1<true> : k_extend1<false>) : (p.mode == 2 ? k_extend<true> : k_extend<false>);
     // the late walk of a large call set: a quad per cluster (EB_RIGHT_LANES=1: one lane, the form the early walk keeps)
     // With the FL table (eb_psi_lookup) a step is one 16-byte read by one lane: one lane per cluster, 64 walks per wave.
