@@ -57,11 +57,9 @@ struct alignas(16) Survivor {
     uint64_t pad;
 };
 
-// the neighbour lane's value (lane i gets lane i-1's, lane 0 gets 0) as a DPP wave shift on a v_mov instead of __shfl_up, which
-// compiles to ds_bpermute_b32 (an LDS round trip)
-#ifndef EB_SCAN_DPP_SHIFT
-#define EB_SCAN_DPP_SHIFT 0
-#endif
+// the neighbour lane's value (lane i gets lane i-1's, lane 0 gets 0) as a DPP wave shift on a v_mov (v_mov_b32_dpp wave_shr:1)
+// instead of __shfl_up, which compiles to ds_bpermute_b32, an LDS round trip: six of them per tile in k_scan (round 4: -1 % on the
+// scan and on the step, profiles/r04_dpp_shift_ab.txt)
 __device__ __forceinline__ uint64_t eb_wave_shr1_64(uint64_t v) {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
     const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x138, 0xF, 0xF, false);
@@ -427,15 +425,9 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
         uint64_t fw = td.fw;
         Planes cur = td.cur, prv;
         // previous word: neighbour lane's registers; lane 0 fetched it from memory
-#if EB_SCAN_DPP_SHIFT
         uint64_t pfw = eb_wave_shr1_64(fw);
         prv.x = eb_wave_shr1_64(cur.x);
         prv.y = eb_wave_shr1_64(cur.y);
-#else
-        uint64_t pfw = __shfl_up((unsigned long long)fw, 1);
-        prv.x = __shfl_up((unsigned long long)cur.x, 1);
-        prv.y = __shfl_up((unsigned long long)cur.y, 1);
-#endif
         if (lane == 0) { pfw = td.l0_pfw; prv = td.l0_prv; }
         const uint64_t ea = active ? ~fw & ((fw << 1) | (pfw >> 63)) : 0ull; // positions e with flag[e]=0 and flag[e-1]=1
         // keep closing positions inside [begin,end) and below n (a run still open at n-1 is dropped, ebwt2InDel.cpp:1609-1655)
