@@ -41,6 +41,18 @@ def test_full_size_config_equals_the_oracle_record(name):
     assert res.cluster_nr - 1 == want["cluster_numbers"]
     st, sc = res.calls.stats, want["scan_counters"]
     assert (int(st.runs_closed), int(st.clusters), int(st.bases_in_runs)) == (sc["runs_closed"], sc["clusters"], sc["bases_in_runs"])
+    # phase 4 again through the FL table of repeatedly scanned indexes (round 4: one 16-byte chunk per 16 occurrences of a letter
+    # instead of the select directory): the same whole-run text, about half the memory requests in the right-context walk
+    from ebwt2indel_amd import api
+    for b in inp.bwts:
+        b.build_psi()
+        assert b.psi()[0]
+    b2 = inp.bwts[1] if inp.mode == 2 else None
+    calls = api.scan_clusters(inp.bwts[0], res.flags, res.params, bwt2=b2)
+    import hashlib as _h
+    assert _h.sha256(calls.format_snp(res.params, inp.mode != 1)[0]).hexdigest() == want["oracle_snp_sha256"], ".snp through the FL table differs"
+    assert calls.stats.requests_right < 0.6 * res.calls.stats.requests_right
+    del calls
     if "half_a" in want:
         # the oracle walked this input's phase 4 in two GPU-box calls, [0, cut) and [cut, n), cut where no cluster straddles it:
         # each half of the product's output against the oracle's, and the whole-run text = the halves with a running cluster_nr
