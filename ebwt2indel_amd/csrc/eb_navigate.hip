@@ -937,6 +937,191 @@ __global__ void __launch_bounds__(256) k_leaves1c(eb_dev_index x1, eb_dev_flags 
     flush_stats(stat_rows, st);
 }
 
+// ---- phase 2, two BWTs, chains followed in registers: k_leaves1c for merged leaves (two sa_leaves: four block loads per turn; the DA
+// slots of the leaf's rows are written with its LCP bits).
+__global__ void __launch_bounds__(256) k_leaves2c(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, uint64_t* __restrict__ kr, NavParams p, const NavLaunch* __restrict__ la,
+                                                 NavCounters* cnt, unsigned long long* __restrict__ stat_rows) {
+    using Rec = Leaf2P;
+    constexpr int STAGE = 256;
+    __shared__ uint4 s_buf[STAGE * (sizeof(Rec) / 16)];
+    __shared__ uint32_t s_count;
+    __shared__ unsigned long long s_base;
+    __shared__ int s_alive;
+    const Rec* __restrict__ in = static_cast<const Rec*>(la->in);
+    Rec* out = static_cast<Rec*>(la->out);
+    const uint64_t count = la->count, out_cap = la->out_cap;
+    p.write = la->write;
+    const bool follow = la->follow != 0;
+    if ((uint64_t)blockIdx.x * 64 >= count) return; // the grid is sized for a full batch: nothing for this workgroup (uniform)
+    Stager<Rec, STAGE> stage{s_buf, &s_count, &s_base};
+    if (threadIdx.x == 0) { s_count = 0; s_alive = 0; }
+    __syncthreads();
+    const uint32_t j = threadIdx.x & 3u, lane = threadIdx.x & 63u;
+    uint64_t n_leaf = 0, n_lcp = 0, n_da = 0, n_rank = 0, n_s1 = 0, n_s2 = 0;
+    const uint64_t F1 = pick4(x1.F, j), F2 = pick4(x2.F, j);
+    const uint64_t waves = (count + 15) / 16 < (uint64_t)gridDim.x * 4 ? (count + 15) / 16 : (uint64_t)gridDim.x * 4;
+    uint64_t chunk = count / (waves * 4);
+    chunk = chunk < 16 ? 16 : (chunk > 256 ? 256 : chunk);
+    uint64_t w_next = 0, w_end = 0;
+    bool dry = false;
+    // DA and LCP slots of a merged leaf (update_DA ebwt2InDel.cpp:394-425, update_LCP_leaf :344-355), as in k_leaves<2>: DA = 1 on the
+    // second collection's rows [s2, e), LCP bits on [s1 + 1, e); the quad splits the touched words
+    auto mark = [&](const Leaf2& L) {
+        const uint64_t s1 = L.l1 + L.l2, s2 = L.l2 + L.r1, e = L.r1 + L.r2;
+        const bool setK = ((int64_t)L.depth >= p.K) != (p.below != 0), setR = ((int64_t)L.depth >= p.k_right) != (p.below != 0);
+        const uint64_t w0 = s1 >> 6, w1 = e > s1 ? (e - 1) >> 6 : w0;
+        for (uint64_t w = w0 + j; w <= w1 && e > s1; w += 4) {
+            const uint64_t base = w << 6;
+            auto span = [&](uint64_t lo, uint64_t hi) -> uint64_t { // bits of word w inside [lo,hi)
+                if (hi <= lo || hi <= base || lo >= base + 64) return 0ull;
+                uint64_t m = ~0ull;
+                if (lo > base) m &= ~0ull << (lo - base);
+                if (hi < base + 64) m &= ~0ull >> (base + 64 - hi);
+                return m;
+            };
+            const uint64_t md = span(s2, e), ml = span(s1 + 1, e);
+            if (md) atomicOr(reinterpret_cast<unsigned long long*>(f.da + w), md);
+            if (!p.lcpb) {
+                if (ml && setK) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * w), ml);
+                if (ml && setR) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * w + 1), ml);
+            }
+        }
+        if (p.lcpb && (setK || setR)) {
+            const uint8_t v = (uint8_t)((setK ? 1 : 0) | (setR ? 2 : 0));
+            for (uint64_t i2 = s1 + 1 + j; i2 < e; i2 += 4) p.lcpb[i2] = v;
+        }
+        if (j == 0) {
+            ++n_leaf;
+            n_da += e - s1;
+            if (e > s1 + 1) { n_lcp += e - s1 - 1; n_s1 += eb_tri(e) - eb_tri(s1 + 1); n_s2 += eb_sq(e) - eb_sq(s1 + 1); }
+            n_rank += (L.r1 > L.l1 ? 2 : 1) + (L.r2 > L.l2 ? 2 : 1);
+        }
+    };
+    auto take = [&](bool& want, uint64_t& idx) { // as in k_nodes1c
+        for (;;) {
+            const unsigned long long m = __ballot(want && j == 0);
+            if (!m || dry) break;
+            if (w_next == w_end) {
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(&cnt->taken, (unsigned long long)chunk);
+                base = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+                w_next = base < count ? base : count;
+                w_end = base + chunk < count ? base + chunk : count;
+                if (w_next == w_end) { dry = true; break; }
+            }
+            const uint64_t avail = w_end - w_next;
+            const uint32_t rank = (uint32_t)__popcll(m & ((1ull << (lane & ~3u)) - 1ull));
+            if (want && rank < avail) { idx = w_next + rank; want = false; }
+            const uint64_t asked = (uint64_t)__popcll(m);
+            w_next += asked < avail ? asked : avail;
+        }
+    };
+    struct Chain { Leaf2 L; uint4 cl1, cr1, cl2, cr2; bool act; };
+    Chain C0, C1;
+    bool have_spare = false;
+    uint64_t spare = 0; // index of the input record reserved for this quad's next chain
+    // a chain's new leaf: its DA / LCP bits, its statistics, its four block loads (consumed in the chain's next turn)
+    auto arm = [&](Chain& C) {
+        if (C.act && p.write) mark(C.L);
+        C.cl1 = eb_rank4_quad_load(x1, C.act ? C.L.l1 : 0ull, j);
+        C.cr1 = eb_rank4_quad_load(x1, C.act ? (C.L.r1 > C.L.l1 ? C.L.r1 : C.L.l1) : 0ull, j);
+        C.cl2 = eb_rank4_quad_load(x2, C.act ? C.L.l2 : 0ull, j);
+        C.cr2 = eb_rank4_quad_load(x2, C.act ? (C.L.r2 > C.L.l2 ? C.L.r2 : C.L.l2) : 0ull, j);
+    };
+    auto start = [&](Chain& C) {
+        bool want = true;
+        uint64_t idx = 0;
+        take(want, idx);
+        C.act = !want;
+        Rec r;
+        for (uint64_t& w : r.w) w = 0;
+        if (C.act) r = eb_load_global(in + idx);
+        unpack_rec(r, C.L);
+        arm(C);
+    };
+    start(C0);
+    start(C1);
+    {
+        bool want = true;
+        uint64_t idx = 0;
+        take(want, idx);
+        have_spare = !want;
+        spare = idx;
+    }
+    for (;;) {
+        const bool wave_alive = __ballot(C0.act || C1.act || have_spare) != 0ull;
+        if (wave_alive) {
+#pragma unroll
+            for (int rep = 0; rep < 3; ++rep) {
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
+                    Chain& C = sl ? C1 : C0;
+                    // next_leaves on both BWTs (ebwt2InDel.cpp:452-472): the child obtained by prepending letter j
+                    const uint64_t a1 = eb_rank4_quad_finish(x1, C.cl1, C.L.l1, j), b1 = eb_rank4_quad_finish(x1, C.cr1, C.L.r1 > C.L.l1 ? C.L.r1 : C.L.l1, j);
+                    const uint64_t a2 = eb_rank4_quad_finish(x2, C.cl2, C.L.l2, j), b2 = eb_rank4_quad_finish(x2, C.cr2, C.L.r2 > C.L.l2 ? C.L.r2 : C.L.l2, j);
+                    Leaf2 child;
+                    child.l1 = F1 + a1; child.r1 = F1 + b1; child.l2 = F2 + a2; child.r2 = F2 + b2; child.depth = C.L.depth + 1;
+                    child.pad[0] = child.pad[1] = child.pad[2] = 0;
+                    const bool keep = C.act && ((b1 - a1) + (b2 - a2) >= 2);
+                    const uint32_t km = eb_quad_or(keep ? (1u << j) : 0u);
+                    const uint32_t jc = follow && km ? (uint32_t)__ffs((int)km) - 1u : 4u;
+                    {
+                        const bool px = keep && j != jc;
+                        const unsigned long long pm = __ballot(px);
+                        if (pm) {
+                            const Rec rec = pack_rec(child);
+                            uint32_t wbase = 0;
+                            if (lane == 0) wbase = atomicAdd(&s_count, (uint32_t)__popcll(pm));
+                            wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+                            if (px) {
+                                const uint32_t slot = wbase + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
+                                const uint4* src = reinterpret_cast<const uint4*>(&rec);
+                                if (slot < (uint32_t)STAGE) {
+                                    for (int q = 0; q < (int)(sizeof(Rec) / 16); ++q) s_buf[slot * (sizeof(Rec) / 16) + q] = src[q];
+                                } else {
+                                    const unsigned long long g = atomicAdd(&cnt->pushed, 1ull);
+                                    if (g < out_cap)
+                                        for (int q = 0; q < (int)(sizeof(Rec) / 16); ++q) eb_store_global(reinterpret_cast<uint4*>(out) + g * (sizeof(Rec) / 16) + q, src[q]);
+                                }
+                            }
+                        }
+                    }
+                    bool want = false;
+                    if (jc < 4u) {
+                        C.L.l1 = eb_quad_pick64(child.l1, j == jc);
+                        C.L.r1 = eb_quad_pick64(child.r1, j == jc);
+                        C.L.l2 = eb_quad_pick64(child.l2, j == jc);
+                        C.L.r2 = eb_quad_pick64(child.r2, j == jc);
+                        C.L.depth = child.depth;
+                    } else {
+                        C.act = have_spare;
+                        if (have_spare) { unpack_rec(eb_load_global(in + spare), C.L); want = true; }
+                        have_spare = false;
+                    }
+                    uint64_t idx = 0;
+                    const bool asked = want;
+                    take(want, idx);
+                    if (asked && !want) { spare = idx; have_spare = true; }
+                    arm(C);
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0 && s_count > (uint32_t)STAGE) s_count = STAGE; // (the excess went straight to the stack)
+        stage.flush(out, out_cap, &cnt->pushed);
+        const bool still = __ballot(C0.act || C1.act || have_spare) != 0ull;
+        if (threadIdx.x == 0) s_alive = 0;
+        __syncthreads();
+        if (lane == 0 && still) s_alive = 1;
+        __syncthreads();
+        const int go_on = s_alive;
+        __syncthreads();
+        if (!go_on) break;
+    }
+    const uint64_t st[EB_NAV_STATS] = {n_leaf, 0, n_lcp, n_da, 0, n_rank, n_s1, n_s2};
+    flush_stats(stat_rows, st);
+}
+
 // ---- phase 3, two BWTs, software-pipelined the same way (k_nodes1p).  A merged node is two sa_nodes (12 boundaries); as in
 // k_nodes<2, 1> a block is loaded ONCE for the boundaries of a node that share it (they are sorted and a few dozen rows apart):
 // which boundaries issue a load is decided in stage A and kept as a 12-bit mask for stage D.
@@ -1843,7 +2028,8 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
         if ((r = d.init(arena, bytes, n, batch_max)) != EB_OK) return r;
         if ((r = d.push_host(pack_rec(Leaf2{0, b1->F[0], 0, b2->F[0], 0, {0, 0, 0}}))) != EB_OK) return r;
         r = d.run<1>(dc, nb.state, nb.h_state, [&](const NavLaunch* la, unsigned grid) {
-            hipLaunchKernelGGL(k_leaves<2>, dim3(grid), dim3(256), 0, sx, x1, x2, df, d_kr, p, la, dc, rows);
+            if (chains) hipLaunchKernelGGL(k_leaves2c, dim3(grid), dim3(256), 0, sx, x1, x2, df, d_kr, p, la, dc, rows);
+            else hipLaunchKernelGGL(k_leaves<2>, dim3(grid), dim3(256), 0, sx, x1, x2, df, d_kr, p, la, dc, rows);
         });
         launches_l = d.launches;
         return r;
