@@ -378,6 +378,26 @@ def main():
         st0 = None
         for _ in range(2):
             st0 = api.scan_clusters(bwt, flags, p, begin=begin, end=end).stats
+        # the same pipelined steps WITHOUT the table (a short timed region of its own, before the table exists; EB_PSI=0 keeps the
+        # library from building it with the third job): what the step costs a caller whose index does not get one -- too large for
+        # the spare HBM, or scanned once -- and the figure to compare with rounds 1-3
+        ms_without = None
+        if os.environ.get("EB_PSI") != "0" and not args.no_pipeline:
+            psi_env = os.environ.get("EB_PSI")
+            os.environ["EB_PSI"] = "0"
+            try:
+                run_steps(3)
+                sync()
+                t1 = time.perf_counter()
+                run_steps(10)
+                sync()
+                ms_without = (time.perf_counter() - t1) / 10 * 1e3
+            finally:
+                if psi_env is None:
+                    del os.environ["EB_PSI"]
+                else:
+                    os.environ["EB_PSI"] = psi_env
+            gathered_events.clear()
         before = {"scan_ms": round(st0.ms_scan / max(1, int(st0.scan_launches)), 4), "extend_ms": round(st0.ms_extend, 4), "right_ms": round(st0.ms_right, 4),
                   "context_span_ms": round(st0.ms_context, 4), "requests_right": int(st0.requests_right), "pass_ms_first_launch_to_records_on_host": round(st0.ms_total, 4),
                   "what": "the second pass on the index, run by itself: no table yet (what a one-shot run of the tool gets)"}
@@ -391,6 +411,7 @@ def main():
         have, psi_bytes, psi_void = bwt.psi()
         fl_table = {"present": have, "bytes": int(psi_bytes), "void_chunks": int(psi_void), "build_ms": round(t_psi * 1e3, 2) if have else None,
                     "pass_before_it": before,
+                    "ms_per_step_without_it": round(ms_without, 4) if ms_without is not None else None,
                     "what": "FL table of a repeatedly scanned index: one 16-byte chunk per 16 occurrences of a letter (38-bit position, 15-bit bitmap of the occurrences that do not sit right behind their predecessor, their distances in 75 bits); "
                             "FL = one 16-byte read by one lane instead of a directory read + a block probe by four; built once, outside the timed region"}
         if rank == 0:
