@@ -548,6 +548,79 @@ __global__ void __launch_bounds__(256) k_nodes1p(eb_dev_index x1, eb_dev_flags f
     flush_stats(stat_rows, st);
 }
 
+// ---- pieces shared by the chain-following kernels (k_nodes1c, k_leaves1c, k_nodes2c, k_leaves2c)
+// The launch's input records are handed out through a cursor (NavCounters::taken): a wave takes a chunk with ONE returning atomic,
+// its quads take records from the chunk as their chains end.  Everything here is wave-uniform except `want` / `idx`.
+struct NavCursor {
+    uint64_t next = 0, end = 0; // this wave's chunk
+    uint64_t chunk, count;
+    bool dry = false;           // the input is used up
+    // records per chunk: 16 (one per quad) for small launches, up to 256
+    __device__ __forceinline__ NavCursor(uint64_t count_, uint32_t grid) : count(count_) {
+        const uint64_t waves = (count + 15) / 16 < (uint64_t)grid * 4 ? (count + 15) / 16 : (uint64_t)grid * 4;
+        chunk = count / (waves * 4);
+        chunk = chunk < 16 ? 16 : (chunk > 256 ? 256 : chunk);
+    }
+    // hands input records to the quads that ask for one (`want`, the same in the four lanes of a quad): idx = the record's index,
+    // want stays set where the input ran out
+    __device__ __forceinline__ void take(NavCounters* cnt, bool& want, uint64_t& idx, uint32_t j, uint32_t lane) {
+        for (;;) {
+            const unsigned long long m = __ballot(want && j == 0);
+            if (!m || dry) break;
+            if (next == end) {
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(&cnt->taken, (unsigned long long)chunk);
+                base = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+                next = base < count ? base : count;
+                end = base + chunk < count ? base + chunk : count;
+                if (next == end) { dry = true; break; }
+            }
+            const uint64_t avail = end - next;
+            const uint32_t rank = (uint32_t)__popcll(m & ((1ull << (lane & ~3u)) - 1ull)); // askers in the quads below this one
+            if (want && rank < avail) { idx = next + rank; want = false; }
+            const uint64_t asked = (uint64_t)__popcll(m);
+            next += asked < avail ? asked : avail;
+        }
+    }
+};
+// A kept child that does not continue in registers: into the small staging buffer, or -- buffer full: the bushy top of the tree --
+// straight to the stack with an atomic of its own.  `make()` packs the record; it is called only when some lane of the wave pushes.
+template <typename Rec, int STAGE, typename Make>
+__device__ __forceinline__ void nav_push_or_spill(bool px, Make make, uint4* s_buf, uint32_t* s_count, Rec* out, uint64_t out_cap, NavCounters* cnt, uint32_t lane) {
+    const unsigned long long pm = __ballot(px);
+    if (!pm) return; // (uniform; most turns nobody pushes)
+    const Rec rec = make();
+    uint32_t wbase = 0;
+    if (lane == 0) wbase = atomicAdd(s_count, (uint32_t)__popcll(pm));
+    wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+    if (px) {
+        constexpr int W = sizeof(Rec) / 16;
+        const uint32_t slot = wbase + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
+        const uint4* src = reinterpret_cast<const uint4*>(&rec);
+        if (slot < (uint32_t)STAGE) {
+            for (int q = 0; q < W; ++q) s_buf[slot * W + q] = src[q];
+        } else {
+            const unsigned long long g = atomicAdd(&cnt->pushed, 1ull);
+            if (g < out_cap)
+                for (int q = 0; q < W; ++q) eb_store_global(reinterpret_cast<uint4*>(out) + g * W + q, src[q]);
+        }
+    }
+}
+// End of a round of turns: the staging buffer is emptied, and the workgroup goes on while any of its waves has work.
+template <typename Rec, int STAGE>
+__device__ __forceinline__ bool nav_round_end(Stager<Rec, STAGE>& stage, uint32_t* s_count, int* s_alive, Rec* out, uint64_t out_cap, NavCounters* cnt, bool wave_has_work, uint32_t lane) {
+    __syncthreads();
+    if (threadIdx.x == 0 && *s_count > (uint32_t)STAGE) *s_count = STAGE; // (the excess went straight to the stack)
+    stage.flush(out, out_cap, &cnt->pushed);
+    if (threadIdx.x == 0) *s_alive = 0;
+    __syncthreads();
+    if (lane == 0 && wave_has_work) *s_alive = 1;
+    __syncthreads();
+    const int go_on = *s_alive;
+    __syncthreads(); // (nobody resets the flag before everybody has read it)
+    return go_on != 0;
+}
+
 // ---- phase 3, one BWT, CHAINS FOLLOWED IN REGISTERS (round 4).  The suffix tree of a read collection is mostly unary under Weiner
 // links: W is right-maximal because some read ends behind it ('#') while the others go on with one letter, and the same holds for
 // cW, c'cW, ... until the reads run out -- ~135 nodes in a row whose only kept child is the next one (6.1 G nodes, ~50 M such
@@ -590,12 +663,7 @@ __global__ void __launch_bounds__(256) k_nodes1c(eb_dev_index x1, eb_dev_flags f
     const uint32_t j = threadIdx.x & 3u, lane = threadIdx.x & 63u;
     uint64_t n_node = 0, n_lcp = 0, n_rank = 0, n_min = 0, n_s1 = 0, n_s2 = 0;
     const uint64_t Fj = pick4(x1.F, j);
-    // records per chunk a wave takes from the cursor: 16 (one per quad) for small launches, up to 256
-    const uint64_t waves = (count + 15) / 16 < (uint64_t)gridDim.x * 4 ? (count + 15) / 16 : (uint64_t)gridDim.x * 4;
-    uint64_t chunk = count / (waves * 4);
-    chunk = chunk < 16 ? 16 : (chunk > 256 ? 256 : chunk);
-    uint64_t w_next = 0, w_end = 0; // this wave's chunk (wave-uniform)
-    bool dry = false;               // the input is used up (wave-uniform)
+    NavCursor cursor(count, gridDim.x);
 
     // border bits of a node (update_lcp_threshold include.hpp:826-860, update_lcp_minima ebwt2InDel.cpp:357-391), as in k_nodes1p
     auto mark = [&](const Node1& N) {
@@ -619,27 +687,6 @@ __global__ void __launch_bounds__(256) k_nodes1c(eb_dev_index x1, eb_dev_flags f
             ++n_min;
         }
     };
-    // Hands input records to the quads that ask for one (`want`, the same in the four lanes of a quad): idx = the record's index,
-    // want stays set where the input ran out.  Wave-uniform control flow; one returning atomic per chunk.
-    auto take = [&](bool& want, uint64_t& idx) {
-        for (;;) {
-            const unsigned long long m = __ballot(want && j == 0);
-            if (!m || dry) break;
-            if (w_next == w_end) {
-                unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(&cnt->taken, (unsigned long long)chunk);
-                base = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
-                w_next = base < count ? base : count;
-                w_end = base + chunk < count ? base + chunk : count;
-                if (w_next == w_end) { dry = true; break; }
-            }
-            const uint64_t avail = w_end - w_next;
-            const uint32_t rank = (uint32_t)__popcll(m & ((1ull << (lane & ~3u)) - 1ull)); // askers in the quads below this one
-            if (want && rank < avail) { idx = w_next + rank; want = false; }
-            const uint64_t asked = (uint64_t)__popcll(m);
-            w_next += asked < avail ? asked : avail;
-        }
-    };
 
     // ---- two chains per quad + one record fetched ahead
     Node1 N0, N1;
@@ -650,7 +697,7 @@ __global__ void __launch_bounds__(256) k_nodes1c(eb_dev_index x1, eb_dev_flags f
     auto start = [&](Node1& N, uint4 (&c)[6], bool& act) {
         bool want = true;
         uint64_t idx = 0;
-        take(want, idx);
+        cursor.take(cnt, want, idx, j, lane);
         act = !want;
         Rec r;
         r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0;
@@ -665,7 +712,7 @@ __global__ void __launch_bounds__(256) k_nodes1c(eb_dev_index x1, eb_dev_flags f
     {
         bool want = true;
         uint64_t idx = 0;
-        take(want, idx);
+        cursor.take(cnt, want, idx, j, lane);
         have_spare = !want;
         if (have_spare) spare = eb_load_global(in + idx);
     }
@@ -705,27 +752,7 @@ __global__ void __launch_bounds__(256) k_nodes1c(eb_dev_index x1, eb_dev_flags f
                     // the quad goes on with its first kept child; the others travel through the stack
                     const uint32_t km = eb_quad_or(keep ? (1u << j) : 0u);
                     const uint32_t jc = follow && km ? (uint32_t)__ffs((int)km) - 1u : 4u;
-                    {
-                        const bool px = keep && j != jc;
-                        const unsigned long long pm = __ballot(px);
-                        if (pm) { // (uniform; most turns nobody pushes and the record is not even packed)
-                            const Rec rec = pack_rec(child);
-                            uint32_t wbase = 0;
-                            if (lane == 0) wbase = atomicAdd(&s_count, (uint32_t)__popcll(pm));
-                            wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
-                            if (px) {
-                                const uint32_t slot = wbase + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
-                                const uint4* src = reinterpret_cast<const uint4*>(&rec);
-                                if (slot < (uint32_t)STAGE) {
-                                    for (int q = 0; q < (int)(sizeof(Rec) / 16); ++q) s_buf[slot * (sizeof(Rec) / 16) + q] = src[q];
-                                } else {
-                                    const unsigned long long g = atomicAdd(&cnt->pushed, 1ull);
-                                    if (g < out_cap)
-                                        for (int q = 0; q < (int)(sizeof(Rec) / 16); ++q) eb_store_global(reinterpret_cast<uint4*>(out) + g * (sizeof(Rec) / 16) + q, src[q]);
-                                }
-                            }
-                        }
-                    }
+                    nav_push_or_spill<Rec, STAGE>(keep && j != jc, [&] { return pack_rec(child); }, s_buf, &s_count, out, out_cap, cnt, lane);
                     bool want = false;
                     if (jc < 4u) {
 #pragma unroll
@@ -739,7 +766,7 @@ __global__ void __launch_bounds__(256) k_nodes1c(eb_dev_index x1, eb_dev_flags f
                     }
                     uint64_t idx = 0;
                     bool asked = want;
-                    take(want, idx);
+                    cursor.take(cnt, want, idx, j, lane);
                     if (asked && !want) { spare = eb_load_global(in + idx); have_spare = true; }
                     // the new node of this chain: its border bits, its block loads (consumed in this chain's next turn)
                     if (act && p.write) mark(N);
@@ -749,17 +776,7 @@ __global__ void __launch_bounds__(256) k_nodes1c(eb_dev_index x1, eb_dev_flags f
             }
         }
         // six turns add at most 6 x 256 records: the staging buffer is emptied here, and the workgroup goes on while any of its waves does
-        __syncthreads();
-        if (threadIdx.x == 0 && s_count > (uint32_t)STAGE) s_count = STAGE; // (the excess went straight to the stack)
-        stage.flush(out, out_cap, &cnt->pushed);
-        const bool still = __ballot(act0 || act1 || have_spare) != 0ull;
-        if (threadIdx.x == 0) s_alive = 0;
-        __syncthreads();
-        if (lane == 0 && still) s_alive = 1;
-        __syncthreads();
-        const int go_on = s_alive;
-        __syncthreads(); // (nobody resets the flag before everybody has read it)
-        if (!go_on) break;
+        if (!nav_round_end<Rec, STAGE>(stage, &s_count, &s_alive, out, out_cap, cnt, __ballot(act0 || act1 || have_spare) != 0ull, lane)) break;
     }
     const uint64_t st[EB_NAV_STATS] = {0, n_node, n_lcp, 0, n_min, n_rank, n_s1, n_s2};
     flush_stats(stat_rows, st);
@@ -790,11 +807,7 @@ __global__ void __launch_bounds__(256) k_leaves1c(eb_dev_index x1, eb_dev_flags 
     const uint32_t j = threadIdx.x & 3u, lane = threadIdx.x & 63u;
     uint64_t n_leaf = 0, n_lcp = 0, n_rank = 0, n_s1 = 0, n_s2 = 0;
     const uint64_t Fj = pick4(x1.F, j);
-    const uint64_t waves = (count + 15) / 16 < (uint64_t)gridDim.x * 4 ? (count + 15) / 16 : (uint64_t)gridDim.x * 4;
-    uint64_t chunk = count / (waves * 4);
-    chunk = chunk < 16 ? 16 : (chunk > 256 ? 256 : chunk);
-    uint64_t w_next = 0, w_end = 0;
-    bool dry = false;
+    NavCursor cursor(count, gridDim.x);
     // LCP slots l+1 .. r-1 of a leaf (update_LCP_leaf, ebwt2InDel.cpp:344-355): the quad splits the touched words
     auto mark = [&](uint64_t l, uint64_t r, uint64_t depth) {
         if (r <= l + 1) return;
@@ -815,25 +828,6 @@ __global__ void __launch_bounds__(256) k_leaves1c(eb_dev_index x1, eb_dev_flags 
         }
         if (j == 0) { n_lcp += hi - lo; n_s1 += eb_tri(hi) - eb_tri(lo); n_s2 += eb_sq(hi) - eb_sq(lo); }
     };
-    auto take = [&](bool& want, uint64_t& idx) { // as in k_nodes1c
-        for (;;) {
-            const unsigned long long m = __ballot(want && j == 0);
-            if (!m || dry) break;
-            if (w_next == w_end) {
-                unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(&cnt->taken, (unsigned long long)chunk);
-                base = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
-                w_next = base < count ? base : count;
-                w_end = base + chunk < count ? base + chunk : count;
-                if (w_next == w_end) { dry = true; break; }
-            }
-            const uint64_t avail = w_end - w_next;
-            const uint32_t rank = (uint32_t)__popcll(m & ((1ull << (lane & ~3u)) - 1ull));
-            if (want && rank < avail) { idx = w_next + rank; want = false; }
-            const uint64_t asked = (uint64_t)__popcll(m);
-            w_next += asked < avail ? asked : avail;
-        }
-    };
     struct Chain { uint64_t l, r, depth; uint4 cl, cr; bool act; };
     Chain C0, C1;
     bool have_spare = false;
@@ -851,7 +845,7 @@ __global__ void __launch_bounds__(256) k_leaves1c(eb_dev_index x1, eb_dev_flags 
     auto start = [&](Chain& C) {
         bool want = true;
         uint64_t idx = 0;
-        take(want, idx);
+        cursor.take(cnt, want, idx, j, lane);
         C.act = !want;
         Rec r;
         r.l = r.r = r.depth = r.pad = 0;
@@ -864,7 +858,7 @@ __global__ void __launch_bounds__(256) k_leaves1c(eb_dev_index x1, eb_dev_flags 
     {
         bool want = true;
         uint64_t idx = 0;
-        take(want, idx);
+        cursor.take(cnt, want, idx, j, lane);
         have_spare = !want;
         if (have_spare) spare = eb_load_global(in + idx);
     }
@@ -883,26 +877,7 @@ __global__ void __launch_bounds__(256) k_leaves1c(eb_dev_index x1, eb_dev_flags 
                     const bool keep = C.act && (b - a >= 2);
                     const uint32_t km = eb_quad_or(keep ? (1u << j) : 0u);
                     const uint32_t jc = follow && km ? (uint32_t)__ffs((int)km) - 1u : 4u;
-                    {
-                        const bool px = keep && j != jc;
-                        const unsigned long long pm = __ballot(px);
-                        if (pm) {
-                            uint32_t wbase = 0;
-                            if (lane == 0) wbase = atomicAdd(&s_count, (uint32_t)__popcll(pm));
-                            wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
-                            if (px) {
-                                const uint32_t slot = wbase + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
-                                const uint4* src = reinterpret_cast<const uint4*>(&child);
-                                if (slot < (uint32_t)STAGE) {
-                                    for (int q = 0; q < (int)(sizeof(Rec) / 16); ++q) s_buf[slot * (sizeof(Rec) / 16) + q] = src[q];
-                                } else {
-                                    const unsigned long long g = atomicAdd(&cnt->pushed, 1ull);
-                                    if (g < out_cap)
-                                        for (int q = 0; q < (int)(sizeof(Rec) / 16); ++q) eb_store_global(reinterpret_cast<uint4*>(out) + g * (sizeof(Rec) / 16) + q, src[q]);
-                                }
-                            }
-                        }
-                    }
+                    nav_push_or_spill<Rec, STAGE>(keep && j != jc, [&] { return child; }, s_buf, &s_count, out, out_cap, cnt, lane);
                     bool want = false;
                     if (jc < 4u) {
                         C.l = eb_quad_pick64(child.l, j == jc);
@@ -915,23 +890,13 @@ __global__ void __launch_bounds__(256) k_leaves1c(eb_dev_index x1, eb_dev_flags 
                     }
                     uint64_t idx = 0;
                     const bool asked = want;
-                    take(want, idx);
+                    cursor.take(cnt, want, idx, j, lane);
                     if (asked && !want) { spare = eb_load_global(in + idx); have_spare = true; }
                     arm(C);
                 }
             }
         }
-        __syncthreads();
-        if (threadIdx.x == 0 && s_count > (uint32_t)STAGE) s_count = STAGE; // (the excess went straight to the stack)
-        stage.flush(out, out_cap, &cnt->pushed);
-        const bool still = __ballot(C0.act || C1.act || have_spare) != 0ull;
-        if (threadIdx.x == 0) s_alive = 0;
-        __syncthreads();
-        if (lane == 0 && still) s_alive = 1;
-        __syncthreads();
-        const int go_on = s_alive;
-        __syncthreads();
-        if (!go_on) break;
+        if (!nav_round_end<Rec, STAGE>(stage, &s_count, &s_alive, out, out_cap, cnt, __ballot(C0.act || C1.act || have_spare) != 0ull, lane)) break;
     }
     const uint64_t st[EB_NAV_STATS] = {n_leaf, 0, n_lcp, 0, 0, n_rank, n_s1, n_s2};
     flush_stats(stat_rows, st);
@@ -959,11 +924,7 @@ __global__ void __launch_bounds__(256) k_leaves2c(eb_dev_index x1, eb_dev_index 
     const uint32_t j = threadIdx.x & 3u, lane = threadIdx.x & 63u;
     uint64_t n_leaf = 0, n_lcp = 0, n_da = 0, n_rank = 0, n_s1 = 0, n_s2 = 0;
     const uint64_t F1 = pick4(x1.F, j), F2 = pick4(x2.F, j);
-    const uint64_t waves = (count + 15) / 16 < (uint64_t)gridDim.x * 4 ? (count + 15) / 16 : (uint64_t)gridDim.x * 4;
-    uint64_t chunk = count / (waves * 4);
-    chunk = chunk < 16 ? 16 : (chunk > 256 ? 256 : chunk);
-    uint64_t w_next = 0, w_end = 0;
-    bool dry = false;
+    NavCursor cursor(count, gridDim.x);
     // DA and LCP slots of a merged leaf (update_DA ebwt2InDel.cpp:394-425, update_LCP_leaf :344-355), as in k_leaves<2>: DA = 1 on the
     // second collection's rows [s2, e), LCP bits on [s1 + 1, e); the quad splits the touched words
     auto mark = [&](const Leaf2& L) {
@@ -997,25 +958,6 @@ __global__ void __launch_bounds__(256) k_leaves2c(eb_dev_index x1, eb_dev_index 
             n_rank += (L.r1 > L.l1 ? 2 : 1) + (L.r2 > L.l2 ? 2 : 1);
         }
     };
-    auto take = [&](bool& want, uint64_t& idx) { // as in k_nodes1c
-        for (;;) {
-            const unsigned long long m = __ballot(want && j == 0);
-            if (!m || dry) break;
-            if (w_next == w_end) {
-                unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(&cnt->taken, (unsigned long long)chunk);
-                base = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
-                w_next = base < count ? base : count;
-                w_end = base + chunk < count ? base + chunk : count;
-                if (w_next == w_end) { dry = true; break; }
-            }
-            const uint64_t avail = w_end - w_next;
-            const uint32_t rank = (uint32_t)__popcll(m & ((1ull << (lane & ~3u)) - 1ull));
-            if (want && rank < avail) { idx = w_next + rank; want = false; }
-            const uint64_t asked = (uint64_t)__popcll(m);
-            w_next += asked < avail ? asked : avail;
-        }
-    };
     struct Chain { Leaf2 L; uint4 cl1, cr1, cl2, cr2; bool act; };
     Chain C0, C1;
     bool have_spare = false;
@@ -1031,7 +973,7 @@ __global__ void __launch_bounds__(256) k_leaves2c(eb_dev_index x1, eb_dev_index 
     auto start = [&](Chain& C) {
         bool want = true;
         uint64_t idx = 0;
-        take(want, idx);
+        cursor.take(cnt, want, idx, j, lane);
         C.act = !want;
         Rec r;
         for (uint64_t& w : r.w) w = 0;
@@ -1044,7 +986,7 @@ __global__ void __launch_bounds__(256) k_leaves2c(eb_dev_index x1, eb_dev_index 
     {
         bool want = true;
         uint64_t idx = 0;
-        take(want, idx);
+        cursor.take(cnt, want, idx, j, lane);
         have_spare = !want;
         spare = idx;
     }
@@ -1065,27 +1007,7 @@ __global__ void __launch_bounds__(256) k_leaves2c(eb_dev_index x1, eb_dev_index 
                     const bool keep = C.act && ((b1 - a1) + (b2 - a2) >= 2);
                     const uint32_t km = eb_quad_or(keep ? (1u << j) : 0u);
                     const uint32_t jc = follow && km ? (uint32_t)__ffs((int)km) - 1u : 4u;
-                    {
-                        const bool px = keep && j != jc;
-                        const unsigned long long pm = __ballot(px);
-                        if (pm) {
-                            const Rec rec = pack_rec(child);
-                            uint32_t wbase = 0;
-                            if (lane == 0) wbase = atomicAdd(&s_count, (uint32_t)__popcll(pm));
-                            wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
-                            if (px) {
-                                const uint32_t slot = wbase + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
-                                const uint4* src = reinterpret_cast<const uint4*>(&rec);
-                                if (slot < (uint32_t)STAGE) {
-                                    for (int q = 0; q < (int)(sizeof(Rec) / 16); ++q) s_buf[slot * (sizeof(Rec) / 16) + q] = src[q];
-                                } else {
-                                    const unsigned long long g = atomicAdd(&cnt->pushed, 1ull);
-                                    if (g < out_cap)
-                                        for (int q = 0; q < (int)(sizeof(Rec) / 16); ++q) eb_store_global(reinterpret_cast<uint4*>(out) + g * (sizeof(Rec) / 16) + q, src[q]);
-                                }
-                            }
-                        }
-                    }
+                    nav_push_or_spill<Rec, STAGE>(keep && j != jc, [&] { return pack_rec(child); }, s_buf, &s_count, out, out_cap, cnt, lane);
                     bool want = false;
                     if (jc < 4u) {
                         C.L.l1 = eb_quad_pick64(child.l1, j == jc);
@@ -1100,23 +1022,13 @@ __global__ void __launch_bounds__(256) k_leaves2c(eb_dev_index x1, eb_dev_index 
                     }
                     uint64_t idx = 0;
                     const bool asked = want;
-                    take(want, idx);
+                    cursor.take(cnt, want, idx, j, lane);
                     if (asked && !want) { spare = idx; have_spare = true; }
                     arm(C);
                 }
             }
         }
-        __syncthreads();
-        if (threadIdx.x == 0 && s_count > (uint32_t)STAGE) s_count = STAGE; // (the excess went straight to the stack)
-        stage.flush(out, out_cap, &cnt->pushed);
-        const bool still = __ballot(C0.act || C1.act || have_spare) != 0ull;
-        if (threadIdx.x == 0) s_alive = 0;
-        __syncthreads();
-        if (lane == 0 && still) s_alive = 1;
-        __syncthreads();
-        const int go_on = s_alive;
-        __syncthreads();
-        if (!go_on) break;
+        if (!nav_round_end<Rec, STAGE>(stage, &s_count, &s_alive, out, out_cap, cnt, __ballot(C0.act || C1.act || have_spare) != 0ull, lane)) break;
     }
     const uint64_t st[EB_NAV_STATS] = {n_leaf, 0, n_lcp, n_da, 0, n_rank, n_s1, n_s2};
     flush_stats(stat_rows, st);
@@ -1309,11 +1221,7 @@ __global__ void __launch_bounds__(256) k_nodes2c(eb_dev_index x1, eb_dev_index x
     uint32_t n_node = 0, n_lcp = 0, n_da = 0, n_rank = 0, n_min = 0; // per lane and launch: far below 2^32
     uint64_t n_s1 = 0, n_s2 = 0;
     const uint64_t F1 = pick4(x1.F, j), F2 = pick4(x2.F, j);
-    const uint64_t waves = (count + 15) / 16 < (uint64_t)gridDim.x * 4 ? (count + 15) / 16 : (uint64_t)gridDim.x * 4;
-    uint64_t chunk = count / (waves * 4);
-    chunk = chunk < 16 ? 16 : (chunk > 256 ? 256 : chunk);
-    uint64_t w_next = 0, w_end = 0;
-    bool dry = false;
+    NavCursor cursor(count, gridDim.x);
 
     // border bits in merged coordinates (merge_nodes, include.hpp:476-490), DA slots of singleton leaves: as in k_nodes2p
     auto mark = [&](const Node2& N) {
@@ -1357,25 +1265,6 @@ __global__ void __launch_bounds__(256) k_nodes2c(eb_dev_index x1, eb_dev_index x
         }
         return m;
     };
-    auto take = [&](bool& want, uint64_t& idx) { // as in k_nodes1c
-        for (;;) {
-            const unsigned long long m = __ballot(want && j == 0);
-            if (!m || dry) break;
-            if (w_next == w_end) {
-                unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(&cnt->taken, (unsigned long long)chunk);
-                base = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
-                w_next = base < count ? base : count;
-                w_end = base + chunk < count ? base + chunk : count;
-                if (w_next == w_end) { dry = true; break; }
-            }
-            const uint64_t avail = w_end - w_next;
-            const uint32_t rank = (uint32_t)__popcll(m & ((1ull << (lane & ~3u)) - 1ull));
-            if (want && rank < avail) { idx = w_next + rank; want = false; }
-            const uint64_t asked = (uint64_t)__popcll(m);
-            w_next += asked < avail ? asked : avail;
-        }
-    };
     Node2 N0;
     uint4 a0[6], b0[6];
     uint32_t m0 = 0;
@@ -1394,7 +1283,7 @@ __global__ void __launch_bounds__(256) k_nodes2c(eb_dev_index x1, eb_dev_index x
     auto start = [&](Node2& N, uint4 (&ca)[6], uint4 (&cb)[6], uint32_t& m, bool& act) {
         bool want = true;
         uint64_t idx = 0;
-        take(want, idx);
+        cursor.take(cnt, want, idx, j, lane);
         act = !want;
         Rec r;
         for (uint64_t& w : r.w) w = 0;
@@ -1406,7 +1295,7 @@ __global__ void __launch_bounds__(256) k_nodes2c(eb_dev_index x1, eb_dev_index x
     {
         bool want = true;
         uint64_t idx = 0;
-        take(want, idx);
+        cursor.take(cnt, want, idx, j, lane);
         have_spare = !want;
         spare = idx;
     }
@@ -1450,27 +1339,7 @@ __global__ void __launch_bounds__(256) k_nodes2c(eb_dev_index x1, eb_dev_index x
                     }
                     const uint32_t km = eb_quad_or(keep ? (1u << j) : 0u);
                     const uint32_t jc = follow && km ? (uint32_t)__ffs((int)km) - 1u : 4u;
-                    {
-                        const bool px = keep && j != jc;
-                        const unsigned long long pm = __ballot(px);
-                        if (pm) { // (uniform; most turns nobody pushes and the record is not even packed)
-                            const Rec rec = pack_rec(child);
-                            uint32_t wbase = 0;
-                            if (lane == 0) wbase = atomicAdd(&s_count, (uint32_t)__popcll(pm));
-                            wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
-                            if (px) {
-                                const uint32_t slot = wbase + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
-                                const uint4* src = reinterpret_cast<const uint4*>(&rec);
-                                if (slot < (uint32_t)STAGE) {
-                                    for (int q = 0; q < (int)(sizeof(Rec) / 16); ++q) s_buf[slot * (sizeof(Rec) / 16) + q] = src[q];
-                                } else {
-                                    const unsigned long long g = atomicAdd(&cnt->pushed, 1ull);
-                                    if (g < out_cap)
-                                        for (int q = 0; q < (int)(sizeof(Rec) / 16); ++q) eb_store_global(reinterpret_cast<uint4*>(out) + g * (sizeof(Rec) / 16) + q, src[q]);
-                                }
-                            }
-                        }
-                    }
+                    nav_push_or_spill<Rec, STAGE>(keep && j != jc, [&] { return pack_rec(child); }, s_buf, &s_count, out, out_cap, cnt, lane);
                     bool want = false;
                     if (jc < 4u) {
 #pragma unroll
@@ -1486,23 +1355,13 @@ __global__ void __launch_bounds__(256) k_nodes2c(eb_dev_index x1, eb_dev_index x
                     }
                     uint64_t idx = 0;
                     const bool asked = want;
-                    take(want, idx);
+                    cursor.take(cnt, want, idx, j, lane);
                     if (asked && !want) { spare = idx; have_spare = true; }
                     arm(N, ca, cb, mc, act);
                 }
             }
         }
-        __syncthreads();
-        if (threadIdx.x == 0 && s_count > (uint32_t)STAGE) s_count = STAGE; // (the excess went straight to the stack)
-        stage.flush(out, out_cap, &cnt->pushed);
-        const bool still = __ballot(act0 || have_spare) != 0ull;
-        if (threadIdx.x == 0) s_alive = 0;
-        __syncthreads();
-        if (lane == 0 && still) s_alive = 1;
-        __syncthreads();
-        const int go_on = s_alive;
-        __syncthreads();
-        if (!go_on) break;
+        if (!nav_round_end<Rec, STAGE>(stage, &s_count, &s_alive, out, out_cap, cnt, __ballot(act0 || have_spare) != 0ull, lane)) break;
     }
     const uint64_t st[EB_NAV_STATS] = {0, n_node, n_lcp, n_da, n_min, n_rank, n_s1, n_s2};
     flush_stats(stat_rows, st);
