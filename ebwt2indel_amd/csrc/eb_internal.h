@@ -26,7 +26,6 @@ struct eb_scan_ctx {
     hipStream_t prep = nullptr, ext = nullptr, right = nullptr, copy = nullptr;
     std::vector<hipEvent_t> events;
     hipEvent_t last_ext = nullptr, last_right = nullptr; // end of the most recent job's context kernels
-    bool last_small = false;                             // the most recent job's call set was a small one (early right-context walk)
     std::vector<unsigned long long*> h_bad_pool; // pinned words recycled between jobs
     std::mutex half_mu;                          // half_job and the jobs' `half` flags
     struct eb_scan_job* half_job = nullptr;      // EB_SCAN_PIPELINED: the job whose last part is held back until the next _begin

@@ -73,10 +73,6 @@ __host__ __device__ __forceinline__ void unpack_rec(const Node2P& p, Node2& n) {
 __host__ __device__ __forceinline__ void unpack_rec(const Leaf2P& p, Leaf2& l) { l.depth = unpack_fields<4>(p, &l.l1); l.pad[0] = l.pad[1] = l.pad[2] = 0; }
 __host__ __device__ __forceinline__ void unpack_rec(const Leaf1& p, Leaf1& l) { l = p; }
 
-#ifndef EB_NODES_PER_QUAD
-#define EB_NODES_PER_QUAD 2 /* one-BWT nodes per quad and trip in k_nodes (1, 2, 3 or 6: must divide 1536 / 256) */
-#endif
-
 struct NavCounters {
     unsigned long long pushed;     // children appended by the current launch
     unsigned long long pad0[7];    // keep the hot word on its own 64-byte line
@@ -260,166 +256,8 @@ __global__ void __launch_bounds__(256) k_leaves(eb_dev_index x1, eb_dev_index x2
     flush_stats(stat_rows, st);
 }
 
-// ---- phase 3: right-maximal nodes.  update_lcp_threshold (include.hpp:826-860), update_lcp_minima
-// (ebwt2InDel.cpp:357-391), find_leaves (:474-527), LF(sa_node) (dna_bwt.hpp:323-356), next_nodes
-// (dna_bwt.hpp:381-404 / ebwt2InDel.cpp:529-553).  Four lanes per node: lane j loads the j-th chunk of the
-// six boundary blocks (one coalesced 64-byte segment per rank query), owns letter j, i.e. the Weiner-link
-// child "ACGT"[j] + W, and writes border j's LCP / minimum bits.
-// U nodes per quad and trip: the kernel is bound by memory latency x occupancy (three workgroups per CU because of the staging
-// buffer), so every lane puts the 6 U block loads of its U nodes in flight before it touches the first result.
-template <int NB, int U>
-__global__ void __launch_bounds__(256) k_nodes(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, uint64_t* __restrict__ kr, NavParams p,
-                                              const NavLaunch* __restrict__ la, NavCounters* cnt, unsigned long long* __restrict__ stat_rows) {
-    using Node = typename std::conditional<NB == 1, Node1, Node2>::type;
-    using Rec = typename std::conditional<NB == 1, Node1P, Node2P>::type; // the record as it lies in the stacks
-    constexpr int STAGE = NB == 1 ? 1536 : 768;
-    static_assert(STAGE % (256 * U) == 0, "a whole number of trips fills the staging buffer");
-    const void* in_ = la->in;
-    void* out_ = la->out;
-    const uint64_t count = la->count, out_cap = la->out_cap;
-    p.write = la->write;
-    if ((uint64_t)blockIdx.x * 64 * U >= count) return; // the grid is sized for a full batch: nothing for this workgroup (uniform)
-    __shared__ uint4 s_buf[STAGE * (sizeof(Rec) / 16)];
-    __shared__ uint32_t s_count;
-    __shared__ unsigned long long s_base;
-    Stager<Rec, STAGE> stage{s_buf, &s_count, &s_base};
-    if (threadIdx.x == 0) s_count = 0;
-    __syncthreads();
-    const Rec* in = static_cast<const Rec*>(in_);
-    Rec* out = static_cast<Rec*>(out_);
-    const uint32_t j = threadIdx.x & 3u, q = threadIdx.x >> 2;
-    uint64_t n_node = 0, n_lcp = 0, n_da = 0, n_rank = 0, n_min = 0, n_s1 = 0, n_s2 = 0;
-    const uint64_t tiles = (count + 64 * U - 1) / (64 * U);
-    uint32_t trips = 0;
-    for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        Node N[U];
-        bool active[U];
-        uint4 ca[U][6], cb[NB == 2 ? U : 1][6];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint64_t i = (tile * U + u) * 64 + q;
-            active[u] = i < count;
-            memset(&N[u], 0, sizeof(Node));
-            if (active[u]) unpack_rec(eb_load_global(in + i), N[u]);
-        }
-        // All rank loads of the trip, back to back.  With two BWTs a block is loaded ONCE: the six boundaries of a node are
-        // sorted and, below the top of the tree, a few dozen rows apart, so most of them share the block of their left
-        // neighbour; the skipped lanes are masked off in the load instruction (no request), and which block a boundary
-        // uses is resolved when the results are consumed, so no load waits for another.  Twelve quad loads per node
-        // become about four: two-BWT traversal 0.98 -> 0.91-0.94 s at 2 x 3.775 G positions.  (With one BWT the same trade -- six
-        // loads become two, 20 more registers -- LOSES: 0.433 -> 0.463 s; repeated loads hit in the L2 and cost less there
-        // than the bookkeeping.)
-        bool la[NB == 2 ? U : 1][6], lb[NB == 2 ? U : 1][6];
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                if constexpr (NB == 1) {
-                    ca[u][k] = eb_rank4_quad_load(x1, N[u].b[k], j);
-                } else {
-                    la[u][k] = k == 0 || (N[u].a[k] >> 7) != (N[u].a[k - 1] >> 7);
-                    lb[u][k] = k == 0 || (N[u].b[k] >> 7) != (N[u].b[k - 1] >> 7);
-                    if (la[u][k]) ca[u][k] = eb_rank4_quad_load(x1, N[u].a[k], j);
-                    if (lb[u][k]) cb[u][k] = eb_rank4_quad_load(x2, N[u].b[k], j);
-                }
-            }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const Node& Nu = N[u];
-            uint64_t m[6]; // merged boundaries (merge_nodes, include.hpp:476-490)
-            if constexpr (NB == 1) {
-                for (int k = 0; k < 6; ++k) m[k] = Nu.b[k];
-            } else {
-                for (int k = 0; k < 6; ++k) m[k] = Nu.a[k] + Nu.b[k];
-            }
-            if (active[u] && p.write) {
-                // lane j looks after border j (right end of child TERM,A,C,G)
-                uint64_t lo = 0, hi = 0;
-                for (int k = 0; k < 4; ++k) if (j == (uint32_t)k) { lo = m[k]; hi = m[k + 1]; }
-                if (hi > lo && hi != m[5]) {
-                    // the two threshold bits of a position sit in adjacent words of the same line (second atomic hits in L2)
-                    const bool setK = ((int64_t)Nu.depth >= p.K) != (p.below != 0), setR = ((int64_t)Nu.depth >= p.k_right) != (p.below != 0);
-                    if (p.lcpb) {
-                        // each LCP slot has exactly one writer (ebwt2InDel.cpp:617,670): a plain byte store replaces two
-                        // memory-side atomics (integer atomics on random lines cost ~2x a store and bypass L2)
-                        uint8_t v = (uint8_t)((setK ? 1 : 0) | (setR ? 2 : 0));
-                        if (v && !(EB_NDBG(p) & 1u)) p.lcpb[hi] = v;
-                    } else {
-                        if (setK) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * (hi >> 6)), 1ull << (hi & 63u));
-                        if (setR) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * (hi >> 6) + 1), 1ull << (hi & 63u));
-                    }
-                    ++n_lcp;
-                    n_s1 += hi;
-                    n_s2 += hi * hi;
-                }
-                // a local LCP minimum follows each child A,C,G of size >= 2 that ends before last-1
-                if (j >= 1 && hi - lo >= 2 && hi < m[5] - 1) {
-                    if (!(EB_NDBG(p) & 2u)) eb_bit_set_atomic(f.minima, hi);
-                    ++n_min;
-                }
-                if constexpr (NB == 2) {
-                    // leaves of merged size 1 were not visited in phase 2: write their DA slot now (find_leaves)
-                    for (int k = 0; k < 5; ++k) {
-                        if ((uint32_t)(k & 3) != j || (k == 4 && j != 0)) continue;
-                        uint64_t s1 = Nu.a[k + 1] - Nu.a[k], s2 = Nu.b[k + 1] - Nu.b[k];
-                        if (s1 + s2 == 1) {
-                            if (s2 && !(EB_NDBG(p) & 8u)) eb_bit_set_atomic(f.da, Nu.b[k] + Nu.a[k + 1]);
-                            ++n_da;
-                        }
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const Node& Nu = N[u];
-            Node child;
-            memset(&child, 0, sizeof child);
-            bool keep = false;
-            if constexpr (NB == 1) {
-                uint64_t Fj = pick4(x1.F, j);
-                int kids = 0;
-                for (int k = 0; k < 6; ++k) child.b[k] = Fj + eb_rank4_quad_finish(x1, ca[u][k], Nu.b[k], j);
-                for (int k = 0; k < 5; ++k) kids += child.b[k + 1] > child.b[k];
-                child.depth = Nu.depth + 1;
-                keep = active[u] && kids >= 2; // number_of_children (include.hpp:760-768)
-                if (active[u] && p.write && j == 0) {
-                    ++n_node;
-                    n_rank += 1;
-                    for (int k = 1; k < 6; ++k) n_rank += Nu.b[k] != Nu.b[k - 1]; // the reference shares the query of equal neighbours
-                }
-            } else {
-                uint64_t F1 = pick4(x1.F, j), F2 = pick4(x2.F, j);
-                int kids = 0;
-                uint4 cur_a = ca[u][0], cur_b = cb[u][0];
-#pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    if (la[u][k]) cur_a = ca[u][k]; // else: the block of the boundary to the left
-                    if (lb[u][k]) cur_b = cb[u][k];
-                    child.a[k] = F1 + eb_rank4_quad_finish(x1, cur_a, Nu.a[k], j);
-                    child.b[k] = F2 + eb_rank4_quad_finish(x2, cur_b, Nu.b[k], j);
-                }
-                for (int k = 0; k < 5; ++k) kids += (child.a[k + 1] > child.a[k]) || (child.b[k + 1] > child.b[k]); // include.hpp:784-792
-                child.depth = Nu.depth + 1;
-                keep = active[u] && kids >= 2;
-                if (active[u] && p.write && j == 0) {
-                    ++n_node;
-                    n_rank += 2;
-                    for (int k = 1; k < 6; ++k) n_rank += (Nu.a[k] != Nu.a[k - 1]) + (Nu.b[k] != Nu.b[k - 1]);
-                }
-            }
-            stage.push(keep, pack_rec(child));
-        }
-        // every trip adds at most 256 U records: flushing every STAGE / (256 U) trips never overflows the buffer, and the
-        // decision is the same in every thread without looking at shared state
-        if (++trips % (STAGE / (256 * U)) == 0) stage.flush(out, out_cap, &cnt->pushed);
-    }
-    stage.flush(out, out_cap, &cnt->pushed);
-    const uint64_t st[EB_NAV_STATS] = {0, n_node, n_lcp, n_da, n_min, n_rank, n_s1, n_s2};
-    flush_stats(stat_rows, st);
-}
-
-// ---- phase 3, one BWT, software-pipelined (round 3).  Same work per node as k_nodes<1, U>, one node per quad and trip, but the
+// ---- phase 3, one BWT, software-pipelined (round 3).  One node per quad and trip (four lanes per node: lane j loads the j-th chunk
+// of the six boundary blocks, owns letter j -- the Weiner-link child "ACGT"[j] + W -- and writes border j's LCP / minimum bits), and the
 // memory operations of the NEXT trips are under way while a trip is worked on:
 //   stage A  the record of trip t+1 (loaded during trip t-1) is unpacked; its LCP / minimum bits are set at once -- they
 //            depend on the record alone (borders and depth), not on any rank -- and its six block loads are issued;
@@ -1035,7 +873,7 @@ __global__ void __launch_bounds__(256) k_leaves2c(eb_dev_index x1, eb_dev_index 
 }
 
 // ---- phase 3, two BWTs, software-pipelined the same way (k_nodes1p).  A merged node is two sa_nodes (12 boundaries); as in
-// k_nodes<2, 1> a block is loaded ONCE for the boundaries of a node that share it (they are sorted and a few dozen rows apart):
+// the round-2 kernel a block is loaded ONCE for the boundaries of a node that share it (they are sorted and a few dozen rows apart):
 // which boundaries issue a load is decided in stage A and kept as a 12-bit mask for stage D.
 template <bool SUPER_LDS>
 __global__ void __launch_bounds__(256) k_nodes2p(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, uint64_t* __restrict__ kr, NavParams p,
@@ -1894,8 +1732,6 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
         return r;
     };
     // phase 3 (ebwt2InDel.cpp:622-673 / :764-823); root (dna_bwt.hpp:296-308)
-    // EB_NAV_PIPELINED=0: the round-2 one-BWT node kernel (record load, wait, block loads, wait, compute) instead of k_nodes1p
-    const bool pipelined_nodes = env_u64("EB_NAV_PIPELINED", 1) != 0;
     auto phase_nodes = [&](hipStream_t sx, NavBufs& nb, void* arena, uint64_t bytes) -> int {
         int r;
         NavCounters* dc = nb.cnt;
@@ -1908,11 +1744,11 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
             Node1 root{{0, b1->F[0], b1->F[1], b1->F[2], b1->F[3], b1->n}, 0, 0};
             if ((r = d.push_host(pack_rec(root))) != EB_OK) return r;
             r = d.run<-1>(dc, nb.state, nb.h_state, [&](const NavLaunch* la, unsigned grid) {
-                if (pipelined_nodes && chains && (b1->n >> EB_SUPER_SHIFT) + 1 <= EB_NAV_SUPER_LDS) hipLaunchKernelGGL((k_nodes1c<true>), dim3(grid), dim3(256), 0, sx, x1, df, d_kr, p, la, dc, rows);
-                else if (pipelined_nodes && chains) hipLaunchKernelGGL((k_nodes1c<false>), dim3(grid), dim3(256), 0, sx, x1, df, d_kr, p, la, dc, rows);
-                else if (pipelined_nodes && (b1->n >> EB_SUPER_SHIFT) + 1 <= EB_NAV_SUPER_LDS) hipLaunchKernelGGL((k_nodes1p<true>), dim3(grid), dim3(256), 0, sx, x1, df, d_kr, p, la, dc, rows);
-                else if (pipelined_nodes) hipLaunchKernelGGL((k_nodes1p<false>), dim3(grid), dim3(256), 0, sx, x1, df, d_kr, p, la, dc, rows);
-                else hipLaunchKernelGGL((k_nodes<1, EB_NODES_PER_QUAD>), dim3(grid), dim3(256), 0, sx, x1, x2, df, d_kr, p, la, dc, rows);
+                const bool super_lds = (b1->n >> EB_SUPER_SHIFT) + 1 <= EB_NAV_SUPER_LDS;
+                if (chains && super_lds) hipLaunchKernelGGL((k_nodes1c<true>), dim3(grid), dim3(256), 0, sx, x1, df, d_kr, p, la, dc, rows);
+                else if (chains) hipLaunchKernelGGL((k_nodes1c<false>), dim3(grid), dim3(256), 0, sx, x1, df, d_kr, p, la, dc, rows);
+                else if (super_lds) hipLaunchKernelGGL((k_nodes1p<true>), dim3(grid), dim3(256), 0, sx, x1, df, d_kr, p, la, dc, rows);
+                else hipLaunchKernelGGL((k_nodes1p<false>), dim3(grid), dim3(256), 0, sx, x1, df, d_kr, p, la, dc, rows);
             });
             launches_n = d.launches;
             return r;
@@ -1925,11 +1761,10 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
         if ((r = d.push_host(pack_rec(root))) != EB_OK) return r;
         const bool super_fits = (b1->n >> EB_SUPER_SHIFT) + 1 <= EB_NAV_SUPER_LDS && (b2->n >> EB_SUPER_SHIFT) + 1 <= EB_NAV_SUPER_LDS;
         r = d.run<1>(dc, nb.state, nb.h_state, [&](const NavLaunch* la, unsigned grid) {
-            if (pipelined_nodes && chains && super_fits) hipLaunchKernelGGL((k_nodes2c<true>), dim3(grid), dim3(256), 0, sx, x1, x2, df, d_kr, p, la, dc, rows);
-            else if (pipelined_nodes && chains) hipLaunchKernelGGL((k_nodes2c<false>), dim3(grid), dim3(256), 0, sx, x1, x2, df, d_kr, p, la, dc, rows);
-            else if (pipelined_nodes && super_fits) hipLaunchKernelGGL((k_nodes2p<true>), dim3(grid), dim3(256), 0, sx, x1, x2, df, d_kr, p, la, dc, rows);
-            else if (pipelined_nodes) hipLaunchKernelGGL((k_nodes2p<false>), dim3(grid), dim3(256), 0, sx, x1, x2, df, d_kr, p, la, dc, rows);
-            else hipLaunchKernelGGL((k_nodes<2, 1>), dim3(grid), dim3(256), 0, sx, x1, x2, df, d_kr, p, la, dc, rows);
+            if (chains && super_fits) hipLaunchKernelGGL((k_nodes2c<true>), dim3(grid), dim3(256), 0, sx, x1, x2, df, d_kr, p, la, dc, rows);
+            else if (chains) hipLaunchKernelGGL((k_nodes2c<false>), dim3(grid), dim3(256), 0, sx, x1, x2, df, d_kr, p, la, dc, rows);
+            else if (super_fits) hipLaunchKernelGGL((k_nodes2p<true>), dim3(grid), dim3(256), 0, sx, x1, x2, df, d_kr, p, la, dc, rows);
+            else hipLaunchKernelGGL((k_nodes2p<false>), dim3(grid), dim3(256), 0, sx, x1, x2, df, d_kr, p, la, dc, rows);
         });
         launches_n = d.launches;
         return r;

@@ -1003,13 +1003,12 @@ __global__ void __launch_bounds__(256) k_extend1(eb_dev_index x1, eb_dev_index x
 
 // One lane per cluster: record header + right context (extract_dna, ebwt2InDel.cpp:325-342) at the first
 // cluster position whose LCP >= k_right (:979-988; two BWTs :896-912); bases packed 2 bits each in text order.
-// It needs nothing but the survivors in BWT order, so it is launched as soon as they are -- before the host knows their
-// number (ns_ptr, device memory) and before the call set's image exists: records and contexts go to temporaries,
-// k_right_finish moves them into the image and adds the chain offsets.
+// Launched behind the left-context extension, straight into the call set's image (ns_ptr: the number of survivors, in device
+// memory; gate_chains: the extension's records when the clusters that cannot print are skipped).
 template <bool TWO, int LANES> // LANES = 1: one lane per cluster; 4: a quad per cluster (eb_select_quad)
 __global__ void __launch_bounds__(256) k_right(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, ScanParams p,
                                               const Survivor* __restrict__ surv, const uint32_t* __restrict__ ns_ptr,
-                                              const uint32_t* __restrict__ chain_off /* null: temporaries, k_right_finish adds it */, uint32_t chain_base,
+                                              const uint32_t* __restrict__ chain_off, uint32_t chain_base,
                                               eb_cluster* __restrict__ recs, uint64_t* __restrict__ right, uint32_t right_words,
                                               unsigned long long* __restrict__ req_slots, const eb_chain* __restrict__ gate_chains) {
     const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES;
@@ -1078,7 +1077,7 @@ __global__ void __launch_bounds__(256) k_right(eb_dev_index x1, eb_dev_index x2,
     eb_cluster r;
     r.begin = s.b;
     r.end = s.e;
-    r.first_chain = chain_off ? chain_off[i] + chain_base : 0u;
+    r.first_chain = chain_off[i] + chain_base;
     r.n_slots = (uint16_t)(__popc(s.fmask0) + __popc(s.fmask1));
     r.right_found = pos != ~0ull ? 1 : 0;
     r.right_len = len;
@@ -1112,16 +1111,6 @@ __global__ void __launch_bounds__(256) k_merge_planes(eb_dev_index x1, eb_dev_in
     }
 }
 
-__global__ void __launch_bounds__(256) k_right_finish(const eb_cluster* __restrict__ tmp_recs, const uint64_t* __restrict__ tmp_right, const uint32_t* __restrict__ chain_off,
-                                                     uint32_t chain_base, uint64_t nsurv, uint32_t right_words, eb_cluster* __restrict__ recs, uint64_t* __restrict__ right) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nsurv) return;
-    eb_cluster r = tmp_recs[i];
-    r.first_chain = chain_off[i] + chain_base;
-    recs[i] = r;
-    for (uint32_t k = 0; k < right_words; ++k) right[i * (uint64_t)right_words + k] = tmp_right[i * (uint64_t)right_words + k];
-}
-
 #define EB_PINNED_RING_BYTES (2ull << 30) /* most host memory a pipelining caller's ring of eight page-locked blobs may take */
 #define EB_JOB_PINNED_BYTES (512 + 16 * (sizeof(ScanCounters) + 64)) /* page-locked words of one job (<= 16 sub-shards) */
 struct DevMem { // per-call temporary from the caching scratch allocator
@@ -1153,7 +1142,7 @@ namespace {
 enum { E_SCAN0, E_SCAN1, E_SCAN_DONE, E_PREP_CNT, E_PREP_DONE, E_EXT0, E_EXT_DONE, E_RIGHT0, E_RIGHT_DONE, E_SORTED, E_PER_SHARD };
 struct SubShard {
     uint64_t begin = 0, end = 0, w_lo = 0, w_count = 0, cap = 0;
-    DevMem cnt, part, surv, sorted, bcnt, boff, tmp, nch, choff, chains, recs, crec, left, right, blob, rt_rec, rt_right; // bcnt/boff: position buckets (ordered scan: survivors kept per batch / their offsets); rt_*: k_right's temporaries
+    DevMem cnt, part, surv, sorted, bcnt, boff, tmp, nch, choff, chains, recs, crec, left, right, blob; // bcnt/boff: position buckets (ordered scan: survivors kept per batch / their offsets)
     DevMem slots, bcount;            // ordered scan: the batches' survivors and counts
     bool ordered = false;            // this sub-shard's scan ran in ordered mode
     uint64_t n_batches = 0;
@@ -1161,7 +1150,6 @@ struct SubShard {
     eb_chain* d_crec = nullptr;
     uint64_t *d_left = nullptr, *d_right = nullptr;
     uint64_t ns_raw = 0, ns = 0, n_chains = 0, rec_base = 0, chain_base = 0;
-    bool right_early = false;        // k_right was launched with the preparation (small call set); only its finishing kernel is left
     uint64_t n_buckets = 0;          // position buckets of the ordering step
     const uint32_t* d_ns = nullptr;  // survivors kept, in device memory (k_right's bound)
     hipEvent_t e[E_PER_SHARD]; // scan_t0, scan_t1, scan_done, prep_cnt, prep_done, ext_t0, ext_done, right_t0, right_done, sorted
@@ -1314,13 +1302,12 @@ static int launch_contexts(eb_scan_job* job) {
     for (int k = 0; k < S; ++k) {
         SubShard& x = sh[(size_t)k];
         if (x.ns == 0) continue;
-        const bool right_early = x.right_early;
-        // Small call set: the two context kernels are independent chains of dependent loads, one stream each (the walk
-        // was launched with the ordering step).  Large call set: the walk runs BEHIND the extension, so both simply follow
-        // the ordering step on its stream -- a hand-over between streams costs 15-25 us of idle device each time.
+        // The walk runs BEHIND the extension, so both simply follow the ordering step on its stream -- a hand-over between streams
+        // costs 15-25 us of idle device each time.  (Rounds 1-2 launched the walk of a small call set early, with the ordering step,
+        // into temporaries; round 3 measured that against the late walk and retired it: docs/EXPERIMENTS.md.)
         // (Round 4, with the FL table: the walk of pass i on its own stream beside the extension of pass i+1 -- own streams for a
         // pipelining caller's large call sets too -- 2.50-2.61 against 2.20-2.31 ms per step: not kept, profiles/r04_overlap_ab.txt.)
-        const bool own_streams = right_early || S > 1; // (sub-shards overlap one shard's ordering with the previous one's kernels)
+        const bool own_streams = S > 1; // (sub-shards overlap one shard's ordering with the previous one's kernels)
         const hipStream_t sB = own_streams ? job->s_ext : ctx->prep, sC = own_streams ? job->s_right : ctx->prep;
         EB_HIP(hipStreamWaitEvent(sB, x.e[E_PREP_DONE], 0));
         EB_HIP(hipEventRecord(x.e[E_EXT0], sB));
@@ -1330,7 +1317,7 @@ static int launch_contexts(eb_scan_job* job) {
         EB_HIP(hipEventRecord(x.e[E_EXT_DONE], sB));
         EB_HIP(hipEventRecord(ctx->last_ext, sB));
         EB_HIP(hipStreamWaitEvent(sC, x.e[E_PREP_DONE], 0));
-        if (!right_early) {
+        {
             // A large call set keeps the memory system busy with either kernel alone, so nothing is lost by running the
             // right-context walk BEHIND the left-context extension -- and it can then skip the clusters whose chains came
             // out too short to ever print (see the gate in k_right): straight into the image, one request in nine saved.
@@ -1344,9 +1331,7 @@ static int launch_contexts(eb_scan_job* job) {
             hipLaunchKernelGGL(kern_right, dim3(grid_of(x.ns * (uint64_t)right_lanes)), dim3(256), 0, sC, x1, x2, df, p, x.sorted.as<Survivor>(), x.d_ns,
                                x.choff.as<uint32_t>(), (uint32_t)x.chain_base, x.d_recs, x.d_right, rw, x.cnt.as<ScanCounters>()->req_right,
                                gated ? (const eb_chain*)x.d_crec : (const eb_chain*)nullptr);
-        } else
-            hipLaunchKernelGGL(k_right_finish, dim3(grid_of(x.ns)), dim3(256), 0, sC, x.rt_rec.as<eb_cluster>(), x.rt_right.as<uint64_t>(), x.choff.as<uint32_t>(),
-                           (uint32_t)x.chain_base, x.ns, rw, x.d_recs, x.d_right);
+        }
         EB_HIP(hipEventRecord(x.e[E_RIGHT_DONE], sC));
         EB_HIP(hipEventRecord(ctx->last_right, sC));
         EB_HIP(hipGetLastError());
@@ -1394,7 +1379,7 @@ static int launch_contexts(eb_scan_job* job) {
         size_t set_bytes = 0, free_b = 0, total_b = 0;
         for (SubShard& x : job->sh)
             for (DevMem* m : {&x.cnt, &x.part, &x.surv, &x.sorted, &x.bcnt, &x.boff, &x.tmp, &x.nch, &x.choff, &x.chains, &x.recs, &x.crec, &x.left, &x.right, &x.blob,
-                              &x.rt_rec, &x.rt_right, &x.slots, &x.bcount})
+                              &x.slots, &x.bcount})
                 if (m->p) set_bytes += m->cap;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
         std::vector<std::pair<void*, size_t>> held;
@@ -1402,7 +1387,7 @@ static int launch_contexts(eb_scan_job* job) {
         for (int copy = 0; copy < 5 && !failed; ++copy)
             for (SubShard& x : job->sh)
                 for (DevMem* m : {&x.cnt, &x.part, &x.surv, &x.sorted, &x.bcnt, &x.boff, &x.tmp, &x.nch, &x.choff, &x.chains, &x.recs, &x.crec, &x.left, &x.right, &x.blob,
-                                  &x.rt_rec, &x.rt_right, &x.slots, &x.bcount}) {
+                                  &x.slots, &x.bcount}) {
                     if (!m->p || failed) continue;
                     size_t cap = 0;
                     void* q = eb_scratch_get(b1->device, m->cap - m->cap / 16, &cap); // a block of this job's class (a cached one of that class does as well)
@@ -1643,7 +1628,7 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
         const char* e = getenv("EB_SCAN_OVERLAP");
         const int v = e ? atoi(e) : -1;
         if (v >= 0) return (unsigned)(v > 8 ? 8 : v);
-        if (!(options & EB_SCAN_PIPELINED) || ctx->last_small) return 0u;
+        if (!(options & EB_SCAN_PIPELINED)) return 0u;
         // (4 per CU in round 3, when the walk took as long as the extension; with the FL table the context kernels are the shorter
         // side and the scan gets every slot it can use: 2.60 / 2.46 / 2.36 / 2.22 ms per step for 4 / 5 / 6 / 8, profiles/r04_overlap_ab.txt)
         const unsigned share = (b1->d_psi && (!b2 || b2->d_psi)) ? 8u : 4u;
@@ -1657,8 +1642,6 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
     // Measured at 7.55 G positions (EB_SCAN_SUBSHARDS=1/2/4/8): 6.5 / 6.1 / 6.4 / 11.0 ms per call -- the streaming scan and
     // the random-access chains compete for the same memory request rate, so overlap buys little and slows each kernel.
     // Default: one shard (kernels run alone, cleanest timings); the knob stays for experiments.
-    uint64_t right_early_max = 0; // the early right-context walk of rounds 1-2 (see the launch of k_right below): off since round 3; EB_RIGHT_EARLY_MAX=<clusters> brings it back
-    if (const char* e = getenv("EB_RIGHT_EARLY_MAX")) right_early_max = strtoull(e, nullptr, 10);
     const uint64_t small_set_max = 524288; // call sets up to this size: every cluster gets its right context, the job's last part may be held back
     int S = 1;
     if (const char* e = getenv("EB_SCAN_SUBSHARDS")) { int v = atoi(e); if (v >= 1 && v <= 16) S = v; }
@@ -1685,7 +1668,6 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
     job->s_ext = ctx->ext;
     job->s_right = ctx->right;
     job->s_order = sP;
-    const hipStream_t sC = job->s_right;
     {
         std::lock_guard<std::mutex> lk(ctx->pool_mu);
         if (!ctx->h_bad_pool.empty()) {
@@ -1727,8 +1709,6 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
     const bool prefetch = scan_prefetch < 0 ? overlap_wgs != 0 : scan_prefetch != 0;
     auto kern = prefetch ? (p.mode == 1 ? k_scan<1, true> : (p.mode == 2 ? k_scan<2, true> : k_scan<3, true>))
                          : (p.mode == 1 ? k_scan<1, false> : (p.mode == 2 ? k_scan<2, false> : k_scan<3, false>));
-    static const int early_lanes = getenv("EB_RIGHT_LANES_EARLY") && atoi(getenv("EB_RIGHT_LANES_EARLY")) == 4 ? 4 : 1; // the early walk of a small call set
-    auto kern_right = p.mode == 2 ? (early_lanes == 4 ? k_right<true, 4> : k_right<true, 1>) : (early_lanes == 4 ? k_right<false, 4> : k_right<false, 1>);
     // The scan hands its survivors over in BWT-ordered batches (ScanParams.ordered) unless a batch overflows, which it
     // reports (ScanCounters.spilled): that scan is then run again the unordered way, into one list that position buckets put
     // in order.  EB_SCAN_ORDERED=0: always the unordered way.
@@ -1779,18 +1759,14 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
     // itself starts only after job i's context kernels (they would just slow each other down: same memory system).
     // (measured again in round 2 with the serialised context kernels: letting the scan start under the previous job's
     // right-context walk or under both context kernels: 4.41 / 4.37 ms per step against 3.89)
-    // A SMALL call set (a rank's share of a multi-GPU job) is different: its context kernels are short chains of dependent
-    // loads that leave the memory system room, and the scan -> counters on the host -> ordering kernels -> lists chain
-    // of the next job is mostly waiting; there the next scan starts at once (EB_SCAN_AFTER_CONTEXTS=1: always wait).
-    static const bool always_wait = getenv("EB_SCAN_AFTER_CONTEXTS") && atoi(getenv("EB_SCAN_AFTER_CONTEXTS")) == 1;
-    if (always_wait || (!ctx->last_small && !overlap_wgs)) {
+    if (!overlap_wgs) {
         EB_HIP(hipStreamWaitEvent(sA, ctx->last_ext, 0));
         EB_HIP(hipStreamWaitEvent(sA, ctx->last_right, 0));
     }
     EB_HIP(hipEventRecord(ev_begin, sA));
     for (int k = 0; k < S; ++k) {
         SubShard& x = sh[(size_t)k];
-        for (DevMem* m : {&x.cnt, &x.part, &x.surv, &x.sorted, &x.bcnt, &x.boff, &x.tmp, &x.nch, &x.choff, &x.chains, &x.recs, &x.crec, &x.left, &x.right, &x.blob, &x.rt_rec, &x.rt_right, &x.slots, &x.bcount})
+        for (DevMem* m : {&x.cnt, &x.part, &x.surv, &x.sorted, &x.bcnt, &x.boff, &x.tmp, &x.nch, &x.choff, &x.chains, &x.recs, &x.crec, &x.left, &x.right, &x.blob, &x.slots, &x.bcount})
             m->device = b1->device;
         for (int i = 0; i < E_PER_SHARD; ++i) x.e[i] = job->events[2 + (size_t)E_PER_SHARD * (size_t)k + (size_t)i];
         x.h_cnt = reinterpret_cast<ScanCounters*>(reinterpret_cast<uint8_t*>(job->h_bad) + 512 + (size_t)k * (sizeof(ScanCounters) + 64));
@@ -1820,7 +1796,7 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
     bt.at("pending-out");
     ScanCounters c;
     memset(&c, 0, sizeof c);
-    bool small = true, defer = true; // small: every sub-shard walks early; defer: every sub-shard's call set is a small one
+    bool defer = true; // every sub-shard's call set is a small one
     for (int k = 0; k < S; ++k) {
         SubShard& x = sh[(size_t)k];
         if (S == 1) x.h_last = reinterpret_cast<uint32_t*>(job->h_bad + 40); // the job's own pinned words: a held-back tail reads them later
@@ -1903,26 +1879,7 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
                            x.sorted.as<Survivor>());
         hipLaunchKernelGGL(k_bucket_fix, dim3(grid_of(n_buckets)), dim3(256), 0, sP, d_boff, n_buckets, x.sorted.as<Survivor>());
         }
-        // The right-context walk needs nothing else.  Rounds 1-2 started it NOW for a small call set (a rank's slice of a multi-GPU
-        // job), one lane per cluster into temporaries, under the rest of the preparation and the host round trip (per step then:
-        // 0.78 -> 0.69 ms at 98 k clusters, 1.32 -> 1.24 at 197 k, 2.30 -> 2.16 at 395 k, no difference at 793 k).  Round 3 measured
-        // it again with what the late walk has gained since -- a quad per cluster, straight into the image, the next scan beside it
-        // at 4 workgroups per CU: a rank's share of 1/2, 1/4, 1/8, 1/16 takes 1.79 / 0.93 / 0.57 / 0.40 ms per pass with the early walk
-        // and 1.60 / 0.86 / 0.48 / 0.32 without (profiles/r03_rank_share_rehearsal.txt).  Off by default (right_early_max = 0).
-        x.right_early = x.ns_raw <= right_early_max;
-        small = small && x.right_early;
         defer = defer && x.ns_raw <= small_set_max;
-        const unsigned right_grid = grid_of(x.ns_raw * (uint64_t)early_lanes);
-        if (x.right_early) {
-            if ((rc = x.rt_rec.alloc(x.ns_raw * sizeof(eb_cluster))) != EB_OK || (rc = x.rt_right.alloc(x.ns_raw * (size_t)rw * 8)) != EB_OK) return rc;
-            EB_HIP(hipEventRecord(x.e[E_SORTED], sP));
-            EB_HIP(hipStreamWaitEvent(sC, x.e[E_SORTED], 0));
-            EB_HIP(hipEventRecord(x.e[E_RIGHT0], sC));
-            EB_HIP(hipMemsetAsync(x.rt_right.p, 0, x.ns_raw * (size_t)rw * 8, sC));
-            hipLaunchKernelGGL(kern_right, dim3(right_grid), dim3(256), 0, sC, x1, x2, df, p, x.sorted.as<Survivor>(), d_boff + n_buckets,
-                               (const uint32_t*)nullptr, 0u, x.rt_rec.as<eb_cluster>(), x.rt_right.as<uint64_t>(), rw, x.cnt.as<ScanCounters>()->req_right,
-                               (const eb_chain*)nullptr);
-        }
         if (!x.ordered) hipLaunchKernelGGL(k_surv_chains, dim3(grid_of(x.ns_raw)), dim3(256), 0, sP, x.sorted.as<Survivor>(), d_boff + n_buckets, x.ns_raw, x.nch.as<uint32_t>());
         // dense chain list: exclusive scan of the per-cluster chain counts
         EB_HIP(hipcub::DeviceScan::ExclusiveSum(x.tmp.p, tmp_bytes, x.nch.as<uint32_t>(), x.choff.as<uint32_t>(), (int)x.ns_raw, sP));
@@ -1934,11 +1891,10 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
     }
     bt.at("ordering-enqueued");
     job->c = c;
-    ctx->last_small = small;
     // Last part: the call set's image, the chain list, the context kernels and the hand-over.  It needs the ordering
     // step's counts on the host.  A pipelining caller (EB_SCAN_PIPELINED, one shard, small call set) gets the job back
     // now; the part goes out with the next _begin on this index, or when the job is waited for / ended.
-    if ((options & EB_SCAN_PIPELINED) && S == 1 && (small || defer)) {
+    if ((options & EB_SCAN_PIPELINED) && S == 1 && defer) {
         std::lock_guard<std::mutex> lk(ctx->half_mu);
         job->half = true;
         ctx->half_job = job;

@@ -10,7 +10,7 @@ src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 # the summary goes next to them, under gpurun_out/, and is copied to profiles/ by hand
 dst_dir = sys.argv[2] if len(sys.argv) > 2 else os.path.join(root, "profiles")
 KERNELS = {"k_scan<1>": r"k_scan<1",   # k_scan<1, false> / <1, true> since round 3 (second parameter: tile loads one tile ahead)
-            "k_extend": r"k_extend", "k_right": r"k_right", "k_nodes<1>": r"k_nodes<1>", "k_nodes1p": r"k_nodes1p",
+            "k_extend": r"k_extend", "k_right": r"k_right", "k_nodes1c": r"k_nodes1c", "k_nodes1p": r"k_nodes1p", "k_leaves1c": r"k_leaves1c",
            "k_leaves<1>": r"k_leaves<1>", "k_rank4_batch": r"k_rank4_batch", "k_long_runs": r"k_long_runs"}
 
 

@@ -273,16 +273,14 @@ NAV_MODES = {
     # one byte per position with plain stores (needs n spare bytes of HBM), or bit words with atomicOr when memory is short
     "classic_bytes": {"EB_NAV_COMPLEMENT": "0", "EB_NAV_BYTES": "1"},
     "classic_words": {"EB_NAV_COMPLEMENT": "0", "EB_NAV_BYTES": "0"},
-    # the round-2 node kernels (record load, wait, block loads, wait, compute) instead of the software-pipelined ones of round 3,
-    # and the drain's planner read back after every launch instead of once per group of eight
-    "round2_node_kernels": {"EB_NAV_PIPELINED": "0"},
+    # the drain's planner read back after every launch instead of once per group of eight
     # the round-3 one-BWT node kernel (every node through the stack) instead of the chain-following one of round 4; and the
     # chain-following walk thrown away as if a launch had overflowed its stack (the caller then walks again the round-3 way)
     "round3_node_kernel": {"EB_NAV_CHAINS": "0"},
     "chains_overflow_walks_again": {"EB_NAV_CHAINS": "2"},
     "chains_classic_words": {"EB_NAV_COMPLEMENT": "0", "EB_NAV_BYTES": "0", "EB_NAV_GROUP": "2"},
     "one_launch_per_readback": {"EB_NAV_GROUP": "1"},
-    "classic_words_round2_kernels": {"EB_NAV_COMPLEMENT": "0", "EB_NAV_BYTES": "0", "EB_NAV_PIPELINED": "0", "EB_NAV_GROUP": "3"},
+    "classic_words_round3_kernels": {"EB_NAV_COMPLEMENT": "0", "EB_NAV_BYTES": "0", "EB_NAV_CHAINS": "0", "EB_NAV_GROUP": "3"},
 }
 
 
@@ -319,10 +317,10 @@ def test_flags_batch_size_does_not_change_result(oracle, monkeypatch):
     e = golden_bytes("dip.ebwt")
     g = api.DnaBwt(e)
     ref = api.Flags.build(g, None, 16, 30).export()
-    for batch, mode in (("64", "complement"), ("1000", "classic_bytes"), ("777", "classic_words"), ("300", "complement_one_stream"), ("200", "round2_node_kernels"),
+    for batch, mode in (("64", "complement"), ("1000", "classic_bytes"), ("777", "classic_words"), ("300", "complement_one_stream"), ("200", "classic_words_round3_kernels"),
                         ("130", "one_launch_per_readback"), ("64", "round3_node_kernel"), ("17", "complement")):
         monkeypatch.setenv("EB_NAV_BATCH", batch)                 # tiny batches: many launches, depth-first order
-        for k in ("EB_NAV_COMPLEMENT", "EB_NAV_BYTES", "EB_NAV_CONCURRENT", "EB_NAV_PIPELINED", "EB_NAV_GROUP", "EB_NAV_CHAINS"):
+        for k in ("EB_NAV_COMPLEMENT", "EB_NAV_BYTES", "EB_NAV_CONCURRENT", "EB_NAV_GROUP", "EB_NAV_CHAINS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in NAV_MODES[mode].items():
             monkeypatch.setenv(k, v)
@@ -432,18 +430,15 @@ def test_snp_byte_identical_to_reference(case):
 
 @pytest.mark.parametrize("case", [c for c in CASES if c["name"] in ("m1_default", "m1_edge_m2", "m2_het_default", "m2_edge_default",
                                                                       "m3_het_default", "m3_edge_default")], ids=lambda c: c["name"])
-@pytest.mark.parametrize("early_max,psi", [(None, "0"), ("524288", "0"), ("0", "0"), (None, "1"), ("524288", "1"), ("0", "1")],
-                         ids=["walks_late_every_cluster", "walks_early", "walks_late_gated", "fl_table_every_cluster", "fl_table_walks_early", "fl_table_gated"])
-def test_cluster_records_match_oracle(oracle, monkeypatch, case, early_max, psi):
+@pytest.mark.parametrize("gated,psi", [(False, "0"), (True, "0"), (False, "1"), (True, "1")],
+                         ids=["walks_every_cluster", "walks_gated", "fl_table_every_cluster", "fl_table_gated"])
+def test_cluster_records_match_oracle(oracle, monkeypatch, case, gated, psi):
     """Record-level parity of phase 4 (clusters, supports, contexts, counters), whole range and sharded -- with the right-context
-    walk behind the extension for every cluster (small call sets, the default since round 3), launched early into temporaries
-    (the small call sets of rounds 1-2, EB_RIGHT_EARLY_MAX) and behind the extension for the clusters that can print only (large
-    call sets; forced on these small ones by EB_RIGHT_GATE_MIN=0) -- each through the directory select (EB_PSI=0) and through the
-    FL table of repeatedly scanned indexes (round 4, EB_PSI=1: built with the first job instead of the third)."""
+    walk for every cluster (small call sets) and for the clusters that can print only (large call sets; forced on these small
+    ones by EB_RIGHT_GATE_MIN=0: `gated`) -- each through the directory select (EB_PSI=0) and through the FL table of
+    repeatedly scanned indexes (round 4, EB_PSI=1: built with the first job instead of the third)."""
     monkeypatch.setenv("EB_PSI", psi)
-    if early_max is not None:
-        monkeypatch.setenv("EB_RIGHT_EARLY_MAX", early_max)
-    if early_max == "0":
+    if gated:
         monkeypatch.setenv("EB_RIGHT_GATE_MIN", "0")
     p, e1, e2, da = _flag_case(oracle, case)
     pp = api.make_params(case["args"])
@@ -460,7 +455,7 @@ def test_cluster_records_match_oracle(oracle, monkeypatch, case, early_max, psi)
         plain = []
         for b, e in zip(cuts[:-1], cuts[1:]):
             want = of.scan(p, b, e, capture=True)
-            if early_max == "0":
+            if gated:
                 # the path of large call sets: the walk runs behind the left-context extension and skips the clusters that
                 # cannot print (EB_RIGHT_SKIPPED); the golden .snp below shows that nothing the writer needs is missing
                 want = _oracle.apply_right_gate(want, p.k_left, p.k_right, case["mode"])
@@ -479,7 +474,7 @@ def test_cluster_records_match_oracle(oracle, monkeypatch, case, early_max, psi)
             t, cluster_nr, events = calls.format_snp(pp, case["mode"] != 1, cluster_nr, events)
             text += t
             plain.append(bytes(calls.blob()))
-            if early_max == "0" and len(calls):                   # the compact wire image carries the flag too
+            if gated and len(calls):                   # the compact wire image carries the flag too
                 job = api.scan_clusters_begin(g1, gf, pp, bwt2=g2, begin=b, end=e, device_only=True, wire=True)
                 job.wait()
                 ptr, length = job.device_wire()
@@ -492,7 +487,7 @@ def test_cluster_records_match_oracle(oracle, monkeypatch, case, early_max, psi)
         jobs = [api.scan_clusters_begin(g1, gf, pp, bwt2=g2, begin=b, end=e, pipelined=True) for b, e in zip(cuts[:-1], cuts[1:])]
         assert [bytes(j.finish().blob()) for j in jobs] == plain
     assert g1.psi()[0] == (psi == "1") and (g2 is None or g2.psi()[0] == (psi == "1"))
-    if early_max == "0" and case["name"] in ("m1_default", "m2_het_default", "m3_het_default"):
+    if gated and case["name"] in ("m1_default", "m2_het_default", "m3_het_default"):
         assert skipped > 0                                           # the gate is exercised, not just present
 
 
@@ -790,7 +785,7 @@ def test_pipelined_jobs_hold_back_their_last_part(dip):
 @pytest.mark.parametrize("subshards", ["2", "3", "7"])
 def test_sub_shards_give_the_same_call_set(oracle, monkeypatch, case, subshards):
     """EB_SCAN_SUBSHARDS (experiments knob of the phase-4 driver): a range cut into sub-shards inside one call gives the
-    records, counters and .snp of the uncut call -- whole range and an odd slice, early and late context walks."""
+    records, counters and .snp of the uncut call -- whole range and an odd slice, ungated and gated context walks."""
     p, e1, e2, da = _flag_case(oracle, case)
     pp = api.make_params(case["args"])
     g1 = api.DnaBwt(e1, term=p.term)
@@ -799,10 +794,8 @@ def test_sub_shards_give_the_same_call_set(oracle, monkeypatch, case, subshards)
     if da is not None:
         gf.set_da(da)
     n = g1.n + (g2.n if g2 is not None else 0)
-    for early in (None, "524288", "0"):         # the walk: late for every cluster (default), early (rounds 1-2), late and gated (large call sets)
-        if early is not None:
-            monkeypatch.setenv("EB_RIGHT_EARLY_MAX", early)
-        if early == "0":
+    for gated in (False, True):                 # the walk: for every cluster (small call sets), gated (large call sets)
+        if gated:
             monkeypatch.setenv("EB_RIGHT_GATE_MIN", "0")
         for b, e in ((0, n), (n // 5 + 3, n - n // 7)):
             monkeypatch.delenv("EB_SCAN_SUBSHARDS", raising=False)
@@ -814,7 +807,7 @@ def test_sub_shards_give_the_same_call_set(oracle, monkeypatch, case, subshards)
             a, c = plain.stats, cut.stats
             assert (a.runs_closed, a.clusters, a.bases_in_runs, a.survivors, a.chains, list(a.hist)) == \
                    (c.runs_closed, c.clusters, c.bases_in_runs, c.survivors, c.chains, list(c.hist))
-            if (b, e) == (0, n) and early is None:
+            if (b, e) == (0, n) and not gated:
                 assert cut.format_snp(pp, case["mode"] != 1)[0] == golden_bytes(case["snp"])
 
 
