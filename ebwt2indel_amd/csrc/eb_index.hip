@@ -294,7 +294,7 @@ __global__ void __launch_bounds__(256) k_build_psi(eb_dev_index x, uint4* __rest
                 bitmap |= 1u << (k - 1);
                 // (the jumps are kept in a register array indexed by compile-time constants only: nj-th slot by a select chain)
 #pragma unroll
-                for (uint32_t t = 0; t < 15; ++t) if (t == nj) jump[t] = (uint32_t)skipped;
+                for (uint32_t slot = 0; slot < 15; ++slot) if (slot == nj) jump[slot] = (uint32_t)skipped;
                 ++nj;
                 widest = skipped > widest ? (uint32_t)skipped : widest;
             }
