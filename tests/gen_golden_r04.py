@@ -11,6 +11,7 @@ script's own cases):
   deep      80x coverage: clusters longer than the 64..128 rows the scan keeps in registers (the memory path of long runs)
   short     35-base reads with -L 31 -R 30: most left contexts run into a read start before they reach k_left
   uneq      mode 2 / 3 with the second collection three times the first (and the other way round)
+  options   K above k_right, -m 1, contexts of three words (-L 70 -R 66), -k 5
 
 Usage:  python tests/gen_golden_r04.py
 """
@@ -118,6 +119,18 @@ def main():
     add_case("m2_uneq_large_small", 2, {"bwt1": ("uneq_b.ebwt", b), "bwt2": ("uneq_a.ebwt", a)}, [])
     m, da = sim.build_merged_ebwt(u0, u1)
     add_case("m3_uneq", 3, {"bwt1": ("uneq_m.ebwt", m.tobytes()), "da": ("uneq_m.da", da.tobytes())}, [])
+
+    # ---- option corners on the round-1 diploid sample (its input file is in the tree already): K above k_right, coverage threshold 1,
+    # contexts of three 64-bit words, a K so small that clusters run over hundreds of rows
+    import gzip
+    with gzip.open(os.path.join(GOLD, "dip.ebwt.gz"), "rb") as f:
+        dip = f.read()
+    fd = {"bwt1": ("dip.ebwt", dip)}
+    add_case("m1_k32_R20", 1, fd, ["-k", "32", "-R", "20"])
+    add_case("m1_m1", 1, fd, ["-m", "1"])
+    add_case("m1_L70_R66", 1, fd, ["-L", "70", "-R", "66"])
+    add_case("m1_k5", 1, fd, ["-k", "5"])
+    add_case("m1_err_m1_q1", 1, f1, ["-m", "1", "-q", "1"])
 
     man["cases"] += cases
     man["generator"] = "tests/gen_golden.py; cases marked with \"generator\": tests/gen_golden_r04.py"
