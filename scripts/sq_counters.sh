@@ -20,7 +20,7 @@ for path in glob.glob(os.path.join(out, "g*", "**", "*counter_collection.csv"), 
     with open(path, newline="") as f:
         for row in csv.DictReader(f):
             name = row.get("Kernel_Name", "")
-            for key in ("k_scan<1", "k_extend", "k_right<", "k_nodes1p", "k_leaves<1"):
+            for key in ("k_scan<1", "k_extend", "k_right<false, 1", "k_right<false, 4", "k_nodes1c", "k_nodes1p", "k_leaves1c", "k_leaves<1"):
                 if key in name:
                     acc[key][row["Counter_Name"]].append(float(row["Counter_Value"]))
 with open(os.path.join(out, "sq_summary.txt"), "w") as f:
