@@ -3,7 +3,8 @@
 
 One step = one full pass of the cluster scan + left/right context extraction over the whole BWT
 (all ranks together: the BWT and flag vectors are replicated per GPU, the scan range is partitioned,
-the emitted cluster records are gathered to rank 0 over RCCL).  Inputs are resident in HBM before
+the emitted cluster records of every rank are delivered to rank 0's host memory -- each rank's share over
+its own PCIe link into a host arena; EB_BENCH_GATHER=rccl: the RCCL gather over xGMI of rounds 2-4).  Inputs are resident in HBM before
 the timed region.  Prints ONE JSON line on rank 0 (contract in the task statement), with
   roofline      dominant kernel of the step (k_scan): 0.75 algorithmic bytes per BWT position
                 (3-bit symbol + 2 LCP-threshold bits + 1 LCP-minimum bit) vs 8 TB/s HBM,
@@ -230,17 +231,44 @@ def main():
     # (eb_scan_clusters_begin) ahead of the one whose records are waited for / gathered, so the PCIe download and the
     # RCCL gather of step i overlap the kernels of the steps behind it.  Exactly `steps` passes start and finish between
     # the two barriers.
-    # With RCCL the call set never visits a non-root host: each rank's device image goes GPU -> GPU over xGMI and rank 0
-    # downloads once.  (gloo rehearsal / single GPU: records are downloaded by the library into page-locked memory.)
-    device_gather = use_dist and comm_dev.type == "cuda" and os.environ.get("EB_BENCH_HOST_GATHER", "0") != "1"
+    # How the ranks' records reach rank 0's host memory (N > 1, or one rank with EB_BENCH_FORCE_DIST=1):
+    #   arena (default, round 5): every rank downloads its own compact wire image over its OWN PCIe link into its slot of a
+    #         host arena all ranks of the node map (ebd.NodeArena); rank 0 reads the slots.  No collective on the data path.
+    #   rccl  (EB_BENCH_GATHER=rccl; rounds 2-4): sizes by all_gather, images GPU -> GPU over xGMI to rank 0, which downloads
+    #         all of them over its one link (35 MB per step at N = 8: longer than a rank's kernels).
+    #   host  (EB_BENCH_GATHER=host, and gloo without GPUs of their own): every rank downloads its call set, gather of the blobs.
+    gather_mode = os.environ.get("EB_BENCH_GATHER", "arena") if use_dist else "none"
+    if os.environ.get("EB_BENCH_HOST_GATHER", "0") == "1":
+        gather_mode = "host"
+    if gather_mode == "rccl" and comm_dev.type != "cuda":
+        gather_mode = "host"
+    device_gather = gather_mode == "rccl"
+    arena_mode = gather_mode == "arena"
+    on_device = device_gather or arena_mode          # the call set stays in HBM, the job packs its wire image
 
     def begin_step():
-        return api.scan_clusters_begin(bwt, flags, p, begin=begin, end=end, device_only=device_gather, wire=device_gather, pipelined=not args.no_pipeline)
+        return api.scan_clusters_begin(bwt, flags, p, begin=begin, end=end, device_only=on_device, wire=on_device, pipelined=not args.no_pipeline)
+
+    arena = None
+    if arena_mode:
+        # the arena's slots are sized from one pass: twice the largest image over the ranks
+        j0 = begin_step()
+        j0.wait()
+        _, len0 = j0.device_wire()
+        j0.finish()
+        t = torch.tensor([len0], dtype=torch.int64, device=comm_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        arena = ebd.NodeArena(cap=2 * int(t.item()) + (1 << 20), depth=6)
 
     # collect(job) hands the job's records over and may leave the hand-over in flight; resolve() completes it.
     wait_us = []
 
     def collect(job):
+        if arena_mode:
+            t0 = time.perf_counter()
+            arena.publish_job(job)               # waits for the job's last kernel, then one DMA over this rank's link
+            wait_us.append((time.perf_counter() - t0) * 1e6)
+            return job
         if device_gather:
             t0 = time.perf_counter()
             job.wait()
@@ -254,6 +282,12 @@ def main():
     gathered_events = []   # device_gather: one event per step, "all ranks' images resident in rank 0's HBM"
 
     def resolve(pending):
+        if arena_mode:
+            parts = None
+            if rank == 0:
+                parts = arena.collect()          # every rank's image of this step is in host memory
+                arena.release()                  # (nothing reads them before the next slot of that rank is written: the writer below runs after the last step)
+            return pending.finish(), parts
         if device_gather:
             parts = pending.result()                                     # rank 0: records of all ranks in page-locked host memory
             if pending.gathered is not None:
@@ -283,11 +317,12 @@ def main():
                 done(collect(begin_step()))
             return last
         # A caller with a queue of work runs the two halves of a pass on two host threads: this one begins passes
-        # (eb_scan_clusters_begin: scan, ordering, context kernels; it waits twice for a few words from the device), the
-        # helper takes each begun pass, waits for its records and hands them over (PCIe download, or size exchange + RCCL
-        # gather + rank 0's download) and resolves the previous pass's hand-over.  At most five passes are in flight (one just begun and held here, one being handed over, one awaiting its resolution, two of slack).  The
-        # device work of consecutive passes overlaps as the library orders it (eb_scan.hip); the hand-over of pass i runs under
-        # the kernels of the passes behind it.  Exactly k passes start and finish inside this call.
+        # (eb_scan_clusters_begin enqueues the whole pass -- scan, ordering, context kernels, wire image -- without waiting for the
+        # device), the helper takes each begun pass, waits for its records and hands them over (PCIe download into the host
+        # arena / the library's page-locked blob, or size exchange + RCCL gather + rank 0's download) and resolves the previous
+        # pass's hand-over.  At most five passes are in flight (one being begun, one being handed over, one awaiting its
+        # resolution, two of slack).  The device work of consecutive passes overlaps as the library orders it (eb_scan_job.cpp);
+        # the hand-over of pass i runs under the kernels of the passes behind it.  Exactly k passes start and finish inside this call.
         import queue
         import threading
         sys.setswitchinterval(2e-5)   # the two threads hand the interpreter lock over within microseconds, not CPython's default 5 ms
@@ -335,17 +370,11 @@ def main():
         th = threading.Thread(target=helper, name="hand-over")
         th.start()
         try:
-            newest = None                       # handed to the helper once the NEXT pass is begun: that sends its last part out
             for _ in range(k):
                 in_flight.acquire()
                 if failure:
                     break
-                job = (begin_t if trace else begin_step)()
-                if newest is not None:
-                    begun_q.put(newest)
-                newest = job
-            if newest is not None:
-                begun_q.put(newest)
+                begun_q.put((begin_t if trace else begin_step)())
         finally:
             begun_q.put(None)
             th.join()
@@ -373,11 +402,15 @@ def main():
     # it by itself with the third job on an index -- a one-shot run of the tool never pays for it -- so the first two passes below run
     # without it and are reported as such; then it is built here, timed.  It is part of the resident index the timed region runs on,
     # like the select directory and the scan planes.  EB_PSI=0: no table (the round-3 walk).
-    fl_table = None
+    fl_table = one_shot = None
     if rank == 0 or use_dist:
-        st0 = None
-        for _ in range(2):
-            st0 = api.scan_clusters(bwt, flags, p, begin=begin, end=end).stats
+        # the FIRST pass on the index, as a one-shot run of the tool gets it: scan planes built, buffers allocated, blob pinned
+        t1 = time.perf_counter()
+        c_first = api.scan_clusters(bwt, flags, p, begin=begin, end=end)
+        one_shot_ms = (time.perf_counter() - t1) * 1e3
+        st_first = c_first.stats
+        del c_first
+        st0 = api.scan_clusters(bwt, flags, p, begin=begin, end=end).stats
         # the same pipelined steps WITHOUT the table (a short timed region of its own, before the table exists; EB_PSI=0 keeps the
         # library from building it with the third job): what the step costs a caller whose index does not get one -- too large for
         # the spare HBM, or scanned once -- and the figure to compare with rounds 1-3
@@ -385,6 +418,7 @@ def main():
         if os.environ.get("EB_PSI") != "0" and not args.no_pipeline:
             psi_env = os.environ.get("EB_PSI")
             os.environ["EB_PSI"] = "0"
+            api.config_reload()                  # (the library reads its switches once)
             try:
                 run_steps(3)
                 sync()
@@ -397,6 +431,7 @@ def main():
                     del os.environ["EB_PSI"]
                 else:
                     os.environ["EB_PSI"] = psi_env
+                api.config_reload()
             gathered_events.clear()
         before = {"scan_ms": round(st0.ms_scan / max(1, int(st0.scan_launches)), 4), "extend_ms": round(st0.ms_extend, 4), "right_ms": round(st0.ms_right, 4),
                   "context_span_ms": round(st0.ms_context, 4), "requests_right": int(st0.requests_right), "pass_ms_first_launch_to_records_on_host": round(st0.ms_total, 4),
@@ -409,6 +444,10 @@ def main():
                 log(f"[bench] FL table not built: {e}")
         t_psi = time.perf_counter() - t1
         have, psi_bytes, psi_void = bwt.psi()
+        one_shot = {"ms": round(one_shot_ms, 3), "device_ms_first_launch_to_records_on_host": round(st_first.ms_total, 4), "scan_ms": round(st_first.ms_scan, 4),
+                    "extend_ms": round(st_first.ms_extend, 4), "right_ms": round(st_first.ms_right, 4), "scan_reruns": int(st_first.scan_reruns),
+                    "what": "the FIRST phase-4 pass on the index, wall clock of the call: what a one-shot run of the tool pays -- scan planes built if the traversal "
+                            "has not left them behind, device temporaries and the page-locked blob allocated, no FL table"}
         fl_table = {"present": have, "bytes": int(psi_bytes), "void_chunks": int(psi_void), "build_ms": round(t_psi * 1e3, 2) if have else None,
                     "pass_before_it": before,
                     "ms_per_step_without_it": round(ms_without, 4) if ms_without is not None else None,
@@ -441,6 +480,8 @@ def main():
     calls, parts = run_steps(args.steps, record)
     sync()
     elapsed = time.perf_counter() - t0
+    if arena_mode and parts is not None:
+        parts = [bytes(v) for v in parts]    # (views into the arena)
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -706,6 +747,9 @@ def main():
     # FL table, or 64 bytes (directory line / block) without it
     right_bytes = 16 if (fl_table and fl_table["present"]) else 64
     ctx_bytes = float(np.mean(req_ext)) * 64 + float(np.mean(req_right)) * right_bytes
+    if fl_table and fl_table.get("present") and fl_table.get("ms_per_step_without_it") and fl_table["ms_per_step_without_it"] > ms_per_step:
+        fl_table["break_even_passes"] = round(fl_table["build_ms"] / (fl_table["ms_per_step_without_it"] - ms_per_step), 1)
+        fl_table["break_even_note"] = "passes after which building the table has paid for itself: build_ms / (ms_per_step_without_it - ms_per_step)"
     if rank == 0:
         line = {
             **({"rehearsal": f"ONE rank's share of a {args.rehearse_rank_of}-GPU run on one GPU (positions [{begin}, {end}), collectives with a single rank): "
@@ -721,7 +765,9 @@ def main():
             "config": {"workload": workload, "mode": 1, "options": "-L31 -R30 -k16 -g10 -v2 -m3 -c20 -q0",
                        # every path-selecting switch of the library / this script that is set in the environment (none: the defaults ran)
                        "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith(("EB_", "EBGEN_")) or k in ("GPU_MAX_HW_QUEUES", "HSA_ENABLE_IPC_MODE_LEGACY")},
-                       "parallelism": f"scan range split over {world} GPU(s), BWT+flags replicated, gather of cluster records to rank 0; " + ("steps back to back" if args.no_pipeline else "steps pipelined (one host thread begins passes, a second hands their records over; at most five in flight)")},
+                       "records_to_rank0": {"none": "one rank: the library downloads the call set into page-locked host memory", "arena": "every rank downloads its own compact wire image over its own PCIe link into a host arena all ranks map; rank 0 reads the slots",
+                                            "rccl": "sizes by all_gather, wire images GPU -> GPU over xGMI (RCCL gather), rank 0 downloads all of them", "host": "every rank downloads its call set; gather of the blobs"}[gather_mode],
+                       "parallelism": f"scan range split over {world} GPU(s), BWT+flags replicated, cluster records of all ranks delivered to rank 0's host memory; " + ("steps back to back" if args.no_pipeline else "steps pipelined (one host thread begins passes, a second hands their records over; at most five in flight)")},
             "roofline": {"bound": "hbm", "achieved": round(scan_gbs, 2), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(scan_gbs / 8000.0, 5), "traffic": traffic, "kernel": "k_scan",
                          "avg_launch_ms": round(scan_avg_ms, 4), "launches_per_step": scan_launches, "positions_per_launch": int(positions_per_launch),
@@ -753,6 +799,7 @@ def main():
                                                "frac": round(ctx_bytes / (alone["context_span_ms"] * 1e-3) / 1e9 / 8000.0, 5),
                                                "requests_per_s": round((np.mean(req_ext) + np.mean(req_right)) / (alone["context_span_ms"] * 1e-3), 1)}} if alone else {})},
             "rank_roofline": rank_info,
+            "one_shot": one_shot,
             "fl_table": fl_table,
             "cpu_baseline": cpu,
             "phase4_device_ms": {"scan": round(scan_sum_ms, 4), "extend": round(float(np.mean(ext_ms)), 4),
@@ -773,6 +820,8 @@ def main():
         }
         line.update(out)
         print(json.dumps(line), flush=True)
+    if arena is not None:
+        arena.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

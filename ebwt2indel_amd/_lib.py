@@ -47,7 +47,7 @@ class Chain(C.Structure):
 class ScanStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("begin", "end", "runs_closed", "clusters", "bases_in_runs", "survivors", "chains")] + \
                [("hist", C.c_uint64 * 201)] + [(n, C.c_float) for n in ("ms_scan", "ms_extend", "ms_right", "ms_total")] + \
-               [("scan_launches", C.c_uint32), ("ms_context", C.c_float), ("requests_extend", C.c_uint64), ("requests_right", C.c_uint64), ("scan_reruns", C.c_uint32), ("reserved", C.c_uint32)]
+               [("scan_launches", C.c_uint32), ("ms_context", C.c_float), ("requests_extend", C.c_uint64), ("requests_right", C.c_uint64), ("scan_reruns", C.c_uint32), ("batch_tiles", C.c_uint32)]
 
 
 class CallsView(C.Structure):
@@ -63,9 +63,9 @@ ABI_SYMBOLS = [
     "eb_index_info", "eb_index_build_psi", "eb_index_has_psi", "eb_rank4_batch", "eb_access_batch", "eb_lf_range_batch", "eb_lf_range_sym_batch", "eb_fl_batch",
     "eb_lf_node_batch", "eb_rank4_batch_device", "eb_flags_build", "eb_nav_covers_every_slot_once", "eb_flags_build_shard", "eb_flags_device_vectors", "eb_flags_popcounts", "eb_flags_finalize", "eb_flags_set_da", "eb_flags_words", "eb_flags_has_da",
     "eb_flags_export", "eb_flags_import", "eb_flags_import_shard_sum", "eb_flags_destroy", "eb_scan_clusters", "eb_scan_clusters_begin", "eb_scan_clusters_end",
-    "eb_scan_clusters_cancel", "eb_scan_clusters_begin_ex", "eb_scan_job_wait", "eb_scan_job_device_blob", "eb_scan_job_device_wire", "eb_calls_get", "eb_calls_free",
+    "eb_scan_clusters_cancel", "eb_scan_clusters_begin_ex", "eb_scan_job_wait", "eb_scan_job_device_blob", "eb_scan_job_device_wire", "eb_scan_job_wire_to_host", "eb_host_register", "eb_host_unregister", "eb_calls_get", "eb_calls_free",
     "eb_calls_packed_size", "eb_calls_pack", "eb_calls_unpack", "eb_calls_blob", "eb_write_snp", "eb_format_snp", "eb_free",
-    "eb_selftest_pack_fields",
+    "eb_config_reload", "eb_selftest_pack_fields",
 ]
 
 
@@ -135,6 +135,11 @@ def load():
     L.eb_scan_job_wait.argtypes = [vp]
     L.eb_scan_job_device_blob.argtypes = [vp, P(vp), P(u64)]
     L.eb_scan_job_device_wire.argtypes = [vp, P(vp), P(u64)]
+    L.eb_scan_job_wire_to_host.argtypes = [vp, vp, u64, P(u64)]
+    L.eb_host_register.argtypes = [vp, u64]
+    L.eb_host_unregister.argtypes = [vp]
+    L.eb_config_reload.argtypes = []
+    L.eb_config_reload.restype = None
     L.eb_scan_clusters_cancel.argtypes = [vp]
     L.eb_scan_clusters_cancel.restype = None
     L.eb_calls_get.argtypes = [vp, P(CallsView)]

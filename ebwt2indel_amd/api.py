@@ -377,6 +377,19 @@ class ScanJob:
         return int(ptr.value or 0), int(ln.value)
 
 
+    def wire_to_host(self, dst_ptr: int, cap: int) -> int:
+        """Copies the compact wire image into the caller's host memory (page-locked for DMA speed) over this GPU's own PCIe
+        link (eb_scan_job_wire_to_host); returns its length."""
+        ln = C.c_uint64()
+        _check(lib().eb_scan_job_wire_to_host(self._h, C.c_void_p(dst_ptr), cap, C.byref(ln)))
+        return int(ln.value)
+
+
+def config_reload() -> None:
+    """The library reads its EB_* switches once, when it is loaded; call this after changing one inside the process."""
+    lib().eb_config_reload()
+
+
 SCAN_DEVICE_ONLY = 1
 SCAN_WIRE = 2
 SCAN_PIPELINED = 4
@@ -387,7 +400,7 @@ def scan_clusters_begin(bwt1: DnaBwt, flags: Flags, params: Params, bwt2: Option
     """Enqueue phase 4 and return at once; the record download overlaps whatever the caller launches next.
     device_only: keep the call set in HBM (ScanJob.device_blob) -- for ranks that forward it with RCCL;
     wire: the job also packs the compact wire image (ScanJob.device_wire) as its last step;
-    pipelined: the caller keeps jobs coming (EB_SCAN_PIPELINED): a small call set's last part goes out with the next begin."""
+    pipelined: the caller keeps jobs coming (EB_SCAN_PIPELINED): scans share the CUs with the previous job's context kernels."""
     n = bwt1.n + (bwt2.n if bwt2 is not None else 0)
     h = C.c_void_p()
     _check(lib().eb_scan_clusters_begin_ex(bwt1._h, bwt2._h if bwt2 is not None else None, flags._h, begin, n if end is None else end,

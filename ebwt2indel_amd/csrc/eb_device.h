@@ -447,6 +447,16 @@ __device__ __forceinline__ uint64_t eb_FL(const eb_dev_index& x, uint64_t i, int
 }
 
 __device__ __forceinline__ bool eb_bit(const uint64_t* b, uint64_t i) { return (b[i >> 6] >> (i & 63u)) & 1ull; }
+// ones in DA[0,p): row p of the merge of two BWTs is row eb_da_rank(p) of the second or p - eb_da_rank(p) of the first
+// (ebwt2InDel.cpp:1431-1432); da_rank[] holds the ones before every 512 positions
+__device__ __forceinline__ uint64_t eb_da_rank(const eb_dev_flags& f, uint64_t p) {
+    uint64_t g = p >> 9, w = p >> 6;
+    uint64_t s = f.da_rank[g];
+    for (uint64_t k = g << 3; k < w; ++k) s += (uint64_t)__popcll(f.da[k]);
+    uint32_t o = (uint32_t)(p & 63u);
+    if (o) s += (uint64_t)__popcll(f.da[w] & ((1ull << o) - 1ull));
+    return s;
+}
 __device__ __forceinline__ void eb_bit_set_atomic(uint64_t* b, uint64_t i) {
     atomicOr(reinterpret_cast<unsigned long long*>(b + (i >> 6)), 1ull << (i & 63u));
 }

@@ -9,6 +9,9 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <condition_variable>
+
+#include "eb_config.h"
 #include "eb_internal.h"
 
 // ------------------------------------------------------------------ errors / params
@@ -89,7 +92,7 @@ void* eb_scratch_get(int device, size_t bytes, size_t* capacity) {
         eb_scratch_release(device); // give cached blocks back and retry once
         if (hipMalloc(&p, cap) != hipSuccess) return nullptr;
     }
-    if (getenv("EB_ALLOC_TRACE")) fprintf(stderr, "[scratch] hipMalloc of %.1f MB (no cached block fits)\n", cap / 1e6);
+    if (eb_cfg().trace_alloc) fprintf(stderr, "[scratch] hipMalloc of %.1f MB (no cached block fits)\n", cap / 1e6);
     *capacity = cap;
     return p;
 }
@@ -339,21 +342,25 @@ extern "C" int eb_index_build_psi(eb_index* h) {
     // leave room for what phase 4 itself allocates (call-set images, scratch): the table may take at most half of what is free
     if (bytes > free_b / 2) { eb_set_error("FL table of %zu bytes refused: %zu bytes of HBM free", bytes, free_b); return EB_ERR_NOMEM; }
     uint4* d = nullptr;
-    unsigned long long* d_void = nullptr;
     hipError_t e = hipMalloc(&d, bytes);
-    if (e == hipSuccess) e = hipMalloc(&d_void, sizeof(unsigned long long));
-    if (e != hipSuccess) { if (d) (void)hipFree(d); eb_set_error("FL table allocation failed (%zu bytes): %s", bytes, hipGetErrorString(e)); return EB_ERR_NOMEM; }
-    EB_HIP(hipMemsetAsync(d_void, 0, sizeof(unsigned long long), h->stream));
+    if (e != hipSuccess) { eb_set_error("FL table allocation failed (%zu bytes): %s", bytes, hipGetErrorString(e)); return EB_ERR_NOMEM; }
+    // (the counter of void chunks comes from the scratch cache: a hipFree would synchronise the device in the middle of a caller's pipeline)
+    size_t void_cap = 0;
+    unsigned long long* d_void = static_cast<unsigned long long*>(eb_scratch_get(h->device, sizeof(unsigned long long), &void_cap));
+    if (!d_void) { (void)hipFree(d); eb_set_error("FL table: no scratch memory"); return EB_ERR_NOMEM; }
     eb_dev_index x = h->dev();
     x.psi = nullptr; // (the kernel's own select goes through the directory)
     for (int c = 0; c < 4; ++c) x.psi_off[c] = off[c];
     const unsigned grid = (unsigned)((n_chunks + 255) / 256 < 65536u * 16u ? (n_chunks + 255) / 256 : 65536u * 16u);
-    hipLaunchKernelGGL(k_build_psi, dim3(grid), dim3(256), 0, h->stream, x, d, tot[0], tot[1], tot[2], tot[3], n_chunks, d_void);
     unsigned long long voids = 0;
-    e = hipMemcpyAsync(&voids, d_void, sizeof voids, hipMemcpyDeviceToHost, h->stream);
+    e = hipMemsetAsync(d_void, 0, sizeof(unsigned long long), h->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_build_psi, dim3(grid), dim3(256), 0, h->stream, x, d, tot[0], tot[1], tot[2], tot[3], n_chunks, d_void);
+        e = hipMemcpyAsync(&voids, d_void, sizeof voids, hipMemcpyDeviceToHost, h->stream);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e == hipSuccess) e = hipGetLastError();
-    (void)hipFree(d_void);
+    eb_scratch_put(h->device, d_void, void_cap);
     if (e != hipSuccess) { (void)hipFree(d); eb_set_error("FL table build failed: %s", hipGetErrorString(e)); return EB_ERR_DEVICE; }
     // a BWT in which a letter is absent from 64 rows in a row every few chunks gains nothing from the table: give the memory back
     if (voids > n_chunks / 4) { (void)hipFree(d); eb_set_error("FL table dropped: %llu of %llu chunks void (gaps of 64 rows or more)", voids, (unsigned long long)n_chunks); return EB_ERR_STATE; }
@@ -376,16 +383,22 @@ extern "C" int eb_index_has_psi(const eb_index* h, uint64_t* bytes, uint64_t* vo
     return h->d_psi != nullptr;
 }
 
-// Phase 4 calls this once per job begun on the index.  A caller that is on its third job will likely begin a fourth: the
-// table costs about as much as five passes of the walk it speeds up (and n bytes), so a one-shot run never builds it.
-// EB_PSI=0: never; EB_PSI=1: with the first job.
-void eb_index_note_phase4_job(eb_index* h) {
-    ++h->phase4_jobs;
+// Phase 4 calls this once per job begun on the index, with the number of positions the job scans.  The table costs about as much
+// as five whole-range passes of the walk it speeds up (and n bytes): it is built once the jobs on the index have scanned three
+// times its length -- the third pass of a caller that keeps scanning the whole range, the 24th job of a rank that scans an eighth
+// -- so a one-shot run never builds it.  EB_PSI=0: never; EB_PSI=1: with the first job.  A build that fails or is refused is not an
+// error of the job that triggered it: the thread's error text is left as it was.
+void eb_index_note_phase4_job(eb_index* h, uint64_t positions) {
+    h->phase4_positions += positions;
     if (h->d_psi || h->psi_tried) return;
-    const int mode = getenv("EB_PSI") ? atoi(getenv("EB_PSI")) : -1; // (read per job: tests switch it inside one process)
+    const int mode = eb_cfg().psi;
     if (mode == 0) return;
-    if (mode == 1 || h->phase4_jobs >= 3) {
-        if (eb_index_build_psi(h) != EB_OK && getenv("EB_ALLOC_TRACE")) fprintf(stderr, "[index] %s\n", eb_last_error());
+    if (mode == 1 || (h->n && h->phase4_positions / h->n >= 3)) {
+        const std::string saved = eb_last_error();
+        if (eb_index_build_psi(h) != EB_OK) {
+            if (eb_cfg().trace_alloc) fprintf(stderr, "[index] %s\n", eb_last_error());
+            eb_set_error("%s", saved.c_str());
+        }
     }
 }
 
@@ -471,12 +484,10 @@ static int finish_index(eb_index* h, unsigned long long* d_bad, const uint8_t* d
     }
     uint64_t n_tiles = (h->n_blocks + TILE_BLOCKS - 1) / TILE_BLOCKS;
     uint64_t* d_tiles = nullptr;
-    uint64_t* d_tmp = nullptr;
     EB_HIP(hipMalloc(&d_tiles, (n_tiles + 1) * 4 * sizeof(uint64_t)));
-    EB_HIP(hipMalloc(&d_tmp, eb_scan4_tmp_elems(n_tiles + 1) * 4 * sizeof(uint64_t)));
     EB_HIP(hipMemsetAsync(d_tiles, 0, (n_tiles + 1) * 4 * sizeof(uint64_t), h->stream));
     hipLaunchKernelGGL(k_tile_sums, dim3((unsigned)n_tiles), dim3(TILE_BLOCKS), 0, h->stream, h->d_chunks, h->n_blocks, d_tiles);
-    int rc = eb_scan4_exclusive(d_tiles, n_tiles + 1, d_tmp, h->stream); // element n_tiles becomes the grand total
+    int rc = eb_scan4_exclusive(d_tiles, n_tiles + 1, h->stream); // element n_tiles becomes the grand total
     if (rc != EB_OK) return rc;
     hipLaunchKernelGGL(k_write_counters, dim3((unsigned)n_tiles), dim3(TILE_BLOCKS), 0, h->stream, h->d_chunks, h->n_blocks,
                        d_tiles, h->d_super);
@@ -485,25 +496,22 @@ static int finish_index(eb_index* h, unsigned long long* d_bad, const uint8_t* d
     EB_HIP(hipStreamSynchronize(h->stream));
     EB_HIP(hipGetLastError());
     EB_HIP(hipFree(d_tiles));
-    EB_HIP(hipFree(d_tmp));
     // select directory (eb_select): samples beyond a letter's last occurrence point at the last block
     if (h->n_blocks > 0xFFFFFFFFull) { eb_set_error("BWT too large for the 32-bit select directory"); return EB_ERR_ARG; }
     // Sampling distance of the directory: the right-context walk reads one directory entry and then 1.24 (every 32nd occurrence)
     // or 1.52 (every 128th) blocks per FL step; the dense form costs n/8 instead of n/32 bytes, which the largest inputs
-    // (BASELINE configs[4]: 151 G symbols, 277 of 309 GB of HBM in use) cannot spare.  EB_SEL_SHIFT=5..10 overrides.
+    // (BASELINE configs[4]: 151 G symbols, 277 of 309 GB of HBM in use) cannot spare.  EB_SELECT=<5..10> overrides.
     h->sel_shift = h->n <= (1ull << 35) ? EB_SEL_SHIFT_DENSE : EB_SEL_SHIFT_SPARSE;
-    if (const char* e = getenv("EB_SEL_SHIFT")) { int v = atoi(e); if (v >= 5 && v <= 10) h->sel_shift = (uint32_t)v; }
+    if (eb_cfg().sel_shift) h->sel_shift = (uint32_t)eb_cfg().sel_shift;
     // bits of an entry the block index leaves free carry the sample's ordinal inside its block (at least three, else none)
     {
         uint32_t bb = 1;
         while (bb < 32u && (h->n_blocks >> bb) != 0) ++bb;
         h->sel_blk_bits = bb <= 29u ? (bb < 25u ? 25u : bb) : 32u;
-        // EB_SEL_BLK_BITS=32: plain entries (round 3's interpolation); 25..29: ordinals in coarser units than the index needs
+        // EB_SELECT=<shift>,32: plain entries (round 3's interpolation); 25..29: ordinals in coarser units than the index needs
         // (what a larger index would use: tests run the layouts of 2^32 .. 2^36 symbols on small inputs)
-        if (const char* e = getenv("EB_SEL_BLK_BITS")) {
-            const int v = atoi(e);
-            if (v == 32 || (v >= 25 && v <= 29 && (uint32_t)v >= bb)) h->sel_blk_bits = (uint32_t)v;
-        }
+        const int v = eb_cfg().sel_blk_bits;
+        if (v == 32 || (v >= 25 && v <= 29 && (uint32_t)v >= bb)) h->sel_blk_bits = (uint32_t)v;
     }
     uint64_t sel_entries = 0;
     for (int c = 0; c < 4; ++c) {
@@ -544,90 +552,173 @@ extern "C" int eb_index_create_from_device(const void* d_ascii, uint64_t n, uint
 }
 
 // ascii: the symbols in host memory, or NULL with fd >= 0: the symbols are the file's bytes (read with pread)
+static double idx_now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
+
+namespace {
+// Host threads that fill page-locked pieces from the input (pread of the file: page cache -> piece with no page faults of a
+// mapping in between; or memcpy from the caller's buffer).  They live for one index creation and take 4 MB chunks off a queue, so
+// that several pieces are being filled while the one before them is uploaded and packed (round 4 started and joined a set of
+// threads per piece and read one piece at a time: 0.20 s of reads for the 7.55 GB file, on the critical path, plus ~2000 thread
+// starts).
+struct PieceReaders {
+    struct Chunk { uint8_t* dst; uint64_t off, len; int piece; };
+    const uint8_t* src = nullptr; // host buffer, or null: read fd
+    int fd = -1;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::vector<Chunk> queue;
+    size_t head = 0;
+    std::vector<int> left;        // chunks still to be read, per piece
+    bool stop = false, io_error = false;
+    std::vector<std::thread> pool;
+    void start(unsigned threads, size_t n_pieces) {
+        left.assign(n_pieces, 0);
+        for (unsigned t = 0; t < threads; ++t) pool.emplace_back([this] { run(); });
+    }
+    void run() {
+        for (;;) {
+            Chunk c;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return stop || head < queue.size(); });
+                if (head >= queue.size()) return; // stop, nothing left
+                c = queue[head++];
+            }
+            bool ok = true;
+            if (src) memcpy(c.dst, src + c.off, c.len);
+            else
+                for (uint64_t got = 0; got < c.len;) {
+                    ssize_t r = pread(fd, c.dst + got, c.len - got, (off_t)(c.off + got));
+                    if (r <= 0) { ok = false; break; }
+                    got += (uint64_t)r;
+                }
+            std::lock_guard<std::mutex> lk(mu);
+            if (!ok) io_error = true;
+            if (--left[(size_t)c.piece] == 0) cv_done.notify_all();
+        }
+    }
+    void post(int piece, uint8_t* dst, uint64_t off, uint64_t len) {
+        const uint64_t CH = 4ull << 20;
+        std::lock_guard<std::mutex> lk(mu);
+        int k = 0;
+        for (uint64_t a = 0; a < len; a += CH, ++k) queue.push_back({dst + a, off + a, len - a < CH ? len - a : CH, piece});
+        left[(size_t)piece] = k;
+        cv_work.notify_all();
+    }
+    bool wait(int piece) { // false: read error
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return left[(size_t)piece] == 0; });
+        return !io_error;
+    }
+    ~PieceReaders() {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; head = queue.size(); }
+        cv_work.notify_all();
+        for (std::thread& t : pool) t.join();
+    }
+};
+}  // namespace
+
+// ascii: the symbols in host memory, or NULL with fd >= 0: the symbols are the file's bytes (read with pread)
 static int index_create_from(const uint8_t* ascii, int fd, uint64_t n, uint8_t term, int device, eb_index** out) {
     *out = nullptr;
-    eb_index* h = nullptr;
-    int rc = index_alloc(n, term, device, &h);
-    if (rc != EB_OK) return rc;
-    // Upload in pieces (multiple of 128 symbols) through staging buffers so that copies overlap packing.  Large inputs
-    // (a memory-mapped file, or any pageable buffer) are first copied into page-locked pieces by a few host threads:
-    // the runtime's own staging of pageable memory runs at ~16 GB/s, PCIe at ~50.
-    uint64_t pinned_min = 256ull << 20, piece_pinned = 64ull << 20; // EB_INDEX_PINNED_MIN / _PIECE: tests exercise the path on small inputs
-    if (const char* ev = getenv("EB_INDEX_PINNED_MIN")) pinned_min = strtoull(ev, nullptr, 10);
-    if (const char* ev = getenv("EB_INDEX_PINNED_PIECE")) piece_pinned = strtoull(ev, nullptr, 10) & ~127ull;
-    if (piece_pinned < 128) piece_pinned = 128;
-    const bool pinned_path = n >= pinned_min || !ascii;
-    const uint64_t PIECE = pinned_path ? piece_pinned : (256ull << 20);
-    const int SLOTS = pinned_path ? 3 : 2;
+    const EbConfig& cfg = eb_cfg();
+    const bool trace = cfg.trace_index;
+    const double tr0 = idx_now();
+    {
+        int ndev = eb_device_count();
+        if (ndev <= 0) { eb_set_error("no HIP device available: the ebwt2InDel hot path runs on the GPU only (no CPU fallback)"); return EB_ERR_DEVICE; }
+        if (device < 0 || device >= ndev) { eb_set_error("device %d out of range (have %d)", device, ndev); return EB_ERR_ARG; }
+        EB_HIP(hipSetDevice(device));
+    }
+    // Upload in pieces (multiple of 128 symbols) through staging buffers so that copies overlap packing.  Large inputs (a file, or
+    // any pageable buffer) are first copied into page-locked pieces by a few host threads: the runtime's own staging of pageable
+    // memory runs at ~16 GB/s, PCIe at ~50.  EB_INDEX_PINNED: tests exercise the path on small inputs.
+    const bool pinned_path = n >= cfg.pinned_min || !ascii;
+    const uint64_t PIECE = pinned_path ? cfg.pinned_piece : (256ull << 20);
+    const int SLOTS = 3;
+    const uint64_t stage_bytes = n < PIECE ? (n ? n : 1) : PIECE;
+    const size_t n_pieces = n ? (size_t)((n + PIECE - 1) / PIECE) : 1;
     uint8_t* d_stage[3] = {nullptr, nullptr, nullptr};
     uint8_t* h_stage[3] = {nullptr, nullptr, nullptr};
+    uint64_t h_cap[3] = {0, 0, 0};
+    size_t d_cap[3] = {0, 0, 0};
     hipEvent_t done[3] = {nullptr, nullptr, nullptr};
     unsigned long long* d_bad = nullptr;
-    unsigned long long init = ~0ull;
-    uint64_t stage_bytes = n < PIECE ? (n ? n : 1) : PIECE;
-    hipError_t e = hipMalloc(&d_bad, sizeof init);
-    for (int i = 0; i < SLOTS && e == hipSuccess; ++i) {
-        e = hipMalloc(&d_stage[i], stage_bytes);
-        if (e == hipSuccess && pinned_path) e = hipHostMalloc(reinterpret_cast<void**>(&h_stage[i]), stage_bytes, hipHostMallocDefault);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
-    }
-    auto release = [&]() {
+    eb_index* h = nullptr;
+    PieceReaders readers;
+    readers.src = ascii;
+    readers.fd = fd;
+    auto release = [&]() { // staging buffers go back to the library's pools (a second index -- two-BWT mode -- takes them from there)
         for (int i = 0; i < 3; ++i) {
-            if (d_stage[i]) (void)hipFree(d_stage[i]);
-            if (h_stage[i]) (void)hipHostFree(h_stage[i]);
+            if (d_stage[i]) eb_scratch_put(device, d_stage[i], d_cap[i]);
+            if (h_stage[i]) eb_pinned_put(h_stage[i], h_cap[i]);
             if (done[i]) (void)hipEventDestroy(done[i]);
         }
         if (d_bad) (void)hipFree(d_bad);
     };
+    auto piece_len = [&](size_t k) -> uint64_t { const uint64_t pos = (uint64_t)k * PIECE; return n - pos < PIECE ? n - pos : PIECE; };
+    // the readers start on the first pieces as soon as their page-locked buffers exist: the index's own allocation (a few GB of
+    // hipMalloc, tens of milliseconds) happens beside them
+    size_t posted = 0;
+    hipError_t e = hipSuccess;
+    if (pinned_path) {
+        readers.start(cfg.copy_threads, n_pieces);
+        for (int i = 0; i < SLOTS && (size_t)i < n_pieces && e == hipSuccess; ++i) {
+            h_stage[i] = static_cast<uint8_t*>(eb_pinned_get(stage_bytes, &h_cap[i]));
+            if (!h_stage[i]) { e = hipErrorOutOfMemory; break; }
+            if (n) readers.post((int)posted, h_stage[i], (uint64_t)posted * PIECE, piece_len(posted));
+            ++posted;
+        }
+    }
+    const double tr1 = idx_now();
+    int rc = e == hipSuccess ? index_alloc(n, term, device, &h) : EB_ERR_NOMEM;
+    if (rc != EB_OK) { if (e != hipSuccess) eb_set_error("staging allocation failed: %s", hipGetErrorString(e)); release(); return rc; }
+    unsigned long long init = ~0ull;
+    e = hipMalloc(&d_bad, sizeof init);
+    for (int i = 0; i < SLOTS && (size_t)i < n_pieces && e == hipSuccess; ++i) {
+        d_stage[i] = static_cast<uint8_t*>(eb_scratch_get(device, stage_bytes, &d_cap[i]));
+        if (!d_stage[i]) e = hipErrorOutOfMemory;
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
+    }
     if (e != hipSuccess) { eb_set_error("staging allocation failed: %s", hipGetErrorString(e)); release(); eb_index_destroy(h); return EB_ERR_NOMEM; }
     e = hipMemcpy(d_bad, &init, sizeof init, hipMemcpyHostToDevice);
     if (e != hipSuccess) { eb_set_error("hipMemcpy failed: %s", hipGetErrorString(e)); release(); eb_index_destroy(h); return EB_ERR_DEVICE; }
-    unsigned copy_threads = 4; // measured on the 7.55 GB file: 4 / 8 / 16 / 32 threads -> 36 / 29 / 30 / 24 GB/s
-    if (const char* ev = getenv("EB_INDEX_COPY_THREADS")) { int v = atoi(ev); if (v >= 1 && v <= 64) copy_threads = (unsigned)v; }
-    int io_error = 0;
-    uint64_t pos = 0;
-    int slot = 0;
-    bool first_use[3] = {true, true, true};
-    do {
-        uint64_t len = n - pos < PIECE ? n - pos : PIECE;
-        bool last = pos + len == n;
-        if (!first_use[slot] && (e = hipEventSynchronize(done[slot])) != hipSuccess) break;
-        first_use[slot] = false;
+    const double tr2 = idx_now();
+    double tr_read = 0, tr_slot = 0;
+    for (size_t k = 0; k < n_pieces; ++k) {
+        const int slot = (int)(k % SLOTS);
+        const uint64_t pos = (uint64_t)k * PIECE, len = n ? piece_len(k) : 0;
+        const bool last = k + 1 == n_pieces;
         const uint8_t* src = ascii ? ascii + pos : nullptr;
         if (pinned_path && len) {
-            std::vector<std::thread> pool(copy_threads);
-            int* err = &io_error;
-            for (unsigned t = 0; t < copy_threads; ++t) {
-                uint64_t a0 = len * t / copy_threads, a1 = len * (t + 1) / copy_threads;
-                uint8_t* dst = h_stage[slot] + a0;
-                if (src) {
-                    pool[t] = std::thread([=]() { memcpy(dst, src + a0, a1 - a0); });
-                } else {
-                    pool[t] = std::thread([=]() { // page-cache -> page-locked piece, no page faults of a mapping in between
-                        uint64_t got = 0;
-                        while (got < a1 - a0) {
-                            ssize_t r = pread(fd, dst + got, a1 - a0 - got, (off_t)(pos + a0 + got));
-                            if (r <= 0) { *err = 1; return; }
-                            got += (uint64_t)r;
-                        }
-                    });
-                }
-            }
-            for (std::thread& th : pool) th.join();
-            if (io_error) { eb_set_error("read error in the input file"); rc = EB_ERR_IO; break; }
+            const double t0 = idx_now();
+            if (!readers.wait((int)k)) { eb_set_error("read error in the input file"); rc = EB_ERR_IO; break; }
+            tr_read += idx_now() - t0;
             src = h_stage[slot];
-        }
+        } else if (k >= (size_t)SLOTS && (e = hipEventSynchronize(done[slot])) != hipSuccess) break; // (the device staging buffer is free again)
         if (len && (e = hipMemcpyAsync(d_stage[slot], src, len, hipMemcpyHostToDevice, h->stream)) != hipSuccess) break;
         rc = pack_piece(h, d_stage[slot], pos, len, last, d_bad);
         if (rc != EB_OK) break;
         if ((e = hipEventRecord(done[slot], h->stream)) != hipSuccess) break;
-        pos += len;
-        slot = (slot + 1) % SLOTS;
-    } while (pos < n);
+        // the piece SLOTS further on goes into this slot once its upload is done
+        if (pinned_path && posted < n_pieces && posted == k + (size_t)SLOTS) {
+            const double t0 = idx_now();
+            if ((e = hipEventSynchronize(done[slot])) != hipSuccess) break;
+            tr_slot += idx_now() - t0;
+            readers.post((int)posted, h_stage[slot], (uint64_t)posted * PIECE, piece_len(posted));
+            ++posted;
+        }
+    }
     if (e != hipSuccess) { eb_set_error("upload failed: %s", hipGetErrorString(e)); rc = EB_ERR_DEVICE; }
     if (rc != EB_OK) (void)hipStreamSynchronize(h->stream);
+    const double tr3 = idx_now();
     if (rc == EB_OK) rc = finish_index(h, d_bad, nullptr, ascii, fd);
+    const double tr4 = idx_now();
     release();
+    if (trace)
+        fprintf(stderr, "[index] n=%llu: page-locked pieces + readers started %.3f s, index + staging allocation %.3f, piece loop %.3f (waits for the readers %.3f, "
+                        "for an upload %.3f), counters + directory %.3f, release %.3f\n",
+                (unsigned long long)n, tr1 - tr0, tr2 - tr1, tr3 - tr2, tr_read, tr_slot, tr4 - tr3, idx_now() - tr4);
     if (rc != EB_OK) { eb_index_destroy(h); return rc; }
     *out = h;
     return EB_OK;

@@ -21,17 +21,16 @@ void eb_set_error(const char* fmt, ...);
         }                                                                                         \
     } while (0)
 
-// streams / events / pinned counters of the pipelined phase-4 driver (eb_scan.hip), created on first use
+// streams / events / page-locked report blocks of the phase-4 driver (eb_scan_job.cpp), created with the first job on an index
 struct eb_scan_ctx {
-    hipStream_t prep = nullptr, ext = nullptr, right = nullptr, copy = nullptr;
-    std::vector<hipEvent_t> events;
-    hipEvent_t last_ext = nullptr, last_right = nullptr; // end of the most recent job's context kernels
-    std::vector<unsigned long long*> h_bad_pool; // pinned words recycled between jobs
-    std::mutex half_mu;                          // half_job and the jobs' `half` flags
-    struct eb_scan_job* half_job = nullptr;      // EB_SCAN_PIPELINED: the job whose last part is held back until the next _begin
-    std::mutex pool_mu;                          // events / h_bad_pool: a job may be ended on one host thread while the next is begun on another
-    uint64_t scratch_reserved = 0;               // call-set size (clusters) a ring of device-scratch sets was reserved for (likewise)
-    uint64_t pinned_reserved = 0;                // largest call-set size a ring of page-locked blobs was reserved for (EB_SCAN_PIPELINED callers)
+    hipStream_t ctx = nullptr, copy = nullptr;   // context kernels; record downloads (the scan runs on the index's own stream)
+    hipEvent_t last_ctx = nullptr;               // end of the most recent job's context kernels
+    std::mutex pool_mu;                          // events / reports: a job may be ended on one host thread while the next is begun on another
+    std::vector<hipEvent_t> events;              // recycled between jobs
+    std::vector<void*> reports;                  // page-locked JobReport blocks, recycled between jobs
+    uint32_t batch_shift = 0;                    // log2 of the tiles per batch of the ordered hand-over (0: not chosen yet); shrinks when a batch overflows
+    uint64_t scratch_reserved = 0;               // job capacity (clusters) a ring of device-scratch sets was reserved for (EB_SCAN_PIPELINED callers)
+    uint64_t pinned_reserved = 0;                // largest call-set size a ring of page-locked blobs was reserved for (likewise)
 };
 void eb_scan_ctx_destroy(eb_scan_ctx* c);
 
@@ -50,7 +49,7 @@ struct eb_index {
     uint32_t sel_blk_bits = 32;               // block bits of a directory entry (eb_select_guess)
     uint4* d_psi = nullptr;                   // FL table (eb_index_build_psi), or null
     uint64_t psi_off[4] = {0, 0, 0, 0};
-    uint32_t phase4_jobs = 0;                 // phase-4 jobs begun on this index (the third one builds the FL table)
+    uint64_t phase4_positions = 0;            // positions scanned by the phase-4 jobs begun on this index so far (3 n of them: the FL table is built)
     bool psi_tried = false;                   // a build was attempted (and failed or was refused): not again
     uint64_t psi_void_chunks = 0;             // chunks of the table that fall back to the directory select
     uint64_t device_bytes = 0;
@@ -139,7 +138,11 @@ struct eb_calls {
     uint64_t right_words() const { return ((uint64_t)k_right + 31) / 32; }
 };
 uint64_t eb_calls_blob_size(uint64_t count, uint64_t n_chains, int32_t k_left, int32_t k_right);
-// makes sure the pool of page-locked blobs holds `count` of at least `size` bytes (eb_writer.cpp)
+// the pool of page-locked host blocks (eb_writer.cpp): call-set blobs and the loader's staging pieces are recycled through it --
+// pinning tens of MB per use would cost more than the copy it speeds up.  get: a block of at least `size` bytes, *got its capacity
+void* eb_pinned_get(uint64_t size, uint64_t* got);
+void eb_pinned_put(void* p, uint64_t cap);
+// makes sure the pool holds `count` blocks of at least `size` bytes
 void eb_pinned_reserve(uint64_t size, int count, const void* d_warm, uint64_t warm_bytes);
 // allocates the blob (zeroed), fills the header and the section pointers; nullptr on failure (error set)
 eb_calls* eb_calls_alloc(uint64_t count, uint64_t n_chains, int32_t k_left, int32_t k_right, bool pinned);
@@ -149,9 +152,7 @@ static inline uint64_t eb_bit_words(uint64_t n) { return (n + 63) / 64; }
 static inline uint64_t eb_bit_alloc_words(uint64_t n) { return (n + 63) / 64 + 2; }
 
 // eb_scanutil.hip: exclusive prefix sum of `count` vectors of 4 x u64 (in place), on `stream`.
-// tmp must hold eb_scan4_tmp_elems(count) vectors.
-uint64_t eb_scan4_tmp_elems(uint64_t count);
-int eb_scan4_exclusive(uint64_t* d_vec4, uint64_t count, uint64_t* d_tmp, hipStream_t stream);
+int eb_scan4_exclusive(uint64_t* d_vec4, uint64_t count, hipStream_t stream);
 
 // (re)builds d_da_rank from d_da
 int eb_flags_build_da_rank(eb_flags* f);
@@ -159,8 +160,8 @@ int eb_flags_build_da_rank(eb_flags* f);
 int eb_flags_derive(eb_flags* f);
 // builds the scan planes of an index if absent (eb_index.hip)
 int eb_index_scan_planes(eb_index* h);
-// phase 4 counts its jobs per index and builds the FL table when a caller keeps scanning (eb_index.hip)
-void eb_index_note_phase4_job(eb_index* h);
+// phase 4 counts the positions it scans per index and builds the FL table when a caller keeps scanning (eb_index.hip)
+void eb_index_note_phase4_job(eb_index* h, uint64_t positions);
 int eb_flags_alloc(uint64_t n, int device, bool with_da, eb_flags** out);
 
 // Caching device-scratch allocator (eb_index.hip).  hipMalloc / hipFree cost 0.1-1 ms each and hipFree synchronises

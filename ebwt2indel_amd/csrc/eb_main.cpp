@@ -1,13 +1,16 @@
 // eb_main.cpp -- the `ebwt2InDel` command line, same flags / defaults / messages as the reference
 // (ebwt2InDel.cpp:76-103 help, :1677-1823 main), driving the GPU hot path through the C ABI only.
 // Extra flags (not in the reference): -D <device> selects the GPU (default 0); -G <n> runs on n GPUs of the node:
-// ONE process, one host thread per GPU, RCCL communicators from ncclCommInitAll (set up in the background while the
-// ranks load and traverse) -- the input files come off the disk once (the ranks read the same page-cache pages) and are
-// uploaded to every GPU (BWT replicated), phases 2-3 are split by Weiner-link subtrees and combined by an in-place
-// ncclAllReduce (SUM == OR: one writer per bit, checked by popcounts), phase 4 is split by closing position and the
-// ranks' compact call-set images travel GPU -> GPU (ncclSend / ncclRecv over xGMI) to GPU 0, whose thread downloads
-// them and writes the .snp -- the same bytes as -G 1 and as the reference.  (EB_MULTI_BACKEND=host replaces the two
-// collectives by exchanges through host memory and lets ranks share devices: rehearsal on a box with fewer GPUs.)
+// ONE process, one host thread per GPU.  The input files come off the disk once (the ranks read the same page-cache pages) and
+// are uploaded to every GPU (BWT replicated); phases 2-3 are split by Weiner-link subtrees and combined by an in-place
+// ncclAllReduce over xGMI (SUM == OR: one writer per bit, checked by popcounts); phase 4 is split by closing position and every
+// rank downloads its own compact call-set image over its OWN PCIe link into one page-locked arena (the node's host memory is
+// shared: no link carries another rank's records), from which GPU 0's thread writes the .snp -- the same bytes as -G 1 and as
+// the reference.  The RCCL communicators come up FIRST (ncclCommInitAll holds the HIP runtime for seconds: 2.4 s before any
+// other HIP work, 5-6 s beside it, scripts/rccl_init_probe.cpp) while the input files are read ahead into the page cache; one
+// GPU needs none.  EB_MULTI_BACKEND=rccl-gather: the call sets travel GPU -> GPU (ncclSend / ncclRecv) to GPU 0, which
+// downloads all of them (rounds 3-4); =host: both exchanges through host memory, ranks may share devices (rehearsal on a box
+// with fewer GPUs).
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -114,7 +117,10 @@ void shard_range(uint64_t n, int rank, int world, uint64_t* b, uint64_t* e) {
 
 struct MultiJob {
     int world = 1;
-    bool host_backend = false;
+    bool host_backend = false; // no RCCL at all: vectors and call sets through host memory
+    bool rccl_gather = false;  // call sets GPU -> GPU to rank 0 (instead of every rank downloading its own)
+    uint8_t* arena = nullptr;  // page-locked: the ranks' wire images one behind the other (rank 0 allocates it once the lengths are known)
+    std::vector<uint64_t> arena_off;
     std::vector<int> dev;
     std::vector<ncclComm_t> comm;
     // inputs: mapped once, read-only; every rank uploads from the same pages (the page cache holds the files once)
@@ -122,8 +128,7 @@ struct MultiJob {
     const uint8_t* da = nullptr; // the document array is mapped once, read-only; every rank packs it from the same pages
     uint64_t n_da = 0;
     bool two = false;
-    std::thread* comm_init = nullptr; // ncclCommInitAll runs beside phase 1 and the traversal; joined before the first collective
-    ncclResult_t comm_rc = ncclSuccess;
+    double t_comm = 0;         // seconds ncclCommInitAll took (0: no communicator needed)
     eb_params p;
     Barrier* bar = nullptr;
     // per rank
@@ -134,7 +139,6 @@ struct MultiJob {
     std::vector<std::array<uint64_t, 4>> ones;
     std::vector<const void*> wire_ptr;
     std::vector<uint64_t> wire_len;
-    std::vector<std::vector<uint8_t>> image; // rank 0's host copies of all ranks' call-set images, in rank order
     // host backend: OR of the shards' vectors
     std::mutex mu;
     std::vector<uint64_t> acc[4];
@@ -226,17 +230,14 @@ void rank_main(MultiJob& J, int r) {
     uint64_t words = 0;
     (void)eb_flags_device_vectors(fl, v, &words);
     if (!J.host_backend) {
-        // the communicators were being set up beside all the work so far (RCCL takes seconds to come up): needed from here on
-        if (r == 0 && J.comm_init) {
-            J.comm_init->join();
-            if (J.comm_rc != ncclSuccess) MJ_FAIL(EB_ERR_DEVICE, "ncclCommInitAll failed: %s", ncclGetErrorString(J.comm_rc));
-        }
-        if (!sync_ok()) return cleanup();
         // every bit has ONE writer over all ranks: integer SUM == OR (RCCL has no bitwise OR); in place, in HBM, over xGMI
-        for (int k = 0; k < 4; ++k)
-            if (v[k]) MJ_NCCL(ncclAllReduce(v[k], v[k], words, ncclUint64, ncclSum, J.comm[(size_t)r], st));
-        MJ_HIP(hipStreamSynchronize(st));
-        if (J.rc[(size_t)r] != EB_OK) collective_failure(J, r);
+        // (one rank: the sum of one vector is the vector)
+        if (J.world > 1) {
+            for (int k = 0; k < 4; ++k)
+                if (v[k]) MJ_NCCL(ncclAllReduce(v[k], v[k], words, ncclUint64, ncclSum, J.comm[(size_t)r], st));
+            MJ_HIP(hipStreamSynchronize(st));
+            if (J.rc[(size_t)r] != EB_OK) collective_failure(J, r);
+        }
     } else {
         std::vector<uint64_t> h[4];
         for (int k = 0; k < 4; ++k) if (v[k]) h[k].resize(words);
@@ -279,45 +280,50 @@ void rank_main(MultiJob& J, int r) {
     t0 = now_s();
     uint64_t begin = 0, end = 0;
     shard_range(n, r, J.world, &begin, &end);
-    if (!J.host_backend) {
+    {
         rc = eb_scan_clusters_begin_ex(b1, b2, fl, begin, end, &J.p, EB_SCAN_DEVICE_ONLY | EB_SCAN_WIRE, &job);
-        if (rc == EB_OK) rc = eb_scan_job_wait(job);
-        if (rc == EB_OK) rc = eb_scan_job_device_wire(job, &J.wire_ptr[(size_t)r], &J.wire_len[(size_t)r]);
+        if (rc == EB_OK) rc = eb_scan_job_device_wire(job, &J.wire_ptr[(size_t)r], &J.wire_len[(size_t)r]); // (waits for the job's kernels)
         if (rc != EB_OK) MJ_FAIL(rc, "%s", eb_last_error());
         if (!sync_ok()) return cleanup();
-        // variable-length gather to rank 0: the lengths are known to everyone (one process), the payloads go GPU -> GPU
+        // the lengths are known to everyone (one process): rank 0 lays the images out one behind the other
         if (r == 0) {
-            recv.assign((size_t)J.world, nullptr);
-            for (int q = 1; q < J.world; ++q) MJ_HIP(hipMalloc(&recv[(size_t)q], J.wire_len[(size_t)q]));
-        }
-        if (!sync_ok()) return cleanup();
-        if (r == 0) {
-            MJ_NCCL(ncclGroupStart());
-            for (int q = 1; q < J.world; ++q) MJ_NCCL(ncclRecv(recv[(size_t)q], J.wire_len[(size_t)q], ncclUint8, q, J.comm[0], st));
-            MJ_NCCL(ncclGroupEnd());
-        } else {
-            MJ_NCCL(ncclSend(J.wire_ptr[(size_t)r], J.wire_len[(size_t)r], ncclUint8, 0, J.comm[(size_t)r], st));
-        }
-        MJ_HIP(hipStreamSynchronize(st));
-        if (J.rc[(size_t)r] != EB_OK) collective_failure(J, r);
-        if (r == 0) {
-            for (int q = 0; q < J.world; ++q) {
-                J.image[(size_t)q].resize(J.wire_len[(size_t)q]);
-                MJ_HIP(hipMemcpy(J.image[(size_t)q].data(), q == 0 ? J.wire_ptr[0] : recv[(size_t)q], J.wire_len[(size_t)q], hipMemcpyDeviceToHost));
+            uint64_t total = 0;
+            J.arena_off.assign((size_t)J.world, 0);
+            for (int q = 0; q < J.world; ++q) { J.arena_off[(size_t)q] = total; total += (J.wire_len[(size_t)q] + 63) & ~63ull; }
+            // page-locked and visible to every device of the process: each GPU's DMA engine writes its own part
+            MJ_HIP(hipHostMalloc(reinterpret_cast<void**>(&J.arena), total ? total : 64, hipHostMallocPortable));
+            if (J.rccl_gather) {
+                recv.assign((size_t)J.world, nullptr);
+                for (int q = 1; q < J.world; ++q) MJ_HIP(hipMalloc(&recv[(size_t)q], J.wire_len[(size_t)q] ? J.wire_len[(size_t)q] : 1));
             }
         }
-        J.bar->wait(); // the senders' images may be released now
+        if (!sync_ok()) return cleanup();
+        if (!J.rccl_gather) {
+            // every rank's records over its own PCIe link (GPU r -> host), side by side
+            uint64_t len = 0;
+            rc = eb_scan_job_wire_to_host(job, J.arena + J.arena_off[(size_t)r], J.wire_len[(size_t)r], &len);
+            if (rc != EB_OK) MJ_FAIL(rc, "%s", eb_last_error());
+        } else {
+            // variable-length gather to rank 0: the payloads go GPU -> GPU, rank 0's link then carries all of them
+            if (J.world > 1) {
+                if (r == 0) {
+                    MJ_NCCL(ncclGroupStart());
+                    for (int q = 1; q < J.world; ++q) MJ_NCCL(ncclRecv(recv[(size_t)q], J.wire_len[(size_t)q], ncclUint8, q, J.comm[0], st));
+                    MJ_NCCL(ncclGroupEnd());
+                } else {
+                    MJ_NCCL(ncclSend(J.wire_ptr[(size_t)r], J.wire_len[(size_t)r], ncclUint8, 0, J.comm[(size_t)r], st));
+                }
+                MJ_HIP(hipStreamSynchronize(st));
+                if (J.rc[(size_t)r] != EB_OK) collective_failure(J, r);
+            }
+            if (r == 0)
+                for (int q = 0; q < J.world; ++q)
+                    if (J.wire_len[(size_t)q])
+                        MJ_HIP(hipMemcpy(J.arena + J.arena_off[(size_t)q], q == 0 ? J.wire_ptr[0] : recv[(size_t)q], J.wire_len[(size_t)q], hipMemcpyDeviceToHost));
+        }
+        J.bar->wait(); // every image is in the arena; the device images may be released
         rc = eb_scan_clusters_end(job, nullptr, &J.ss[(size_t)r]);
         job = nullptr;
-        if (rc != EB_OK) MJ_FAIL(rc, "%s", eb_last_error());
-    } else {
-        rc = eb_scan_clusters(b1, b2, fl, begin, end, &J.p, &calls, &J.ss[(size_t)r]);
-        if (rc == EB_OK) {
-            const uint8_t* blob = nullptr;
-            uint64_t len = 0;
-            rc = eb_calls_blob(calls, &blob, &len);
-            if (rc == EB_OK) J.image[(size_t)r].assign(blob, blob + len);
-        }
         if (rc != EB_OK) MJ_FAIL(rc, "%s", eb_last_error());
     }
     J.bar->wait();
@@ -351,6 +357,7 @@ static int run_multi(int world, const std::string& input1, const std::string& in
     const bool two_bwts = !input2.empty(), with_da = !input_da.empty();
     const char* be = getenv("EB_MULTI_BACKEND");
     const bool host_backend = be && !strcmp(be, "host");
+    const bool rccl_gather = be && !strcmp(be, "rccl-gather"); // (the vectors' all-reduce is RCCL's either way; =host: none of it)
     const int ndev = eb_device_count();
     if (world < 1 || world > 64) { printf("Error: -G %d: between 1 and 64 GPUs\n", world); return 1; }
     if (!host_backend && world > ndev) {
@@ -360,6 +367,7 @@ static int run_multi(int world, const std::string& input1, const std::string& in
     MultiJob J;
     J.world = world;
     J.host_backend = host_backend;
+    J.rccl_gather = rccl_gather;
     J.p = p;
     for (int r = 0; r < world; ++r) J.dev.push_back(r % ndev);
     printf(two_bwts ? "Phase 1/4: loading and indexing eBWTs on %d GPU(s) ... " : "Phase 1/4: loading and indexing eBWT on %d GPU(s) ... ", world);
@@ -393,11 +401,30 @@ static int run_multi(int world, const std::string& input1, const std::string& in
     J.two = two_bwts;
     J.da = with_da ? (mda.n ? mda.p : &empty) : nullptr;
     J.n_da = mda.n;
-    std::thread comm_thread;
-    if (!host_backend) {
+    if (!host_backend && world > 1) {
+        // The communicators first, before this process does any other HIP work: ncclCommInitAll holds the runtime (a kernel launch
+        // issued beside it waits until it is done) and takes twice as long when other HIP work runs beside it.  What the host can do
+        // meanwhile is bring the input files into the page cache.
         J.comm.resize((size_t)world);
-        comm_thread = std::thread([&J, world] { J.comm_rc = ncclCommInitAll(J.comm.data(), world, J.dev.data()); });
-        J.comm_init = &comm_thread;
+        std::thread readahead([&] {
+            for (const std::string* path : {&input1, &input2, &input_da}) {
+                if (path->empty()) continue;
+                int fd = ::open(path->c_str(), O_RDONLY);
+                if (fd < 0) continue;
+                struct stat st;
+                if (fstat(fd, &st) == 0) {
+                    (void)posix_fadvise(fd, 0, 0, POSIX_FADV_SEQUENTIAL);
+                    std::vector<char> buf(8u << 20);
+                    while (read(fd, buf.data(), buf.size()) > 0) {} // (pages that are cached already cost a copy: ~5 GB/s)
+                }
+                ::close(fd);
+            }
+        });
+        const double c0 = now_s();
+        const ncclResult_t crc = ncclCommInitAll(J.comm.data(), world, J.dev.data());
+        J.t_comm = now_s() - c0;
+        readahead.join();
+        if (crc != ncclSuccess) { printf("\nError: ncclCommInitAll failed: %s\n", ncclGetErrorString(crc)); return 1; }
     }
     Barrier bar(world);
     J.bar = &bar;
@@ -408,14 +435,12 @@ static int run_multi(int world, const std::string& input1, const std::string& in
     J.ones.resize((size_t)world);
     J.wire_ptr.assign((size_t)world, nullptr);
     J.wire_len.assign((size_t)world, 0);
-    J.image.resize((size_t)world);
     for (auto& s : J.ns) memset(&s, 0, sizeof s);
     for (auto& s : J.ss) memset(&s, 0, sizeof s);
     std::vector<std::thread> th;
     for (int r = 1; r < world; ++r) th.emplace_back(rank_main, std::ref(J), r);
     rank_main(J, 0);
     for (std::thread& t : th) t.join();
-    if (comm_thread.joinable()) comm_thread.join(); // a rank failed before the first collective
     // (the communicators are not torn down one by one: the process is about to end, and ncclCommDestroy takes seconds)
     for (int r = 0; r < world; ++r)
         if (J.rc[(size_t)r] != EB_OK) {
@@ -470,17 +495,19 @@ static int run_multi(int world, const std::string& input1, const std::string& in
     uint64_t cluster_nr = 1, events = 0;
     for (int r = 0; r < world; ++r) {
         eb_calls* calls = nullptr;
-        int rc = eb_calls_unpack(J.image[(size_t)r].data(), J.image[(size_t)r].size(), &calls);
+        int rc = eb_calls_unpack(J.arena + J.arena_off[(size_t)r], J.wire_len[(size_t)r], &calls);
         if (rc == EB_OK) rc = eb_write_snp(calls, &p, two_bwts || with_da, output.c_str(), r > 0, &cluster_nr, &events);
         if (calls) eb_calls_free(calls);
         if (rc != EB_OK) return fail("Error while writing the output");
     }
     double t5 = now_s();
     print_report(ns, ss, two_bwts, with_da, events, cluster_nr);
-    printf("\nTimings (s) on %d GPU(s)%s: read %.3f, upload+index %.3f, phases 2-3 %.3f (%llu rank queries, %llu launches over all ranks), "
-           "phase 4 + gather %.3f (slowest rank: scan %.3f ms, extend %.3f ms, right %.3f ms), write %.3f\n",
-           world, host_backend ? " [host-memory exchange]" : " [RCCL]", t_read, J.t_index, J.t_nav, (unsigned long long)ns.rank_queries,
+    printf("\nTimings (s) on %d GPU(s)%s: communicators %.3f, upload+index %.3f, phases 2-3 %.3f (%llu rank queries, %llu launches over all ranks), "
+           "phase 4 + records to host %.3f (slowest rank: scan %.3f ms, extend %.3f ms, right %.3f ms), write %.3f\n",
+           world, host_backend ? " [host-memory exchange, records over every rank's own link]" : (world == 1 ? " [one rank: no communicator]" : (rccl_gather ? " [RCCL, records gathered to GPU 0]" : " [RCCL all-reduce, records over every GPU's own link]")),
+           J.t_comm + t_read, J.t_index, J.t_nav, (unsigned long long)ns.rank_queries,
            (unsigned long long)ns.batches, J.t_scan, ss.ms_scan, ss.ms_extend, ss.ms_right, t5 - t4);
+    if (J.arena) (void)hipHostFree(J.arena);
     return 0;
 }
 

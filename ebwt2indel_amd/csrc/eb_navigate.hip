@@ -18,6 +18,7 @@
 #include <thread>
 #include <type_traits>
 
+#include "eb_config.h"
 #include "eb_internal.h"
 
 namespace {
@@ -1315,10 +1316,11 @@ unsigned nav_grid_for(uint64_t batch) { return nav_grid(batch, 1); } // per_quad
 
 // ---- the drain's bookkeeping, on the DEVICE.  Round 2 ran it on the host: after every launch the host read back how many
 // children it had pushed (8 bytes, a blocking round trip: ~700 of them at 7.55 G positions) and chose the next batch.  Now a
-// one-thread kernel does exactly that between two expansions, so the host enqueues EB_NAV_GROUP launches back to back, reads the
+// one-thread kernel does exactly that between two expansions, so the host enqueues eight launches back to back, reads the
 // state once per group, and always keeps one group queued ahead of the one it waits for: the device never idles on the host.
 enum { DRAIN_NONE = 0, DRAIN_EXPAND = 1, DRAIN_SPLIT = 2 };
 enum { DRAIN_ERR_CAPACITY = 1, DRAIN_ERR_OVERFLOW = 2 };
+#define EB_NAV_OVERFLOW (-100) /* internal: a launch pushed more records than it was given room for (never leaves this file) */
 struct DrainState {
     unsigned long long stack[2];          // device addresses of the two LIFO stacks
     unsigned long long top[2];            // records on each
@@ -1330,6 +1332,7 @@ struct DrainState {
     uint32_t last, last_src;              // what the previous step was (DRAIN_*) and which stack it popped
     unsigned long long last_base, last_room;
     uint32_t shard, n_shards, split_done, error;
+    unsigned long long room_hook;         // tests (EB_NAV_CHAINS=3): most room a launch is TOLD it has, so that it really overflows (0: the truth)
     NavLaunch expand;                     // what the next expansion kernel works on (count 0: nothing)
     NavLaunch split;                      // ... and the next k_keep_shard (count 0: nothing)
 };
@@ -1385,13 +1388,14 @@ __global__ void k_drain_plan(DrainState* st, NavCounters* cnt) {
     st->expand.in = reinterpret_cast<const void*>(st->stack[src] + base * ib);
     st->expand.count = B;
     st->expand.out = reinterpret_cast<void*>(st->stack[dst] + st->top[dst] * ib);
-    st->expand.out_cap = room;
+    const unsigned long long handed = st->room_hook && st->room_hook < room ? st->room_hook : room;
+    st->expand.out_cap = handed;
     st->expand.write = (st->n_shards == 1 || st->split_done || st->shard == 0) ? 1 : 0;
     st->expand.follow = (st->n_shards == 1 || st->split_done) ? 1 : 0;
     st->last = DRAIN_EXPAND;
     st->last_src = src;
     st->last_base = base;
-    st->last_room = room;
+    st->last_room = handed;
     ++st->launches;
 }
 
@@ -1408,6 +1412,7 @@ struct Drain {
     // down to the first level of at least split_min * n_shards records, which is then cut by k_keep_shard
     uint32_t shard = 0, n_shards = 1;
     uint64_t split_min = 4096;
+    uint64_t room_hook = 0; // see DrainState
 
     // The stacks live in one arena shared by both phases (allocating HBM costs ~20 ms per GB, so the arena is sized from
     // the batch, not from n).  A depth-first drain needs a few batches of room (observed: < 7 batches at 7.55 G
@@ -1425,7 +1430,7 @@ struct Drain {
         d_stack[0] = static_cast<Item*>(arena);
         d_stack[1] = d_stack[0] + cap;
         top[0] = top[1] = 0;
-        if (getenv("EB_NAV_TRACE")) fprintf(stderr, "[nav] 2 stacks x %llu records (%.2f GB) batch=%llu\n", (unsigned long long)cap, 2 * cap * sizeof(Item) / 1e9, (unsigned long long)batch);
+        if (eb_cfg().trace_nav) fprintf(stderr, "[nav] 2 stacks x %llu records (%.2f GB) batch=%llu\n", (unsigned long long)cap, 2 * cap * sizeof(Item) / 1e9, (unsigned long long)batch);
         return EB_OK;
     }
     int push_host(const Item& it) {
@@ -1437,9 +1442,9 @@ struct Drain {
     // d_state: sizeof(DrainState) bytes of device memory; h_state: two DrainState in page-locked host memory
     template <int W2, typename Launch>
     int run(NavCounters* d_cnt, DrainState* d_state, DrainState* h_state, Launch launch) {
-        const bool trace = getenv("EB_NAV_TRACE") != nullptr;
+        const bool trace = eb_cfg().trace_nav;
         const double t_start = now_s();
-        const int group = [] { const char* e = getenv("EB_NAV_GROUP"); int v = e ? atoi(e) : 8; return v < 1 ? 1 : (v > 64 ? 64 : v); }(); // launches per read-back
+        const int group = 8; // launches per read-back
         DrainState init;
         memset(&init, 0, sizeof init);
         init.stack[0] = reinterpret_cast<unsigned long long>(d_stack[0]);
@@ -1452,6 +1457,7 @@ struct Drain {
         init.item_bytes = (uint32_t)sizeof(Item);
         init.shard = shard;
         init.n_shards = n_shards;
+        init.room_hook = room_hook;
         init.max_top = top[0] + top[1];
         h_state[0] = init;
         EB_HIP(hipMemsetAsync(&d_cnt->pushed, 0, sizeof(unsigned long long), stream));
@@ -1497,7 +1503,7 @@ struct Drain {
                 launches = e.launches;
                 max_top = e.max_top;
                 if (e.error == DRAIN_ERR_CAPACITY) { eb_set_error("traversal stack capacity exceeded (cap %llu records)", (unsigned long long)cap); return EB_ERR_NOMEM; }
-                if (e.error) { eb_set_error("traversal stack overflow"); return EB_ERR_STATE; }
+                if (e.error) { eb_set_error("traversal stack overflow"); return EB_NAV_OVERFLOW; }
                 return EB_OK;
             }
             ++g;
@@ -1506,12 +1512,6 @@ struct Drain {
         return rc;
     }
 };
-
-uint64_t env_u64(const char* name, uint64_t dflt) {
-    const char* s = getenv(name);
-    if (!s || !*s) return dflt;
-    return strtoull(s, nullptr, 10);
-}
 
 }  // namespace
 
@@ -1548,7 +1548,7 @@ int eb_flags_build_da_rank(eb_flags* f) {
     EB_HIP(hipMalloc(&f->d_da_rank, groups * sizeof(uint64_t)));
     unsigned grid = (unsigned)((groups + 255) / 256);
     hipLaunchKernelGGL(k_da_group_counts, dim3(grid), dim3(256), 0, f->stream, f->d_da, f->words, groups, d_vec);
-    int rc = eb_scan4_exclusive(d_vec, groups, nullptr, f->stream);
+    int rc = eb_scan4_exclusive(d_vec, groups, f->stream);
     if (rc != EB_OK) return rc;
     hipLaunchKernelGGL(k_take_first, dim3(grid), dim3(256), 0, f->stream, d_vec, groups, f->d_da_rank);
     EB_HIP(hipMemcpyAsync(&f->da_ones, f->d_da_rank + (groups - 1), sizeof(uint64_t), hipMemcpyDeviceToHost, f->stream)); // the extra last group: ones before the end
@@ -1591,7 +1591,7 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
     *out = nullptr;
     EB_HIP(hipSetDevice(b1->device));
     const uint64_t n = b1->n + (b2 ? b2->n : 0);
-    const bool trace_alloc = getenv("EB_NAV_TRACE") != nullptr;
+    const bool trace_alloc = eb_cfg().trace_nav;
     double ta = now_s();
     auto lap = [&](const char* what) {
         if (!trace_alloc) return;
@@ -1640,14 +1640,14 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
     eb_dev_flags df = f->dev();
     NavParams p{K, k_right, 1, nullptr, complement ? 1 : 0};
 #ifdef EB_SCAN_EXPERIMENTS
-    p.dbg = (uint32_t)env_u64("EB_NAV_DEBUG", 0);
+    p.dbg = getenv("EB_NAV_DEBUG") ? (uint32_t)atoi(getenv("EB_NAV_DEBUG")) : 0u; // (profiling build only)
 #endif
-    const uint64_t split_min = env_u64("EB_NAV_SPLIT_MIN", 4096);
+    const uint64_t split_min = eb_cfg().nav_split_min;
     hipStream_t st = f->stream;
-    const uint64_t batch_max = env_u64("EB_NAV_BATCH", 16ull << 20);
-    // one arena for both traversals: two stacks of EB_NAV_STACK_BATCHES / 2 batches of the largest record each
+    const uint64_t batch_max = eb_cfg().nav_batch;
+    // one arena for both traversals: two stacks of half the arena's batches (EB_NAV_BATCH) of the largest record each
     const uint64_t item_bytes = b2 ? sizeof(Node2P) : sizeof(Node1P); // the largest record of the two traversals
-    uint64_t arena_batches = env_u64("EB_NAV_STACK_BATCHES", 12) + 1; // observed peak: 5 batches pending
+    uint64_t arena_batches = eb_cfg().nav_arena_batches + 1; // observed peak: 5 batches pending
     uint64_t eff_batch = batch_max < n / 2 + 64 ? batch_max : n / 2 + 64;
     uint64_t arena_records = arena_batches * eff_batch + (n < (1ull << 20) ? n + 4 * eff_batch + 64 : 0);
     if (arena_records < (1ull << 16)) arena_records = 1ull << 16;
@@ -1665,12 +1665,11 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
     void* d_arena = eb_scratch_get(device, arena_bytes, &arena_cap);
     if (!d_arena) { eb_set_error("traversal arena allocation failed (%llu bytes)", (unsigned long long)arena_bytes); return EB_ERR_NOMEM; }
     struct Guard3 { int dev; void* p; size_t cap; ~Guard3() { eb_scratch_put(dev, p, cap); } } guard3{device, d_arena, arena_cap};
-    const bool concurrent = env_u64("EB_NAV_CONCURRENT", 1) != 0;
     size_t arena2_cap = 0;
-    uint64_t arena2_bytes = concurrent ? arena_bytes / 2 : 0; // the leaf frontier stays far smaller than the node frontier
-    void* d_arena2 = concurrent ? eb_scratch_get(device, arena2_bytes, &arena2_cap) : nullptr;
+    uint64_t arena2_bytes = arena_bytes / 2; // the leaf frontier stays far smaller than the node frontier
+    void* d_arena2 = eb_scratch_get(device, arena2_bytes, &arena2_cap);
     struct Guard6 { int dev; void* p; size_t cap; ~Guard6() { if (p) eb_scratch_put(dev, p, cap); } } guard6{device, d_arena2, arena2_cap};
-    const bool side_by_side = concurrent && d_arena2 != nullptr;
+    const bool side_by_side = d_arena2 != nullptr; // (one after the other in one arena when memory is that short)
     lap("arena allocated");
     // Threshold bits are collected either as one byte per position (plain stores; needs n bytes of spare HBM) or, when
     // memory is short, as interleaved bit words set with atomics; both are converted to the two bit vectors afterwards.
@@ -1682,9 +1681,9 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
         size_t free_b = 0, total_b = 0;
         EB_HIP(hipMemGetInfo(&free_b, &total_b));
         // Complement form (the default): writers are few, so atomicOr on the interleaved bit words costs nothing and the n-byte
-        // array, its clearing and its packing pass are saved.  The reference's form (EB_NAV_COMPLEMENT=0, and the fallback
+        // array, its clearing and its packing pass are saved.  The reference's form (EB_NAV_FORM=bytes / words, and the fallback
         // for inputs that are no eBWT) writes every position: bytes with plain stores when n spare bytes of HBM exist.
-        bool want_bytes = !complement && env_u64("EB_NAV_BYTES", 1) != 0 && lcpb_bytes + (4ull << 30) < free_b;
+        bool want_bytes = !complement && eb_cfg().nav_form != EbConfig::NAV_WORDS && lcpb_bytes + (4ull << 30) < free_b;
         if (want_bytes) d_lcpb = static_cast<uint8_t*>(eb_scratch_get(device, lcpb_bytes, &thr_cap));
         if (!d_lcpb) {
             d_kr = static_cast<uint64_t*>(eb_scratch_get(device, eb_bit_alloc_words(n) * 16, &thr_cap));
@@ -1701,6 +1700,7 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
     s.n = n;
     EB_HIP(hipStreamSynchronize(f->stream)); // the cleared threshold words, before either traversal touches them
     uint64_t launches_l = 0, launches_n = 0;
+    const uint64_t room_hook = chains && eb_cfg().nav_chains == 3 ? 64 : 0; // tests: the chain-following walk is told it has room for 64 records per launch
     // phase 2 (ebwt2InDel.cpp:577-615 / :708-756); first_leaf = {[0,F_A), 0} (dna_bwt.hpp:313-317)
     auto phase_leaves = [&](hipStream_t sx, NavBufs& nb, void* arena, uint64_t bytes) -> int {
         int r;
@@ -1709,7 +1709,7 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
         if (!b2) {
             Drain<Leaf1> d;
             d.device = b1->device; d.stream = sx;
-            d.shard = shard; d.n_shards = n_shards; d.split_min = split_min;
+            d.shard = shard; d.n_shards = n_shards; d.split_min = split_min; d.room_hook = room_hook;
             if ((r = d.init(arena, bytes, n, batch_max)) != EB_OK) return r;
             if ((r = d.push_host(Leaf1{0, b1->F[0], 0, 0})) != EB_OK) return r;
             r = d.run<-1>(dc, nb.state, nb.h_state, [&](const NavLaunch* la, unsigned grid) {
@@ -1721,7 +1721,7 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
         }
         Drain<Leaf2P> d;
         d.device = b1->device; d.stream = sx;
-        d.shard = shard; d.n_shards = n_shards; d.split_min = split_min;
+        d.shard = shard; d.n_shards = n_shards; d.split_min = split_min; d.room_hook = room_hook;
         if ((r = d.init(arena, bytes, n, batch_max)) != EB_OK) return r;
         if ((r = d.push_host(pack_rec(Leaf2{0, b1->F[0], 0, b2->F[0], 0, {0, 0, 0}}))) != EB_OK) return r;
         r = d.run<1>(dc, nb.state, nb.h_state, [&](const NavLaunch* la, unsigned grid) {
@@ -1739,7 +1739,7 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
         if (!b2) {
             Drain<Node1P> d;
             d.device = b1->device; d.stream = sx;
-            d.shard = shard; d.n_shards = n_shards; d.split_min = split_min;
+            d.shard = shard; d.n_shards = n_shards; d.split_min = split_min; d.room_hook = room_hook;
             if ((r = d.init(arena, bytes, n, batch_max)) != EB_OK) return r;
             Node1 root{{0, b1->F[0], b1->F[1], b1->F[2], b1->F[3], b1->n}, 0, 0};
             if ((r = d.push_host(pack_rec(root))) != EB_OK) return r;
@@ -1755,7 +1755,7 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
         }
         Drain<Node2P> d;
         d.device = b1->device; d.stream = sx;
-        d.shard = shard; d.n_shards = n_shards; d.split_min = split_min;
+        d.shard = shard; d.n_shards = n_shards; d.split_min = split_min; d.room_hook = room_hook;
         if ((r = d.init(arena, bytes, n, batch_max)) != EB_OK) return r;
         Node2 root{{0, b1->F[0], b1->F[1], b1->F[2], b1->F[3], b1->n}, {0, b2->F[0], b2->F[1], b2->F[2], b2->F[3], b2->n}, 0, {0, 0, 0}};
         if ((r = d.push_host(pack_rec(root))) != EB_OK) return r;
@@ -1868,17 +1868,22 @@ extern "C" int eb_nav_covers_every_slot_once(const eb_nav_stats* s) {
 // walked again the round-3 way.
 static int flags_build_chains(eb_index* b1, eb_index* b2, int32_t K, int32_t k_right, uint32_t shard, uint32_t n_shards, eb_flags** out,
                               eb_nav_stats* stats, bool complement, bool derive) {
-    const uint64_t mode = env_u64("EB_NAV_CHAINS", 1); // 2 (tests): the first walk's result is thrown away as if it had overflowed
+    // EB_NAV_CHAINS (tests): 0 the fallback's kernels at once; 2 the first walk's result is thrown away as if it had overflowed; 3 the
+    // first walk is told its stacks have room for 64 records per launch, so that it really overflows (records dropped in mid-launch,
+    // error set on the device, the group queued ahead finding nothing to do, the leaf thread joined)
+    const int mode = eb_cfg().nav_chains;
     const bool chains = mode != 0;
     int rc = flags_build_impl(b1, b2, K, k_right, shard, n_shards, out, stats, complement, derive, chains);
-    if (mode == 2 && rc == EB_OK) { eb_flags_destroy(*out); *out = nullptr; rc = EB_ERR_STATE; }
-    if (chains && (rc == EB_ERR_STATE || rc == EB_ERR_NOMEM)) rc = flags_build_impl(b1, b2, K, k_right, shard, n_shards, out, stats, complement, derive, false);
-    return rc;
+    if (mode == 2 && rc == EB_OK) { eb_flags_destroy(*out); *out = nullptr; rc = EB_NAV_OVERFLOW; }
+    // only an overflow of the chain-following walk is answered by the other kernels; anything else (memory, a device error) would
+    // fail the same way again
+    if (chains && rc == EB_NAV_OVERFLOW) rc = flags_build_impl(b1, b2, K, k_right, shard, n_shards, out, stats, complement, derive, false);
+    return rc == EB_NAV_OVERFLOW ? EB_ERR_STATE : rc;
 }
 
 extern "C" int eb_flags_build(eb_index* b1, eb_index* b2, int32_t K, int32_t k_right, eb_flags** out, eb_nav_stats* stats) {
     if (!out) { eb_set_error("null argument"); return EB_ERR_ARG; }
-    const bool complement = env_u64("EB_NAV_COMPLEMENT", 1) != 0;
+    const bool complement = eb_cfg().nav_form == EbConfig::NAV_COMPLEMENT;
     eb_nav_stats s;
     int rc = flags_build_chains(b1, b2, K, k_right, 0, 1, out, &s, complement, true);
     if (rc != EB_OK) return rc;

@@ -4,8 +4,6 @@
 // no temporary storage is needed.
 #include "eb_internal.h"
 
-uint64_t eb_scan4_tmp_elems(uint64_t) { return 1; }
-
 __global__ void __launch_bounds__(1024) k_scan4(uint64_t* __restrict__ v, uint64_t count) {
     __shared__ uint64_t wave_tot[4][16];
     __shared__ uint64_t carry[4];
@@ -42,7 +40,7 @@ __global__ void __launch_bounds__(1024) k_scan4(uint64_t* __restrict__ v, uint64
     }
 }
 
-int eb_scan4_exclusive(uint64_t* d_vec4, uint64_t count, uint64_t*, hipStream_t stream) {
+int eb_scan4_exclusive(uint64_t* d_vec4, uint64_t count, hipStream_t stream) {
     if (count == 0) return EB_OK;
     hipLaunchKernelGGL(k_scan4, dim3(1), dim3(1024), 0, stream, d_vec4, count);
     EB_HIP(hipGetLastError());

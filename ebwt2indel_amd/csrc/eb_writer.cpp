@@ -15,6 +15,7 @@
 #include <utility>
 #include <vector>
 
+#include "eb_config.h"
 #include "eb_internal.h"
 
 namespace {
@@ -206,7 +207,7 @@ int format_calls(const eb_calls* c, const eb_params* p, int two_samples, uint64_
     if (!c || !p || !cluster_nr) { eb_set_error("null argument"); return EB_ERR_ARG; }
     if (c->k_left != p->k_left || c->k_right != p->k_right) { eb_set_error("call set was produced with other -L/-R values"); return EB_ERR_ARG; }
     unsigned threads = 1;
-    if (const char* e = getenv("EB_WRITER_THREADS")) threads = (unsigned)atoi(e);                  // tests: any split
+    if (eb_cfg().writer_threads > 0) threads = (unsigned)eb_cfg().writer_threads;                  // EB_WRITER_THREADS (tests: any split)
     else if (c->count >= 50000) threads = std::min(std::thread::hardware_concurrency(), 32u);     // ~1 us per cluster: worth it from here
     if (threads < 1) threads = 1;
     if ((uint64_t)threads > c->count) threads = c->count ? (unsigned)c->count : 1u;
@@ -260,7 +261,8 @@ namespace {
 std::mutex g_pool_mu;
 std::vector<std::pair<void*, uint64_t>> g_pool;
 
-void* pinned_get(uint64_t size, uint64_t* got) {
+}  // namespace
+void* eb_pinned_get(uint64_t size, uint64_t* got) {
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
         for (size_t i = 0; i < g_pool.size(); ++i)
@@ -274,15 +276,16 @@ void* pinned_get(uint64_t size, uint64_t* got) {
     void* p = nullptr;
     uint64_t cap = size + size / 4 + 4096;
     if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
-    if (getenv("EB_ALLOC_TRACE")) fprintf(stderr, "[calls] pinned a new blob of %.1f MB (none of that size in the pool)\n", cap / 1e6);
+    if (eb_cfg().trace_alloc) fprintf(stderr, "[calls] pinned a new block of %.1f MB (none of that size in the pool)\n", cap / 1e6);
     *got = cap;
     return p;
 }
-void pinned_put(void* p, uint64_t cap) {
+void eb_pinned_put(void* p, uint64_t cap) {
     std::lock_guard<std::mutex> lk(g_pool_mu);
     if (g_pool.size() < 16) { g_pool.emplace_back(p, cap); return; }
     (void)hipHostFree(p);
 }
+namespace {
 uint64_t align8(uint64_t v) { return (v + 7) & ~7ull; }
 }  // namespace
 
@@ -316,7 +319,7 @@ void eb_pinned_reserve(uint64_t size, int count, const void* d_warm, uint64_t wa
         for (auto& s : st)
             if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
     }
-    for (const auto& e : fresh) pinned_put(e.first, e.second);
+    for (const auto& e : fresh) eb_pinned_put(e.first, e.second);
 }
 
 namespace {
@@ -353,7 +356,7 @@ eb_calls* eb_calls_alloc(uint64_t count, uint64_t n_chains, int32_t k_left, int3
     c->pinned = pinned;
     if (pinned) {
         uint64_t cap = 0;
-        c->blob = static_cast<uint8_t*>(pinned_get(c->size, &cap));
+        c->blob = static_cast<uint8_t*>(eb_pinned_get(c->size, &cap));
         if (c->blob) {
             std::lock_guard<std::mutex> lk(g_caps_mu);
             g_caps.emplace_back(c, cap);
@@ -393,7 +396,7 @@ extern "C" void eb_calls_free(eb_calls* c) {
                 for (size_t i = 0; i < g_caps.size(); ++i)
                     if (g_caps[i].first == c) { cap = g_caps[i].second; g_caps.erase(g_caps.begin() + i); break; }
             }
-            pinned_put(c->blob, cap);
+            eb_pinned_put(c->blob, cap);
         } else {
             free(c->blob);
         }

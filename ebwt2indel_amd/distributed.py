@@ -145,6 +145,124 @@ def gather_packed(packed, group=None, device=None, dst: int = 0) -> Optional[Lis
     return [memoryview(base[r * cap: r * cap + sizes[r]]) for r in range(world)]
 
 
+class NodeArena:
+    """The ranks of ONE node hand their records to rank 0 through host memory they all map (round 5): every rank downloads its
+    own wire image over its own PCIe link into its slot of a shared-memory segment, rank 0 reads the slots -- no rank's link
+    carries another rank's records (the RCCL gather to GPU 0, gather_device_async, puts every record of the job on GPU 0's link:
+    35 MB per step at N = 8, longer than a rank's kernels).  No collective on the data path: a slot carries its own sequence
+    number and length, rank 0 polls them, and a counter of consumed steps holds the ranks back from a slot rank 0 still reads.
+
+        layout   [consumed u64, 56 B pad] then per rank `depth` slots of [seq u64, len u64, 48 B pad, image (cap bytes)]
+
+    Set up collectively (one broadcast of the segment's name, one barrier); `cap` must hold the largest image of a step
+    (EbError otherwise: the caller falls back to the gather).  Page-locked per rank (eb_host_register) when the ranks have
+    GPUs; plain shared memory otherwise (CPU rehearsal with byte strings)."""
+
+    HDR = 64
+
+    def __init__(self, cap: int, depth: int = 4, group=None, pin: bool = True):
+        import mmap
+        import os
+        import torch.distributed as dist
+
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.group, self.depth = group, depth
+        self.cap = (int(cap) + 4095) & ~4095
+        self.slot = self.HDR + self.cap
+        self.size = 4096 + self.world * depth * self.slot
+        name = [None]
+        if self.rank == 0:
+            name[0] = f"/dev/shm/ebwt2indel_arena_{os.getpid()}_{id(self) & 0xFFFFFF:x}"
+            fd = os.open(name[0], os.O_CREAT | os.O_EXCL | os.O_RDWR, 0o600)
+            os.ftruncate(fd, self.size)
+        if self.world > 1:
+            dist.broadcast_object_list(name, src=0, group=group)
+        if self.rank != 0:
+            fd = os.open(name[0], os.O_RDWR)
+        self._mm = mmap.mmap(fd, self.size)
+        os.close(fd)
+        if self.world > 1:
+            dist.barrier(group=group)                 # everyone has it mapped
+        if self.rank == 0:
+            os.unlink(name[0])                        # the mappings keep it alive; nothing is left behind whatever happens later
+        self._np = np.frombuffer(self._mm, dtype=np.uint8)
+        self._u64 = self._np[: self.size // 8 * 8].view(np.uint64)
+        self._base = self._np.ctypes.data
+        self._pinned = None
+        if pin:
+            from . import api
+            mine = self._base + 4096 + self.rank * depth * self.slot
+            api._check(api.lib().eb_host_register(mine, depth * self.slot))
+            self._pinned = mine
+        if self.rank == 0:
+            self._u64[0] = 0
+        self.step = 0                                 # next step this rank publishes
+        self.taken = 0                                # rank 0: steps collected so far
+
+    def _slot_off(self, rank: int, step: int) -> int:
+        return 4096 + (rank * self.depth + step % self.depth) * self.slot
+
+    def _wait_free(self, step: int):
+        import time
+        while step >= int(self._u64[0]) + self.depth:   # rank 0 still reads the slot's previous occupant
+            time.sleep(0)
+
+    def publish_job(self, job) -> int:
+        """This rank's share of the next step: the job's compact wire image, downloaded straight into the slot."""
+        step = self.step
+        self._wait_free(step)
+        off = self._slot_off(self.rank, step)
+        n = job.wire_to_host(self._base + off + self.HDR, self.cap)
+        self._u64[off // 8 + 1] = n
+        self._u64[off // 8] = step + 1                # (x86: stores are seen in order; the image was complete before wire_to_host returned)
+        self.step += 1
+        return n
+
+    def publish_bytes(self, data) -> int:
+        """The same with a byte string (a call set already in host memory; CPU rehearsal)."""
+        step = self.step
+        self._wait_free(step)
+        off = self._slot_off(self.rank, step)
+        n = len(data)
+        if n > self.cap:
+            raise ValueError(f"the image takes {n} bytes, a slot of the arena holds {self.cap}")
+        self._np[off + self.HDR: off + self.HDR + n] = np.frombuffer(data, dtype=np.uint8)
+        self._u64[off // 8 + 1] = n
+        self._u64[off // 8] = step + 1
+        self.step += 1
+        return n
+
+    def collect(self) -> List[memoryview]:
+        """Rank 0: the images of every rank for the next step, in rank order, as views into the arena -- valid until release()."""
+        import time
+        step = self.taken
+        views = []
+        for r in range(self.world):
+            off = self._slot_off(r, step)
+            while int(self._u64[off // 8]) != step + 1:
+                time.sleep(0)
+            n = int(self._u64[off // 8 + 1])
+            views.append(memoryview(self._np[off + self.HDR: off + self.HDR + n]))
+        self.taken += 1
+        return views
+
+    def release(self):
+        """Rank 0 is done with every step collected so far: their slots may be written again."""
+        self._u64[0] = self.taken
+
+    def close(self):
+        if self._pinned is not None:
+            from . import api
+            api.lib().eb_host_unregister(self._pinned)
+            self._pinned = None
+        self._u64 = self._np = None
+        try:
+            self._mm.close()
+        except BufferError:
+            pass                                       # a caller still holds a view: the mapping goes with the process
+
+
 class _DeviceWords:
     """`words` int64 words of device memory at `ptr`, for torch.as_tensor (no copy)."""
 

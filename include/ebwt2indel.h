@@ -91,7 +91,8 @@ int eb_index_info(const eb_index* h, eb_index_info_t* info);
  * rank every time).  One 16-byte chunk per 16 occurrences of a letter spells their positions out, so that FL -- the step of the
  * right-context walk extract_dna, ebwt2InDel.cpp:325-342 -- is one 16-byte read instead of a directory read plus a block probe.
  * Costs n bytes of HBM and about the time of five phase-4 walks to build; results are those of select either way.  Phase 4
- * builds it by itself when a THIRD job is begun on an index (EB_PSI=0: never, EB_PSI=1: with the first); this call builds it now.
+ * builds it by itself once the jobs begun on an index have scanned three times its length -- the third whole-range pass, the
+ * 24th job of a rank that scans an eighth (EB_PSI=0: never, EB_PSI=1: with the first job); this call builds it now.
  * EB_ERR_STATE beyond 2^38 - 2 symbols, EB_ERR_NOMEM if the device cannot spare the memory: the index works on without it. */
 int eb_index_build_psi(eb_index* h);
 /* 1 iff the table exists; *bytes its size, *void_chunks the chunks that fall back to the directory (a gap of 64 rows or more). */
@@ -225,16 +226,17 @@ typedef struct {
     uint64_t survivors;        /* records emitted */
     uint64_t chains;           /* left-context chains extended */
     uint64_t hist[201];        /* CLUST_SIZES (:1604,1627) */
-    float    ms_scan, ms_extend, ms_right; /* HIP-event kernel times summed over the sub-shard launches */
+    float    ms_scan, ms_extend, ms_right; /* HIP-event kernel times on the streams the kernels run on */
     float    ms_total;                     /* first scan launch .. last record byte in host memory */
-    uint32_t scan_launches;                /* k_scan launches (sub-shards) behind ms_scan */
-    float    ms_context;                   /* first start .. last end of the two context kernels (they run side by side) */
+    uint32_t scan_launches;                /* k_scan launches behind ms_scan (1) */
+    float    ms_context;                   /* start of the left-context extension .. end of the right-context walk behind it */
     /* memory requests the context kernels issued, counted on the device where they are issued: k_extend one per
      * 64-byte block of a rank pair (1 or 2 per LF step), k_right one per select-directory read + one per block probed */
     uint64_t requests_extend, requests_right;
-    /* scans that ran a second time: a batch of the ordered hand-over held more survivors than its slots (the scan then
-     * runs again the unordered way), or the unordered survivor list was too short (it runs again with room for all) */
-    uint32_t scan_reruns, reserved;
+    /* scans that ran a second time: a batch of the ordered hand-over held more survivors than its slots (the job is then
+     * done again with smaller batches), or the unordered survivor list was too short (it runs again with room for all) */
+    uint32_t scan_reruns;
+    uint32_t batch_tiles;                  /* tiles (16 384 positions each) per batch of the ordered hand-over the job ended with; 0: the unordered hand-over */
 } eb_scan_stats;
 
 /* Replaces the phase-4 loops run_one_dataset (:1609-1655), run_two_datasets (:1395-1445)
@@ -246,19 +248,17 @@ int eb_scan_clusters(eb_index* b1, eb_index* b2, eb_flags* f, uint64_t begin, ui
                      eb_calls** out, eb_scan_stats* stats);
 
 /* Split form for callers that pipeline calls (the record download of one call overlaps the kernels of the next).
- * _begin enqueues the scan, waits for it on the host (the number of surviving clusters sizes the next buffers; a list
- * that overflowed is scanned again with room), enqueues the ordering of the survivors, waits a second time (survivor
- * and chain counts size the call set's image), enqueues the context kernels, the copy to page-locked host memory and,
- * if asked for, the wire image -- and returns.  So _begin blocks for about the time of the scan (plus ~0.25 ms); what
- * is still in flight when it returns are the context kernels and the hand-over of the records, i.e. most of the job.
- * _end waits for those and hands over the results.  (Making _begin enqueue-only was tried twice in round 2 -- sizing
- * everything by the survivor list's capacity with device-resident counts, and holding the context kernels back for the
- * next job's scan -- and measured slower both times: DESIGN.md section 3.)
+ * _begin ENQUEUES the whole job -- scan, ordering of the survivors, context kernels, wire image -- and returns without waiting
+ * for the device (round 5; about 0.1 ms): buffers are sized by capacity, the survivor and chain counts stay in device memory
+ * where the kernels read them, and the host learns them from a report the kernels write into page-locked memory.  _wait / _end
+ * and the device-image accessors look at that report first: should a batch of the scan's ordered hand-over have held more
+ * survivors than its slots, they run the job again with smaller batches (eb_scan_stats.scan_reruns; the size is remembered per
+ * index), so a caller never sees a partial call set.  _end then copies the dense image of the call set into a page-locked
+ * blob (one copy of exactly its size), waits for it and hands the results over.
  * Several jobs may be in flight on the same handles; each must be ended (or cancelled) exactly once, in any order.
  * Threads: _begin calls on one index are made from one host thread at a time; _wait / _end / the device-image accessors
  * of a begun job may be called from another thread while the next job is being begun (bench.py hands records over
- * that way).  A job with a small call set (a rank's share of a multi-GPU run) lets the next job's scan start under its
- * context kernels; large ones keep the scan behind them (they would only slow each other down). */
+ * that way). */
 typedef struct eb_scan_job eb_scan_job;
 int eb_scan_clusters_begin(eb_index* b1, eb_index* b2, eb_flags* f, uint64_t begin, uint64_t end, const eb_params* p,
                            eb_scan_job** job);
@@ -270,21 +270,16 @@ void eb_scan_clusters_cancel(eb_scan_job* job);
 /* EB_SCAN_WIRE: the job also packs the compact wire image (eb_scan_job_device_wire) as its last step, so that asking
  * for it later costs no extra launch or wait. */
 #define EB_SCAN_WIRE 2u
-/* EB_SCAN_PIPELINED: the caller keeps jobs coming on this index (or ends this one promptly).  For a small call set
- * (a rank's share of a multi-GPU run; one sub-shard) _begin then returns after ONE host wait -- the scan's -- and holds
- * the job's last part (image layout, chain list, context kernels, hand-over; it needs the ordering step's counts on
- * the host) back until the next _begin on the index, which sends it out behind its own scan, so that the two waits of
- * consecutive jobs overlap; _wait / _end / the device-image accessors send it out themselves if it is still pending.
- * Whatever the size of the call set: while the previous job's context kernels are still running, the scan of this job
- * shares every CU with them instead of waiting for them (round 3), and the library reserves, with the caller's first call
- * set, what several live jobs need -- page-locked blobs, device temporaries, copy-engine queues (+0.14 s on that call). */
+/* EB_SCAN_PIPELINED: the caller keeps jobs coming on this index.  While the previous job's context kernels are still running,
+ * the scan of this job shares every CU with them instead of waiting for them (round 3), and the library reserves, with the
+ * caller's first job of a size, what several live jobs need -- page-locked blobs, device temporaries, copy-engine queues. */
 #define EB_SCAN_PIPELINED 4u
 int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f, uint64_t begin, uint64_t end, const eb_params* p,
                               uint32_t options, eb_scan_job** job);
 /* Blocks until the job's kernels and copies are complete; the job stays valid. */
 int eb_scan_job_wait(eb_scan_job* job);
-/* The job's call set as one contiguous image in DEVICE memory (same format as eb_calls_blob), valid until _end.
- * EB_ERR_STATE when the job was split into sub-shards (EB_SCAN_SUBSHARDS > 1). */
+/* The job's call set as one contiguous image in DEVICE memory (same format as eb_calls_blob), valid until _end; its kernels
+ * may still be running (eb_scan_job_wait). */
 int eb_scan_job_device_blob(eb_scan_job* job, const void** d_data, uint64_t* len);
 /* The same call set as a COMPACT wire image in device memory (44 instead of 80 bytes per two-allele cluster), for the
  * gather to rank 0 and its download -- the PCIe link of rank 0 carries every record of an N-GPU job:
@@ -298,6 +293,15 @@ int eb_scan_job_device_blob(eb_scan_job* job, const void** d_data, uint64_t* len
  * else on first call; valid until _end.  EB_ERR_STATE if not even the full-width records fit: use
  * eb_scan_job_device_blob then. */
 int eb_scan_job_device_wire(eb_scan_job* job, const void** d_data, uint64_t* len);
+/* The same wire image copied into the CALLER's host memory (`cap` bytes at `dst`; page-locked memory makes it a DMA at link
+ * rate) over this GPU's own PCIe link; *len = its size, also when it does not fit (EB_ERR_ARG then).  What a rank of a one-node
+ * multi-GPU run does with its records: the node's host memory is shared, so every rank downloads its own share over its own
+ * link into one arena and no link carries another rank's records (the RCCL gather to GPU 0 put all of them on GPU 0's link). */
+int eb_scan_job_wire_to_host(eb_scan_job* job, void* dst, uint64_t cap, uint64_t* len);
+/* Page-locks `bytes` of the caller's host memory at `p` for such downloads (a shared-memory arena that several processes of one
+ * node map: each rank registers the part it writes), and releases the lock again (before the memory is unmapped). */
+int eb_host_register(void* p, uint64_t bytes);
+int eb_host_unregister(void* p);
 
 typedef struct {
     uint64_t count;                /* clusters */
@@ -329,6 +333,12 @@ int eb_write_snp(const eb_calls* c, const eb_params* p, int two_samples, const c
 int eb_format_snp(const eb_calls* c, const eb_params* p, int two_samples, uint64_t* cluster_nr, uint64_t* events,
                   char** text, uint64_t* len);
 void eb_free(void* p);
+
+/* ------------------------------------------------------------------ environment switches
+ * The library reads its switches (EB_PSI, EB_SELECT, EB_NAV_CHAINS, EB_NAV_FORM, EB_NAV_BATCH, EB_SCAN_OVERLAP, EB_SCAN_ORDERED,
+ * EB_CONTEXT, EB_INDEX_PINNED, EB_WRITER_THREADS, EB_TRACE: DESIGN.md section 10 -- every one result-neutral, none needed for
+ * normal use) ONCE, when it is loaded.  Tests that change them inside one process call this afterwards. */
+void eb_config_reload(void);
 
 /* ------------------------------------------------------------------ self-test hooks (host only, no GPU needed)
  * Round trip of the traversal's packed stack records (eb_navigate.hip: 40-bit positions + saturating 16-bit depth;

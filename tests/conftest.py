@@ -47,3 +47,34 @@ CASE_IDS = [c["name"] for c in CASES]
 def oracle():
     from tests import _oracle
     return _oracle.Oracle()
+
+
+class _EbMonkeyPatch(pytest.MonkeyPatch):
+    """The library reads its EB_* switches once, when it is loaded (csrc/eb_config.cpp); tests that change one inside the
+    process need it read again: setenv / delenv of an EB_* name do that (eb_config_reload), and so does the undo at the end."""
+
+    @staticmethod
+    def _reload(name):
+        if name.startswith("EB_") and "ebwt2indel_amd.api" in sys.modules:
+            api = sys.modules["ebwt2indel_amd.api"]
+            if api._L is not None:
+                api._L.eb_config_reload()
+
+    def setenv(self, name, value, prepend=None):
+        super().setenv(name, value, prepend)
+        self._reload(name)
+
+    def delenv(self, name, raising=True):
+        super().delenv(name, raising)
+        self._reload(name)
+
+    def undo(self):
+        super().undo()
+        self._reload("EB_")
+
+
+@pytest.fixture
+def monkeypatch():
+    mp = _EbMonkeyPatch()
+    yield mp
+    mp.undo()

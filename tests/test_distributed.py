@@ -15,7 +15,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, case, out_path):
+def _worker(rank, world, port, case, out_path, arena=False):
     import torch.distributed as dist
 
     from ebwt2indel_amd import api
@@ -37,7 +37,21 @@ def _worker(rank, world, port, case, out_path):
         b, e = ebd.shard_range(n, rank, world)
         rec = fl.scan(p, b, e, capture=True)
         calls = api.Calls.unpack(_oracle.pack_calls(rec, p.k_left, p.k_right))     # product container
-        parts = ebd.gather_packed(calls.pack())
+        if arena:
+            # round 5: every rank puts its records into its slot of a host arena all ranks map (on GPUs: downloaded over the
+            # rank's own PCIe link), rank 0 reads the slots -- no collective on the data path.  Three steps through a ring of two
+            # slots: the third must wait until rank 0 has released the first.
+            ar = ebd.NodeArena(cap=len(calls.pack()) + 100, depth=2, pin=False)
+            parts = None
+            for step in range(3):
+                ar.publish_bytes(calls.pack())
+                if rank == 0:
+                    parts = [bytes(v) for v in ar.collect()]
+                    ar.release()
+            dist.barrier()
+            ar.close()
+        else:
+            parts = ebd.gather_packed(calls.pack())
         if rank == 0:
             assert len(parts) == world
             text, cluster_nr, events, total = ebd.write_gathered(parts, api.make_params(case["args"]), case["mode"] != 1)
@@ -69,6 +83,17 @@ def test_eight_rank_gather_reproduces_golden(tmp_path, name):
     case = [c for c in CASES if c["name"] == name][0]
     out = tmp_path / "out.snp"
     mp.spawn(_worker, args=(8, _free_port(), case, str(out)), nprocs=8, join=True)
+    assert out.read_bytes() == golden_bytes(case["snp"])
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_host_arena_reproduces_golden(tmp_path, world):
+    """The same with the records handed over through the node's shared host arena (ebd.NodeArena) instead of a gather."""
+    import torch.multiprocessing as mp
+
+    case = [c for c in CASES if c["name"] == "m1_default"][0]
+    out = tmp_path / "out.snp"
+    mp.spawn(_worker, args=(world, _free_port(), case, str(out), True), nprocs=world, join=True)
     assert out.read_bytes() == golden_bytes(case["snp"])
 
 

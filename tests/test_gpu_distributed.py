@@ -22,9 +22,9 @@ def _case(name):
 
 
 @pytest.mark.parametrize("name", ["m1_default", "m2_het_default"])
-@pytest.mark.parametrize("n_shards,split_min,nav_bytes", [(2, 1, "1"), (3, 4, "1"), (8, 16, "1"), (2, 1 << 40, "1"), (3, 4, "0")])
-def test_shards_partition_the_flag_vectors(monkeypatch, name, n_shards, split_min, nav_bytes):
-    monkeypatch.setenv("EB_NAV_BYTES", nav_bytes)               # "0": the memory-short traversal (atomicOr on bit words)
+@pytest.mark.parametrize("n_shards,split_min,nav_form", [(2, 1, "bytes"), (3, 4, "bytes"), (8, 16, "bytes"), (2, 1 << 40, "bytes"), (3, 4, "words")])
+def test_shards_partition_the_flag_vectors(monkeypatch, name, n_shards, split_min, nav_form):
+    monkeypatch.setenv("EB_NAV_FORM", nav_form)                 # the form of the WHOLE build the shards are held to ("words": the memory-short one, atomicOr on bit words)
     case = _case(name)
     inp = case["inputs"]
     p = api.make_params(case["args"])
@@ -32,7 +32,7 @@ def test_shards_partition_the_flag_vectors(monkeypatch, name, n_shards, split_mi
     b2 = api.DnaBwt(golden_bytes(inp["bwt2"]), term=p.term) if case["mode"] == 2 else None
     whole = api.Flags.build(b1, b2, p.K, p.k_right)
     want = whole.export()
-    monkeypatch.setenv("EB_NAV_SPLIT_MIN", str(split_min))      # tiny inputs: cut the tree after a handful of records
+    monkeypatch.setenv("EB_NAV_BATCH", f",,{split_min}")        # tiny inputs: cut the tree after a handful of records
     acc = [np.zeros_like(v) if v is not None else None for v in want]
     totals = dict.fromkeys(_COUNTERS, 0)
     busy = 0
@@ -78,7 +78,7 @@ def _worker(rank, world, port, case, out_path):
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    os.environ["EB_NAV_SPLIT_MIN"] = "8"
+    os.environ["EB_NAV_BATCH"] = ",,8"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         inp = case["inputs"]
@@ -120,7 +120,8 @@ def test_two_ranks_one_gpu_reproduce_golden(tmp_path, name):
 
 def _worker_forced(rank, world, port, case, out_path, complement):
     os.environ["EB_FORCE_COLLECTIVES"] = "1"
-    os.environ["EB_NAV_COMPLEMENT"] = complement
+    if complement == "0":
+        os.environ["EB_NAV_FORM"] = "bytes"
     _worker(rank, world, port, case, out_path)
 
 
@@ -153,7 +154,7 @@ def test_multi_gpu_launcher_two_ranks(tmp_path, name):
         files[key] = str(pth)
     out = tmp_path / "out.snp"
     args = ["-1", files["bwt1"], "-o", str(out)] + (["-2", files["bwt2"]] if case["mode"] == 2 else []) + (["-d", files["da"]] if case["mode"] == 3 else [])
-    env = dict(os.environ, EB_DIST_BACKEND="gloo", EB_NAV_SPLIT_MIN="8")
+    env = dict(os.environ, EB_DIST_BACKEND="gloo", EB_NAV_BATCH=",,8")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
            str(_free_port()), "-m", "ebwt2indel_amd.run_distributed"] + args + list(case["args"])
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -62,8 +62,7 @@ def test_threaded_pinned_upload_gives_the_same_index(monkeypatch, dip):
     """Large inputs go to the GPU through page-locked pieces filled by host threads; forced here on a small one, with
     pieces that do not divide it."""
     e, g, _ = dip
-    monkeypatch.setenv("EB_INDEX_PINNED_MIN", "1")
-    monkeypatch.setenv("EB_INDEX_PINNED_PIECE", str(128 * 37))
+    monkeypatch.setenv("EB_INDEX_PINNED", f"1,{128 * 37},3")       # from 1 byte on, pieces of 4736 symbols, 3 reader threads
     g2 = api.DnaBwt(e)
     assert g2.F_arr == g.F_arr and g2.n == g.n
     pos = _positions(len(e), 20_000, 5)
@@ -140,8 +139,8 @@ def test_fl_is_inverse_of_lf(dip):
 @pytest.mark.parametrize("name", ["dip.ebwt", "edge.ebwt", "het_m.ebwt"])
 def test_fl_under_every_select_sampling(oracle, monkeypatch, name, shift):
     """The select directory samples every 32nd occurrence of a letter up to 2^35 symbols and every 128th beyond
-    (EB_SEL_SHIFT overrides): FL, and a whole run's .snp through the right-context walk, must not depend on it."""
-    monkeypatch.setenv("EB_SEL_SHIFT", shift)
+    (EB_SELECT overrides): FL, and a whole run's .snp through the right-context walk, must not depend on it."""
+    monkeypatch.setenv("EB_SELECT", shift)
     e = golden_bytes(name)
     g, o = api.DnaBwt(e), oracle.index(e)
     pos = _rng(int(shift)).integers(g.F_arr[0], len(e), size=30_000, dtype=np.uint64)
@@ -155,10 +154,9 @@ def test_fl_under_every_select_sampling(oracle, monkeypatch, name, shift):
 def test_fl_under_every_directory_entry_layout(oracle, monkeypatch, shift, bits):
     """A select-directory entry keeps the block of its sample in its low bits and the sample's ordinal inside that block in
     the bits an index of that size leaves free, in units of 1 (up to 2^32 symbols) to 16 (up to 2^36), none beyond
-    (eb_select_guess); EB_SEL_BLK_BITS puts the layouts of the large indexes on a small one.  FL, and a whole run's .snp
+    (eb_select_guess); EB_SELECT=<shift>,<bits> puts the layouts of the large indexes on a small one.  FL, and a whole run's .snp
     through the right-context walk, must not depend on the layout: the guess only chooses where the probes start."""
-    monkeypatch.setenv("EB_SEL_SHIFT", shift)
-    monkeypatch.setenv("EB_SEL_BLK_BITS", bits)
+    monkeypatch.setenv("EB_SELECT", f"{shift},{bits}")
     e = golden_bytes("dip.ebwt")
     g, o = api.DnaBwt(e), oracle.index(e)
     pos = _rng(int(shift) * 37 + int(bits)).integers(g.F_arr[0], len(e), size=30_000, dtype=np.uint64)
@@ -268,19 +266,19 @@ NAV_MODES = {
     # default: writers BELOW the thresholds mark their positions in interleaved bit words (atomicOr), inverted at the end;
     # leaves and nodes side by side on two streams
     "complement": {},
-    "complement_one_stream": {"EB_NAV_CONCURRENT": "0"},
     # the reference's form (also the fallback for inputs that are no eBWT): writers at or above the thresholds set their bits --
     # one byte per position with plain stores (needs n spare bytes of HBM), or bit words with atomicOr when memory is short
-    "classic_bytes": {"EB_NAV_COMPLEMENT": "0", "EB_NAV_BYTES": "1"},
-    "classic_words": {"EB_NAV_COMPLEMENT": "0", "EB_NAV_BYTES": "0"},
-    # the drain's planner read back after every launch instead of once per group of eight
-    # the round-3 one-BWT node kernel (every node through the stack) instead of the chain-following one of round 4; and the
-    # chain-following walk thrown away as if a launch had overflowed its stack (the caller then walks again the round-3 way)
+    "classic_bytes": {"EB_NAV_FORM": "bytes"},
+    "classic_words": {"EB_NAV_FORM": "words"},
+    # the round-3 one-BWT node kernel (every node through the stack) instead of the chain-following one of round 4; the
+    # chain-following walk thrown away as if a launch had overflowed its stack (the caller then walks again the round-3 way); and
+    # the chain-following walk REALLY overflowing (told it has room for 64 records per launch: records dropped in mid-launch, the
+    # error raised on the device, the group queued ahead idling, the leaf thread joined) before the round-3 kernels walk again
     "round3_node_kernel": {"EB_NAV_CHAINS": "0"},
     "chains_overflow_walks_again": {"EB_NAV_CHAINS": "2"},
-    "chains_classic_words": {"EB_NAV_COMPLEMENT": "0", "EB_NAV_BYTES": "0", "EB_NAV_GROUP": "2"},
-    "one_launch_per_readback": {"EB_NAV_GROUP": "1"},
-    "classic_words_round3_kernels": {"EB_NAV_COMPLEMENT": "0", "EB_NAV_BYTES": "0", "EB_NAV_CHAINS": "0", "EB_NAV_GROUP": "3"},
+    "chains_really_overflow": {"EB_NAV_CHAINS": "3"},
+    "chains_really_overflow_classic_words": {"EB_NAV_CHAINS": "3", "EB_NAV_FORM": "words"},
+    "classic_words_round3_kernels": {"EB_NAV_FORM": "words", "EB_NAV_CHAINS": "0"},
 }
 
 
@@ -317,10 +315,10 @@ def test_flags_batch_size_does_not_change_result(oracle, monkeypatch):
     e = golden_bytes("dip.ebwt")
     g = api.DnaBwt(e)
     ref = api.Flags.build(g, None, 16, 30).export()
-    for batch, mode in (("64", "complement"), ("1000", "classic_bytes"), ("777", "classic_words"), ("300", "complement_one_stream"), ("200", "classic_words_round3_kernels"),
-                        ("130", "one_launch_per_readback"), ("64", "round3_node_kernel"), ("17", "complement")):
-        monkeypatch.setenv("EB_NAV_BATCH", batch)                 # tiny batches: many launches, depth-first order
-        for k in ("EB_NAV_COMPLEMENT", "EB_NAV_BYTES", "EB_NAV_CONCURRENT", "EB_NAV_GROUP", "EB_NAV_CHAINS"):
+    for batch, mode in (("64", "complement"), ("1000", "classic_bytes"), ("777", "classic_words"), ("300,3", "complement"), ("200", "classic_words_round3_kernels"),
+                        ("130", "chains_really_overflow"), ("64", "round3_node_kernel"), ("17", "complement")):
+        monkeypatch.setenv("EB_NAV_BATCH", batch)                 # tiny batches: many launches, depth-first order ("300,3": and a three-batch arena)
+        for k in ("EB_NAV_FORM", "EB_NAV_CHAINS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in NAV_MODES[mode].items():
             monkeypatch.setenv(k, v)
@@ -352,13 +350,13 @@ def test_input_that_is_no_ebwt_falls_back_to_the_reference_form(oracle, monkeypa
     assert oc["lcp_values"] != len(e)                              # the premise
     g = api.DnaBwt(e)
     got = api.Flags.build(g, None, 16, 30)
-    monkeypatch.setenv("EB_NAV_COMPLEMENT", "0")
+    monkeypatch.setenv("EB_NAV_FORM", "bytes")
     classic = api.Flags.build(g, None, 16, 30)
     for a, b, c in zip(got.export()[:3], classic.export()[:3], of.export()[:3]):
         assert np.array_equal(a, b) and np.array_equal(a, c)
     assert got.stats.lcp_values == classic.stats.lcp_values == oc["lcp_values"]
     want, _ = oracle.run(e)
-    monkeypatch.delenv("EB_NAV_COMPLEMENT")
+    monkeypatch.delenv("EB_NAV_FORM")
     assert api.run_one_dataset(e) == want
 
 
@@ -435,11 +433,11 @@ def test_snp_byte_identical_to_reference(case):
 def test_cluster_records_match_oracle(oracle, monkeypatch, case, gated, psi):
     """Record-level parity of phase 4 (clusters, supports, contexts, counters), whole range and sharded -- with the right-context
     walk for every cluster (small call sets) and for the clusters that can print only (large call sets; forced on these small
-    ones by EB_RIGHT_GATE_MIN=0: `gated`) -- each through the directory select (EB_PSI=0) and through the FL table of
+    ones by EB_CONTEXT=gate=0: `gated`) -- each through the directory select (EB_PSI=0) and through the FL table of
     repeatedly scanned indexes (round 4, EB_PSI=1: built with the first job instead of the third)."""
     monkeypatch.setenv("EB_PSI", psi)
     if gated:
-        monkeypatch.setenv("EB_RIGHT_GATE_MIN", "0")
+        monkeypatch.setenv("EB_CONTEXT", "gate=0")
     p, e1, e2, da = _flag_case(oracle, case)
     pp = api.make_params(case["args"])
     o1 = oracle.index(e1, p.term)
@@ -504,7 +502,7 @@ def test_extension_by_one_lane_per_chain_gives_the_same_call_set(monkeypatch, ca
         fl.set_da(golden_bytes(inp["da"]))
     out = {}
     for lanes in ("4", "1"):
-        monkeypatch.setenv("EB_EXTEND_LANES", lanes)
+        monkeypatch.setenv("EB_CONTEXT", f"extend={lanes}")
         calls = api.scan_clusters(g1, fl, p, bwt2=g2)
         out[lanes] = (bytes(calls.blob()), calls.stats.requests_extend, calls.format_snp(p, case["mode"] != 1)[0])
     assert out["1"] == out["4"]
@@ -782,10 +780,11 @@ def test_pipelined_jobs_hold_back_their_last_part(dip):
 
 
 @pytest.mark.parametrize("case", [c for c in CASES if c["name"] in ("m1_default", "m2_het_default", "m3_het_default")], ids=lambda c: c["name"])
-@pytest.mark.parametrize("subshards", ["2", "3", "7"])
-def test_sub_shards_give_the_same_call_set(oracle, monkeypatch, case, subshards):
-    """EB_SCAN_SUBSHARDS (experiments knob of the phase-4 driver): a range cut into sub-shards inside one call gives the
-    records, counters and .snp of the uncut call -- whole range and an odd slice, ungated and gated context walks."""
+@pytest.mark.parametrize("tiles", ["1", "4", "32"])
+def test_batch_size_of_the_ordered_hand_over_does_not_change_the_call_set(oracle, monkeypatch, case, tiles):
+    """The scan hands its survivors over in BWT-ordered batches of 128 tiles (2 M positions) that shrink by themselves when one
+    overflows; EB_SCAN_ORDERED=<tiles> starts with smaller ones.  Records, counters and .snp are those of the default -- whole
+    range and an odd slice, ungated and gated context walks -- and read data needs no second run at any size."""
     p, e1, e2, da = _flag_case(oracle, case)
     pp = api.make_params(case["args"])
     g1 = api.DnaBwt(e1, term=p.term)
@@ -794,15 +793,18 @@ def test_sub_shards_give_the_same_call_set(oracle, monkeypatch, case, subshards)
     if da is not None:
         gf.set_da(da)
     n = g1.n + (g2.n if g2 is not None else 0)
+    # (the batch size is remembered per index: the small batches get indexes of their own)
+    h1 = api.DnaBwt(e1, term=p.term)
+    h2 = api.DnaBwt(e2, term=p.term) if e2 is not None else None
     for gated in (False, True):                 # the walk: for every cluster (small call sets), gated (large call sets)
-        if gated:
-            monkeypatch.setenv("EB_RIGHT_GATE_MIN", "0")
         for b, e in ((0, n), (n // 5 + 3, n - n // 7)):
-            monkeypatch.delenv("EB_SCAN_SUBSHARDS", raising=False)
+            monkeypatch.setenv("EB_CONTEXT", "gate=0" if gated else "gate=524288")
+            monkeypatch.delenv("EB_SCAN_ORDERED", raising=False)
             plain = api.scan_clusters(g1, gf, pp, bwt2=g2, begin=b, end=e)
-            monkeypatch.setenv("EB_SCAN_SUBSHARDS", subshards)
-            cut = api.scan_clusters(g1, gf, pp, bwt2=g2, begin=b, end=e)
-            assert cut.stats.scan_launches == int(subshards)
+            monkeypatch.setenv("EB_SCAN_ORDERED", tiles)
+            cut = api.scan_clusters(h1, gf, pp, bwt2=h2, begin=b, end=e)
+            assert plain.stats.batch_tiles == 128 and cut.stats.batch_tiles == int(tiles)
+            assert plain.stats.scan_reruns == 0 and cut.stats.scan_reruns == 0
             assert bytes(cut.blob()) == bytes(plain.blob())
             a, c = plain.stats, cut.stats
             assert (a.runs_closed, a.clusters, a.bases_in_runs, a.survivors, a.chains, list(a.hist)) == \
@@ -820,7 +822,7 @@ def _pack_bits(bits):
     return np.packbits(np.concatenate([bits, np.zeros(pad, dtype=bool)]), bitorder="little").view(np.uint64).copy()
 
 
-_STRESS_RERUNS = {}
+_STRESS_RERUNS, _STRESS_TILES = {}, {}
 _STRESS = {
     # name: (n, P(symbol is TERM), flag pattern)
     "dense_runs_of_20": (200_000, 0.02, lambda r, n: _bits(r, n, 0.95)),
@@ -834,7 +836,7 @@ _STRESS = {
 }
 
 
-@pytest.mark.parametrize("scan_form", ["default", "overlap3_prefetch", "prefetch_only"])
+@pytest.mark.parametrize("scan_form", ["default", "overlap3", "one_tile_batches", "unordered"])
 @pytest.mark.parametrize("mode", [1, 2, 3])
 @pytest.mark.parametrize("name", sorted(_STRESS))
 def test_scan_on_adversarial_flag_patterns(oracle, monkeypatch, name, mode, scan_form):
@@ -843,10 +845,12 @@ def test_scan_on_adversarial_flag_patterns(oracle, monkeypatch, name, mode, scan
     cases of the run logic -- runs ending on word boundaries, spanning exactly two words, spanning hundreds, nine
     clusters in one word.  The scan only reads these vectors (ebwt2InDel.cpp:1609-1655); records, counters and
     CLUST_SIZES must equal the oracle's, whole range and cut at odd positions."""
-    if scan_form == "overlap3_prefetch":       # the scan that shares the CUs with the context kernels: 3 workgroups per CU, tile loads one tile ahead
+    if scan_form == "overlap3":                # the scan that shares the CUs with the context kernels: 3 workgroups per CU, tile loads one tile ahead
         monkeypatch.setenv("EB_SCAN_OVERLAP", "3")
-    elif scan_form == "prefetch_only":
-        monkeypatch.setenv("EB_SCAN_PREFETCH", "1")
+    elif scan_form == "one_tile_batches":      # the ordered hand-over from its smallest batches on
+        monkeypatch.setenv("EB_SCAN_ORDERED", "1")
+    elif scan_form == "unordered":             # the fallback at once
+        monkeypatch.setenv("EB_SCAN_ORDERED", "0")
     n, p_term, pattern = _STRESS[name]
     rng = _rng(sum(name.encode()) * 7 + mode)
     sym = rng.choice(np.frombuffer(b"ACGT#", dtype=np.uint8), size=n, p=[(1 - p_term) / 4] * 4 + [p_term])
@@ -872,7 +876,7 @@ def test_scan_on_adversarial_flag_patterns(oracle, monkeypatch, name, mode, scan
         g1 = api.DnaBwt(sym, term=p.term)
     of = _oracle.OracleFlags(oracle, o1, o2, vectors=(thrK, thrR, minima, da))
     gf = api.Flags.from_host(n, thrK, thrR, minima, da)
-    seen, reruns = [], []
+    seen, reruns, tiles = [], [], []
     for cuts in ([0, n], [0, 64 * 700 + 1, n // 2 + 17, n - 5, n]):
         for b, e in zip(cuts[:-1], cuts[1:]):
             want = of.scan(p, b, e, capture=True)
@@ -881,6 +885,7 @@ def test_scan_on_adversarial_flag_patterns(oracle, monkeypatch, name, mode, scan
             cl, chains, left, right = calls.arrays()
             st = calls.stats
             reruns.append(st.scan_reruns)
+            tiles.append(st.batch_tiles)
             assert dict(runs_closed=st.runs_closed, clusters=st.clusters, bases_in_runs=st.bases_in_runs,
                         survivors=st.survivors, chains=st.chains) == want["stats"]
             assert np.array_equal(np.array(list(st.hist), dtype=np.uint64), want["hist"])
@@ -889,21 +894,66 @@ def test_scan_on_adversarial_flag_patterns(oracle, monkeypatch, name, mode, scan
             assert np.array_equal(left, want["left"])
             assert np.array_equal(right, want["right"])
     assert seen[0] == sum(seen[1:]) and seen[0] > 0              # the cuts partition the clusters; the input is not trivial
-    _STRESS_RERUNS[(name, mode)] = max(reruns)
+    if scan_form == "default":
+        _STRESS_RERUNS[(name, mode)] = max(reruns)
+        _STRESS_TILES[(name, mode)] = min(tiles)
+    elif scan_form == "unordered":
+        assert max(tiles) == 0
 
 
-def test_adversarial_patterns_reach_the_unordered_scan():
-    """The scan hands its survivors over in BWT-ordered batches of 128 slots; a batch that overflows makes it run again the
-    unordered way (eb_scan_stats.scan_reruns).  Read data never does that, the dense patterns above must -- or the fallback
-    would go untested."""
+def test_adversarial_patterns_reach_the_smaller_batches_and_the_unordered_scan():
+    """The scan hands its survivors over in BWT-ordered batches of 512 slots; a batch that overflows makes the job run again with
+    smaller batches, and the unordered way when not even one-tile batches hold it (eb_scan_stats.scan_reruns, .batch_tiles).  Read
+    data never does that, the dense patterns above must -- or both fallbacks would go untested."""
     if not _STRESS_RERUNS:
         pytest.skip("runs after test_scan_on_adversarial_flag_patterns")
     assert max(_STRESS_RERUNS.values()) > 0, _STRESS_RERUNS
+    assert 0 in _STRESS_TILES.values(), _STRESS_TILES                       # some pattern overflows one-tile batches too
+
+
+def test_batches_shrink_to_the_density_they_meet(monkeypatch):
+    """A range long enough for a workgroup to own several tiles (2048 workgroups x 4 tiles of 16 384 positions), with a surviving
+    cluster every 64 positions: four-tile batches hold 1024 of them in 512 slots, so the first job spills, is done again with
+    one-tile batches (256 each) and the index remembers that size -- the call set is the unordered hand-over's, byte for byte."""
+    n = 2048 * 4 * 16384 + 777
+    rng = _rng(77)
+    sym = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=n)
+    sym[:8] = ord("#")
+    thrK = _pack_bits((np.arange(n) % 64) < 20)
+    thrR = thrK.copy()
+    minima = np.zeros_like(thrK)
+    p = api.make_params()
+    g = api.DnaBwt(sym)
+    gf = api.Flags.from_host(n, thrK, thrR, minima, None)
+    first = api.scan_clusters(g, gf, p)
+    assert first.stats.scan_reruns >= 1 and 0 < first.stats.batch_tiles < 4, (first.stats.scan_reruns, first.stats.batch_tiles)
+    assert first.stats.survivors > n // 64 * 0.9
+    again = api.scan_clusters(g, gf, p)                      # the index remembers
+    assert again.stats.scan_reruns == 0 and again.stats.batch_tiles == first.stats.batch_tiles
+    jobs = [api.scan_clusters_begin(g, gf, p, pipelined=True) for _ in range(3)]
+    monkeypatch.setenv("EB_SCAN_ORDERED", "0")
+    g2 = api.DnaBwt(sym)
+    plain = api.scan_clusters(g2, gf, p)
+    assert plain.stats.batch_tiles == 0
+    want = bytes(plain.blob())
+    assert bytes(first.blob()) == want and bytes(again.blob()) == want
+    assert [bytes(j.finish().blob()) for j in jobs] == [want] * 3
+    a, c = first.stats, plain.stats
+    assert (a.runs_closed, a.clusters, a.bases_in_runs, a.survivors, a.chains, list(a.hist)) == \
+           (c.runs_closed, c.clusters, c.bases_in_runs, c.survivors, c.chains, list(c.hist))
+    del first, again, plain, jobs
+    # three jobs of a pipelining caller in flight on a fresh index when the first of them turns out to have spilled: each is done again
+    monkeypatch.delenv("EB_SCAN_ORDERED")
+    g3 = api.DnaBwt(sym)
+    jobs = [api.scan_clusters_begin(g3, gf, p, pipelined=True) for _ in range(3)]
+    outs = [j.finish() for j in jobs]
+    assert [bytes(o.blob()) for o in outs] == [want] * 3
+    assert outs[0].stats.scan_reruns >= 1 and api.scan_clusters(g3, gf, p).stats.scan_reruns == 0
 
 
 def test_ordered_and_unordered_scan_give_the_same_call_set(dip, monkeypatch):
     """EB_SCAN_ORDERED=0 (one survivor list put in order by position buckets) against the default (ordered batches) on
-    read data: same bytes, and the ordered scan needs no second run."""
+    read data: same bytes, and neither needs a second run."""
     e, g, _ = dip
     n = len(e)
     p = api.make_params()
