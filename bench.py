@@ -80,6 +80,10 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--coverage", type=float, default=30.0)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--error-rate-ppm", type=int, default=0, help="substitution errors per million bases in the reads (the reference's documented input "
+                    "is simulated reads with an error profile, README.md:88-100); 0: error-free reads, the BASELINE workload")
+    ap.add_argument("--reverse-complements", action="store_true", help="add the reverse complement of every read to the collection (README.md:90); "
+                    "with --reads 25000000 the collection has the BASELINE's 50 M reads")
     ap.add_argument("--rank-queries", type=int, default=1 << 28)   # SURVEY.md §8(d) metric 2: 2^28 uniform random positions
     ap.add_argument("--cpu-sample-reads", type=int, default=400_000, help="reads in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-dram-reads", type=int, default=7_000_000, help="reads in the DRAM-resident CPU-baseline sample (n = 151 x reads; 0 = skip)")
@@ -169,12 +173,23 @@ def main():
     # (the slab-by-slab generator since round 3: 1.2 s instead of 6 s at this size and a tenth of the temporaries; the same bytes --
     # tests/test_gpu_fullsize.py holds both generators to the recorded SHA-256 of this input; EB_BENCH_ONE_PASS_GENERATOR=1: the old one)
     build = sim.build_ebwt_gpu if os.environ.get("EB_BENCH_ONE_PASS_GENERATOR") == "1" else sim.build_ebwt_gpu_slabbed
-    dev_ebwt = build(text, starts, args.read_len, device=local)
+    realistic = args.error_rate_ppm > 0 or args.reverse_complements
+    if realistic:
+        # reads with substitution errors (and their reverse complements) are substrings of no genome: the reads themselves, one behind
+        # the other, are the generator's text (sim.error_sample_gpu; tests/test_gpu_generator.py holds it to the host builder)
+        d_reads, d_starts = sim.error_sample_gpu(text, starts, args.read_len, args.seed, args.error_rate_ppm, rc=args.reverse_complements, device=local)
+        dev_ebwt = sim.build_ebwt_gpu_slabbed(int(d_reads.data_ptr()), int(d_starts.data_ptr()), args.read_len, n_reads=int(d_starts.numel()), text_len=int(d_reads.numel()), device=local)
+        del d_reads, d_starts
+        torch.cuda.empty_cache()
+    else:
+        dev_ebwt = build(text, starts, args.read_len, device=local)
     n = dev_ebwt.n
     t_gen = time.time() - t0
     del text, starts
     workload = (f"mode 1, {args.reads} x {args.read_len} bp reads, {args.coverage:g}x diploid genome {genome_len} bp, "
-                f"n={n} BWT positions (BASELINE.json configs[1] when reads=50000000)")
+                + (f"{args.error_rate_ppm / 1e4:g} % substitution errors, " if args.error_rate_ppm else "")
+                + (f"+ the reverse complement of every read ({2 * args.reads} reads in all), " if args.reverse_complements else "")
+                + f"n={n} BWT positions (BASELINE.json configs[1] when reads=50000000" + (" and the reads are error-free)" if realistic else ")"))
     if rank == 0:
         log(f"[bench] workload: {workload}; haplotypes+read starts {t_host:.1f}s on host, eBWT built on GPU in {t_gen:.1f}s")
 
@@ -459,7 +474,7 @@ def main():
     if args.warmup > 0:
         run_steps(args.warmup)
     gathered_events.clear()
-    scan_ms, ext_ms, right_ms, tot_ms, ctx_ms, req_ext, req_right = [], [], [], [], [], [], []
+    scan_ms, ext_ms, right_ms, tot_ms, ctx_ms, req_ext, req_right, reruns, batch_tiles = [], [], [], [], [], [], [], [], []
     scan_launches = 1
 
     def record(st):
@@ -472,6 +487,8 @@ def main():
         ctx_ms.append(st.ms_context)
         req_ext.append(int(st.requests_extend))
         req_right.append(int(st.requests_right))
+        reruns.append(int(st.scan_reruns))
+        batch_tiles.append(int(st.batch_tiles))
 
     sync()
     if os.environ.get("EB_BENCH_TRACE") == "1":
@@ -588,17 +605,20 @@ def main():
         # CPU oracle on the GPU box's host threads -- flag vectors and .snp identical to the GPU's -- and left the SHA-256
         # under profiles/.  Every default run is held to it (any number of GPUs: the shards' call sets concatenate to the same text).
         out["snp_verified"] = None
+        record = ("r03_fullsize_config2.json" if not realistic else
+                  "r05_fullsize_config2err.json" if (args.error_rate_ppm, args.reverse_complements) == (10_000, False) else
+                  "r05_fullsize_config2rc.json" if (args.error_rate_ppm, args.reverse_complements) == (10_000, True) else "none")
         try:
-            with open(os.path.join(ROOT, "profiles", "r03_fullsize_config2.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", record)) as fh:
                 known = json.load(fh)
         except OSError:
             known = None
         default_input = (args.read_len, args.coverage, args.seed) == (150, 30.0, 1)
         if args.rehearse_rank_of <= 1 and known is not None and default_input and known["input"]["reads_per_collection"] == args.reads and known["input"]["n"] == [int(n)]:
             if out["snp_sha256"] != known["oracle_snp_sha256"] or out["snp_records"] != known["snp_records"]:
-                raise SystemExit(f"[bench] .snp of the timed path differs from the full-size CPU oracle run (profiles/r03_fullsize_config2.json): "
+                raise SystemExit(f"[bench] .snp of the timed path differs from the full-size CPU oracle run (profiles/{record}): "
                                  f"{out['snp_sha256']} vs {known['oracle_snp_sha256']}")
-            out["snp_verified"] = ("sha256 equals the CPU oracle's whole-run .snp of this very input at full size (profiles/r03_fullsize_config2.json; "
+            out["snp_verified"] = (f"sha256 equals the CPU oracle's whole-run .snp of this very input at full size (profiles/{record}; "
                                    "tests/test_gpu_fullsize.py also holds the input's SHA-256 and every bit vector to that record)")
 
     # ---------------- CPU baseline on a bounded sample of the same workload family (rank 0, N=1 only)
@@ -805,6 +825,7 @@ def main():
             "phase4_device_ms": {"scan": round(scan_sum_ms, 4), "extend": round(float(np.mean(ext_ms)), 4),
                                  "right": round(float(np.mean(right_ms)), 4), "context_span": round(float(np.mean(ctx_ms)), 4),
                                  "total": round(float(np.mean(tot_ms)), 4), "what": "per kernel in the timed region (passes overlap: kernels share the chip)",
+                                 "scan_reruns": int(sum(reruns)), "batch_tiles": int(batch_tiles[-1]) if batch_tiles else None,
                                  "alone": alone},
             # seconds: the two traversals (leaves and nodes side by side) + packing of the bit vectors, first launch to last result;
             # wall_seconds: the whole call, i.e. also HBM allocation (which, right behind the generator's 100 GB of frees, can wait

@@ -317,29 +317,23 @@ __global__ void k_finish(const ScanCounters* __restrict__ c, JobReport* __restri
 
 // ------------------------------------------------------------------ launchers (eb_scan_internal.h)
 
-void eb_launch_contexts(hipStream_t st, const eb_dev_index& x1, const eb_dev_index& x2, const eb_dev_flags& f, const ScanParams& p, const Survivor* sorted,
-                        const uint64_t* chains, const uint32_t* choff, ScanCounters* cnt, uint8_t* blob, uint32_t lw, uint32_t rw, uint64_t cap_ns,
-                        uint64_t cap_chains, int extend_lanes, int right_lanes, uint64_t gate_min, hipEvent_t ext0, hipEvent_t ext1, hipEvent_t right0,
-                        hipEvent_t right1) {
+void eb_launch_extend(hipStream_t st, const eb_dev_index& x1, const eb_dev_index& x2, const ScanParams& p, const Survivor* sorted, const uint64_t* chains,
+                      ScanCounters* cnt, uint8_t* blob, uint32_t lw, uint64_t cap_chains, int extend_lanes) {
     // One lane per chain (k_extend1) since round 4: 0.98 -> 0.80 ms alone at 7.55 G positions, 1.42 -> 0.87 beside the scan
     // (profiles/r04_extend_ab.txt).  Two BWTs keep the quad form -- with a lane's index chosen at run time the one-lane form
     // loses, 1.49 against 0.96 ms at 2 x 3.8 G -- and so do large indexes: a lane's four 16-byte loads are four address
     // translations where the quad's coalesced request is one, and once the index outgrows what the translation caches reach that
     // is what counts: 0.72 / 0.82 ms (one lane / quad) at 7.55 G symbols, 1.92 / 1.82 at 15.1 G, 45 / 23 ms at 151 G.
     auto kern_extend = extend_lanes == 1 ? (p.mode == 2 ? k_extend1<true> : k_extend1<false>) : (p.mode == 2 ? k_extend<true> : k_extend<false>);
+    hipLaunchKernelGGL(kern_extend, dim3(eb_grid_of(cap_chains * (uint64_t)extend_lanes)), dim3(256), 0, st, x1, x2, p, sorted, chains, cnt, blob, lw);
+}
+
+void eb_launch_right(hipStream_t st, const eb_dev_index& x1, const eb_dev_index& x2, const eb_dev_flags& f, const ScanParams& p, const Survivor* sorted,
+                     const uint32_t* choff, ScanCounters* cnt, uint8_t* blob, uint32_t rw, uint64_t cap_ns, int right_lanes, uint64_t gate_min) {
     // With the FL table (eb_psi_lookup) a step of the walk is one 16-byte read by one lane: one lane per cluster, 64 walks per
     // wave; with the directory select a quad per cluster (eb_select_quad).
     auto kern_right = p.mode == 2 ? (right_lanes == 4 ? k_right<true, 4> : k_right<true, 1>) : (right_lanes == 4 ? k_right<false, 4> : k_right<false, 1>);
-    // The walk runs BEHIND the extension on the same stream: a large call set keeps the memory system busy with either kernel
-    // alone, a hand-over between streams costs 15-25 us of idle device, and the walk can then skip the clusters whose chains came
-    // out too short to ever print (the gate in k_right): one request in nine saved.  A small call set (a rank's share) walks every
-    // cluster: its records then equal the reference's cluster for cluster.
-    if (ext0) (void)hipEventRecord(ext0, st);
-    hipLaunchKernelGGL(kern_extend, dim3(eb_grid_of(cap_chains * (uint64_t)extend_lanes)), dim3(256), 0, st, x1, x2, p, sorted, chains, cnt, blob, lw);
-    if (ext1) (void)hipEventRecord(ext1, st);
-    if (right0 && right0 != ext1) (void)hipEventRecord(right0, st);
     hipLaunchKernelGGL(kern_right, dim3(eb_grid_of(cap_ns * (uint64_t)right_lanes)), dim3(256), 0, st, x1, x2, f, p, sorted, choff, cnt, blob, rw, gate_min);
-    if (right1) (void)hipEventRecord(right1, st);
 }
 
 void eb_launch_finish(hipStream_t st, ScanCounters* cnt, JobReport* report) {

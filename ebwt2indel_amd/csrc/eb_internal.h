@@ -23,7 +23,7 @@ void eb_set_error(const char* fmt, ...);
 
 // streams / events / page-locked report blocks of the phase-4 driver (eb_scan_job.cpp), created with the first job on an index
 struct eb_scan_ctx {
-    hipStream_t ctx = nullptr, copy = nullptr;   // context kernels; record downloads (the scan runs on the index's own stream)
+    hipStream_t ctx = nullptr, right = nullptr, copy = nullptr; // context kernels (right: the walk of a small call set, beside its extension); record downloads (the scan runs on the index's own stream)
     hipEvent_t last_ctx = nullptr;               // end of the most recent job's context kernels
     std::mutex pool_mu;                          // events / reports: a job may be ended on one host thread while the next is begun on another
     std::vector<hipEvent_t> events;              // recycled between jobs

@@ -15,11 +15,11 @@ struct ScanParams {
     int k_left, k_right;
     uint64_t begin, end; // closing positions owned by this call
     uint64_t n;          // merged length
-    // ordered != 0: every workgroup scans ONE contiguous range of tiles_per_wg tiles and hands its survivors over in batches of
-    // 2^batch_shift tiles, batch b of workgroup g into slots [ (g * batches_per_wg + b) * EB_BATCH_SLOTS, ... ):
-    // the batches are in BWT order as they lie, only their few dozen members need sorting (k_batch_compact).  ordered == 0: the
-    // workgroups stride over the tiles and append to one list in arrival order (position buckets put it in order).
-    uint32_t ordered, tiles_per_wg, batch_shift, batches_per_wg;
+    // ordered != 0: every workgroup scans ONE contiguous run of tiles_per_wg tiles and the survivors are handed over in batches
+    // of 2^batch_shift consecutive tiles of the range, batch b into slots [ b * EB_BATCH_SLOTS, ... ): the batches are in BWT
+    // order as they lie, only their few dozen members need sorting (k_batch_compact).  ordered == 0: the workgroups stride over
+    // the tiles and append to one list in arrival order (position buckets put it in order).
+    uint32_t ordered, tiles_per_wg, batch_shift, reserved;
 #ifdef EB_SCAN_EXPERIMENTS
     uint32_t dbg;        // EB_SCAN_DEBUG bits: 1 no length histogram, 2 no cluster analysis, 4 no run loop, 8 no queues, 16 no statistics
 #endif
@@ -113,12 +113,13 @@ void eb_launch_chain_list(hipStream_t st, const Survivor* sorted, const uint32_t
 #define EB_BUCKET_SHIFT 11 /* position buckets of the unordered hand-over: 2048 positions each */
 
 // ---- eb_context.hip
-// left-context extension of every chain, then the right-context walk of every cluster, into the image `blob` laid out by
-// cnt->lay; grids by capacity.  Events (may be null) bracket the two kernels.
-void eb_launch_contexts(hipStream_t st, const eb_dev_index& x1, const eb_dev_index& x2, const eb_dev_flags& f, const ScanParams& p, const Survivor* sorted,
-                        const uint64_t* chains, const uint32_t* choff, ScanCounters* cnt, uint8_t* blob, uint32_t lw, uint32_t rw, uint64_t cap_ns,
-                        uint64_t cap_chains, int extend_lanes, int right_lanes, uint64_t gate_min, hipEvent_t ext0, hipEvent_t ext1, hipEvent_t right0,
-                        hipEvent_t right1);
+// left-context extension of every chain / right-context walk of every cluster, into the image `blob` laid out by cnt->lay;
+// grids by capacity.  gate_min: call-set size from which the walk skips clusters that cannot print -- it must then run BEHIND the
+// extension; below it the two are independent.
+void eb_launch_extend(hipStream_t st, const eb_dev_index& x1, const eb_dev_index& x2, const ScanParams& p, const Survivor* sorted, const uint64_t* chains,
+                      ScanCounters* cnt, uint8_t* blob, uint32_t lw, uint64_t cap_chains, int extend_lanes);
+void eb_launch_right(hipStream_t st, const eb_dev_index& x1, const eb_dev_index& x2, const eb_dev_flags& f, const ScanParams& p, const Survivor* sorted,
+                     const uint32_t* choff, ScanCounters* cnt, uint8_t* blob, uint32_t rw, uint64_t cap_ns, int right_lanes, uint64_t gate_min);
 // the job's last kernel: request counts and wire overflow count -> report
 void eb_launch_finish(hipStream_t st, ScanCounters* cnt, JobReport* report);
 

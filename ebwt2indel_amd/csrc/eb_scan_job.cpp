@@ -46,7 +46,7 @@ unsigned scan_grid(uint64_t words, unsigned per_cu) {
     return (unsigned)(tiles < 1 ? 1 : (tiles > cap ? cap : tiles));
 }
 
-enum { E_BEGIN, E_SCAN1, E_ORDER, E_EXT0, E_EXT1, E_RIGHT1, E_CTX_DONE, E_END, E_PER_JOB };
+enum { E_BEGIN, E_SCAN1, E_ORDER, E_EXT0, E_EXT1, E_RIGHT0, E_RIGHT1, E_CTX_DONE, E_END, E_PER_JOB };
 
 // EB_TRACE=begin[:ms]: host-side timeline of every _begin call that takes longer than <ms> (stderr)
 struct BeginTrace {
@@ -78,6 +78,7 @@ struct eb_scan_job {
     hipStream_t s_scan = nullptr, s_ctx = nullptr; // scan + ordering of the survivors; context kernels + wire image
     unsigned overlap_wgs = 0;                      // != 0: the scan shares every CU with the previous job's context kernels
     int extend_lanes = 1, right_lanes = 1;
+    bool split = false;                            // the right-context walk on its own stream, beside the extension (small call sets)
     // geometry of the scan and capacities of everything behind it
     uint64_t w_lo = 0, w_count = 0;
     bool ordered = true;
@@ -97,7 +98,7 @@ struct eb_scan_job {
 
 void eb_scan_ctx_destroy(eb_scan_ctx* c) {
     if (!c) return;
-    for (hipStream_t st : {c->ctx, c->copy})
+    for (hipStream_t st : {c->ctx, c->right, c->copy})
         if (st) (void)hipStreamDestroy(st);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     if (c->last_ctx) (void)hipEventDestroy(c->last_ctx);
@@ -122,20 +123,38 @@ void job_release(eb_scan_job* job) { // events and the report go back to the con
 // ---- the context kernels, the wire image and the job's last kernel, behind the ordering step (E_ORDER recorded on s_scan)
 int enqueue_contexts(eb_scan_job* job) {
     eb_scan_ctx* ctx = job->ctx;
-    const hipStream_t st = job->s_ctx;
-    if (st != job->s_scan) EB_HIP(hipStreamWaitEvent(st, job->e[E_ORDER], 0));
+    const hipStream_t sE = job->s_ctx;
     ScanCounters* cnt = job->cnt.as<ScanCounters>();
-    eb_launch_contexts(st, job->x1, job->x2, job->df, job->p, job->sorted.as<Survivor>(), job->chains.as<uint64_t>(), job->choff.as<uint32_t>(), cnt,
-                       job->blob.as<uint8_t>(), job->lw, job->rw, job->cap_ns ? job->cap_ns : 1, job->cap_chains ? job->cap_chains : 1, job->extend_lanes,
-                       job->right_lanes, eb_cfg().right_gate_min, job->e[E_EXT0], job->e[E_EXT1], nullptr, job->e[E_RIGHT1]);
+    const uint64_t cap_ns = job->cap_ns ? job->cap_ns : 1, cap_chains = job->cap_chains ? job->cap_chains : 1;
+    const uint64_t gate_min = eb_cfg().right_gate_min;
+    // A LARGE call set keeps the memory system busy with either kernel alone, so nothing is lost by running the right-context
+    // walk BEHIND the left-context extension on the same stream -- and it can then skip the clusters whose chains came out too
+    // short to ever print (the gate in k_right): one request in nine saved.  A SMALL call set (a rank's share of a multi-GPU
+    // run: no cluster is skipped, its records equal the reference's cluster for cluster) is another matter: 30 dependent steps
+    // per lane and only a few waves per SIMD -- each kernel waits for memory LATENCY, not for lines -- so its walk runs on a
+    // stream of its own, beside its own extension and beside the next job's scan (a rank's eighth at 7.55 G positions: 0.320-0.335 ms
+    // per pass against 0.340-0.347 one behind the other; two alternating sets of such streams: 0.50-0.59, not kept;
+    // profiles/r05_rank_share.txt).
+    const bool split = job->split && job->cap_ns <= gate_min; // (never with a gated walk)
+    const hipStream_t sR = split ? ctx->right : sE;
+    if (sE != job->s_scan) EB_HIP(hipStreamWaitEvent(sE, job->e[E_ORDER], 0));
+    if (split) EB_HIP(hipStreamWaitEvent(sR, job->e[E_ORDER], 0));
+    EB_HIP(hipEventRecord(job->e[E_EXT0], sE));
+    eb_launch_extend(sE, job->x1, job->x2, job->p, job->sorted.as<Survivor>(), job->chains.as<uint64_t>(), cnt, job->blob.as<uint8_t>(), job->lw, cap_chains, job->extend_lanes);
+    EB_HIP(hipEventRecord(job->e[E_EXT1], sE));
+    EB_HIP(hipEventRecord(job->e[E_RIGHT0], sR));
+    eb_launch_right(sR, job->x1, job->x2, job->df, job->p, job->sorted.as<Survivor>(), job->choff.as<uint32_t>(), cnt, job->blob.as<uint8_t>(), job->rw, cap_ns,
+                    job->right_lanes, split ? ~0ull : gate_min);
+    EB_HIP(hipEventRecord(job->e[E_RIGHT1], sR));
+    if (split) EB_HIP(hipStreamWaitEvent(sR, job->e[E_EXT1], 0)); // what follows needs both kernels' records
     if (job->options & EB_SCAN_WIRE) {
         int rc = job->wire.alloc(eb_wire4_size(job->cap_ns, job->cap_chains, job->k_left, job->k_right));
         if (rc != EB_OK) return rc;
-        eb_launch_wire4(st, job->blob.as<uint8_t>(), cnt, job->wire.as<uint8_t>(), job->lw, job->rw, job->k_left, job->k_right, job->cap_ns, job->cap_chains);
+        eb_launch_wire4(sR, job->blob.as<uint8_t>(), cnt, job->wire.as<uint8_t>(), job->lw, job->rw, job->k_left, job->k_right, job->cap_ns, job->cap_chains);
     }
-    eb_launch_finish(st, cnt, job->report);
-    EB_HIP(hipEventRecord(job->e[E_CTX_DONE], st));
-    EB_HIP(hipEventRecord(ctx->last_ctx, st));
+    eb_launch_finish(sR, cnt, job->report);
+    EB_HIP(hipEventRecord(job->e[E_CTX_DONE], sR));
+    EB_HIP(hipEventRecord(ctx->last_ctx, sR));
     EB_HIP(hipGetLastError());
     return EB_OK;
 }
@@ -168,9 +187,8 @@ int enqueue_ordered(eb_scan_job* job, bool* fits) {
     q.ordered = 1;
     q.tiles_per_wg = (uint32_t)((tiles + grid - 1) / grid);
     q.batch_shift = job->batch_shift;
-    q.batches_per_wg = (uint32_t)((q.tiles_per_wg + (1u << q.batch_shift) - 1u) >> q.batch_shift);
-    if (q.batches_per_wg == 0) q.batches_per_wg = 1;
-    job->n_batches = (uint64_t)grid * q.batches_per_wg;
+    q.reserved = 0;
+    job->n_batches = (((uint64_t)grid * q.tiles_per_wg) >> q.batch_shift) + 1; // (tile indexes run up to grid x tiles_per_wg)
     if (job->n_batches > EB_MAX_BATCHES) { *fits = false; return EB_OK; }
     uint64_t cap = job->n_batches * EB_BATCH_SLOTS;
     if (cap > 0x1FFFFFFFull) cap = 0x1FFFFFFFull; // (a call set has fewer than 2^29 clusters: more survivors than that is an error either way)
@@ -207,7 +225,7 @@ int run_unordered(eb_scan_job* job) {
     q.ordered = 0;
     q.tiles_per_wg = 0;
     q.batch_shift = 0;
-    q.batches_per_wg = 0;
+    q.reserved = 0;
     const hipStream_t st = job->s_scan;
     int rc;
     if ((rc = job->cnt.alloc(sizeof(ScanCounters))) != EB_OK || (rc = job->part.alloc((size_t)grid * EB_SCAN_PARTIAL * 8)) != EB_OK) return rc;
@@ -409,6 +427,7 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
         ctx = new eb_scan_ctx();
         b1->scan_ctx = ctx;
         EB_HIP(hipStreamCreateWithFlags(&ctx->ctx, hipStreamNonBlocking));
+        EB_HIP(hipStreamCreateWithFlags(&ctx->right, hipStreamNonBlocking));
         EB_HIP(hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking));
         EB_HIP(hipEventCreateWithFlags(&ctx->last_ctx, hipEventDisableTiming));
         EB_HIP(hipEventRecord(ctx->last_ctx, ctx->ctx));
@@ -424,10 +443,16 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
     // the full-width scan.  EB_SCAN_OVERLAP=0: never; =k: always, k per CU.  (4 per CU in round 3, when the walk took as long as
     // the extension; with the FL table the context kernels are the shorter side and the scan gets every slot it can use: 2.60 /
     // 2.46 / 2.36 / 2.22 ms per step for 4 / 5 / 6 / 8, profiles/r04_overlap_ab.txt.)
+    // A SMALL call set (a rank's share: at most 2^19 clusters by the capacity of its batches) is another regime: its context kernels
+    // are a few waves per SIMD waiting for memory latency, and they must find wave slots whenever they arrive -- the scan then
+    // holds HALF of each CU (0.373 / 0.362 / 0.335 / 0.426 ms per pass of a rank's eighth for 8 / 6 / 4 / 3 workgroups per CU).
+    const uint64_t w_lo = begin >> 6, w_hi = (end + 63) >> 6;
+    const uint64_t w_count = w_hi > w_lo ? w_hi - w_lo : 0;
+    const bool small_set = ((((w_count + 255) / 256) >> EB_BATCH_SHIFT_MAX) + 2) * EB_BATCH_SLOTS <= cfg.right_gate_min;
     unsigned overlap_wgs = 0;
     if (cfg.scan_overlap >= 0) overlap_wgs = (unsigned)cfg.scan_overlap;
     else if (options & EB_SCAN_PIPELINED) {
-        const unsigned share = (b1->d_psi && (!b2 || b2->d_psi)) ? 8u : 4u;
+        const unsigned share = small_set ? 4u : ((b1->d_psi && (!b2 || b2->d_psi)) ? 8u : 4u);
         overlap_wgs = hipEventQuery(ctx->last_ctx) == hipErrorNotReady ? share : 0u;
     }
 
@@ -474,9 +499,9 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
     job->extend_lanes = cfg.extend_lanes ? cfg.extend_lanes : (p.mode == 2 || job->x1.n > (1ull << 33) ? 4 : 1);
     const bool have_psi = job->x1.psi && (p.mode != 2 || job->x2.psi);
     job->right_lanes = cfg.right_lanes ? cfg.right_lanes : (have_psi ? 1 : 4);
-    const uint64_t w_lo = begin >> 6, w_hi = (end + 63) >> 6;
     job->w_lo = w_lo;
-    job->w_count = w_hi > w_lo ? w_hi - w_lo : 0;
+    job->w_count = w_count;
+    job->split = small_set;
     for (DevMem* m : {&job->cnt, &job->part, &job->slots, &job->kept, &job->sorted, &job->choff, &job->chains, &job->blob, &job->wire, &job->surv, &job->bcnt, &job->boff,
                       &job->tmp, &job->nch})
         m->device = b1->device;
@@ -539,8 +564,13 @@ extern "C" int eb_scan_clusters_end(eb_scan_job* job, eb_calls** out, eb_scan_st
         for (int k = 0; k < 201; ++k) stats->hist[k] = R.hist[k];
         (void)hipEventElapsedTime(&stats->ms_scan, job->e[E_BEGIN], job->e[E_SCAN1]);
         (void)hipEventElapsedTime(&stats->ms_extend, job->e[E_EXT0], job->e[E_EXT1]);
-        (void)hipEventElapsedTime(&stats->ms_right, job->e[E_EXT1], job->e[E_RIGHT1]);
-        (void)hipEventElapsedTime(&stats->ms_context, job->e[E_EXT0], job->e[E_RIGHT1]);
+        (void)hipEventElapsedTime(&stats->ms_right, job->e[E_RIGHT0], job->e[E_RIGHT1]);
+        for (int a : {E_EXT0, E_RIGHT0})        // first start .. last end of the two (side by side for a small call set)
+            for (int b : {E_EXT1, E_RIGHT1}) {
+                float t = 0;
+                (void)hipEventElapsedTime(&t, job->e[a], job->e[b]);
+                if (t > stats->ms_context) stats->ms_context = t;
+            }
         (void)hipEventElapsedTime(&stats->ms_total, job->e[E_BEGIN], end_event(job));
         stats->scan_launches = 1;
         stats->requests_extend = R.req_ext;

@@ -219,8 +219,9 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
             }
         }
         if (keep && ordered) {
-            // straight into the slots of the batch at hand: one cursor per batch (thousands of them: no contention).  A wave
-            // empties its queues before it enters the next batch, so nothing of this batch is staged later.
+            // straight into the slots of the batch at hand: one cursor per batch (hundreds to thousands of them, shared by the one or
+            // two workgroups whose tile runs meet in the batch: no contention).  A wave empties its queues before it enters the
+            // next batch, so nothing of this batch is staged later.
             const uint32_t pos = atomicAdd(&bcount[cur_batch], 1u);
             if (pos < EB_BATCH_SLOTS) slots[cur_batch * EB_BATCH_SLOTS + pos] = s;
             else cnt->spilled = 1ull;
@@ -362,7 +363,7 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
     if (PREFETCH) nxt = load_tile(tile_of(0));
     for (uint64_t it = 0; it < iters; ++it) {
         const uint64_t tile = tile_of(it);
-        if (ordered) cur_batch = (uint64_t)blockIdx.x * p.batches_per_wg + (it >> p.batch_shift); // (batches of 2^batch_shift tiles)
+        if (ordered) cur_batch = tile >> p.batch_shift; // batches of 2^batch_shift tiles of the RANGE, whichever workgroups scan them
         TileData td;
         if (PREFETCH) { td = nxt; nxt = load_tile(tile_of(it + 1)); }
         else td = load_tile(tile);
@@ -519,7 +520,7 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
         if (ordered) {
             // a batch ends: every cluster that closed in its tiles must be in its slots before this wave moves on, so the wave
             // empties its queues (two part-filled rounds per wave and batch; no barrier: the batch cursor is global)
-            if (((it + 1) & (((uint64_t)1 << p.batch_shift) - 1u)) == 0 || it + 1 == iters) drain();
+            if (((tile + 1) & (((uint64_t)1 << p.batch_shift) - 1u)) == 0 || it + 1 == iters) drain();
         } else if ((++trips & 15u) == 0) {
             __syncthreads();
             if (threadIdx.x == 0 && s_count > (uint32_t)STAGE) s_count = STAGE;

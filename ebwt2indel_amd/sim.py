@@ -256,6 +256,99 @@ def reads_from_starts(text: np.ndarray, starts: np.ndarray, read_len: int) -> np
     return text[starts.astype(np.int64)[:, None] + idx[None, :]]
 
 
+# --------------------------------------------------------------------------- reads with sequencing errors (+ reverse complements)
+# The reference's documented input is simulated reads WITH an error profile and, recommended, their reverse complements
+# (/root/reference/README.md:88-100, datasets/simulate.pdf: SimSeq).  Substitution errors here come from a counter-based hash of
+# (seed, read, position) -- the same integer arithmetic in numpy and in torch, so the sample made on the GPU at 50 M reads and the
+# one made on the host for a small test are the same function of their arguments.
+
+_MASK64 = (1 << 64) - 1
+
+
+def _mix64_np(x: np.ndarray) -> np.ndarray:
+    """splitmix64 finaliser on uint64 arrays."""
+    x = x.astype(np.uint64)
+    with np.errstate(over="ignore"):
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return x ^ (x >> np.uint64(31))
+
+
+def _error_draws_np(seed: int, first_read: int, n_reads: int, read_len: int, per_million: int):
+    """(is_error, offset 1..3) for every base of reads first_read .. first_read + n_reads - 1."""
+    idx = (np.arange(first_read, first_read + n_reads, dtype=np.uint64)[:, None] * np.uint64(read_len) + np.arange(read_len, dtype=np.uint64)[None, :])
+    h = _mix64_np(idx ^ np.uint64((seed * 0x9E3779B97F4A7C15) & _MASK64))
+    return (h & np.uint64(0xFFFFF)) < np.uint64(per_million * (1 << 20) // 1_000_000), (((h >> np.uint64(20)) & np.uint64(0xFFFF)) % np.uint64(3) + np.uint64(1)).astype(np.uint8)
+
+
+def add_substitution_errors(reads: np.ndarray, seed: int, per_million: int = 10_000, first_read: int = 0) -> np.ndarray:
+    """reads (n x L, ASCII ACGT) with a base replaced by one of the three others at every position the hash picks (1 % by default)."""
+    code = np.zeros(256, dtype=np.uint8)
+    code[BASES] = np.arange(4, dtype=np.uint8)
+    c = code[reads]
+    err, off = _error_draws_np(seed, first_read, reads.shape[0], reads.shape[1], per_million)
+    return BASES[np.where(err, (c + off) % 4, c)]
+
+
+def reverse_complement(reads: np.ndarray) -> np.ndarray:
+    code = np.zeros(256, dtype=np.uint8)
+    code[BASES] = np.arange(4, dtype=np.uint8)
+    return BASES[3 - code[reads[:, ::-1]]]
+
+
+def error_sample(text: np.ndarray, starts: np.ndarray, read_len: int, seed: int, per_million: int = 10_000, rc: bool = False) -> np.ndarray:
+    """Host form (small inputs): the reads text[starts[r] : starts[r] + read_len] with substitution errors, followed -- rc -- by the
+    reverse complement of every one of them (read n + r = reverse complement of read r)."""
+    reads = add_substitution_errors(reads_from_starts(text, starts, read_len), seed, per_million)
+    return np.concatenate([reads, reverse_complement(reads)]) if rc else reads
+
+
+def error_sample_gpu(text: np.ndarray, starts: np.ndarray, read_len: int, seed: int, per_million: int = 10_000, rc: bool = False, device: int = 0,
+                     chunk_reads: int = 1 << 21):
+    """The same reads made on the GPU (torch; integer arithmetic only): returns (reads, read_starts) -- a uint8 tensor of all reads one
+    behind the other (plus one separator byte) and the uint64 tensor of their start offsets in it: the `text` / `starts` of
+    build_ebwt_gpu_slabbed (pass their data_ptr()s; T' = "any text that contains every read")."""
+    import torch
+    dev = torch.device(f"cuda:{device}")
+    n, L = len(starts), read_len
+    total = n * (2 if rc else 1)
+    t = torch.from_numpy(np.ascontiguousarray(text)).to(dev)
+    s = torch.from_numpy(np.ascontiguousarray(starts).astype(np.int64)).to(dev)
+    out = torch.empty(total * L + 1, dtype=torch.uint8, device=dev)
+    out[-1] = 1                                   # a separator behind the last read, as haplotype_text puts one behind every haplotype
+    code = torch.zeros(256, dtype=torch.int64, device=dev)
+    code[torch.from_numpy(BASES.astype(np.int64)).to(dev)] = torch.arange(4, dtype=torch.int64, device=dev)
+    ascii_of = torch.from_numpy(BASES.copy()).to(dev)
+    col = torch.arange(L, dtype=torch.int64, device=dev)
+
+    def i64(v):                                   # a 64-bit pattern as the int64 torch computes in (wraps like uint64)
+        v &= _MASK64
+        return v - (1 << 64) if v >> 63 else v
+
+    def lsr(x, k):                                # logical shift right of int64
+        return (x >> k) & ((1 << (64 - k)) - 1)
+    k0, m1, m2 = i64(seed * 0x9E3779B97F4A7C15), i64(0xBF58476D1CE4E5B9), i64(0x94D049BB133111EB)
+    thr = per_million * (1 << 20) // 1_000_000
+    for a in range(0, n, chunk_reads):
+        b = min(n, a + chunk_reads)
+        c = code[t[s[a:b, None] + col[None, :]].long()]
+        x = (torch.arange(a, b, dtype=torch.int64, device=dev)[:, None] * L + col[None, :]) ^ k0
+        x = (x ^ lsr(x, 30)) * m1
+        x = (x ^ lsr(x, 27)) * m2
+        x = x ^ lsr(x, 31)
+        err = (x & 0xFFFFF) < thr
+        off = (lsr(x, 20) & 0xFFFF) % 3 + 1
+        c = torch.where(err, (c + off) % 4, c)
+        out[a * L: b * L] = ascii_of[c].reshape(-1)
+        if rc:
+            out[(n + a) * L: (n + b) * L] = ascii_of[3 - c.flip(1)].reshape(-1)
+        del c, x, err, off
+    read_starts = (torch.arange(total, dtype=torch.int64, device=dev) * L)
+    torch.cuda.synchronize()
+    del t, s
+    return out, read_starts
+
+
 class DeviceEbwt:
     """eBWT (and optional DA) left in GPU memory by the generator; free() releases it."""
 

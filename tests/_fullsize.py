@@ -23,12 +23,18 @@ CONFIGS = {
     "config3": dict(mode=2, reads=25_000_000, baseline="configs[2]: Mode 2: two collections 2 x 25M x 150 bp, dual-BWT LF navigation"),
     "config4": dict(mode=3, reads=50_000_000, baseline="configs[3]: Mode 3: merged BWT + document array, 100M x 150 bp"),
 }
+# round 5: the reference's documented kind of input at configs[1] size -- reads with 1 % substitution errors, and 25 M such reads
+# plus their reverse complements (README.md:88-100); error-free forward-only reads were all that rounds 1-4 had above 0.4 M positions
+CONFIGS["config2err"] = dict(mode=1, reads=50_000_000, err_per_million=10_000, rc=False,
+                             baseline="configs[1] with sequencing errors: Mode 1: 50M x 150 bp reads, 1 % substitution errors (~7.5 Gbp BWT) on one MI355X")
+CONFIGS["config2rc"] = dict(mode=1, reads=25_000_000, err_per_million=10_000, rc=True,
+                            baseline="configs[1] with sequencing errors and reverse complements: Mode 1: 25M x 150 bp reads, 1 % substitution errors, + their 25M reverse complements (~7.5 Gbp BWT) on one MI355X")
 VECTORS = ("thrK", "thrR", "minima", "da")
 COUNTERS = ("leaves", "nodes", "minima", "lcp_values", "da_values")
 
 
 def profile_path(name):
-    return os.path.join(ROOT, "profiles", f"r03_fullsize_{name}.json")
+    return os.path.join(ROOT, "profiles", f"{'r05' if 'err_per_million' in CONFIGS[name] else 'r03'}_fullsize_{name}.json")
 
 
 def sha256(buf) -> str:
@@ -59,6 +65,12 @@ class Inputs:
             h2 = sim.mutate_haplotype(g, 1)
             text, offs = sim.haplotype_text([g, h2])
             groups = [(sim.sample_read_starts([g, h2], offs, self.reads, READ_LEN, 1), None, False)]
+            if "err_per_million" in cfg:
+                # the reads themselves become the generator's text (they are substrings of no genome any more)
+                d_reads, d_starts = sim.error_sample_gpu(text, groups[0][0], READ_LEN, 1, cfg["err_per_million"], rc=cfg["rc"])
+                self._keep = (d_reads, d_starts)
+                text = None
+                groups = [((int(d_reads.data_ptr()), int(d_starts.data_ptr()), int(d_starts.numel()), int(d_reads.numel())), None, False)]
         else:
             # scripts/modes23_scale.py's recipe: genome seed 5, starts seed 99; sample 0 from haplotype 1, sample 1 from haplotype 2
             glen = int(2 * self.reads * READ_LEN / 30)
@@ -76,7 +88,13 @@ class Inputs:
         with ThreadPoolExecutor(2) as ex:            # the host copies are hashed while the GPU goes on
             for starts, n_first, want_da in groups:
                 t0 = time.time()
-                dev = sim.build_ebwt_gpu_slabbed(text, starts, READ_LEN, n_first=n_first, want_da=want_da)   # same bytes as the one-pass generator the records were made with (input SHA-256 below)
+                if isinstance(starts, tuple):
+                    dev = sim.build_ebwt_gpu_slabbed(starts[0], starts[1], READ_LEN, n_reads=starts[2], text_len=starts[3])
+                    self._keep = None
+                    import torch
+                    torch.cuda.empty_cache()
+                else:
+                    dev = sim.build_ebwt_gpu_slabbed(text, starts, READ_LEN, n_first=n_first, want_da=want_da)   # same bytes as the one-pass generator the records were made with (input SHA-256 below)
                 t_gen += time.time() - t0
                 host, da = dev.to_host()
                 shas.append(ex.submit(sha256, host))
@@ -98,21 +116,23 @@ class Inputs:
         log(f"[{name}] mode {self.mode}, n = {' + '.join(str(b.n) for b in self.bwts)}; genome + starts {t_host:.1f}s on host, eBWT on the GPU {t_gen:.1f}s")
 
     def describe(self):
-        return dict(mode=self.mode, reads_per_collection=self.reads, read_len=READ_LEN, n=[int(b.n) for b in self.bwts], **self.sha)
+        cfg = CONFIGS[self.name]
+        extra = dict(substitution_errors_per_million=cfg["err_per_million"], reverse_complements_added=cfg["rc"]) if "err_per_million" in cfg else {}
+        return dict(mode=self.mode, reads_per_collection=self.reads, read_len=READ_LEN, n=[int(b.n) for b in self.bwts], **extra, **self.sha)
 
 
 class Result:
     """One run of the product on `Inputs`: index(es) -> traversal -> phase 4 -> text."""
 
-    def __init__(self, inp: Inputs, log=print):
+    def __init__(self, inp: Inputs, log=print, args=(), flags=None):
         from ebwt2indel_amd import api
-        p = api.make_params()
+        p = api.make_params(list(args))
         self.params = p
         t0 = time.time()
         b1 = inp.bwts[0]
         b2 = inp.bwts[1] if inp.mode == 2 else None
-        self.flags = api.navigate_two_bwts(b1, b2, p) if b2 is not None else api.navigate_one_bwt(b1, p)
-        if inp.mode == 3:
+        self.flags = flags if flags is not None else (api.navigate_two_bwts(b1, b2, p) if b2 is not None else api.navigate_one_bwt(b1, p))
+        if inp.mode == 3 and flags is None:
             self.flags.set_da(inp.da_host)
         t_nav = time.time() - t0
         t0 = time.time()

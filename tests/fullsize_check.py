@@ -81,7 +81,7 @@ class Heartbeat:
 
 def out_path(name, part):
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    return os.path.join(ROOT, "gpurun_out", f"r03_fullsize_{name}_{part}.json")
+    return os.path.join(ROOT, "gpurun_out", os.path.basename(fs.profile_path(name))[:-5] + f"_{part}.json")
 
 
 def oracle_indexes(orc, inp):
@@ -194,6 +194,31 @@ def part_phase4(inp, res, orc, po, idx, of=None, half=None):
     return rec
 
 
+def gpu_phase4_figures(inp, res):
+    """What the product's phase 4 did on this input (the constants of the kernels were tuned on error-free reads: VERDICT r04)."""
+    st = res.calls.stats
+    rec = {"survivors": int(st.survivors), "chains": int(st.chains), "scan_reruns_first_pass": int(st.scan_reruns), "batch_tiles": int(st.batch_tiles),
+           "scan_ms": round(float(st.ms_scan), 3), "extend_ms": round(float(st.ms_extend), 3), "right_ms": round(float(st.ms_right), 3),
+           "requests_extend": int(st.requests_extend), "requests_right": int(st.requests_right)}
+    b2 = inp.bwts[1] if inp.mode == 2 else None
+    again = api.scan_clusters(inp.bwts[0], res.flags, res.params, bwt2=b2).stats      # the size of the batches is remembered: no second run now
+    rec["second_pass"] = {"scan_reruns": int(again.scan_reruns), "batch_tiles": int(again.batch_tiles), "scan_ms": round(float(again.ms_scan), 3),
+                          "extend_ms": round(float(again.ms_extend), 3), "right_ms": round(float(again.ms_right), 3)}
+    if inp.n <= (1 << 38) - 2:
+        for b in inp.bwts:
+            b.build_psi()
+        have, nbytes, voids = inp.bwts[0].psi()
+        if have:
+            c = api.scan_clusters(inp.bwts[0], res.flags, res.params, bwt2=b2)
+            assert hashlib.sha256(c.format_snp(res.params, inp.mode != 1)[0]).hexdigest() == res.snp_sha256, ".snp through the FL table differs"
+            rec["fl_table"] = {"void_chunk_fraction": round(voids / max(1, nbytes // 16), 6), "void_chunks": int(voids), "right_ms": round(float(c.stats.ms_right), 3),
+                               "requests_right": int(c.stats.requests_right), "snp_identical": True}
+    ns = res.flags.stats
+    rec["traversal"] = {"seconds": round(float(ns.seconds_traversal), 3), "nodes": int(ns.nodes), "leaves": int(ns.leaves), "launches": int(ns.batches),
+                        "rank_queries": int(ns.rank_queries)}
+    return rec
+
+
 def main_config():
     if PART == "merge":
         return merge()
@@ -217,6 +242,15 @@ def main_config():
         out.update(rec)
     if PART in ("phase4", "all"):
         out.update(part_phase4(inp, res, orc, po, idx, of))
+        out["gpu_phase4"] = gpu_phase4_figures(inp, res)
+    if PART == "all" and "err_per_million" in fs.CONFIGS[NAME]:
+        # the same input under -m 2 (two reads suffice for an allele: sequencing errors that occur twice become clusters) -- same flag
+        # vectors (they depend on -k and -R only), another phase 4 on both sides
+        args = ["-m", "2"]
+        res2 = fs.Result(inp, log=log, args=args, flags=res.flags)
+        rec2 = part_phase4(inp, res2, orc, _oracle.Params.from_args(args), idx, of)
+        rec2["gpu_phase4"] = gpu_phase4_figures(inp, res2)
+        out["m2"] = rec2
     if PART in ("phase4a", "phase4b"):
         out.update(part_phase4(inp, res, orc, po, idx, None, half=PART[-1]))
     with open(out_path(NAME, PART), "w") as f:

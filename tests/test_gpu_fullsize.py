@@ -64,6 +64,36 @@ def test_full_size_config_equals_the_oracle_record(name):
         assert fs.renumber([h["text"] for h in halves], [h["cluster_numbers"] for h in halves]) == res.text
 
 
+@pytest.mark.parametrize("name", ["config2err", "config2rc"])
+def test_full_size_reads_with_errors_equal_the_oracle_record(name):
+    """configs[1] size with the reference's documented kind of input (round 5): 50 M reads with 1 % substitution errors, and 25 M such
+    reads plus their reverse complements (README.md:88-100) -- input SHA-256, traversal counters, every bit vector and the whole-run
+    .snp against the CPU oracle's record (profiles/r05_fullsize_<name>.json), at the defaults and under -m 2, where errors that occur
+    twice become clusters (7 M survivors instead of 1 M: the ordered hand-over's batches shrink once and stay small)."""
+    import hashlib
+    from ebwt2indel_amd import api
+    want = _expected(name)
+    inp = fs.Inputs(name)
+    assert inp.describe() == want["input"], "the regenerated input is not the recorded one"
+    res = fs.Result(inp)
+    for k, v in want["counters"].items():
+        assert res.counters[k] == v, (k, res.counters[k], v)
+    got_sha, vec = res.vector_shas()
+    del vec
+    assert got_sha == want["oracle_vector_sha256"], "a bit vector differs from the oracle's"
+    assert (res.snp_records, res.snp_sha256, res.cluster_nr - 1) == (want["snp_records"], want["oracle_snp_sha256"], want["cluster_numbers"])
+    st, sc = res.calls.stats, want["scan_counters"]
+    assert (int(st.runs_closed), int(st.clusters), int(st.bases_in_runs)) == (sc["runs_closed"], sc["clusters"], sc["bases_in_runs"])
+    assert st.scan_reruns == 0 and st.batch_tiles == 128          # the defaults' constants hold on error-bearing reads
+    m2 = fs.Result(inp, args=("-m", "2"), flags=res.flags)
+    w2 = want["m2"]
+    assert (m2.snp_records, m2.snp_sha256, m2.cluster_nr - 1) == (w2["snp_records"], w2["oracle_snp_sha256"], w2["cluster_numbers"])
+    assert m2.calls.stats.scan_reruns == 1 and 0 < m2.calls.stats.batch_tiles < 128
+    again = api.scan_clusters(inp.bwts[0], res.flags, m2.params)    # the index remembers the batch size: no second run any more
+    assert again.stats.scan_reruns == 0 and again.stats.batch_tiles == m2.calls.stats.batch_tiles
+    assert hashlib.sha256(again.format_snp(m2.params, False)[0]).hexdigest() == w2["oracle_snp_sha256"]
+
+
 def test_slabbed_generator_reproduces_the_recorded_config2_input():
     """The slab-by-slab generator (tools/ebwt_gen_slabs.hip, what builds the 151 G-position input of configs[4]) at 7.55 G positions: the
     bench's reads through it give the very bytes the one-pass generator gave -- the input whose SHA-256 the oracle record holds."""

@@ -195,3 +195,21 @@ def test_slabbed_generator_states_the_lcp_vectors_of_the_oracle(genome_len, n_re
     assert not (got[2] & ~mask).any()                      # undecided rows are left 0
     assert np.array_equal(got[2], minima[:words] & mask)
     assert int(np.unpackbits((minima[:words] & ~mask).view(np.uint8)).sum()) <= len(unknown)
+
+
+@pytest.mark.parametrize("rc", [False, True])
+@pytest.mark.parametrize("genome_len,n_reads,read_len,seed,prefix_len", [(5000, 1500, 100, 12, -1), (60_000, 20_000, 150, 13, 3), (60_000, 20_000, 150, 14, 5)])
+def test_reads_with_errors_through_the_slabbed_generator(genome_len, n_reads, read_len, seed, prefix_len, rc):
+    """Reads with 1 % substitution errors (and their reverse complements: the reference's documented input, README.md:88-100) are
+    substrings of no genome: the generator's text is then the reads themselves, one behind the other.  The sample made on the GPU
+    (sim.error_sample_gpu) is the host recipe's, byte for byte, and its eBWT the suffix-sorting host builder's."""
+    text, starts = _case(genome_len, n_reads, read_len, seed, snp_every=200, indel_every=700)
+    reads = sim.error_sample(text, starts, read_len, seed, 10_000, rc=rc)
+    assert 0.005 < (reads[:n_reads] != sim.reads_from_starts(text, starts, read_len)).mean() < 0.02
+    d_reads, d_starts = sim.error_sample_gpu(text, starts, read_len, seed, 10_000, rc=rc, chunk_reads=777)
+    assert np.array_equal(d_reads.cpu().numpy()[:-1].reshape(-1, read_len), reads)
+    want = sim.build_ebwt(reads)
+    dev = sim.build_ebwt_gpu_slabbed(d_reads.data_ptr(), d_starts.data_ptr(), read_len, n_reads=len(reads), text_len=int(d_reads.numel()), prefix_len=prefix_len)
+    got, _ = dev.to_host()
+    dev.free()
+    assert np.array_equal(got, want)
