@@ -33,7 +33,7 @@ struct EbConfig {
     // EB_INDEX_PINNED=<min bytes>[,<piece bytes>[,<reader threads>]]: input size from which the loader goes through
     // page-locked pieces, piece size, host threads that fill them
     uint64_t pinned_min = 256ull << 20, pinned_piece = 32ull << 20;
-    unsigned copy_threads = 8;
+    unsigned copy_threads = 12;
     // EB_WRITER_THREADS: host threads of the .snp writer (0: by call-set size)
     int writer_threads = 0;
     // EB_TRACE=<list of alloc, begin[:ms], nav, scan, index>: timelines on stderr

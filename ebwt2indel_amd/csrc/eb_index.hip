@@ -447,7 +447,8 @@ static int index_alloc(uint64_t n, uint8_t term, int device, eb_index** out) {
 
 // Packs one piece of text that is already on the device.
 static int pack_piece(eb_index* h, const uint8_t* d_ascii, uint64_t piece_pos, uint64_t piece_len, bool last,
-                      unsigned long long* d_bad) {
+                      unsigned long long* d_bad, hipStream_t stream = nullptr) {
+    if (!stream) stream = h->stream;
     uint64_t first_chunk = piece_pos / 32;
     uint64_t n_chunks = last ? h->n_blocks * 4 - first_chunk : piece_len / 32;
     if (n_chunks == 0) return EB_OK;
@@ -458,7 +459,7 @@ static int pack_piece(eb_index* h, const uint8_t* d_ascii, uint64_t piece_pos, u
         uint64_t cnt = n_chunks - done < MAX_CHUNKS ? n_chunks - done : MAX_CHUNKS;
         uint64_t byte_off = done * 32;
         uint64_t sub_len = piece_len > byte_off ? piece_len - byte_off : 0;
-        hipLaunchKernelGGL(k_pack, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, d_ascii + byte_off, piece_pos + byte_off,
+        hipLaunchKernelGGL(k_pack, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, stream, d_ascii + byte_off, piece_pos + byte_off,
                            sub_len, first_chunk + done, cnt, (uint32_t)h->term, aligned, h->d_chunks, d_bad);
         EB_HIP(hipGetLastError());
     }
@@ -635,21 +636,21 @@ static int index_create_from(const uint8_t* ascii, int fd, uint64_t n, uint8_t t
     // memory runs at ~16 GB/s, PCIe at ~50.  EB_INDEX_PINNED: tests exercise the path on small inputs.
     const bool pinned_path = n >= cfg.pinned_min || !ascii;
     const uint64_t PIECE = pinned_path ? cfg.pinned_piece : (256ull << 20);
-    const int SLOTS = 3;
+    const int SLOTS = 4;
     const uint64_t stage_bytes = n < PIECE ? (n ? n : 1) : PIECE;
     const size_t n_pieces = n ? (size_t)((n + PIECE - 1) / PIECE) : 1;
-    uint8_t* d_stage[3] = {nullptr, nullptr, nullptr};
-    uint8_t* h_stage[3] = {nullptr, nullptr, nullptr};
-    uint64_t h_cap[3] = {0, 0, 0};
-    size_t d_cap[3] = {0, 0, 0};
-    hipEvent_t done[3] = {nullptr, nullptr, nullptr};
+    uint8_t* d_stage[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint8_t* h_stage[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint64_t h_cap[4] = {0, 0, 0, 0};
+    size_t d_cap[4] = {0, 0, 0, 0};
+    hipEvent_t done[4] = {nullptr, nullptr, nullptr, nullptr};
     unsigned long long* d_bad = nullptr;
     eb_index* h = nullptr;
     PieceReaders readers;
     readers.src = ascii;
     readers.fd = fd;
     auto release = [&]() { // staging buffers go back to the library's pools (a second index -- two-BWT mode -- takes them from there)
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < 4; ++i) {
             if (d_stage[i]) eb_scratch_put(device, d_stage[i], d_cap[i]);
             if (h_stage[i]) eb_pinned_put(h_stage[i], h_cap[i]);
             if (done[i]) (void)hipEventDestroy(done[i]);
@@ -657,8 +658,24 @@ static int index_create_from(const uint8_t* ascii, int fd, uint64_t n, uint8_t t
         if (d_bad) (void)hipFree(d_bad);
     };
     auto piece_len = [&](size_t k) -> uint64_t { const uint64_t pos = (uint64_t)k * PIECE; return n - pos < PIECE ? n - pos : PIECE; };
-    // the readers start on the first pieces as soon as their page-locked buffers exist: the index's own allocation (a few GB of
-    // hipMalloc, tens of milliseconds) happens beside them
+    // The index's own allocation (a few GB of hipMalloc: 40-80 ms in a fresh process) and the device staging buffers are made on a
+    // side thread while this one pins the host pieces and starts the readers on them.
+    unsigned long long init = ~0ull;
+    int rc_alloc = EB_OK;
+    std::string err_alloc;
+    std::thread alloc_thread([&] {
+        (void)hipSetDevice(device);
+        rc_alloc = index_alloc(n, term, device, &h);
+        hipError_t ea = rc_alloc == EB_OK ? hipMalloc(&d_bad, sizeof init) : hipSuccess;
+        for (int i = 0; i < SLOTS && (size_t)i < n_pieces && ea == hipSuccess && rc_alloc == EB_OK; ++i) {
+            d_stage[i] = static_cast<uint8_t*>(eb_scratch_get(device, stage_bytes, &d_cap[i]));
+            if (!d_stage[i]) ea = hipErrorOutOfMemory;
+            if (ea == hipSuccess) ea = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
+        }
+        if (ea == hipSuccess && rc_alloc == EB_OK) ea = hipMemcpy(d_bad, &init, sizeof init, hipMemcpyHostToDevice);
+        if (rc_alloc != EB_OK) err_alloc = eb_last_error(); // (the message is thread-local)
+        else if (ea != hipSuccess) { rc_alloc = EB_ERR_NOMEM; err_alloc = std::string("staging allocation failed: ") + hipGetErrorString(ea); }
+    });
     size_t posted = 0;
     hipError_t e = hipSuccess;
     if (pinned_path) {
@@ -671,21 +688,18 @@ static int index_create_from(const uint8_t* ascii, int fd, uint64_t n, uint8_t t
         }
     }
     const double tr1 = idx_now();
-    int rc = e == hipSuccess ? index_alloc(n, term, device, &h) : EB_ERR_NOMEM;
-    if (rc != EB_OK) { if (e != hipSuccess) eb_set_error("staging allocation failed: %s", hipGetErrorString(e)); release(); return rc; }
-    unsigned long long init = ~0ull;
-    e = hipMalloc(&d_bad, sizeof init);
-    for (int i = 0; i < SLOTS && (size_t)i < n_pieces && e == hipSuccess; ++i) {
-        d_stage[i] = static_cast<uint8_t*>(eb_scratch_get(device, stage_bytes, &d_cap[i]));
-        if (!d_stage[i]) e = hipErrorOutOfMemory;
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
-    }
-    if (e != hipSuccess) { eb_set_error("staging allocation failed: %s", hipGetErrorString(e)); release(); eb_index_destroy(h); return EB_ERR_NOMEM; }
-    e = hipMemcpy(d_bad, &init, sizeof init, hipMemcpyHostToDevice);
-    if (e != hipSuccess) { eb_set_error("hipMemcpy failed: %s", hipGetErrorString(e)); release(); eb_index_destroy(h); return EB_ERR_DEVICE; }
+    alloc_thread.join();
+    int rc = rc_alloc;
+    if (rc == EB_OK && e != hipSuccess) { rc = EB_ERR_NOMEM; err_alloc = std::string("staging allocation failed: ") + hipGetErrorString(e); }
+    if (rc != EB_OK) { eb_set_error("%s", err_alloc.c_str()); release(); if (h) eb_index_destroy(h); return rc; }
+    // consecutive pieces go up on two streams: one copy engine moves ~33 GB/s in a fresh process, the link carries ~50
+    hipStream_t up[2] = {h->stream, nullptr};
+    if (hipStreamCreateWithFlags(&up[1], hipStreamNonBlocking) != hipSuccess) up[1] = h->stream;
+    struct UpGuard { hipStream_t s, own; ~UpGuard() { if (s && s != own) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); } } } up_guard{up[1], h->stream};
     const double tr2 = idx_now();
     double tr_read = 0, tr_slot = 0;
     for (size_t k = 0; k < n_pieces; ++k) {
+        const hipStream_t st = up[k & 1];
         const int slot = (int)(k % SLOTS);
         const uint64_t pos = (uint64_t)k * PIECE, len = n ? piece_len(k) : 0;
         const bool last = k + 1 == n_pieces;
@@ -696,27 +710,31 @@ static int index_create_from(const uint8_t* ascii, int fd, uint64_t n, uint8_t t
             tr_read += idx_now() - t0;
             src = h_stage[slot];
         } else if (k >= (size_t)SLOTS && (e = hipEventSynchronize(done[slot])) != hipSuccess) break; // (the device staging buffer is free again)
-        if (len && (e = hipMemcpyAsync(d_stage[slot], src, len, hipMemcpyHostToDevice, h->stream)) != hipSuccess) break;
-        rc = pack_piece(h, d_stage[slot], pos, len, last, d_bad);
+        if (len && (e = hipMemcpyAsync(d_stage[slot], src, len, hipMemcpyHostToDevice, st)) != hipSuccess) break;
+        rc = pack_piece(h, d_stage[slot], pos, len, last, d_bad, st);
         if (rc != EB_OK) break;
-        if ((e = hipEventRecord(done[slot], h->stream)) != hipSuccess) break;
-        // the piece SLOTS further on goes into this slot once its upload is done
-        if (pinned_path && posted < n_pieces && posted == k + (size_t)SLOTS) {
+        if ((e = hipEventRecord(done[slot], st)) != hipSuccess) break;
+        // the slot of the piece BEFORE this one is free once that piece's upload is done -- likely by now, while this one's upload
+        // has only just been enqueued (waiting for this piece's own upload here would put a host round trip between any two
+        // uploads: 33 GB/s instead of the link's 50) -- and takes the next piece that has no slot yet
+        if (pinned_path && k >= 1 && posted < n_pieces) {
+            const int free_slot = (int)((k - 1) % SLOTS);
             const double t0 = idx_now();
-            if ((e = hipEventSynchronize(done[slot])) != hipSuccess) break;
+            if ((e = hipEventSynchronize(done[free_slot])) != hipSuccess) break;
             tr_slot += idx_now() - t0;
-            readers.post((int)posted, h_stage[slot], (uint64_t)posted * PIECE, piece_len(posted));
+            readers.post((int)posted, h_stage[free_slot], (uint64_t)posted * PIECE, piece_len(posted));
             ++posted;
         }
     }
     if (e != hipSuccess) { eb_set_error("upload failed: %s", hipGetErrorString(e)); rc = EB_ERR_DEVICE; }
+    if (up[1] != h->stream && hipStreamSynchronize(up[1]) != hipSuccess && rc == EB_OK) { eb_set_error("upload failed"); rc = EB_ERR_DEVICE; } // (the counters follow on the index's stream)
     if (rc != EB_OK) (void)hipStreamSynchronize(h->stream);
     const double tr3 = idx_now();
     if (rc == EB_OK) rc = finish_index(h, d_bad, nullptr, ascii, fd);
     const double tr4 = idx_now();
     release();
     if (trace)
-        fprintf(stderr, "[index] n=%llu: page-locked pieces + readers started %.3f s, index + staging allocation %.3f, piece loop %.3f (waits for the readers %.3f, "
+        fprintf(stderr, "[index] n=%llu: page-locked pieces + readers started %.3f s, rest of the index allocation on the side thread %.3f, piece loop %.3f (waits for the readers %.3f, "
                         "for an upload %.3f), counters + directory %.3f, release %.3f\n",
                 (unsigned long long)n, tr1 - tr0, tr2 - tr1, tr3 - tr2, tr_read, tr_slot, tr4 - tr3, idx_now() - tr4);
     if (rc != EB_OK) { eb_index_destroy(h); return rc; }

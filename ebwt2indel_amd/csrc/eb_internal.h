@@ -163,6 +163,9 @@ int eb_index_scan_planes(eb_index* h);
 // phase 4 counts the positions it scans per index and builds the FL table when a caller keeps scanning (eb_index.hip)
 void eb_index_note_phase4_job(eb_index* h, uint64_t positions);
 int eb_flags_alloc(uint64_t n, int device, bool with_da, eb_flags** out);
+// phase 4's first-job costs (scan planes, device temporaries, a page-locked blob) paid ahead of time (eb_scan_job.cpp); called by the
+// traversal on a side thread
+void eb_phase4_warm(eb_index* b1, eb_index* b2, uint64_t n);
 
 // Caching device-scratch allocator (eb_index.hip).  hipMalloc / hipFree cost 0.1-1 ms each and hipFree synchronises
 // the device, so the per-call temporaries of the phase-4 driver are recycled instead of returned to the runtime.

@@ -1671,6 +1671,17 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
     struct Guard6 { int dev; void* p; size_t cap; ~Guard6() { if (p) eb_scratch_put(dev, p, cap); } } guard6{device, d_arena2, arena2_cap};
     const bool side_by_side = d_arena2 != nullptr; // (one after the other in one arena when memory is that short)
     lap("arena allocated");
+    // Phase 4 follows: what its first job would pay before its scan can start -- scan planes, device
+    // temporaries, a page-locked blob: ~50 ms at 7.55 G positions -- is paid HERE, on a side thread, beside the traversal, when the
+    // device has the memory to spare (the traversal's own buffers are allocated by now).
+    std::thread warm;
+    struct WarmGuard { std::thread& t; ~WarmGuard() { if (t.joinable()) t.join(); } } warm_guard{warm};
+    {
+        size_t free_b = 0, total_b = 0;
+        const uint64_t positions = n / (n_shards ? n_shards : 1); // a shard's rank scans its share of the closing positions afterwards
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 3 * (n / 4 + positions / 8 + (512ull << 20)))
+            warm = std::thread([b1, b2, positions] { eb_phase4_warm(b1, b2, positions); });
+    }
     // Threshold bits are collected either as one byte per position (plain stores; needs n bytes of spare HBM) or, when
     // memory is short, as interleaved bit words set with atomics; both are converted to the two bit vectors afterwards.
     uint64_t* d_kr = nullptr;

@@ -130,3 +130,8 @@ void eb_launch_wire4(hipStream_t st, const uint8_t* blob, ScanCounters* cnt, uin
 // full-width wire image (EBCALLS3) for a call set whose counts the host knows; *d_bad counts what does not fit even there
 void eb_launch_wire3(hipStream_t st, const uint8_t* blob, uint64_t count, uint64_t n_chains, uint8_t* wire, uint32_t lw, uint32_t rw, int32_t k_left,
                      int32_t k_right, unsigned long long* d_bad);
+
+// ---- each kernel file: load its code object ahead of the first launch (eb_phase4_warm)
+void eb_scan_kernels_preload();
+void eb_context_preload();
+void eb_wire_preload();

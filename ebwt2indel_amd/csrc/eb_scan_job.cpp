@@ -120,6 +120,27 @@ void job_release(eb_scan_job* job) { // events and the report go back to the con
     delete job;
 }
 
+// streams, the "previous job's context kernels are done" event, a few events and a report block for the first job
+int ensure_ctx(eb_index* b1) {
+    if (b1->scan_ctx) return EB_OK;
+    eb_scan_ctx* ctx = new eb_scan_ctx();
+    b1->scan_ctx = ctx;
+    EB_HIP(hipStreamCreateWithFlags(&ctx->ctx, hipStreamNonBlocking));
+    EB_HIP(hipStreamCreateWithFlags(&ctx->right, hipStreamNonBlocking));
+    EB_HIP(hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking));
+    EB_HIP(hipEventCreateWithFlags(&ctx->last_ctx, hipEventDisableTiming));
+    EB_HIP(hipEventRecord(ctx->last_ctx, ctx->ctx));
+    for (int k = 0; k < E_PER_JOB; ++k) {
+        hipEvent_t e = nullptr;
+        EB_HIP(hipEventCreate(&e));
+        ctx->events.push_back(e);
+    }
+    void* hb = nullptr;
+    EB_HIP(hipHostMalloc(&hb, (sizeof(JobReport) + 255) & ~(size_t)255, hipHostMallocDefault));
+    ctx->reports.push_back(hb);
+    return EB_OK;
+}
+
 // ---- the context kernels, the wire image and the job's last kernel, behind the ordering step (E_ORDER recorded on s_scan)
 int enqueue_contexts(eb_scan_job* job) {
     eb_scan_ctx* ctx = job->ctx;
@@ -422,16 +443,9 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
     eb_index_note_phase4_job(b1, end - begin);
     if (b2) eb_index_note_phase4_job(b2, end - begin);
 
+    int rcc = ensure_ctx(b1);
+    if (rcc != EB_OK) return rcc;
     eb_scan_ctx* ctx = b1->scan_ctx;
-    if (!ctx) {
-        ctx = new eb_scan_ctx();
-        b1->scan_ctx = ctx;
-        EB_HIP(hipStreamCreateWithFlags(&ctx->ctx, hipStreamNonBlocking));
-        EB_HIP(hipStreamCreateWithFlags(&ctx->right, hipStreamNonBlocking));
-        EB_HIP(hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking));
-        EB_HIP(hipEventCreateWithFlags(&ctx->last_ctx, hipEventDisableTiming));
-        EB_HIP(hipEventRecord(ctx->last_ctx, ctx->ctx));
-    }
     const EbConfig& cfg = eb_cfg();
     // THE SCAN BESIDE THE PREVIOUS JOB'S CONTEXT KERNELS (round 3).  The scan is bound by vector instructions (~300 per 64-position
     // word), the context kernels by the fabric's rate of random 128-byte lines with next to no arithmetic: run one after the
@@ -675,6 +689,49 @@ extern "C" int eb_scan_job_wire_to_host(eb_scan_job* job, void* dst, uint64_t ca
     EB_HIP(hipMemcpyAsync(dst, d, n, hipMemcpyDeviceToHost, st));
     EB_HIP(hipStreamSynchronize(st));
     return EB_OK;
+}
+
+// What the FIRST phase-4 job on an index pays before its scan can start, paid beside the traversal instead (eb_flags_build calls
+// this on a side thread once its own buffers are allocated): the scan planes of a one-BWT index, the device temporaries of a
+// whole-range job (into the scratch cache) and a page-locked blob of about the size a call set of read data takes.  The
+// executable's phase 4 on the 7.55 GB file: 57 ms in round 4, of which the kernels took 6.
+void eb_phase4_warm(eb_index* b1, eb_index* b2, uint64_t n) {
+    if (hipSetDevice(b1->device) != hipSuccess) return;
+    const std::string saved = eb_last_error();
+    if (!b2) (void)eb_index_scan_planes(b1);
+    eb_scan_kernels_preload(); // (3-4 ms of code-object loading in front of the first scan otherwise)
+    eb_context_preload();
+    eb_wire_preload();
+    const uint64_t tiles = ((n + 63) / 64 + 255) / 256;
+    const uint64_t n_batches = (tiles >> EB_BATCH_SHIFT_MAX) + 2;
+    if (n_batches <= EB_MAX_BATCHES) {
+        uint64_t cap = n_batches * EB_BATCH_SLOTS;
+        if (cap > 0x1FFFFFFFull) cap = 0x1FFFFFFFull;
+        const uint64_t chains = cap * (b2 ? 8u : 4u);
+        const size_t sizes[] = {((sizeof(ScanCounters) + 255) & ~(size_t)255) + n_batches * 4, (size_t)2048 * EB_SCAN_PARTIAL * 8, n_batches * EB_BATCH_SLOTS * sizeof(Survivor),
+                                4 * (n_batches + 1) * 4, cap * sizeof(Survivor), cap * 4, chains * 8, eb_calls_blob_size(cap, chains, 31, 30)};
+        std::vector<std::pair<void*, size_t>> held;
+        for (size_t bytes : sizes) {
+            size_t got = 0;
+            void* q = eb_scratch_get(b1->device, bytes, &got);
+            if (!q) break;
+            held.emplace_back(q, got);
+        }
+        for (const auto& h : held) eb_scratch_put(b1->device, h.first, h.second);
+    }
+    (void)ensure_ctx(b1);
+    // a page-locked block for the call set (~1e-4 clusters per position x ~85 bytes: the pool hands a block out for requests between
+    // half its size and its size), and a throw-away copy into it: the first device-to-host copy of a process waits 10-30 ms for the
+    // runtime to open a copy-engine queue
+    uint64_t pinned_cap = 0;
+    if (void* h = eb_pinned_get(n / 100 + 4096, &pinned_cap)) {
+        if (b1->scan_ctx && b1->d_chunks && b1->n_blocks * 64 >= (1u << 20)) {
+            (void)hipMemcpyAsync(h, b1->d_chunks, 1u << 20, hipMemcpyDeviceToHost, b1->scan_ctx->copy);
+            (void)hipStreamSynchronize(b1->scan_ctx->copy);
+        }
+        eb_pinned_put(h, pinned_cap);
+    }
+    eb_set_error("%s", saved.c_str());
 }
 
 // Page-locks caller-owned host memory (a shared-memory arena the ranks of one node download their records into), so that

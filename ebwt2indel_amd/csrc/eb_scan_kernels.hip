@@ -943,3 +943,9 @@ void eb_launch_chain_list(hipStream_t st, const Survivor* sorted, const uint32_t
                           uint8_t* blob) {
     hipLaunchKernelGGL(k_chain_list, dim3(eb_grid_of(ns ? ns : 1)), dim3(256), 0, st, sorted, choff, ns, chains, cnt, p, blob);
 }
+
+// loads this file's code object now (the runtime does it with the first launch otherwise: milliseconds in front of the first job)
+void eb_scan_kernels_preload() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(k_scan_reduce));
+}

@@ -17,6 +17,9 @@ t_cli = time.time() - t
 got = open("/tmp/scale.snp", "rb").read()
 print(f"n={len(ebwt)} api {t_api:.2f}s cli {t_cli:.2f}s rc={r.returncode} identical={got == want} records={got.count(b'>')} sha={hashlib.sha256(got).hexdigest()[:16]}")
 print(r.stdout.splitlines()[-1])
+for l in r.stderr.splitlines():
+    if l.startswith("["):
+        print("   " + l[:400])
 # the same file through the multi-GPU mode of the executable with one rank (RCCL communicator, device images, unpack + writer)
 t = time.time()
 r = subprocess.run([_lib.CLI_PATH, "-1", path, "-o", "/tmp/scale_g1.snp", "-G", "1"], capture_output=True, text=True)
