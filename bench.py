@@ -474,7 +474,7 @@ def main():
     if args.warmup > 0:
         run_steps(args.warmup)
     gathered_events.clear()
-    scan_ms, ext_ms, right_ms, tot_ms, ctx_ms, req_ext, req_right, reruns, batch_tiles = [], [], [], [], [], [], [], [], []
+    scan_ms, ext_ms, right_ms, tot_ms, ctx_ms, req_ext, req_right, req_tab, reruns, batch_tiles = [], [], [], [], [], [], [], [], [], []
     scan_launches = 1
 
     def record(st):
@@ -487,6 +487,7 @@ def main():
         ctx_ms.append(st.ms_context)
         req_ext.append(int(st.requests_extend))
         req_right.append(int(st.requests_right))
+        req_tab.append(int(st.requests_right_table))
         reruns.append(int(st.scan_reruns))
         batch_tiles.append(int(st.batch_tiles))
 
@@ -765,8 +766,9 @@ def main():
 
     # algorithmic bytes the context kernels ask for: a 64-byte block per k_extend request; per k_right request a 16-byte chunk of the
     # FL table, or 64 bytes (directory line / block) without it
-    right_bytes = 16 if (fl_table and fl_table["present"]) else 64
-    ctx_bytes = float(np.mean(req_ext)) * 64 + float(np.mean(req_right)) * right_bytes
+    # (the walk's requests are counted by kind on the device: a void chunk of the table costs its 16-byte read AND the directory
+    # select's 64-byte requests -- round-4 advisor finding)
+    ctx_bytes = float(np.mean(req_ext)) * 64 + float(np.mean(req_tab)) * 16 + (float(np.mean(req_right)) - float(np.mean(req_tab))) * 64
     if fl_table and fl_table.get("present") and fl_table.get("ms_per_step_without_it") and fl_table["ms_per_step_without_it"] > ms_per_step:
         fl_table["break_even_passes"] = round(fl_table["build_ms"] / (fl_table["ms_per_step_without_it"] - ms_per_step), 1)
         fl_table["break_even_note"] = "passes after which building the table has paid for itself: build_ms / (ms_per_step_without_it - ms_per_step)"
@@ -809,8 +811,8 @@ def main():
                                  "peak": 8000.0, "unit": "GB/s",
                                  "frac": round(ctx_bytes / (max(np.mean(ctx_ms), 1e-9) * 1e-3) / 1e9 / 8000.0, 5),
                                  "traffic": ctx_traffic, "kernel": "k_extend, then k_right", "ms": round(float(np.mean(ctx_ms)), 4),
-                                 "requests_extend": int(np.mean(req_ext)), "requests_right": int(np.mean(req_right)),
-                                 "bytes_per_request": {"k_extend": 64, "k_right": right_bytes}, "requests_per_s": round((np.mean(req_ext) + np.mean(req_right)) / (max(np.mean(ctx_ms), 1e-9) * 1e-3), 1),
+                                 "requests_extend": int(np.mean(req_ext)), "requests_right": int(np.mean(req_right)), "requests_right_table_chunks": int(np.mean(req_tab)),
+                                 "bytes_per_request": {"k_extend": 64, "k_right": {"table_chunk": 16, "directory_read_or_block": 64}}, "requests_per_s": round((np.mean(req_ext) + np.mean(req_right)) / (max(np.mean(ctx_ms), 1e-9) * 1e-3), 1),
                                  "what": "rank 0's shard, timed region (the next pass's scan shares the chip while these run); k_extend: one request per 64-byte block of a rank "
                                          "pair (1-2 per LF step); k_right: one per FL-table chunk (without the table: one per select-directory read + one per block probed); the chip serves ~47 G independent random 64-byte "
                                          "reads per second, each as a 128-byte line (profiles/r02_rank_probe.txt, r02_rank_probe_cache_policy.txt, r02_pmc_traffic.json)",

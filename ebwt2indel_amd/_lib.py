@@ -47,7 +47,7 @@ class Chain(C.Structure):
 class ScanStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("begin", "end", "runs_closed", "clusters", "bases_in_runs", "survivors", "chains")] + \
                [("hist", C.c_uint64 * 201)] + [(n, C.c_float) for n in ("ms_scan", "ms_extend", "ms_right", "ms_total")] + \
-               [("scan_launches", C.c_uint32), ("ms_context", C.c_float), ("requests_extend", C.c_uint64), ("requests_right", C.c_uint64), ("scan_reruns", C.c_uint32), ("batch_tiles", C.c_uint32)]
+               [("scan_launches", C.c_uint32), ("ms_context", C.c_float), ("requests_extend", C.c_uint64), ("requests_right", C.c_uint64), ("scan_reruns", C.c_uint32), ("batch_tiles", C.c_uint32), ("requests_right_table", C.c_uint64)]
 
 
 class CallsView(C.Structure):

@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(256) k_right(eb_dev_index x1, eb_dev_index x2,
                                               ScanCounters* __restrict__ cnt, uint8_t* __restrict__ blob, uint32_t right_words, uint64_t gate_min) {
     const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / LANES;
     const uint32_t j = LANES == 4 ? threadIdx.x & 3u : 0u, qbase = (threadIdx.x & 63u) & ~3u;
-    uint32_t n_req = 0; // directory reads + 64-byte blocks probed by this cluster's FL steps (counted by its first lane)
+    uint32_t n_req = 0, n_tab = 0; // memory requests of this cluster's FL steps (counted by its first lane): all of them / the FL-table chunks among them
     const JobLayout& L = cnt->lay;
     eb_cluster* __restrict__ recs = reinterpret_cast<eb_cluster*>(blob + sizeof(eb_calls_header));
     uint64_t* __restrict__ right = reinterpret_cast<uint64_t*>(blob + L.off_right);
@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(256) k_right(eb_dev_index x1, eb_dev_index x2,
             ++len;
             if ((len & 31u) == 0) { if (j == 0) out[(len >> 5) - 1] = word; word = 0; }
             if (LANES == 4) row = eb_select_quad(x, row - eb_F_of(x, c), c, j, qbase, n_req);
-            else row = eb_FL(x, row, c, n_req);
+            else row = eb_FL(x, row, c, n_req, n_tab);
             c = eb_F_letter(x, row);
         }
         if ((len & 31u) && j == 0) out[len >> 5] = word;
@@ -303,14 +303,15 @@ __global__ void __launch_bounds__(256) k_right(eb_dev_index x1, eb_dev_index x2,
     if (j == 0) recs[i] = r;
     }
     count_requests(cnt->req_right, j == 0 ? n_req : 0u);
+    count_requests(cnt->req_tab, j == 0 ? n_tab : 0u);
 }
 
 // The job's last kernel (one wave): the context kernels' request counts and the wire image's overflow count go straight into
 // the job's report in page-locked host memory.
 __global__ void k_finish(const ScanCounters* __restrict__ c, JobReport* __restrict__ report) {
-    unsigned long long a = c->req_ext[threadIdx.x], b = c->req_right[threadIdx.x];
-    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
-    if (threadIdx.x == 0) { report->req_ext = a; report->req_right = b; report->wire_bad = c->wire_bad; }
+    unsigned long long a = c->req_ext[threadIdx.x], b = c->req_right[threadIdx.x], t = c->req_tab[threadIdx.x];
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); t += __shfl_xor(t, o); }
+    if (threadIdx.x == 0) { report->req_ext = a; report->req_right = b; report->req_tab = t; report->wire_bad = c->wire_bad; }
 }
 
 }  // namespace

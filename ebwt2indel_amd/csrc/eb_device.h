@@ -435,12 +435,14 @@ __device__ __forceinline__ uint64_t eb_FL(const eb_dev_index& x, uint64_t i, int
     if (x.psi && eb_psi_lookup(x, r, letter, pos)) return pos;
     return eb_select(x, r, letter);
 }
-// `probes`: memory requests issued (one per table chunk; directory read + blocks probed otherwise)
-__device__ __forceinline__ uint64_t eb_FL(const eb_dev_index& x, uint64_t i, int letter, uint32_t& probes) {
+// `probes`: memory requests issued (one per table chunk; directory read + blocks probed otherwise); `table_reads`: the table
+// chunks among them (16-byte requests; a void chunk costs its read AND the select's)
+__device__ __forceinline__ uint64_t eb_FL(const eb_dev_index& x, uint64_t i, int letter, uint32_t& probes, uint32_t& table_reads) {
     const uint64_t r = i - eb_F_of(x, letter);
     uint64_t pos;
     if (x.psi) {
         ++probes;
+        ++table_reads;
         if (eb_psi_lookup(x, r, letter, pos)) return pos;
     }
     return eb_select(x, r, letter, probes);

@@ -533,6 +533,14 @@ __global__ void __launch_bounds__(256) k_nodes1c(eb_dev_index x1, eb_dev_flags f
     bool act0 = false, act1 = false, have_spare = false;
     Rec spare;
     spare.w[0] = spare.w[1] = spare.w[2] = spare.w[3] = 0;
+    // the block loads of a node's six boundaries (consumed in its chain's next turn)
+    auto load6 = [&](const Node1& N, uint4 (&c)[6], bool act) {
+        // (Round 5: letting a boundary in the block of its left neighbour take that neighbour's chunk -- most of a unary node's six
+        // boundaries coincide -- is SLOWER, 0.35 against 0.27 s per traversal at 7.55 G positions: the duplicate loads hit the CU's
+        // L1, the five divergent branches per turn do not come free.  profiles/r05_nav_share_blocks_ab.txt)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) c[k] = eb_rank4_quad_load(x1, act ? N.b[k] : 0ull, j);
+    };
     auto start = [&](Node1& N, uint4 (&c)[6], bool& act) {
         bool want = true;
         uint64_t idx = 0;
@@ -543,8 +551,7 @@ __global__ void __launch_bounds__(256) k_nodes1c(eb_dev_index x1, eb_dev_flags f
         if (act) r = eb_load_global(in + idx);
         unpack_rec(r, N);
         if (act && p.write) mark(N);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) c[k] = eb_rank4_quad_load(x1, N.b[k], j);
+        load6(N, c, true);
     };
     start(N0, c0, act0);
     start(N1, c1, act1);
@@ -609,8 +616,7 @@ __global__ void __launch_bounds__(256) k_nodes1c(eb_dev_index x1, eb_dev_flags f
                     if (asked && !want) { spare = eb_load_global(in + idx); have_spare = true; }
                     // the new node of this chain: its border bits, its block loads (consumed in this chain's next turn)
                     if (act && p.write) mark(N);
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) c[k] = eb_rank4_quad_load(x1, act ? N.b[k] : 0ull, j);
+                    load6(N, c, act);
                 }
             }
         }
@@ -1096,6 +1102,9 @@ __global__ void __launch_bounds__(256) k_nodes2c(eb_dev_index x1, eb_dev_index x
     };
     // which boundaries start a new block (bit k: a[k], bit 6 + k: b[k]); the others reuse their left neighbour's
     auto load_mask = [&](const Node2& N) -> uint32_t {
+#ifdef EB_NAV2_ALL_LOADS
+        return 0xFFFu;
+#endif
         uint32_t m = 1u | (1u << 6);
 #pragma unroll
         for (int k = 1; k < 6; ++k) {

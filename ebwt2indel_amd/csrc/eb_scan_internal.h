@@ -54,7 +54,7 @@ struct JobLayout {
 struct ScanCounters {
     unsigned long long nsurv, runs_closed, clusters, bases, n_long, dropped, spilled;
     unsigned long long hist[201];
-    unsigned long long req_ext[EB_REQ_SLOTS], req_right[EB_REQ_SLOTS]; // memory requests counted by k_extend / k_right (count_requests)
+    unsigned long long req_ext[EB_REQ_SLOTS], req_right[EB_REQ_SLOTS], req_tab[EB_REQ_SLOTS]; // memory requests counted by k_extend / k_right (count_requests); req_tab: k_right's FL-table chunks
     unsigned long long wire_bad;                                       // records that do not fit the tight wire image
     unsigned int max_batch, pad;                                       // most survivors in one batch of the ordered hand-over
     JobLayout lay;
@@ -66,7 +66,7 @@ struct JobReport {
     unsigned long long nsurv_raw, runs_closed, clusters, bases, dropped;
     unsigned long long hist[201];
     JobLayout lay;
-    unsigned long long req_ext, req_right, wire_bad; // part 2
+    unsigned long long req_ext, req_right, req_tab, wire_bad; // part 2
 };
 
 static inline unsigned eb_grid_of(uint64_t threads) { return (unsigned)((threads + 255) / 256); }

@@ -589,6 +589,7 @@ extern "C" int eb_scan_clusters_end(eb_scan_job* job, eb_calls** out, eb_scan_st
         stats->scan_launches = 1;
         stats->requests_extend = R.req_ext;
         stats->requests_right = R.req_right;
+        stats->requests_right_table = R.req_tab;
         stats->scan_reruns = job->reruns;
         stats->batch_tiles = job->ordered ? 1u << job->batch_shift : 0u;
         if (eb_cfg().trace_scan) {

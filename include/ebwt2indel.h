@@ -231,12 +231,13 @@ typedef struct {
     uint32_t scan_launches;                /* k_scan launches behind ms_scan (1) */
     float    ms_context;                   /* start of the left-context extension .. end of the right-context walk behind it */
     /* memory requests the context kernels issued, counted on the device where they are issued: k_extend one per
-     * 64-byte block of a rank pair (1 or 2 per LF step), k_right one per select-directory read + one per block probed */
+     * 64-byte block of a rank pair (1 or 2 per LF step), k_right one per FL-table chunk, select-directory read and block probed */
     uint64_t requests_extend, requests_right;
     /* scans that ran a second time: a batch of the ordered hand-over held more survivors than its slots (the job is then
      * done again with smaller batches), or the unordered survivor list was too short (it runs again with room for all) */
     uint32_t scan_reruns;
     uint32_t batch_tiles;                  /* tiles (16 384 positions each) per batch of the ordered hand-over the job ended with; 0: the unordered hand-over */
+    uint64_t requests_right_table;         /* of requests_right: reads of FL-table chunks (16 bytes each; the others are directory reads and 64-byte block probes) */
 } eb_scan_stats;
 
 /* Replaces the phase-4 loops run_one_dataset (:1609-1655), run_two_datasets (:1395-1445)
