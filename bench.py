@@ -273,7 +273,7 @@ def main():
         j0.finish()
         t = torch.tensor([len0], dtype=torch.int64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        arena = ebd.NodeArena(cap=2 * int(t.item()) + (1 << 20), depth=6)
+        arena = ebd.NodeArena(cap=int(1.5 * t.item()) + (1 << 20), depth=4)
 
     # collect(job) hands the job's records over and may leave the hand-over in flight; resolve() completes it.
     wait_us = []
@@ -746,7 +746,7 @@ def main():
     # profile was taken on the same launch size.  GB/s, the unit of `achieved`.
     traffic = ctx_traffic = rank_traffic = None
     try:
-        pmc_path = next(q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_traffic.json") for r in (4, 3, 2)) if os.path.exists(q))
+        pmc_path = next(q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_traffic.json") for r in (5, 4, 3, 2)) if os.path.exists(q))
         with open(pmc_path) as fh:
             pmc = json.load(fh)
         same = abs(pmc["workload_positions"] - positions_per_launch) <= 0.01 * positions_per_launch

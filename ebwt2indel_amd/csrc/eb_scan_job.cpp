@@ -75,7 +75,8 @@ struct eb_scan_job {
     eb_dev_index x1, x2;
     eb_dev_flags df;
     ScanParams p;
-    hipStream_t s_scan = nullptr, s_ctx = nullptr; // scan + ordering of the survivors; context kernels + wire image
+    hipStream_t s_scan = nullptr, s_ctx = nullptr; // scan (+ ordering of the survivors); context kernels + wire image
+    hipStream_t s_order = nullptr;                 // the stream the ordering step ran on
     unsigned overlap_wgs = 0;                      // != 0: the scan shares every CU with the previous job's context kernels
     int extend_lanes = 1, right_lanes = 1;
     bool split = false;                            // the right-context walk on its own stream, beside the extension (small call sets)
@@ -158,7 +159,7 @@ int enqueue_contexts(eb_scan_job* job) {
     // profiles/r05_rank_share.txt).
     const bool split = job->split && job->cap_ns <= gate_min; // (never with a gated walk)
     const hipStream_t sR = split ? ctx->right : sE;
-    if (sE != job->s_scan) EB_HIP(hipStreamWaitEvent(sE, job->e[E_ORDER], 0));
+    if (sE != job->s_order) EB_HIP(hipStreamWaitEvent(sE, job->e[E_ORDER], 0));
     if (split) EB_HIP(hipStreamWaitEvent(sR, job->e[E_ORDER], 0));
     EB_HIP(hipEventRecord(job->e[E_EXT0], sE));
     eb_launch_extend(sE, job->x1, job->x2, job->p, job->sorted.as<Survivor>(), job->chains.as<uint64_t>(), cnt, job->blob.as<uint8_t>(), job->lw, cap_chains, job->extend_lanes);
@@ -230,9 +231,14 @@ int enqueue_ordered(eb_scan_job* job, bool* fits) {
     if ((rc = scan_preamble(job)) != EB_OK) return rc;
     eb_launch_scan(st, grid, scan_dyn_lds(job->overlap_wgs), job->overlap_wgs != 0, job->x1, job->x2, job->df, q, job->w_lo, job->w_count, nullptr, 0, cnt,
                    job->part.as<unsigned long long>(), job->slots.as<Survivor>(), bcount, job->e[E_SCAN1]);
-    eb_launch_order(st, job->x1, job->x2, job->df, q, job->slots.as<Survivor>(), bcount, job->n_batches, job->kept.as<uint32_t>(), cnt, job->lw, job->rw,
+    // The ordering step follows the scan on ITS stream, ahead of the previous job's context kernels still queued on the context
+    // stream.  (Round 5, a rank's eighth: on the context stream -- the scan stream free for the next scan 45 us earlier -- the pass
+    // takes 0.40 ms instead of 0.33: the ordering then queues behind the previous job's extension.)
+    const hipStream_t so = st;
+    eb_launch_order(so, job->x1, job->x2, job->df, q, job->slots.as<Survivor>(), bcount, job->n_batches, job->kept.as<uint32_t>(), cnt, job->lw, job->rw,
                     job->blob.as<uint8_t>(), job->report, job->sorted.as<Survivor>(), job->choff.as<uint32_t>(), job->chains.as<uint64_t>());
-    EB_HIP(hipEventRecord(job->e[E_ORDER], st));
+    EB_HIP(hipEventRecord(job->e[E_ORDER], so));
+    job->s_order = so;
     EB_HIP(hipGetLastError());
     return enqueue_contexts(job);
 }
@@ -289,6 +295,7 @@ int run_unordered(eb_scan_job* job) {
         return rc;
     eb_launch_chain_list(st, job->sorted.as<Survivor>(), job->choff.as<uint32_t>(), ns, job->chains.as<uint64_t>(), cnt, q, job->blob.as<uint8_t>());
     EB_HIP(hipEventRecord(job->e[E_ORDER], st));
+    job->s_order = st;
     EB_HIP(hipGetLastError());
     return enqueue_contexts(job);
 }

@@ -173,9 +173,19 @@ class NodeArena:
         self.size = 4096 + self.world * depth * self.slot
         name = [None]
         if self.rank == 0:
-            name[0] = f"/dev/shm/ebwt2indel_arena_{os.getpid()}_{id(self) & 0xFFFFFF:x}"
+            # /dev/shm when it has the room (a container may give it 64 MB: writing past that is a SIGBUS, not an error), else a file
+            # in the temporary directory -- a shared mapping of any file is shared memory; its pages are page-locked by the ranks
+            import tempfile
+            where = "/dev/shm"
+            try:
+                st = os.statvfs(where)
+                if st.f_bavail * st.f_frsize < self.size + (self.size >> 3):
+                    where = tempfile.gettempdir()
+            except OSError:
+                where = tempfile.gettempdir()
+            name[0] = os.path.join(where, f"ebwt2indel_arena_{os.getpid()}_{id(self) & 0xFFFFFF:x}")
             fd = os.open(name[0], os.O_CREAT | os.O_EXCL | os.O_RDWR, 0o600)
-            os.ftruncate(fd, self.size)
+            os.posix_fallocate(fd, 0, self.size)           # (the blocks exist: no SIGBUS later)
         if self.world > 1:
             dist.broadcast_object_list(name, src=0, group=group)
         if self.rank != 0:

@@ -4,10 +4,11 @@
         -m ebwt2indel_amd.run_distributed -1 reads.ebwt -o out.snp [-2 other.ebwt | -d reads.da] [-L -R -k -g -v -m -c -q -t]
 
 Every rank loads the eBWT(s) onto its GPU; phases 2-3 are split by Weiner-link subtrees and combined with one all-reduce
-per bit vector; phase 4 is split by closing position; the ranks' call sets travel as compact device images to rank 0
-(RCCL over xGMI), which runs the event logic and writes the .snp -- byte for byte the file of the single-GPU
-executable (tests/test_gpu_distributed.py).  Backend: nccl (= RCCL); EB_DIST_BACKEND=gloo stages through host memory
-(rehearsal with several ranks on one GPU).  The reference has no counterpart (one process, ebwt2InDel.cpp:1677-1823)."""
+per bit vector (RCCL over xGMI); phase 4 is split by closing position; every rank downloads its compact call-set image over
+its own PCIe link into a host arena all ranks map (ebd.NodeArena; EB_DIST_GATHER=rccl: the images travel GPU -> GPU to rank 0
+instead, which downloads all of them), and rank 0 runs the event logic and writes the .snp -- byte for byte the file of the
+single-GPU executable (tests/test_gpu_distributed.py).  Backend: nccl (= RCCL); EB_DIST_BACKEND=gloo stages the vectors through
+host memory (rehearsal with several ranks on one GPU).  The reference has no counterpart (one process, ebwt2InDel.cpp:1677-1823)."""
 from __future__ import annotations
 
 import argparse
@@ -81,15 +82,21 @@ def main(argv=None) -> int:
         t2 = time.time()
         n = b1.n + (b2.n if b2 is not None else 0)
         begin, end = ebd.shard_range(n, rank, world)
-        if comm_dev.type == "cuda":
-            job = api.scan_clusters_begin(b1, fl, p, bwt2=b2, begin=begin, end=end, device_only=True, wire=True)
-            job.wait()
-            ptr, length = job.device_wire()
-            parts = ebd.gather_device(ptr, length, comm_dev)
-            job.finish()
+        job = api.scan_clusters_begin(b1, fl, p, bwt2=b2, begin=begin, end=end, device_only=True, wire=True)
+        job.wait()
+        ptr, length = job.device_wire()
+        if os.environ.get("EB_DIST_GATHER", "arena") == "rccl" and comm_dev.type == "cuda":
+            parts = ebd.gather_device(ptr, length, comm_dev)         # rounds 2-4: GPU -> GPU to rank 0, which downloads every image
         else:
-            calls = api.scan_clusters(b1, fl, p, bwt2=b2, begin=begin, end=end)
-            parts = ebd.gather_packed(calls.blob(), device=comm_dev)
+            # every rank downloads its own image over its own PCIe link into a host arena all ranks map; rank 0 reads the slots
+            t = torch.tensor([length], dtype=torch.int64, device=comm_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            arena = ebd.NodeArena(cap=int(t.item()) + 4096, depth=1)
+            arena.publish_job(job)
+            parts = [bytes(v) for v in arena.collect()] if rank == 0 else None
+            dist.barrier()
+            arena.close()
+        job.finish()
         t3 = time.time()
         if rank == 0:
             text, cluster_nr, events, total = ebd.write_gathered(parts, p, two)

@@ -4,7 +4,9 @@ the input's SHA-256 (so the regenerated input IS the one the oracle walked), the
 every bit vector, the whole-run .snp's SHA-256 and record count.  The oracle runs behind each profile took 5-20 minutes of
 64 host threads; the product's side of the comparison is seconds, which is why it can live here.
 
-Nothing in this file calls the oracle: the expected values are data under profiles/."""
+The record-based tests do not call the oracle: their expected values are data under profiles/.  Since round 5 the LAST test does:
+configs[1] at full size with the CPU oracle walking the very input live on the test box's host threads (traversal ~2 minutes on 64
+threads, phase 4 seconds), so that the full-size expectation no longer rests on figures the builder recorded."""
 import json
 import os
 
@@ -111,3 +113,51 @@ def test_slabbed_generator_reproduces_the_recorded_config2_input():
     dev.free()
     assert [len(host)] == want["n"]
     assert fs.sha256(host) == want["ebwt_sha256"][0]
+
+
+def test_full_size_config2_against_the_oracle_run_live():
+    """BASELINE configs[1] (7.55 G positions) with the ORACLE ITSELF in the loop, on this box: its threaded index + traversal
+    (orc_navigate_one_mt: same expansion rule as the serial, reference-ordered code, held to it on the fixtures by
+    tests/test_oracle_threads.py) against the GPU's counters and bit vectors word for word, then its phase 4 over the whole range
+    against the GPU's whole-run .snp -- and both against the recorded figures, which the builder's own oracle run wrote."""
+    import hashlib
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+
+    import numpy as np
+
+    from ebwt2indel_amd import distributed as ebd
+    from tests import _oracle
+    try:
+        cpus = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = os.cpu_count() or 8
+    if cpus < 16:
+        pytest.skip(f"{cpus} host threads: the oracle's traversal of 7.55 G positions would take tens of minutes")
+    threads = min(cpus, 64)
+    want = _expected("config2")
+    inp = fs.Inputs("config2", keep_host=True)
+    assert inp.describe() == want["input"]
+    res = fs.Result(inp)
+    orc = _oracle.Oracle()
+    po = _oracle.Params.from_args([])
+    idx = orc.index(inp.hosts[0], threads=threads)
+    assert idx.ok
+    inp.hosts = []
+    of = _oracle.OracleFlags(orc, idx, None, po.K, po.k_right, threads=threads)
+    oc = of.counters()
+    for k in ("leaves", "nodes", "minima", "lcp_values"):
+        assert res.counters[k] == oc[k] == want["counters"][k], (k, res.counters[k], oc[k])
+    got = res.flags.export()
+    for name, a, b in zip(fs.VECTORS, got, of.export()):
+        assert (a is None) == (b is None) and (a is None or np.array_equal(a, b)), f"{name} differs from the oracle's"
+    del got
+    shards = threads * 16
+    cuts = [ebd.shard_range(inp.n, i, shards) for i in range(shards)]
+    with ThreadPoolExecutor(threads) as ex:
+        parts = list(ex.map(lambda be: of.scan(po, be[0], be[1]), cuts))
+    text = fs.renumber([p["text"] for p in parts], [p["cluster_nr"] - 1 for p in parts])
+    assert text == res.text, "GPU .snp differs from the oracle's whole-range .snp (run live)"
+    assert hashlib.sha256(text).hexdigest() == want["oracle_snp_sha256"] and text.count(b">") == want["snp_records"]
+    st = res.calls.stats
+    assert (int(st.runs_closed), int(st.clusters), int(st.bases_in_runs)) == tuple(int(sum(p["stats"][k] for p in parts)) for k in ("runs_closed", "clusters", "bases_in_runs"))
