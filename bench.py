@@ -22,9 +22,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# The phase-4 driver uses five streams (scan / prepare / two context kernels / copies); HIP maps streams onto
-# GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue serialise.  Must be set before HIP starts.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# (Rounds 2-4 set GPU_MAX_HW_QUEUES=16 here.  Round 5 leaves the HIP runtime's default of 4 hardware queues: the library creates an
+# index's scan / context / walk / copy streams in a row, so they sit on different queues, and every dispatch is faster with 4 queues than
+# with 8 or 16 -- profiles/r05_hw_queues.txt.  A value in the environment is respected and echoed in config.env.)
 
 import numpy as np  # noqa: E402
 

@@ -85,8 +85,8 @@ def load():
     # If torch is imported AFTER this library has pulled in the system runtime, the process ends up with two
     # runtimes and the second finds no GPU.  So when torch is present, let it load its runtime first; the
     # library then binds to that one.  EB_NO_TORCH=1 skips this (pure C / CLI use binds to /opt/rocm).
-    # five streams per handle: give the HIP runtime enough hardware queues (only effective before HIP initialises)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    # (GPU_MAX_HW_QUEUES is left at the runtime's default of 4 since round 5: the library creates the streams of an index's phase-4
+    # jobs right behind the index's own, which puts them on different hardware queues; more queues slow every dispatch)
     if os.environ.get("EB_NO_TORCH", "0") != "1":
         try:
             import torch  # noqa: F401

@@ -432,7 +432,15 @@ static int index_alloc(uint64_t n, uint8_t term, int device, eb_index** out) {
     h->term = term;
     h->n_blocks = (n + 1 + 127) / 128;                 // dna_string.hpp:62
     h->n_super = (n + 1 + 0xFFFFFFFFull) >> 32;        // dna_string.hpp:61
+    // The index's stream and, RIGHT BEHIND IT, the streams of its phase-4 jobs (eb_scan_ctx: context kernels, a small call set's
+    // walk, record downloads).  The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless the environment says
+    // otherwise): a new stream gets a new queue while the pool has room, the least-used one afterwards -- four streams created in a
+    // row therefore sit on four different queues, the fourth (the copies') at worst beside an idle stream of the host program, and
+    // the scan never shares a queue with the context kernels it runs beside.  (Rounds 2-4 asked for 16 queues instead: more than 4
+    // slows every dispatch -- k_scan alone 171 against 143 us for an eighth of config 2, the ordering kernels 45 + 52 against
+    // 12 + 15 us -- and which streams end up on one pipe is then left to chance: profiles/r05_hw_queues.txt.)
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess && eb_scan_ctx_create(h) != EB_OK) e = hipErrorOutOfMemory;
     if (e == hipSuccess) e = hipMalloc(&h->d_chunks, h->n_blocks * 64);
     if (e == hipSuccess) e = hipMalloc(&h->d_super, h->n_super * 4 * sizeof(uint64_t));
     if (e != hipSuccess) {

@@ -33,6 +33,7 @@ struct eb_scan_ctx {
     uint64_t pinned_reserved = 0;                // largest call-set size a ring of page-locked blobs was reserved for (likewise)
 };
 void eb_scan_ctx_destroy(eb_scan_ctx* c);
+int eb_scan_ctx_create(struct eb_index* h); // (eb_scan_job.cpp; called by index_alloc right behind the index's own stream)
 
 struct eb_index {
     int device = -1;

@@ -512,7 +512,6 @@ static int run_multi(int world, const std::string& input1, const std::string& in
 }
 
 int main(int argc, char** argv) {
-    setenv("GPU_MAX_HW_QUEUES", "16", 0); // the phase-4 driver overlaps five streams; the HIP default of 4 queues serialises them
     if (argc < 3) help();
     eb_params p;
     memset(&p, 0, sizeof p);

@@ -121,8 +121,11 @@ void job_release(eb_scan_job* job) { // events and the report go back to the con
     delete job;
 }
 
-// streams, the "previous job's context kernels are done" event, a few events and a report block for the first job
-int ensure_ctx(eb_index* b1) {
+}  // namespace
+
+// streams of the index's phase-4 jobs (created with the index, right behind its own stream: see index_alloc), the "previous
+// job's context kernels are done" event, a set of events and a report block for the first job
+int eb_scan_ctx_create(eb_index* b1) {
     if (b1->scan_ctx) return EB_OK;
     eb_scan_ctx* ctx = new eb_scan_ctx();
     b1->scan_ctx = ctx;
@@ -141,6 +144,8 @@ int ensure_ctx(eb_index* b1) {
     ctx->reports.push_back(hb);
     return EB_OK;
 }
+
+namespace {
 
 // ---- the context kernels, the wire image and the job's last kernel, behind the ordering step (E_ORDER recorded on s_scan)
 int enqueue_contexts(eb_scan_job* job) {
@@ -450,7 +455,7 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
     eb_index_note_phase4_job(b1, end - begin);
     if (b2) eb_index_note_phase4_job(b2, end - begin);
 
-    int rcc = ensure_ctx(b1);
+    int rcc = eb_scan_ctx_create(b1);
     if (rcc != EB_OK) return rcc;
     eb_scan_ctx* ctx = b1->scan_ctx;
     const EbConfig& cfg = eb_cfg();
@@ -727,7 +732,6 @@ void eb_phase4_warm(eb_index* b1, eb_index* b2, uint64_t n) {
         }
         for (const auto& h : held) eb_scratch_put(b1->device, h.first, h.second);
     }
-    (void)ensure_ctx(b1);
     // a page-locked block for the call set (~1e-4 clusters per position x ~85 bytes: the pool hands a block out for requests between
     // half its size and its size), and a throw-away copy into it: the first device-to-host copy of a process waits 10-30 ms for the
     // runtime to open a copy-engine queue

@@ -24,7 +24,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import torch  # noqa: E402
 
 from ebwt2indel_amd import api, sim  # noqa: E402
