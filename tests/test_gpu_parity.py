@@ -719,10 +719,9 @@ def test_device_image_equals_host_blob(dip):
         assert back.format_snp(p, False)[0] == host.format_snp(p, False)[0]
 
 
-def test_pipelined_jobs_hold_back_their_last_part(dip):
-    """EB_SCAN_PIPELINED: a job's last part (image, chain list, context kernels, hand-over) goes out with the next _begin on
-    the index, or when the job is waited for / ended / asked for its image -- whichever comes first, from whichever host
-    thread.  Every order gives the blob of a plain job."""
+def test_pipelined_jobs_end_in_any_order_and_on_another_thread(dip):
+    """EB_SCAN_PIPELINED: jobs are enqueued whole by _begin and may be waited for / ended / asked for their images in any order,
+    from another host thread than the one that keeps beginning jobs.  Every order gives the blob of a plain job."""
     import threading
     e, g, _ = dip
     n = len(e)
