@@ -291,7 +291,7 @@ uint64_t align8(uint64_t v) { return (v + 7) & ~7ull; }
 
 // A caller that keeps phase-4 jobs coming (EB_SCAN_PIPELINED) has several call sets alive at once -- begun, being handed over,
 // being read -- and each needs a page-locked blob.  Pinning one takes ~6 ms per 80 MB; and the first time a device-to-host copy is
-// issued while another one is still running, the host sits 12-28 ms inside hipMemcpyAsync (EB_BEGIN_TRACE, round 3: one begin
+// issued while another one is still running, the host sits 12-28 ms inside hipMemcpyAsync (EB_TRACE=begin, round 3: one begin
 // call of 19-30 ms among 2.9 ms ones, at a different step of every run, not under the profiler where copies are kernels): the
 // runtime opens a further copy-engine queue on first need.  Neither may land in the middle of the pipeline: makes sure `count`
 // blobs of at least `size` bytes are in the pool, and runs throw-away copies from `d_warm` into the new ones, four at a time on

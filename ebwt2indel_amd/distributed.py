@@ -168,8 +168,8 @@ class NodeArena:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.group, self.depth = group, depth
-        self.cap = (int(cap) + 4095) & ~4095
-        self.slot = self.HDR + self.cap
+        self.cap = ((int(cap) + self.HDR + 4095) & ~4095) - self.HDR     # a slot (header + image) is a whole number of pages: every
+        self.slot = self.HDR + self.cap                                    # rank page-locks pages no other rank writes
         self.size = 4096 + self.world * depth * self.slot
         name = [None]
         if self.rank == 0:

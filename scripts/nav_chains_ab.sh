@@ -4,7 +4,7 @@ ROOT=${GRAFT_REPO_ROOT:-$PWD}
 B="python3 $ROOT/bench.py --cpu-sample-reads 0 --cpu-dram-reads 0 --rank-queries 1048576 --steps 10 --warmup 3"
 for rep in 1 2 3; do
 for c in 1 0; do
-  EB_NAV_CHAINS=$c EB_NAV_TRACE=${TRACE:-} timeout -k 10 200 $B 2>/dev/null | python3 -c "
+  EB_NAV_CHAINS=$c EB_TRACE=${TRACE:-} timeout -k 10 200 $B 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 g=d['phases23_gpu']

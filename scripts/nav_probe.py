@@ -1,4 +1,4 @@
-"""Probe: phases 2-3 only, at a given scale, with EB_NAV_TRACE output."""
+"""Probe: phases 2-3 only, at a given scale, with EB_TRACE=nav output."""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ebwt2indel_amd import sim, api

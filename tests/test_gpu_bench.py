@@ -51,11 +51,13 @@ def test_bench_two_ranks_share_the_gpu_same_snp():
     assert d["clusters_emitted"] == d1["clusters_emitted"]
 
 
-def test_bench_nccl_collectives_with_one_rank_same_snp():
+@pytest.mark.parametrize("gather", ["arena", "rccl"])
+def test_bench_nccl_collectives_with_one_rank_same_snp(gather):
     """The N > 1 code path of the driver's multi-GPU run -- RCCL process group, sharded traversal with its all-reduce,
-    device-only jobs, compact wire images gathered GPU to GPU and resolved one step later -- exercised with a single
-    rank (RCCL refuses two ranks on one device): same .snp as the plain N = 1 run."""
-    env = dict(os.environ, EB_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29519", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    device-only jobs with compact wire images, handed to rank 0 through the node's host arena (every rank's own PCIe link; the
+    default) or gathered GPU to GPU with RCCL and resolved one step later (EB_BENCH_GATHER=rccl, rounds 2-4) -- exercised with a
+    single rank (RCCL refuses two ranks on one device): same .snp as the plain N = 1 run either way."""
+    env = dict(os.environ, EB_BENCH_FORCE_DIST="1", EB_BENCH_GATHER=gather, MASTER_ADDR="127.0.0.1", MASTER_PORT="29519", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-sample-reads", "0", "--steps", "5"] + ARGS[:2] + ARGS[4:],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-3000:]

@@ -160,3 +160,22 @@ def test_multi_gpu_launcher_two_ranks(tmp_path, name):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stderr[-3000:]
     assert out.read_bytes() == golden_bytes(case["snp"])
+
+
+@pytest.mark.parametrize("gather", ["arena", "rccl"])
+def test_multi_gpu_launcher_one_nccl_rank(tmp_path, gather):
+    """The same tool with the real backend (nccl = RCCL) and ONE rank (RCCL refuses two ranks on one device): the flag vectors'
+    all-reduce in HBM, then the records through the host arena (default) or through the RCCL gather of rounds 2-4
+    (EB_DIST_GATHER=rccl) -- the reference's bytes either way."""
+    import subprocess
+    import sys
+    case = _case("m1_default")
+    pth = tmp_path / "bwt1"
+    pth.write_bytes(golden_bytes(case["inputs"]["bwt1"]))
+    out = tmp_path / "out.snp"
+    env = dict(os.environ, EB_DIST_GATHER=gather)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), "-m", "ebwt2indel_amd.run_distributed", "-1", str(pth), "-o", str(out)] + list(case["args"])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert out.read_bytes() == golden_bytes(case["snp"])

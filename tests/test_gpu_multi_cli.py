@@ -33,10 +33,14 @@ def _run(tmp_path, case, gpus, env_extra=None):
     return r, out
 
 
+@pytest.mark.parametrize("records", ["own_link", "rccl_gather"])
 @pytest.mark.parametrize("name", ["m1_default", "m1_edge_m2", "m2_het_default", "m3_hom_default", "m1_tiny_nocluster"])
-def test_cli_G1_rccl_single_rank(tmp_path, name):
+def test_cli_G1_single_rank(tmp_path, name, records):
+    """-G 1: the multi-GPU code path with one rank (no communicator needed) -- shard-form flags + finalize, device-only job with its
+    wire image, the image downloaded over the rank's own link into the page-locked arena (default) or taken the round-4 way
+    (EB_MULTI_BACKEND=rccl-gather: the images meet on GPU 0, which downloads them), unpack, writer: the golden .snp either way."""
     case = _case(name)
-    r, out = _run(tmp_path, case, 1)
+    r, out = _run(tmp_path, case, 1, {"EB_MULTI_BACKEND": "rccl-gather"} if records == "rccl_gather" else None)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert out.read_bytes() == golden_bytes(case["snp"])
     assert "on 1 GPU(s) [one rank: no communicator]" in r.stdout
