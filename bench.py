@@ -71,6 +71,38 @@ def launch_ranks(n_gpus: int) -> int:
     return 0
 
 
+def other_modes(args) -> dict:
+    """Modes 2 and 3 (BASELINE configs[2], and configs[3] on this one GPU) through this very script, one child process each, so that
+    the driver's default run records them too: the same pipelined steps, fewer of them, no CPU leg; a digest of each child's line."""
+    import subprocess
+    out = {"what": "short runs of this script with --mode 2 (two BWTs, --reads as two collections) and --mode 3 (merged BWT + document array, twice "
+                   "--reads: BASELINE configs[3] on ONE GPU), child processes started after the line above was measured; digest of their lines"}
+    for mode, reads in ((2, args.reads), (3, 2 * args.reads)):
+        cmd = [sys.executable, os.path.abspath(__file__), "--mode", str(mode), "--reads", str(reads), "--read-len", str(args.read_len), "--coverage", str(args.coverage),
+               "--steps", str(min(args.steps, 10)), "--warmup", str(min(args.warmup, 3)), "--cpu-sample-reads", "0", "--rank-queries", str(min(args.rank_queries, 1 << 20))]
+        t0 = time.time()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if os.environ.get("EB_BENCH_TRACE") == "1":
+                log(f"[bench] --mode {mode} child, stderr:\n" + "\n".join("    " + ln[:300] for ln in r.stderr.splitlines() if ln.startswith("[")))
+            if r.returncode != 0 or not lines:
+                out[f"mode{mode}"] = {"error": (r.stderr or r.stdout)[-400:], "returncode": r.returncode}
+                continue
+            d = json.loads(lines[-1])
+            out[f"mode{mode}"] = {"workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+                                  "step_roofline_frac": d["step_roofline"]["frac"], "algorithmic_bytes_per_position": d["roofline"]["algorithmic_bytes_per_position"],
+                                  "scan_ms": d["phase4_device_ms"]["scan"], "extend_ms": d["phase4_device_ms"]["extend"], "right_ms": d["phase4_device_ms"]["right"],
+                                  "alone": d["phase4_device_ms"]["alone"], "one_shot_ms": d["one_shot"]["ms"] if d.get("one_shot") else None,
+                                  "traversal_seconds": d["phases23_gpu"]["seconds"], "nodes": d["phases23_gpu"]["nodes"], "leaves": d["phases23_gpu"]["leaves"],
+                                  "document_array_packed_from_hbm_seconds": d["phases23_gpu"].get("document_array_packed_from_hbm_seconds"),
+                                  "snp_records": d.get("snp_records"), "snp_sha256": d.get("snp_sha256"), "snp_verified": d.get("snp_verified"),
+                                  "process_seconds": round(time.time() - t0, 1)}
+        except Exception as e:      # noqa: BLE001 -- the headline line must not depend on these
+            out[f"mode{mode}"] = {"error": repr(e)[-400:]}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,6 +112,9 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--coverage", type=float, default=30.0)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--mode", type=int, default=1, choices=(1, 2, 3),
+                    help="1: one collection (BASELINE configs[1], the metric's workload); 2: the reads as TWO collections of --reads / 2 each, two BWTs "
+                         "(configs[2] at the default --reads); 3: the same two collections merged + document array (configs[3] with --reads 100000000)")
     ap.add_argument("--error-rate-ppm", type=int, default=0, help="substitution errors per million bases in the reads (the reference's documented input "
                     "is simulated reads with an error profile, README.md:88-100); 0: error-free reads, the BASELINE workload")
     ap.add_argument("--reverse-complements", action="store_true", help="add the reverse complement of every read to the collection (README.md:90); "
@@ -90,6 +125,8 @@ def main():
     ap.add_argument("--rehearse-rank-of", type=int, default=0, metavar="W",
                     help="one-GPU rehearsal of ONE rank's share of a W-GPU run: scan range W//2 of W, collectives with a single rank "
                          "(needs EB_BENCH_FORCE_DIST=1); the JSON line is labelled and its value counts the share only")
+    ap.add_argument("--no-other-modes", action="store_true", help="default run (mode 1, one GPU): do not append the short runs of modes 2 and 3 "
+                    "(child processes of this script: configs[2], and configs[3] on this one GPU) to the line as `other_modes`")
     ap.add_argument("--no-pipeline", action="store_true", help="finish every step before the next begins (profiling: under rocprofv3 the "
                     "overlapped record download runs as a blit kernel and slows the scan it overlaps)")
     args = ap.parse_args()
@@ -162,18 +199,26 @@ def main():
     # leaves HBM: generator output -> eb_index_create_from_device.
     genome_len = int(args.reads * args.read_len / args.coverage)
     threads = max(1, (os.cpu_count() or 8) // max(1, world))
+    realistic = args.error_rate_ppm > 0 or args.reverse_complements
+    if args.mode != 1 and realistic:
+        raise SystemExit("--error-rate-ppm / --reverse-complements: mode 1 only")
+    dev_ebwt2 = None
     t0 = time.time()
-    g = sim.random_genome(genome_len, args.seed)
-    h2 = sim.mutate_haplotype(g, args.seed)
-    text, offs = sim.haplotype_text([g, h2])
-    starts = sim.sample_read_starts([g, h2], offs, args.reads, args.read_len, args.seed)
-    del g, h2
+    if args.mode == 1:
+        g = sim.random_genome(genome_len, args.seed)
+        h2 = sim.mutate_haplotype(g, args.seed)
+        text, offs = sim.haplotype_text([g, h2])
+        starts = sim.sample_read_starts([g, h2], offs, args.reads, args.read_len, args.seed)
+        del g, h2
+    else:
+        # two individuals, each homozygous for one haplotype of the same diploid genome, --reads / 2 reads each (the recipe of
+        # tests/_fullsize.py config3 / config4, whose full-size oracle records the .snp below is held to)
+        text, s0, s1 = sim.two_sample_text(args.reads // 2, args.read_len, args.coverage)
     t_host = time.time() - t0
     t0 = time.time()
     # (the slab-by-slab generator since round 3: 1.2 s instead of 6 s at this size and a tenth of the temporaries; the same bytes --
     # tests/test_gpu_fullsize.py holds both generators to the recorded SHA-256 of this input; EB_BENCH_ONE_PASS_GENERATOR=1: the old one)
     build = sim.build_ebwt_gpu if os.environ.get("EB_BENCH_ONE_PASS_GENERATOR") == "1" else sim.build_ebwt_gpu_slabbed
-    realistic = args.error_rate_ppm > 0 or args.reverse_complements
     if realistic:
         # reads with substitution errors (and their reverse complements) are substrings of no genome: the reads themselves, one behind
         # the other, are the generator's text (sim.error_sample_gpu; tests/test_gpu_generator.py holds it to the host builder)
@@ -181,15 +226,27 @@ def main():
         dev_ebwt = sim.build_ebwt_gpu_slabbed(int(d_reads.data_ptr()), int(d_starts.data_ptr()), args.read_len, n_reads=int(d_starts.numel()), text_len=int(d_reads.numel()), device=local)
         del d_reads, d_starts
         torch.cuda.empty_cache()
-    else:
+    elif args.mode == 1:
         dev_ebwt = build(text, starts, args.read_len, device=local)
-    n = dev_ebwt.n
+    elif args.mode == 2:
+        dev_ebwt = sim.build_ebwt_gpu_slabbed(text, s0, args.read_len, device=local)
+        dev_ebwt2 = sim.build_ebwt_gpu_slabbed(text, s1, args.read_len, device=local)
+    else:
+        dev_ebwt = sim.build_ebwt_gpu_slabbed(text, np.concatenate([s0, s1]), args.read_len, n_first=len(s0), want_da=True, device=local)
+    n = dev_ebwt.n + (dev_ebwt2.n if dev_ebwt2 is not None else 0)
     t_gen = time.time() - t0
-    del text, starts
-    workload = (f"mode 1, {args.reads} x {args.read_len} bp reads, {args.coverage:g}x diploid genome {genome_len} bp, "
-                + (f"{args.error_rate_ppm / 1e4:g} % substitution errors, " if args.error_rate_ppm else "")
-                + (f"+ the reverse complement of every read ({2 * args.reads} reads in all), " if args.reverse_complements else "")
-                + f"n={n} BWT positions (BASELINE.json configs[1] when reads=50000000" + (" and the reads are error-free)" if realistic else ")"))
+    del text
+    if args.mode == 1:
+        del starts
+        workload = (f"mode 1, {args.reads} x {args.read_len} bp reads, {args.coverage:g}x diploid genome {genome_len} bp, "
+                    + (f"{args.error_rate_ppm / 1e4:g} % substitution errors, " if args.error_rate_ppm else "")
+                    + (f"+ the reverse complement of every read ({2 * args.reads} reads in all), " if args.reverse_complements else "")
+                    + f"n={n} BWT positions (BASELINE.json configs[1] when reads=50000000" + (" and the reads are error-free)" if realistic else ")"))
+    else:
+        del s0, s1
+        workload = (f"mode {args.mode}, two collections of {args.reads // 2} x {args.read_len} bp reads (two individuals, each homozygous for one haplotype of a "
+                    f"{genome_len} bp diploid genome), " + ("two BWTs" if args.mode == 2 else "one merged BWT + document array")
+                    + f", n={n} BWT positions (BASELINE.json " + ("configs[2] when reads=50000000)" if args.mode == 2 else "configs[3] when reads=100000000, on the GPUs of this run)"))
     if rank == 0:
         log(f"[bench] workload: {workload}; haplotypes+read starts {t_host:.1f}s on host, eBWT built on GPU in {t_gen:.1f}s")
 
@@ -205,10 +262,11 @@ def main():
     # ---------------- resident state: index + flag vectors on this GPU (phases 1-3, outside the timed region)
     p = api.make_params()
     t1 = time.time()
-    bwt = api.DnaBwt(None, device_ptr=dev_ebwt.ptr, n=n, device=local)
+    bwt = api.DnaBwt(None, device_ptr=dev_ebwt.ptr, n=dev_ebwt.n, device=local)
+    bwt2 = api.DnaBwt(None, device_ptr=dev_ebwt2.ptr, n=dev_ebwt2.n, device=local) if dev_ebwt2 is not None else None
     t_index = time.time() - t1
     # a few thousand symbols for the rank spot check, then the ASCII text leaves HBM
-    probe_len = min(n, 1 << 20)
+    probe_len = min(bwt.n, 1 << 20)
     head = np.empty(probe_len, dtype=np.uint8)
     sim._hip_copy_to_host(head, dev_ebwt.ptr, probe_len)
     # The 7.55 GB ASCII text is released only AFTER phases 2-3: a large hipFree is followed by a driver-side wipe and the next
@@ -216,17 +274,26 @@ def main():
     # traversal's first allocations then sat behind the wipe for ~2 s of "phases 2-3" wall time that was no work of the path.
     # EB_BENCH_FREE_EARLY=1: the round-2 order.
     free_early = os.environ.get("EB_BENCH_FREE_EARLY") == "1"
-    if free_early:
+    if free_early and args.mode == 1:
         dev_ebwt.free()
     t1 = time.time()
     # N > 1: the traversal itself is split over the ranks (Weiner-link subtrees) and the bit vectors are combined by
     # one all-reduce each; N = 1: the plain build.
-    flags = ebd.navigate_sharded(bwt, p, device=comm_dev) if use_dist else api.navigate_one_bwt(bwt, p)
+    flags = (ebd.navigate_sharded(bwt, p, bwt2, device=comm_dev) if use_dist else
+             api.navigate_two_bwts(bwt, bwt2, p) if bwt2 is not None else api.navigate_one_bwt(bwt, p))
     if use_dist:
         dist.barrier()
     t_nav = time.time() - t1
-    if not free_early:
+    t_da = None
+    if args.mode == 3:
+        # the document array is the generator's, still in HBM: packed where it lies (a run of the tool reads its -d file: eb_flags_set_da_file)
+        t1 = time.time()
+        flags.set_da_device(dev_ebwt.da_ptr, dev_ebwt.n)
+        t_da = time.time() - t1
+    if not (free_early and args.mode == 1):
         dev_ebwt.free()
+    if dev_ebwt2 is not None:
+        dev_ebwt2.free()
     del wipe_absorber
     ns = flags.stats
     if rank == 0:
@@ -262,7 +329,7 @@ def main():
     on_device = device_gather or arena_mode          # the call set stays in HBM, the job packs its wire image
 
     def begin_step():
-        return api.scan_clusters_begin(bwt, flags, p, begin=begin, end=end, device_only=on_device, wire=on_device, pipelined=not args.no_pipeline)
+        return api.scan_clusters_begin(bwt, flags, p, bwt2=bwt2, begin=begin, end=end, device_only=on_device, wire=on_device, pipelined=not args.no_pipeline)
 
     arena = None
     if arena_mode:
@@ -421,11 +488,11 @@ def main():
     if rank == 0 or use_dist:
         # the FIRST pass on the index, as a one-shot run of the tool gets it: scan planes built, buffers allocated, blob pinned
         t1 = time.perf_counter()
-        c_first = api.scan_clusters(bwt, flags, p, begin=begin, end=end)
+        c_first = api.scan_clusters(bwt, flags, p, bwt2=bwt2, begin=begin, end=end)
         one_shot_ms = (time.perf_counter() - t1) * 1e3
         st_first = c_first.stats
         del c_first
-        st0 = api.scan_clusters(bwt, flags, p, begin=begin, end=end).stats
+        st0 = api.scan_clusters(bwt, flags, p, bwt2=bwt2, begin=begin, end=end).stats
         # the same pipelined steps WITHOUT the table (a short timed region of its own, before the table exists; EB_PSI=0 keeps the
         # library from building it with the third job): what the step costs a caller whose index does not get one -- too large for
         # the spare HBM, or scanned once -- and the figure to compare with rounds 1-3
@@ -533,7 +600,8 @@ def main():
     scan_sum_ms = float(np.mean(scan_ms))
     scan_avg_ms = scan_sum_ms / scan_launches
     positions_per_launch = shard_positions / scan_launches
-    scan_gbs = 0.75 * positions_per_launch / (scan_avg_ms * 1e-3) / 1e9 if scan_avg_ms > 0 else 0.0
+    ALG_B = 0.75 if args.mode == 1 else 0.875   # 3-bit symbol + 2 LCP-threshold bits + 1 minimum bit (+ 1 document bit, modes 2 and 3)
+    scan_gbs = ALG_B * positions_per_launch / (scan_avg_ms * 1e-3) / 1e9 if scan_avg_ms > 0 else 0.0
 
     # ---------------- the same kernels with the chip to themselves.  In the timed region the scan of pass i+1 shares every CU with
     # the context kernels of pass i (eb_scan.hip, "the scan beside the previous job's context kernels"): each kernel then takes
@@ -544,7 +612,7 @@ def main():
     if rank == 0 or use_dist:
         a_scan, a_ext, a_right, a_ctx, a_tot = [], [], [], [], []
         for k in range(7):
-            st1 = api.scan_clusters(bwt, flags, p, begin=begin, end=end).stats
+            st1 = api.scan_clusters(bwt, flags, p, bwt2=bwt2, begin=begin, end=end).stats
             if k >= 2:
                 a_scan.append(st1.ms_scan / max(1, int(st1.scan_launches))); a_ext.append(st1.ms_extend); a_right.append(st1.ms_right)
                 a_ctx.append(st1.ms_context); a_tot.append(st1.ms_total)
@@ -558,7 +626,7 @@ def main():
         m = args.rank_queries
         g = torch.Generator(device=dev)
         g.manual_seed(1234)
-        d_pos = torch.randint(0, n + 1, (m,), dtype=torch.int64, device=dev, generator=g)
+        d_pos = torch.randint(0, bwt.n + 1, (m,), dtype=torch.int64, device=dev, generator=g)
         d_out = torch.empty((m, 4), dtype=torch.int64, device=dev)
         torch.cuda.synchronize()
         for _ in range(2):
@@ -585,7 +653,7 @@ def main():
         # the same kernel on the query pattern the traversal issues: the six boundaries of a deep suffix-tree node lie within
         # a few dozen rows, so they share blocks (nodes in random order; SURVEY.md 8(d) metric 2 (ii) in isolation)
         m_nodes = min(1 << 24, m // 6)
-        base_pos = torch.randint(0, max(n - 64, 1), (m_nodes,), dtype=torch.int64, device=dev, generator=g)
+        base_pos = torch.randint(0, max(bwt.n - 64, 1), (m_nodes,), dtype=torch.int64, device=dev, generator=g)
         node_pos = (base_pos[:, None] + torch.tensor([0, 5, 11, 17, 23, 30], dtype=torch.int64, device=dev)[None, :]).reshape(-1).contiguous()
         torch.cuda.synchronize()
         bwt.rank_device(node_pos.data_ptr(), m_nodes * 6, d_out.data_ptr())
@@ -598,7 +666,7 @@ def main():
         # ---------------- output of the timed path -> .snp (host formatting, outside the metric)
         if parts is None:
             parts = [bytes(calls.blob())]
-        text, cluster_nr, events, total_recs = ebd.write_gathered(parts, p, False)
+        text, cluster_nr, events, total_recs = ebd.write_gathered(parts, p, args.mode != 1)
         out["snp_sha256"] = hashlib.sha256(text).hexdigest()
         out["snp_records"] = text.count(b">")
         out["clusters_emitted"] = total_recs
@@ -606,7 +674,8 @@ def main():
         # CPU oracle on the GPU box's host threads -- flag vectors and .snp identical to the GPU's -- and left the SHA-256
         # under profiles/.  Every default run is held to it (any number of GPUs: the shards' call sets concatenate to the same text).
         out["snp_verified"] = None
-        record = ("r03_fullsize_config2.json" if not realistic else
+        record = ("r03_fullsize_config3.json" if args.mode == 2 else "r03_fullsize_config4.json" if args.mode == 3 else
+                  "r03_fullsize_config2.json" if not realistic else
                   "r05_fullsize_config2err.json" if (args.error_rate_ppm, args.reverse_complements) == (10_000, False) else
                   "r05_fullsize_config2rc.json" if (args.error_rate_ppm, args.reverse_complements) == (10_000, True) else "none")
         try:
@@ -615,7 +684,7 @@ def main():
         except OSError:
             known = None
         default_input = (args.read_len, args.coverage, args.seed) == (150, 30.0, 1)
-        if args.rehearse_rank_of <= 1 and known is not None and default_input and known["input"]["reads_per_collection"] == args.reads and known["input"]["n"] == [int(n)]:
+        if args.rehearse_rank_of <= 1 and known is not None and default_input and known["input"]["mode"] == args.mode and known["input"]["reads_per_collection"] == (args.reads if args.mode == 1 else args.reads // 2) and sum(known["input"]["n"]) == int(n):
             if out["snp_sha256"] != known["oracle_snp_sha256"] or out["snp_records"] != known["snp_records"]:
                 raise SystemExit(f"[bench] .snp of the timed path differs from the full-size CPU oracle run (profiles/{record}): "
                                  f"{out['snp_sha256']} vs {known['oracle_snp_sha256']}")
@@ -629,22 +698,34 @@ def main():
         orc = _oracle.Oracle()
         s_reads = args.cpu_sample_reads
         s_genome = int(s_reads * args.read_len / args.coverage)
-        sr, _, _ = sim.diploid_sample(s_genome, s_reads, args.read_len, seed=args.seed + 1000)
-        se = sim.build_ebwt(sr, threads=threads)
-        del sr
-        # single thread, the reference's algorithm: index, phases 2-3, phase 4
         from concurrent.futures import ThreadPoolExecutor
         po = _oracle.Params.from_args([])
-        n_s = len(se)
-        sidx = orc.index(se)                        # keep the handle alive across the calls
+        se2 = s_da = sidx2 = None
+        if args.mode == 1:
+            sr, _, _ = sim.diploid_sample(s_genome, s_reads, args.read_len, seed=args.seed + 1000)
+            se = sim.build_ebwt(sr, threads=threads)
+            del sr
+        else:
+            r0, r1 = sim.two_samples(s_genome, s_reads // 2, args.read_len, seed=args.seed + 1000)
+            if args.mode == 2:
+                se, se2 = sim.build_ebwt(r0, threads=threads), sim.build_ebwt(r1, threads=threads)
+            else:
+                se, s_da = sim.build_merged_ebwt(r0, r1, threads=threads)
+            del r0, r1
+        # single thread, the reference's algorithm: index, phases 2-3, phase 4
+        n_s = len(se) + (len(se2) if se2 is not None else 0)
+        sidx = orc.index(se)                        # keep the handles alive across the calls
+        if se2 is not None:
+            sidx2 = orc.index(se2)
         t0 = time.perf_counter()
-        of = _oracle.OracleFlags(orc, sidx, None, po.K, po.k_right)
+        of = _oracle.OracleFlags(orc, sidx, sidx2, po.K, po.k_right, s_da)
         t_nav_cpu = time.perf_counter() - t0
         t0 = time.perf_counter()
         res = of.scan(po, 0, n_s)
         t_scan_cpu = time.perf_counter() - t0
         want = res["text"]
-        got = api.run_one_dataset(se, p, device=local)
+        got = (api.run_one_dataset(se, p, device=local) if args.mode == 1 else api.run_two_datasets(se, se2, p, device=local) if args.mode == 2
+               else api.run_two_datasets_da(se, s_da, p, device=local))
         assert got == want, "GPU .snp differs from the CPU oracle on the baseline sample"
         rt = orc.lib.orc_rank_bench(sidx.h, 20_000_000, 7, None)
         # the same scan sharded over the host's cores (the oracle's scan is re-entrant; ctypes releases the GIL)
@@ -665,8 +746,15 @@ def main():
             with tempfile.TemporaryDirectory() as td:
                 pth, outp = os.path.join(td, "sample.ebwt"), os.path.join(td, "ref.snp")
                 se.tofile(pth)
+                more = []
+                if se2 is not None:
+                    se2.tofile(pth + "2")
+                    more = ["-2", pth + "2"]
+                elif s_da is not None:
+                    np.asarray(s_da).tofile(pth + ".da")
+                    more = ["-d", pth + ".da"]
                 t0 = time.perf_counter()
-                rr = subprocess.run([ref_bin, "-1", pth, "-o", outp], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+                rr = subprocess.run([ref_bin, "-1", pth] + more + ["-o", outp], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
                 t_ref = time.perf_counter() - t0
                 with open(outp, "rb") as fh:
                     ref_snp = fh.read()
@@ -679,7 +767,7 @@ def main():
         # would take minutes), the oracle's index and traversal run on all host threads, its scan sharded over them; ONE
         # thread then scans a 128 M-position sub-range of that index: the single-core figure `value` reports.
         dram = None
-        if args.cpu_dram_reads > 0:
+        if args.cpu_dram_reads > 0 and args.mode == 1:
             from tests import _fullsize as fsz
             b_reads = args.cpu_dram_reads
             b_glen = int(b_reads * args.read_len / args.coverage)
@@ -749,7 +837,7 @@ def main():
         pmc_path = next(q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc_traffic.json") for r in (5, 4, 3, 2)) if os.path.exists(q))
         with open(pmc_path) as fh:
             pmc = json.load(fh)
-        same = abs(pmc["workload_positions"] - positions_per_launch) <= 0.01 * positions_per_launch
+        same = args.mode == 1 and abs(pmc["workload_positions"] - positions_per_launch) <= 0.01 * positions_per_launch
         if same and scan_avg_ms > 0:
             traffic = round(pmc["kernels"]["k_scan<1>"]["hbm_bytes_per_launch_by_request_size"] / (scan_avg_ms * 1e-3) / 1e9, 2)
         if same and ctx_ms and np.mean(ctx_ms) > 0:
@@ -784,7 +872,7 @@ def main():
                 "ms_per_step_note": "ms_per_step: records of all ranks in rank 0's HOST memory (the contract `value` is quoted on); ms_per_step_records_in_rank0_hbm: "
                                     "the same steps counted as delivered once the gathered call sets are resident in rank 0's HBM (cadence of the end of the gather on "
                                     "rank 0's stream; its PCIe download then overlaps the following steps)"} if ms_per_step_hbm is not None else {}),
-            "config": {"workload": workload, "mode": 1, "options": "-L31 -R30 -k16 -g10 -v2 -m3 -c20 -q0",
+            "config": {"workload": workload, "mode": args.mode, "options": "-L31 -R30 -k16 -g10 -v2 -m3 -c20 -q0",
                        # every path-selecting switch of the library / this script that is set in the environment (none: the defaults ran)
                        "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith(("EB_", "EBGEN_")) or k in ("GPU_MAX_HW_QUEUES", "HSA_ENABLE_IPC_MODE_LEGACY")},
                        "records_to_rank0": {"none": "one rank: the library downloads the call set into page-locked host memory", "arena": "every rank downloads its own compact wire image over its own PCIe link into a host arena all ranks map; rank 0 reads the slots",
@@ -793,16 +881,16 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(scan_gbs, 2), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(scan_gbs / 8000.0, 5), "traffic": traffic, "kernel": "k_scan",
                          "avg_launch_ms": round(scan_avg_ms, 4), "launches_per_step": scan_launches, "positions_per_launch": int(positions_per_launch),
-                         "algorithmic_bytes_per_position": 0.75,
+                         "algorithmic_bytes_per_position": ALG_B,
                          "measured": "timed region" + ("" if args.no_pipeline else ": the launch shares every CU with the previous pass's context kernels (the scan holds 8 workgroup slots per CU "
                                                        "with the FL table, 4 without), so it lasts longer than alone -- see `alone`"),
-                         **({"alone": {"avg_launch_ms": alone["scan_ms"], "achieved": round(0.75 * positions_per_launch / (alone["scan_ms"] * 1e-3) / 1e9, 2),
-                                       "frac": round(0.75 * positions_per_launch / (alone["scan_ms"] * 1e-3) / 1e9 / 8000.0, 5),
+                         **({"alone": {"avg_launch_ms": alone["scan_ms"], "achieved": round(ALG_B * positions_per_launch / (alone["scan_ms"] * 1e-3) / 1e9, 2),
+                                       "frac": round(ALG_B * positions_per_launch / (alone["scan_ms"] * 1e-3) / 1e9 / 8000.0, 5),
                                        "what": f"the same launch with the chip to itself: {alone['passes']} passes run one at a time after the timed region"}} if alone else {})},
             # the whole step against the scan's roofline (SURVEY.md 8(d) metric 1: 0.75 B x positions / step time): what `value` is worth
-            "step_roofline": {"bound": "hbm", "achieved": round(0.75 * value / 1e9, 2), "peak": 8000.0 * world, "unit": "GB/s",
-                              "frac": round(0.75 * value / 1e9 / (8000.0 * world), 5),
-                              "what": "0.75 algorithmic bytes x all positions / ms_per_step, against the HBM peak of the GPUs used: scan + "
+            "step_roofline": {"bound": "hbm", "achieved": round(ALG_B * value / 1e9, 2), "peak": 8000.0 * world, "unit": "GB/s",
+                              "frac": round(ALG_B * value / 1e9 / (8000.0 * world), 5),
+                              "what": f"{ALG_B} algorithmic bytes x all positions / ms_per_step, against the HBM peak of the GPUs used: scan + "
                                       "survivor ordering + both context kernels + hand-over of the records"},
             # the kernels that dominate the step: k_extend, then k_right (a large call set runs them one behind the other; a small one
             # side by side on two streams), dependent random reads.  Requests
@@ -833,6 +921,7 @@ def main():
             # wall_seconds: the whole call, i.e. also HBM allocation (which, right behind the generator's 100 GB of frees, can wait
             # seconds for the driver's wipe) and, for N > 1, the all-reduce of the vectors
             "phases23_gpu": {"seconds": round(float(ns.seconds_traversal), 4), "wall_seconds": round(t_nav, 4), "waited_before_for_the_generators_freed_hbm_seconds": round(t_wipe, 3), "traversal_shards": world if use_dist else 1,
+                             **({"document_array_packed_from_hbm_seconds": round(t_da, 4)} if t_da is not None else {}),
                              "seconds_leaves": round(float(ns.seconds_leaves), 4), "seconds_nodes": round(float(ns.seconds_nodes), 4),
                              "rank_gq_per_s": round(ns.rank_queries / max(ns.seconds_traversal, 1e-9) / 1e9, 2), "nodes": int(ns.nodes), "leaves": int(ns.leaves), "rank_queries": int(ns.rank_queries),
                              "launches": int(ns.batches),
@@ -842,6 +931,8 @@ def main():
                              "traversal_only_positions_per_s": round(n / max(float(ns.seconds_traversal), 1e-9), 1)},
         }
         line.update(out)
+        if args.mode == 1 and world == 1 and not use_dist and not args.no_other_modes and not realistic and args.rehearse_rank_of <= 1:
+            line["other_modes"] = other_modes(args)
         print(json.dumps(line), flush=True)
     if arena is not None:
         arena.close()

@@ -9,6 +9,7 @@ Everything computes on the GPU through libebwt2indel.so; nothing here falls back
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Sequence
 
 import numpy as np
@@ -222,6 +223,13 @@ class Flags:
     def set_da(self, ascii01):
         d = _u8(ascii01)
         _check(lib().eb_flags_set_da(self._h, d.ctypes.data, len(d)))
+
+    def set_da_file(self, path: str):
+        _check(lib().eb_flags_set_da_file(self._h, os.fsencode(path)))
+
+    def set_da_device(self, d_ptr: int, n: int):
+        """ASCII '0'/'1' bytes already in HBM on the flags' device (a generator's output)."""
+        _check(lib().eb_flags_set_da_device(self._h, C.c_void_p(d_ptr), n))
 
     @property
     def words(self) -> int:

@@ -13,6 +13,7 @@
 
 #include "eb_config.h"
 #include "eb_internal.h"
+#include "eb_pieces.h"
 
 // ------------------------------------------------------------------ errors / params
 
@@ -563,69 +564,6 @@ extern "C" int eb_index_create_from_device(const void* d_ascii, uint64_t n, uint
 // ascii: the symbols in host memory, or NULL with fd >= 0: the symbols are the file's bytes (read with pread)
 static double idx_now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
 
-namespace {
-// Host threads that fill page-locked pieces from the input (pread of the file: page cache -> piece with no page faults of a
-// mapping in between; or memcpy from the caller's buffer).  They live for one index creation and take 4 MB chunks off a queue, so
-// that several pieces are being filled while the one before them is uploaded and packed (round 4 started and joined a set of
-// threads per piece and read one piece at a time: 0.20 s of reads for the 7.55 GB file, on the critical path, plus ~2000 thread
-// starts).
-struct PieceReaders {
-    struct Chunk { uint8_t* dst; uint64_t off, len; int piece; };
-    const uint8_t* src = nullptr; // host buffer, or null: read fd
-    int fd = -1;
-    std::mutex mu;
-    std::condition_variable cv_work, cv_done;
-    std::vector<Chunk> queue;
-    size_t head = 0;
-    std::vector<int> left;        // chunks still to be read, per piece
-    bool stop = false, io_error = false;
-    std::vector<std::thread> pool;
-    void start(unsigned threads, size_t n_pieces) {
-        left.assign(n_pieces, 0);
-        for (unsigned t = 0; t < threads; ++t) pool.emplace_back([this] { run(); });
-    }
-    void run() {
-        for (;;) {
-            Chunk c;
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv_work.wait(lk, [&] { return stop || head < queue.size(); });
-                if (head >= queue.size()) return; // stop, nothing left
-                c = queue[head++];
-            }
-            bool ok = true;
-            if (src) memcpy(c.dst, src + c.off, c.len);
-            else
-                for (uint64_t got = 0; got < c.len;) {
-                    ssize_t r = pread(fd, c.dst + got, c.len - got, (off_t)(c.off + got));
-                    if (r <= 0) { ok = false; break; }
-                    got += (uint64_t)r;
-                }
-            std::lock_guard<std::mutex> lk(mu);
-            if (!ok) io_error = true;
-            if (--left[(size_t)c.piece] == 0) cv_done.notify_all();
-        }
-    }
-    void post(int piece, uint8_t* dst, uint64_t off, uint64_t len) {
-        const uint64_t CH = 4ull << 20;
-        std::lock_guard<std::mutex> lk(mu);
-        int k = 0;
-        for (uint64_t a = 0; a < len; a += CH, ++k) queue.push_back({dst + a, off + a, len - a < CH ? len - a : CH, piece});
-        left[(size_t)piece] = k;
-        cv_work.notify_all();
-    }
-    bool wait(int piece) { // false: read error
-        std::unique_lock<std::mutex> lk(mu);
-        cv_done.wait(lk, [&] { return left[(size_t)piece] == 0; });
-        return !io_error;
-    }
-    ~PieceReaders() {
-        { std::lock_guard<std::mutex> lk(mu); stop = true; head = queue.size(); }
-        cv_work.notify_all();
-        for (std::thread& t : pool) t.join();
-    }
-};
-}  // namespace
 
 // ascii: the symbols in host memory, or NULL with fd >= 0: the symbols are the file's bytes (read with pread)
 static int index_create_from(const uint8_t* ascii, int fd, uint64_t n, uint8_t term, int device, eb_index** out) {

@@ -80,7 +80,9 @@ struct eb_flags {
     uint64_t n = 0, words = 0;
     uint64_t *d_thrK = nullptr, *d_thrR = nullptr, *d_min = nullptr, *d_da = nullptr, *d_da_rank = nullptr;
     uint64_t* d_flag = nullptr; // thrK & ~minima
-    uint4* d_mxy = nullptr;     // two-BWT mode: merged scan planes, built by the first phase-4 call
+    uint4* d_mxy = nullptr;     // two-BWT mode: merged scan planes (eb_flags_merge_planes: behind the traversal, or with the first phase-4 job)
+    uint4* d_mxy_spare = nullptr; // their memory, allocated BEFORE the traversal (an allocation right behind the traversal's frees waits for the driver's wipe)
+    uint64_t phase4_positions = 0; // closing positions the phase-4 jobs on these flags are expected to scan (a shard's share; 0: all)
     uint64_t da_ones = 0;       // ones in d_da (set with the rank directory): two-BWT phase 4 indexes the second BWT by DA ranks
     bool derived = false;       // d_flag / d_da_rank match the vectors (false between a sharded build and eb_flags_finalize)
     bool complemented = false;  // d_thrK / d_thrR hold the complement (bit = LCP BELOW the threshold) until eb_flags_derive inverts them
@@ -166,7 +168,9 @@ void eb_index_note_phase4_job(eb_index* h, uint64_t positions);
 int eb_flags_alloc(uint64_t n, int device, bool with_da, eb_flags** out);
 // phase 4's first-job costs (scan planes, device temporaries, a page-locked blob) paid ahead of time (eb_scan_job.cpp); called by the
 // traversal on a side thread
+int eb_flags_merge_planes(eb_flags* f, eb_index* b1, eb_index* b2); // mode 2: merged scan planes (eb_scan_job.cpp)
 void eb_phase4_warm(eb_index* b1, eb_index* b2, uint64_t n);
+void eb_phase4_reserve(int device, uint64_t positions, bool two_samples); // the reservations alone (eb_flags_set_da*: mode 3 shows itself there)
 
 // Caching device-scratch allocator (eb_index.hip).  hipMalloc / hipFree cost 0.1-1 ms each and hipFree synchronises
 // the device, so the per-call temporaries of the phase-4 driver are recycled instead of returned to the runtime.

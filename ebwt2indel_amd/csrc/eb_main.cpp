@@ -19,7 +19,6 @@
 #include <stdlib.h>
 #include <string.h>
 #include <fcntl.h>
-#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -73,18 +72,6 @@ static int fail(const char* what) {
     return 1;
 }
 
-static int read_file(const std::string& path, std::vector<uint8_t>& out) {
-    FILE* f = fopen(path.c_str(), "rb");
-    if (!f) return -1;
-    fseek(f, 0, SEEK_END);
-    long long sz = ftell(f);
-    fseek(f, 0, SEEK_SET);
-    out.resize(sz > 0 ? (size_t)sz : 0);
-    size_t r = sz > 0 ? fread(out.data(), 1, (size_t)sz, f) : 0;
-    fclose(f);
-    return r == out.size() ? 0 : -1;
-}
-
 // ------------------------------------------------------------------------------------------------ -G n: n GPUs, one process
 namespace {
 
@@ -124,9 +111,7 @@ struct MultiJob {
     std::vector<int> dev;
     std::vector<ncclComm_t> comm;
     // inputs: mapped once, read-only; every rank uploads from the same pages (the page cache holds the files once)
-    std::string path1, path2;
-    const uint8_t* da = nullptr; // the document array is mapped once, read-only; every rank packs it from the same pages
-    uint64_t n_da = 0;
+    std::string path1, path2, path_da;
     bool two = false;
     double t_comm = 0;         // seconds ncclCommInitAll took (0: no communicator needed)
     eb_params p;
@@ -269,8 +254,8 @@ void rank_main(MultiJob& J, int r) {
         else if (memcmp(got, want, sizeof got) != 0) MJ_FAIL(EB_ERR_STATE, "sharded traversal: a bit of the flag vectors was set by more than one rank");
         else if (!J.host_backend && (rc = eb_flags_finalize(fl)) != EB_OK) MJ_FAIL(rc, "%s", eb_last_error());
     }
-    if (J.rc[(size_t)r] == EB_OK && J.da) {
-        rc = eb_flags_set_da(fl, J.da, J.n_da);
+    if (J.rc[(size_t)r] == EB_OK && !J.path_da.empty()) {
+        rc = eb_flags_set_da_file(fl, J.path_da.c_str());
         if (rc != EB_OK) MJ_FAIL(rc, "%s", eb_last_error());
     }
     if (!sync_ok()) return cleanup();
@@ -373,34 +358,17 @@ static int run_multi(int world, const std::string& input1, const std::string& in
     printf(two_bwts ? "Phase 1/4: loading and indexing eBWTs on %d GPU(s) ... " : "Phase 1/4: loading and indexing eBWT on %d GPU(s) ... ", world);
     fflush(stdout);
     double t0 = now_s();
-    // the inputs are mapped, not copied: one set of pages in the page cache serves every rank's upload
-    struct Mapped {
-        const uint8_t* p = nullptr; uint64_t n = 0;
-        ~Mapped() { if (p && n) munmap(const_cast<uint8_t*>(p), n); }
-        bool open_file(const std::string& path) {
-            int fd = ::open(path.c_str(), O_RDONLY);
-            if (fd < 0) return false;
-            struct stat st;
-            if (fstat(fd, &st) != 0) { ::close(fd); return false; }
-            n = (uint64_t)st.st_size;
-            if (n) {
-                void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
-                if (m == MAP_FAILED) { ::close(fd); n = 0; return false; }
-                (void)madvise(m, n, MADV_SEQUENTIAL);
-                p = static_cast<const uint8_t*>(m);
-            }
-            ::close(fd);
-            return true;
-        }
-    } mda;
-    if (with_da && !mda.open_file(input_da)) { printf("Error: could not read file %s\n", input_da.c_str()); return 1; }
+    // the document array is read by every rank from the file (eb_flags_set_da_file): one set of pages in the page cache serves all
+    if (with_da) {
+        int fd = ::open(input_da.c_str(), O_RDONLY);
+        if (fd < 0) { printf("Error: could not read file %s\n", input_da.c_str()); return 1; }
+        ::close(fd);
+    }
     const double t_read = now_s() - t0;
-    static const uint8_t empty = 0;
     J.path1 = input1;
     J.path2 = input2;
     J.two = two_bwts;
-    J.da = with_da ? (mda.n ? mda.p : &empty) : nullptr;
-    J.n_da = mda.n;
+    J.path_da = input_da;
     if (!host_backend && world > 1) {
         // The communicators first, before this process does any other HIP work: ncclCommInitAll holds the runtime (a kernel launch
         // issued beside it waits until it is done) and takes twice as long when other HIP work runs beside it.  What the host can do
@@ -600,11 +568,11 @@ int main(int argc, char** argv) {
     double t2 = now_s();
 
     if (with_da) {
-        std::vector<uint8_t> da;
-        if (read_file(input_da, da) != 0) { printf("Error: could not read file %s\n", input_da.c_str()); return 1; }
-        rc = eb_flags_set_da(fl, da.data(), da.size());
+        rc = eb_flags_set_da_file(fl, input_da.c_str());
+        if (rc == EB_ERR_IO) { printf("Error: could not read file %s\n", input_da.c_str()); return 1; }
         if (rc != EB_OK) return fail("Error while loading the document array");
     }
+    double t2b = now_s();
 
     printf("Phase 4/4: detecting SNPs and indels.\n");
     printf("Output events will be stored in %s\n", output.c_str());
@@ -619,10 +587,11 @@ int main(int argc, char** argv) {
     double t4 = now_s();
 
     print_report(ns, ss, two_bwts, with_da, events, cluster_nr);
+    if (with_da) printf("\nDocument array loaded and packed in %.3f s.", t2b - t2);
     printf("\nTimings (s): load+index %.3f, phases 2-3 %.3f (leaves %.3f and nodes %.3f side by side, %llu rank queries, %llu launches), "
            "phase 4 device %.3f (scan %.3f ms, extend %.3f ms, right %.3f ms), write %.3f\n",
            t1 - t0, t2 - t1, ns.seconds_leaves, ns.seconds_nodes, (unsigned long long)ns.rank_queries, (unsigned long long)ns.batches,
-           t3 - t2, ss.ms_scan, ss.ms_extend, ss.ms_right, t4 - t3);
+           t3 - t2b, ss.ms_scan, ss.ms_extend, ss.ms_right, t4 - t3);
 
     eb_calls_free(calls);
     eb_flags_destroy(fl);

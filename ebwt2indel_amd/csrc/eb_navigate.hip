@@ -9,9 +9,12 @@
 // the top keeps the footprint of a depth-first walk; a batch of millions keeps HBM busy with
 // independent 64-byte block reads.  Bit writes are atomicOr on 64-bit words and are skipped when
 // the value is 0 (vectors start zeroed), i.e. for records shallower than K / k_right.
+#include <fcntl.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <chrono>
 #include <string>
@@ -20,6 +23,7 @@
 
 #include "eb_config.h"
 #include "eb_internal.h"
+#include "eb_pieces.h"
 
 namespace {
 
@@ -1686,7 +1690,14 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
     {
         size_t free_b = 0, total_b = 0;
         const uint64_t positions = n / (n_shards ? n_shards : 1); // a shard's rank scans its share of the closing positions afterwards
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 3 * (n / 4 + positions / 8 + (512ull << 20)))
+        f->phase4_positions = positions;
+        const bool have_info = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+        // (two BWTs, one shard: the merged scan planes are built right behind the traversal -- their memory is taken now)
+        if (have_info && b2 && derive && n_shards <= 1 && free_b > 4 * (n / 4)) {
+            if (hipMalloc(&f->d_mxy_spare, eb_bit_alloc_words(n) * sizeof(uint4)) != hipSuccess) { f->d_mxy_spare = nullptr; (void)hipGetLastError(); }
+            else free_b -= eb_bit_alloc_words(n) * sizeof(uint4);
+        }
+        if (have_info && free_b > 3 * (n / 4 + positions / 8 + (512ull << 20)))
             warm = std::thread([b1, b2, positions] { eb_phase4_warm(b1, b2, positions); });
     }
     // Threshold bits are collected either as one byte per position (plain stores; needs n bytes of spare HBM) or, when
@@ -1821,6 +1832,9 @@ static int flags_build_impl(eb_index* b1, eb_index* b2, int32_t K, int32_t k_rig
     s.seconds_traversal = now_s() - t0;
     f->complemented = complement;
     if (derive && (rc = eb_flags_derive(f)) != EB_OK) return rc; // shards: eb_flags_finalize, after the reduction
+    // two BWTs: phase 4 streams their scan planes merged by the document array, which is complete now (a sharded build's is not:
+    // its first phase-4 job merges them)
+    if (derive && b2 && n_shards <= 1 && f->d_mxy_spare && (rc = eb_flags_merge_planes(f, b1, b2)) != EB_OK) return rc;
     NavCounters c;
     memset(&c, 0, sizeof c);
     {
@@ -2008,34 +2022,143 @@ __global__ void __launch_bounds__(256) k_fill_da_tail(uint64_t* __restrict__ da,
     }
 }
 
-extern "C" int eb_flags_set_da(eb_flags* f, const uint8_t* ascii01, uint64_t n) {
-    if (!f || (!ascii01 && n)) { eb_set_error("null argument"); return EB_ERR_ARG; }
+// The document array from one of three places: a host buffer, the bytes of a file (fd), or ASCII bytes already in HBM (d_src).
+// '1' -> 1, anything else -> 0 (ebwt2InDel.cpp:1503-1508).  A source shorter than the BWT: the reference's read() fails and
+// leaves its one-byte buffer untouched, so every remaining slot repeats the LAST byte of the file (k_fill_da_tail); with an empty
+// file that buffer was never written (undefined upstream): zeros here.
+// Large host / file sources go through page-locked pieces filled by the loader's reader threads while earlier pieces are uploaded
+// and packed, on two streams (eb_pieces.h: what the eBWT itself comes in by) -- round 4 copied the whole array from pageable
+// memory in 256 MB pieces, each waited for: ~10 GB/s.
+static int set_da_from(eb_flags* f, const uint8_t* host, int fd, const uint8_t* d_src, uint64_t n) {
     EB_HIP(hipSetDevice(f->device));
-    // '1' -> 1, anything else -> 0 (ebwt2InDel.cpp:1503-1508).  A file shorter than the BWT: the reference's read() fails
-    // and leaves its one-byte buffer untouched, so every remaining slot repeats the LAST byte of the file (k_fill_da_tail);
-    // with an empty file that buffer was never written (undefined upstream): zeros here.
+    const EbConfig& cfg = eb_cfg();
     const size_t bytes = eb_bit_alloc_words(f->n) * 8;
     if (!f->d_da) EB_HIP(hipMalloc(&f->d_da, bytes));
     EB_HIP(hipMemsetAsync(f->d_da, 0, bytes, f->stream));
     const uint64_t lim = n < f->n ? n : f->n;
-    const bool sticky_one = lim > 0 && lim < f->n && ascii01[lim - 1] == '1';
-    const uint64_t PIECE = 256ull << 20; // multiple of 64 positions
-    uint8_t* d_stage = nullptr;
-    EB_HIP(hipMalloc(&d_stage, lim < PIECE ? (lim ? lim : 1) : PIECE));
-    struct G { void* p; ~G() { (void)hipFree(p); } } g{d_stage};
-    for (uint64_t pos = 0; pos < lim; pos += PIECE) {
-        uint64_t len = lim - pos < PIECE ? lim - pos : PIECE;
-        EB_HIP(hipMemcpyAsync(d_stage, ascii01 + pos, len, hipMemcpyHostToDevice, f->stream));
-        uint64_t n_words = (len + 63) / 64;
-        hipLaunchKernelGGL(k_pack_da, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, f->stream, d_stage, len, pos / 64, n_words, f->d_da);
-        EB_HIP(hipStreamSynchronize(f->stream)); // the staging buffer is reused
+    bool sticky_one = false;
+    if (lim > 0 && lim < f->n) {
+        uint8_t last = 0;
+        if (host) last = host[lim - 1];
+        else if (d_src) EB_HIP(hipMemcpy(&last, d_src + lim - 1, 1, hipMemcpyDeviceToHost));
+        else if (pread(fd, &last, 1, (off_t)(lim - 1)) != 1) { eb_set_error("read error in the document array"); return EB_ERR_IO; }
+        sticky_one = last == '1';
     }
-    if (sticky_one) {
-        hipLaunchKernelGGL(k_fill_da_tail, dim3(2048), dim3(256), 0, f->stream, f->d_da, lim, f->n);
-        EB_HIP(hipStreamSynchronize(f->stream));
+    // a document array means phase 4 in two-sample form (twice the chains per cluster): its first job's reservations are made now,
+    // beside the upload (the traversal reserved for one sample: it could not know)
+    std::thread reserve([dev = f->device, n_pos = f->phase4_positions ? f->phase4_positions : f->n] { eb_phase4_reserve(dev, n_pos, true); });
+    struct ReserveGuard { std::thread& t; ~ReserveGuard() { if (t.joinable()) t.join(); } } reserve_guard{reserve};
+    auto pack = [&](const uint8_t* d_piece, uint64_t pos, uint64_t len, hipStream_t st) {
+        const uint64_t n_words = (len + 63) / 64;
+        hipLaunchKernelGGL(k_pack_da, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, d_piece, len, pos / 64, n_words, f->d_da);
+    };
+    int rc = EB_OK;
+    if (d_src) {
+        const uint64_t PIECE = 1ull << 36; // (one launch's grid holds 2^32 workgroups of 256 words)
+        for (uint64_t pos = 0; pos < lim; pos += PIECE) pack(d_src + pos, pos, lim - pos < PIECE ? lim - pos : PIECE, f->stream);
+    } else if (lim) {
+        const bool pinned_path = lim >= cfg.pinned_min || !host;
+        const uint64_t PIECE = pinned_path ? cfg.pinned_piece : (256ull << 20); // multiples of 64 positions
+        const int SLOTS = 4;
+        const uint64_t stage_bytes = lim < PIECE ? lim : PIECE;
+        const size_t n_pieces = (size_t)((lim + PIECE - 1) / PIECE);
+        uint8_t *d_stage[4] = {nullptr, nullptr, nullptr, nullptr}, *h_stage[4] = {nullptr, nullptr, nullptr, nullptr};
+        uint64_t h_cap[4] = {0, 0, 0, 0};
+        size_t d_cap[4] = {0, 0, 0, 0};
+        hipEvent_t done[4] = {nullptr, nullptr, nullptr, nullptr};
+        hipStream_t up[2] = {f->stream, nullptr};
+        hipError_t e = hipSuccess;
+        {
+            PieceReaders readers; // (joined before the pieces it fills go back to the pool)
+            readers.src = host;
+            readers.fd = fd;
+            auto piece_len = [&](size_t k) -> uint64_t { const uint64_t pos = (uint64_t)k * PIECE; return lim - pos < PIECE ? lim - pos : PIECE; };
+            size_t posted = 0;
+            if (pinned_path) readers.start(cfg.copy_threads, n_pieces);
+            for (int i = 0; i < SLOTS && (size_t)i < n_pieces && e == hipSuccess; ++i) {
+                if (pinned_path) {
+                    h_stage[i] = static_cast<uint8_t*>(eb_pinned_get(stage_bytes, &h_cap[i]));
+                    if (!h_stage[i]) { e = hipErrorOutOfMemory; break; }
+                    readers.post((int)posted, h_stage[i], (uint64_t)posted * PIECE, piece_len(posted));
+                    ++posted;
+                }
+                d_stage[i] = static_cast<uint8_t*>(eb_scratch_get(f->device, stage_bytes, &d_cap[i]));
+                if (!d_stage[i]) { e = hipErrorOutOfMemory; break; }
+                e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
+            }
+            if (e == hipSuccess && n_pieces > 1 && hipStreamCreateWithFlags(&up[1], hipStreamNonBlocking) != hipSuccess) up[1] = nullptr;
+            if (!up[1]) up[1] = f->stream;
+            if (e == hipSuccess && up[1] != f->stream) {
+                // the second stream starts behind the memset of the array
+                hipEvent_t zeroed = nullptr;
+                e = hipEventCreateWithFlags(&zeroed, hipEventDisableTiming);
+                if (e == hipSuccess) e = hipEventRecord(zeroed, f->stream);
+                if (e == hipSuccess) e = hipStreamWaitEvent(up[1], zeroed, 0);
+                if (zeroed) (void)hipEventDestroy(zeroed);
+            }
+            for (size_t k = 0; k < n_pieces && e == hipSuccess && rc == EB_OK; ++k) {
+                const hipStream_t st = up[k & 1];
+                const int slot = (int)(k % SLOTS);
+                const uint64_t pos = (uint64_t)k * PIECE, len = piece_len(k);
+                const uint8_t* src = host ? host + pos : nullptr;
+                if (pinned_path) {
+                    if (!readers.wait((int)k)) { eb_set_error("read error in the document array"); rc = EB_ERR_IO; break; }
+                    src = h_stage[slot];
+                } else if (k >= (size_t)SLOTS && (e = hipEventSynchronize(done[slot])) != hipSuccess) break;
+                if ((e = hipMemcpyAsync(d_stage[slot], src, len, hipMemcpyHostToDevice, st)) != hipSuccess) break;
+                pack(d_stage[slot], pos, len, st);
+                if ((e = hipEventRecord(done[slot], st)) != hipSuccess) break;
+                if (pinned_path && k >= 1 && posted < n_pieces) { // the slot of the piece BEFORE this one takes the next piece (as in the index loader)
+                    const int free_slot = (int)((k - 1) % SLOTS);
+                    if ((e = hipEventSynchronize(done[free_slot])) != hipSuccess) break;
+                    readers.post((int)posted, h_stage[free_slot], (uint64_t)posted * PIECE, piece_len(posted));
+                    ++posted;
+                }
+            }
+            if (up[1] != f->stream) {
+                if (hipStreamSynchronize(up[1]) != hipSuccess && e == hipSuccess) e = hipErrorUnknown;
+                (void)hipStreamDestroy(up[1]);
+            }
+            if (hipStreamSynchronize(f->stream) != hipSuccess && e == hipSuccess) e = hipErrorUnknown;
+        }
+        for (int i = 0; i < 4; ++i) {
+            if (d_stage[i]) eb_scratch_put(f->device, d_stage[i], d_cap[i]);
+            if (h_stage[i]) eb_pinned_put(h_stage[i], h_cap[i]);
+            if (done[i]) (void)hipEventDestroy(done[i]);
+        }
+        if (rc == EB_OK && e != hipSuccess) { eb_set_error("document array upload failed: %s", hipGetErrorString(e)); rc = EB_ERR_DEVICE; }
+        if (rc != EB_OK) return rc;
     }
+    if (sticky_one) hipLaunchKernelGGL(k_fill_da_tail, dim3(2048), dim3(256), 0, f->stream, f->d_da, lim, f->n);
+    EB_HIP(hipStreamSynchronize(f->stream));
     EB_HIP(hipGetLastError());
     return eb_flags_build_da_rank(f);
+}
+
+extern "C" int eb_flags_set_da(eb_flags* f, const uint8_t* ascii01, uint64_t n) {
+    if (!f || (!ascii01 && n)) { eb_set_error("null argument"); return EB_ERR_ARG; }
+    static const uint8_t empty = 0;
+    return set_da_from(f, ascii01 ? ascii01 : &empty, -1, nullptr, n);
+}
+
+extern "C" int eb_flags_set_da_device(eb_flags* f, const void* d_ascii01, uint64_t n) {
+    if (!f || (!d_ascii01 && n)) { eb_set_error("null argument"); return EB_ERR_ARG; }
+    static const uint8_t empty = 0;
+    if (!n) return set_da_from(f, &empty, -1, nullptr, 0);
+    return set_da_from(f, nullptr, -1, static_cast<const uint8_t*>(d_ascii01), n);
+}
+
+extern "C" int eb_flags_set_da_file(eb_flags* f, const char* path) {
+    if (!f || !path) { eb_set_error("null argument"); return EB_ERR_ARG; }
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) { eb_set_error("Error: could not read file %s", path); return EB_ERR_IO; }
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); eb_set_error("cannot stat %s", path); return EB_ERR_IO; }
+    static const uint8_t empty = 0;
+    const uint64_t n = (uint64_t)st.st_size;
+    int rc = n ? set_da_from(f, nullptr, fd, nullptr, n) : set_da_from(f, &empty, -1, nullptr, 0);
+    close(fd);
+    return rc;
 }
 
 extern "C" uint64_t eb_flags_words(const eb_flags* f) { return f ? f->words : 0; }
@@ -2091,6 +2214,7 @@ extern "C" void eb_flags_destroy(eb_flags* f) {
     for (auto p : v)
         if (p) (void)hipFree(p);
     if (f->d_mxy) (void)hipFree(f->d_mxy);
+    if (f->d_mxy_spare) (void)hipFree(f->d_mxy_spare);
     if (f->stream) (void)hipStreamDestroy(f->stream);
     delete f;
 }

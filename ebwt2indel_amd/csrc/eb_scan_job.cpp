@@ -205,6 +205,32 @@ unsigned scan_dyn_lds(unsigned overlap_wgs) {
     return total - 18u * 1024u;
 }
 
+// Buffer sizes of an ordered job over `words` 64-position words -- one statement for the job itself and for the reservations made
+// ahead of the first job (eb_phase4_reserve: a block reserved one batch short of what the job asks for is of no use to it).  The batch
+// count does not depend on the grid: tile indexes run up to grid x tiles_per_wg < tiles + the largest grid.
+struct OrderedSizes {
+    uint64_t n_batches, cap_ns, cap_chains;
+    size_t cnt, part, slots, kept, sorted, choff, chains, blob;
+};
+OrderedSizes ordered_sizes(uint64_t words, uint32_t batch_shift, bool two_samples, int k_left, int k_right) {
+    OrderedSizes z;
+    const uint64_t tiles = (words + 255) / 256;
+    z.n_batches = ((tiles + 256u * 8u) >> batch_shift) + 1;
+    uint64_t cap = z.n_batches * EB_BATCH_SLOTS;
+    if (cap > 0x1FFFFFFFull) cap = 0x1FFFFFFFull; // (a call set has fewer than 2^29 clusters: more survivors than that is an error either way)
+    z.cap_ns = cap;
+    z.cap_chains = cap * (two_samples ? 8u : 4u);
+    z.cnt = ((sizeof(ScanCounters) + 255) & ~(size_t)255) + z.n_batches * 4;
+    z.part = (size_t)256 * 8 * EB_SCAN_PARTIAL * 8;
+    z.slots = z.n_batches * EB_BATCH_SLOTS * sizeof(Survivor);
+    z.kept = 4 * (z.n_batches + 1) * 4;
+    z.sorted = z.cap_ns * sizeof(Survivor);
+    z.choff = z.cap_ns * 4;
+    z.chains = z.cap_chains * 8;
+    z.blob = eb_calls_blob_size(z.cap_ns, z.cap_chains, (uint32_t)k_left, (uint32_t)k_right);
+    return z;
+}
+
 // ---- the ordered hand-over: everything enqueued, nothing waited for.  EB_ERR_STATE + *fits = false: too many batches.
 int enqueue_ordered(eb_scan_job* job, bool* fits) {
     *fits = true;
@@ -215,19 +241,16 @@ int enqueue_ordered(eb_scan_job* job, bool* fits) {
     q.tiles_per_wg = (uint32_t)((tiles + grid - 1) / grid);
     q.batch_shift = job->batch_shift;
     q.reserved = 0;
-    job->n_batches = (((uint64_t)grid * q.tiles_per_wg) >> q.batch_shift) + 1; // (tile indexes run up to grid x tiles_per_wg)
+    const OrderedSizes z = ordered_sizes(job->w_count, q.batch_shift, job->p.mode != 1, (int)job->k_left, (int)job->k_right);
+    job->n_batches = z.n_batches;
     if (job->n_batches > EB_MAX_BATCHES) { *fits = false; return EB_OK; }
-    uint64_t cap = job->n_batches * EB_BATCH_SLOTS;
-    if (cap > 0x1FFFFFFFull) cap = 0x1FFFFFFFull; // (a call set has fewer than 2^29 clusters: more survivors than that is an error either way)
-    job->cap_ns = cap;
-    job->cap_chains = cap * (job->p.mode == 1 ? 4u : 8u);
+    job->cap_ns = z.cap_ns;
+    job->cap_chains = z.cap_chains;
     const size_t cnt_bytes = (sizeof(ScanCounters) + 255) & ~(size_t)255;
     int rc;
-    if ((rc = job->cnt.alloc(cnt_bytes + job->n_batches * 4)) != EB_OK || (rc = job->part.alloc((size_t)grid * EB_SCAN_PARTIAL * 8)) != EB_OK ||
-        (rc = job->slots.alloc(job->n_batches * EB_BATCH_SLOTS * sizeof(Survivor))) != EB_OK || (rc = job->kept.alloc(4 * (job->n_batches + 1) * 4)) != EB_OK ||
-        (rc = job->sorted.alloc(job->cap_ns * sizeof(Survivor))) != EB_OK || (rc = job->choff.alloc(job->cap_ns * 4)) != EB_OK ||
-        (rc = job->chains.alloc(job->cap_chains * 8)) != EB_OK ||
-        (rc = job->blob.alloc(eb_calls_blob_size(job->cap_ns, job->cap_chains, job->k_left, job->k_right))) != EB_OK)
+    if ((rc = job->cnt.alloc(z.cnt)) != EB_OK || (rc = job->part.alloc(z.part)) != EB_OK || (rc = job->slots.alloc(z.slots)) != EB_OK ||
+        (rc = job->kept.alloc(z.kept)) != EB_OK || (rc = job->sorted.alloc(z.sorted)) != EB_OK || (rc = job->choff.alloc(z.choff)) != EB_OK ||
+        (rc = job->chains.alloc(z.chains)) != EB_OK || (rc = job->blob.alloc(z.blob)) != EB_OK)
         return rc;
     ScanCounters* cnt = job->cnt.as<ScanCounters>();
     uint32_t* bcount = reinterpret_cast<uint32_t*>(job->cnt.as<uint8_t>() + cnt_bytes);
@@ -442,18 +465,14 @@ extern "C" int eb_scan_clusters_begin_ex(eb_index* b1, eb_index* b2, eb_flags* f
     if (!b2) { // modes 1 / 3 read symbols in the scan: 2-bit planes, derived from the index on first use
         int rcp = eb_index_scan_planes(b1);
         if (rcp != EB_OK) return rcp;
-    } else if (!f->d_mxy) { // mode 2: planes of the two BWTs merged by the document array, derived on first use
-        const size_t bytes = eb_bit_alloc_words(f->n) * sizeof(uint4);
-        hipError_t e = hipMalloc(&f->d_mxy, bytes);
-        if (e != hipSuccess) { eb_set_error("merged scan plane allocation failed (%zu bytes): %s", bytes, hipGetErrorString(e)); return EB_ERR_NOMEM; }
-        EB_HIP(hipMemsetAsync(f->d_mxy, 0, bytes, f->stream));
-        eb_launch_merge_planes(f->stream, b1->dev(), b2->dev(), f->dev(), f->d_mxy);
-        EB_HIP(hipStreamSynchronize(f->stream));
-        EB_HIP(hipGetLastError());
+    } else if (!f->d_mxy) { // mode 2: planes of the two BWTs merged by the document array (the traversal leaves them behind; flags put together otherwise: now)
+        int rcp = eb_flags_merge_planes(f, b1, b2);
+        if (rcp != EB_OK) return rcp;
     }
     // a caller that keeps scanning an index gets the FL table for its right-context walks (eb_index.hip)
-    eb_index_note_phase4_job(b1, end - begin);
-    if (b2) eb_index_note_phase4_job(b2, end - begin);
+    // (two BWTs: each is credited its share of the merged positions)
+    eb_index_note_phase4_job(b1, b2 ? (uint64_t)((double)(end - begin) * (double)b1->n / (double)(n ? n : 1)) : end - begin);
+    if (b2) eb_index_note_phase4_job(b2, (uint64_t)((double)(end - begin) * (double)b2->n / (double)(n ? n : 1)));
 
     int rcc = eb_scan_ctx_create(b1);
     if (rcc != EB_OK) return rcc;
@@ -708,6 +727,47 @@ extern "C" int eb_scan_job_wire_to_host(eb_scan_job* job, void* dst, uint64_t ca
 // this on a side thread once its own buffers are allocated): the scan planes of a one-BWT index, the device temporaries of a
 // whole-range job (into the scratch cache) and a page-locked blob of about the size a call set of read data takes.  The
 // executable's phase 4 on the 7.55 GB file: 57 ms in round 4, of which the kernels took 6.
+// Mode 2: the scan planes of the two BWTs merged by the document array (what k_scan<2> streams instead of an index's own planes).
+int eb_flags_merge_planes(eb_flags* f, eb_index* b1, eb_index* b2) {
+    if (f->d_mxy) return EB_OK;
+    EB_HIP(hipSetDevice(f->device));
+    const size_t bytes = eb_bit_alloc_words(f->n) * sizeof(uint4);
+    if (f->d_mxy_spare) { f->d_mxy = f->d_mxy_spare; f->d_mxy_spare = nullptr; }
+    else {
+        hipError_t e = hipMalloc(&f->d_mxy, bytes);
+        if (e != hipSuccess) { f->d_mxy = nullptr; eb_set_error("merged scan plane allocation failed (%zu bytes): %s", bytes, hipGetErrorString(e)); return EB_ERR_NOMEM; }
+    }
+    EB_HIP(hipMemsetAsync(f->d_mxy, 0, bytes, f->stream));
+    eb_launch_merge_planes(f->stream, b1->dev(), b2->dev(), f->dev(), f->d_mxy);
+    EB_HIP(hipStreamSynchronize(f->stream));
+    EB_HIP(hipGetLastError());
+    return EB_OK;
+}
+
+// Reservations of the FIRST phase-4 job over `positions` positions on `device`, made ahead of it (beside the traversal, or beside
+// the upload of the document array, which is when a mode-3 run turns out to be one): the device temporaries of an ordered job at the
+// starting batch size, and a page-locked block for the call set -- ~1e-4 clusters per position x ~85 bytes; the pool hands a block
+// out for requests between half its size and its size.
+void eb_phase4_reserve(int device, uint64_t positions, bool two_samples) {
+    if (hipSetDevice(device) != hipSuccess) return;
+    const std::string saved = eb_last_error();
+    const OrderedSizes z = ordered_sizes((positions + 63) / 64 + 1, EB_BATCH_SHIFT_MAX, two_samples, 31, 30);
+    if (z.n_batches <= EB_MAX_BATCHES) {
+        const size_t sizes[] = {z.cnt, z.part, z.slots, z.kept, z.sorted, z.choff, z.chains, z.blob};
+        std::vector<std::pair<void*, size_t>> held;
+        for (size_t bytes : sizes) {
+            size_t got = 0;
+            void* q = eb_scratch_get(device, bytes, &got);
+            if (!q) break;
+            held.emplace_back(q, got);
+        }
+        for (const auto& h : held) eb_scratch_put(device, h.first, h.second);
+    }
+    uint64_t pinned_cap = 0;
+    if (void* h = eb_pinned_get(positions / 100 + 4096, &pinned_cap)) eb_pinned_put(h, pinned_cap);
+    eb_set_error("%s", saved.c_str());
+}
+
 void eb_phase4_warm(eb_index* b1, eb_index* b2, uint64_t n) {
     if (hipSetDevice(b1->device) != hipSuccess) return;
     const std::string saved = eb_last_error();
@@ -715,28 +775,11 @@ void eb_phase4_warm(eb_index* b1, eb_index* b2, uint64_t n) {
     eb_scan_kernels_preload(); // (3-4 ms of code-object loading in front of the first scan otherwise)
     eb_context_preload();
     eb_wire_preload();
-    const uint64_t tiles = ((n + 63) / 64 + 255) / 256;
-    const uint64_t n_batches = (tiles >> EB_BATCH_SHIFT_MAX) + 2;
-    if (n_batches <= EB_MAX_BATCHES) {
-        uint64_t cap = n_batches * EB_BATCH_SLOTS;
-        if (cap > 0x1FFFFFFFull) cap = 0x1FFFFFFFull;
-        const uint64_t chains = cap * (b2 ? 8u : 4u);
-        const size_t sizes[] = {((sizeof(ScanCounters) + 255) & ~(size_t)255) + n_batches * 4, (size_t)2048 * EB_SCAN_PARTIAL * 8, n_batches * EB_BATCH_SLOTS * sizeof(Survivor),
-                                4 * (n_batches + 1) * 4, cap * sizeof(Survivor), cap * 4, chains * 8, eb_calls_blob_size(cap, chains, 31, 30)};
-        std::vector<std::pair<void*, size_t>> held;
-        for (size_t bytes : sizes) {
-            size_t got = 0;
-            void* q = eb_scratch_get(b1->device, bytes, &got);
-            if (!q) break;
-            held.emplace_back(q, got);
-        }
-        for (const auto& h : held) eb_scratch_put(b1->device, h.first, h.second);
-    }
-    // a page-locked block for the call set (~1e-4 clusters per position x ~85 bytes: the pool hands a block out for requests between
-    // half its size and its size), and a throw-away copy into it: the first device-to-host copy of a process waits 10-30 ms for the
-    // runtime to open a copy-engine queue
+    eb_phase4_reserve(b1->device, n, b2 != nullptr);
+    // a throw-away copy into a page-locked block: the first device-to-host copy of a process waits 10-30 ms for the runtime to open
+    // a copy-engine queue
     uint64_t pinned_cap = 0;
-    if (void* h = eb_pinned_get(n / 100 + 4096, &pinned_cap)) {
+    if (void* h = eb_pinned_get(1u << 20, &pinned_cap)) {
         if (b1->scan_ctx && b1->d_chunks && b1->n_blocks * 64 >= (1u << 20)) {
             (void)hipMemcpyAsync(h, b1->d_chunks, 1u << 20, hipMemcpyDeviceToHost, b1->scan_ctx->copy);
             (void)hipStreamSynchronize(b1->scan_ctx->copy);

@@ -251,6 +251,21 @@ def sample_read_starts(haps: Sequence[np.ndarray], offsets: np.ndarray, n_reads:
     return starts
 
 
+def two_sample_text(n_reads_each: int, read_len: int, coverage: float = 30.0, genome_seed: int = 5, starts_seed: int = 99):
+    """Two individuals at benchmark scale (modes 2 / 3): sample 0 homozygous for a random genome, sample 1 for its mutated
+    haplotype, `n_reads_each` error-free reads each (together `coverage` x of the diploid genome).  Returns (text, starts0, starts1)
+    for build_ebwt_gpu_slabbed: two BWTs from the two start lists, or one merged BWT + document array from their concatenation
+    with n_first = n_reads_each.  (The recipe of BASELINE configs[2] / configs[3] in tests/_fullsize.py and scripts/modes23_scale.py.)"""
+    glen = int(2 * n_reads_each * read_len / coverage)
+    g = random_genome(glen, genome_seed)
+    h2 = mutate_haplotype(g, genome_seed)
+    text, offs = haplotype_text([g, h2])
+    rng = np.random.Generator(np.random.PCG64(starts_seed))
+    s0 = (rng.integers(0, len(g) - read_len + 1, size=n_reads_each, dtype=np.int64) + offs[0]).astype(np.uint64)
+    s1 = (rng.integers(0, len(h2) - read_len + 1, size=n_reads_each, dtype=np.int64) + offs[1]).astype(np.uint64)
+    return text, s0, s1
+
+
 def reads_from_starts(text: np.ndarray, starts: np.ndarray, read_len: int) -> np.ndarray:
     idx = np.arange(read_len, dtype=np.int64)
     return text[starts.astype(np.int64)[:, None] + idx[None, :]]

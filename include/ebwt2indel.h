@@ -176,6 +176,11 @@ int eb_flags_finalize(eb_flags* f);
 /* Mode 3: ASCII '0'/'1' document array, '1' -> 1, anything else -> 0 (ebwt2InDel.cpp:1503-1508).  n < BWT length:
  * the remaining slots repeat the file's last byte, as the reference's failed read() leaves its buffer unchanged. */
 int eb_flags_set_da(eb_flags* f, const uint8_t* ascii01, uint64_t n);
+/* The same array read from a file (the -d argument, ebwt2InDel.cpp:1497-1508: one read() per byte there; here page-locked pieces
+ * filled by the loader's reader threads while earlier pieces are uploaded and packed), or taken from ASCII bytes that are already
+ * in HBM on the flags' device (16-byte aligned; a generator's output). */
+int eb_flags_set_da_file(eb_flags* f, const char* path);
+int eb_flags_set_da_device(eb_flags* f, const void* d_ascii01, uint64_t n);
 /* Bit i of each vector is bit (i & 63) of word (i >> 6).  Any pointer may be NULL.
  * export: device -> host (tests, broadcast to other ranks); import: host -> device. */
 uint64_t eb_flags_words(const eb_flags* f);

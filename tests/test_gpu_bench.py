@@ -9,7 +9,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ARGS = ["--reads", "300000", "--steps", "2", "--warmup", "1", "--rank-queries", "1048576", "--cpu-dram-reads", "0"]
+ARGS = ["--no-other-modes", "--reads", "300000", "--steps", "2", "--warmup", "1", "--rank-queries", "1048576", "--cpu-dram-reads", "0"]
 
 
 def _last_json(out: str):
@@ -20,10 +20,15 @@ def _last_json(out: str):
 
 def test_bench_contract_single_gpu():
     # (the DRAM-resident leg of the CPU baseline at a size that keeps the test short; the other tests here skip it)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-sample-reads", "20000"] + ARGS[:-1] + ["300000"],
-                       capture_output=True, text=True, timeout=600)
+    # (and with the short runs of modes 2 and 3 the default run appends: `other_modes`)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-sample-reads", "20000"] + ARGS[1:-1] + ["300000"],
+                       capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
+    for m in ("mode2", "mode3"):
+        o = d["other_modes"][m]
+        assert "error" not in o, o
+        assert o["snp_records"] > 500 and o["ms_per_step"] > 0 and o["algorithmic_bytes_per_position"] == 0.875 and f"mode {m[-1]}" in o["workload"]
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d
@@ -34,6 +39,22 @@ def test_bench_contract_single_gpu():
     assert d["cpu_baseline"]["dram_resident"]["snp_identical_to_gpu"]
     assert d["snp_records"] > 1000
     pytest.single_gpu_sha = d["snp_sha256"]
+
+
+@pytest.mark.parametrize("mode", [2, 3])
+def test_bench_modes_2_and_3(mode):
+    """`--mode 2` (two BWTs) and `--mode 3` (merged BWT + document array packed where the generator left it in HBM): the same line,
+    its CPU leg run by the oracle and the reference binary in that mode on the same sample."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", str(mode), "--cpu-sample-reads", "20000"] + ARGS,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert d["config"]["mode"] == mode and "other_modes" not in d
+    assert d["roofline"]["algorithmic_bytes_per_position"] == 0.875
+    assert d["cpu_baseline"]["snp_identical_to_gpu"] and (d["cpu_baseline"]["reference"] is None or d["cpu_baseline"]["reference"]["snp_identical_to_gpu"])
+    assert d["snp_records"] > 500
+    if mode == 3:
+        assert d["phases23_gpu"]["document_array_packed_from_hbm_seconds"] > 0
 
 
 def test_bench_two_ranks_share_the_gpu_same_snp():
@@ -58,7 +79,7 @@ def test_bench_nccl_collectives_with_one_rank_same_snp(gather):
     default) or gathered GPU to GPU with RCCL and resolved one step later (EB_BENCH_GATHER=rccl, rounds 2-4) -- exercised with a
     single rank (RCCL refuses two ranks on one device): same .snp as the plain N = 1 run either way."""
     env = dict(os.environ, EB_BENCH_FORCE_DIST="1", EB_BENCH_GATHER=gather, MASTER_ADDR="127.0.0.1", MASTER_PORT="29519", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-sample-reads", "0", "--steps", "5"] + ARGS[:2] + ARGS[4:],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-sample-reads", "0", "--steps", "5"] + ARGS[:3] + ARGS[5:],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json(r.stdout)

@@ -400,6 +400,48 @@ def test_short_document_array_repeats_its_last_byte(oracle):
         assert np.array_equal(bits[:cut], (np.frombuffer(bytes(d), dtype=np.uint8) == ord("1")).astype(np.uint8))
 
 
+@pytest.mark.parametrize("pieces", ["plain", "page_locked_pieces"])
+def test_document_array_from_buffer_file_and_device_is_the_same_array(monkeypatch, tmp_path, pieces):
+    """The -d array reaches the flags from a host buffer, from the file itself (page-locked pieces filled by the loader's reader
+    threads: what the executable does) or from ASCII bytes already in HBM: one packed array, short and empty sources included
+    (ebwt2InDel.cpp:1497-1508)."""
+    import torch
+    if pieces == "page_locked_pieces":
+        monkeypatch.setenv("EB_INDEX_PINNED", f"1,{64 * 53},3")     # from 1 byte on, pieces of 3392 positions, 3 reader threads
+    m, da = golden_bytes("het_m.ebwt"), golden_bytes("het_m.da")
+    g = api.DnaBwt(m)
+    fl = api.Flags.build(g, None, 16, 30)
+    junk = bytearray(da)
+    junk[100:110] = b"x2\n 1-1\x00\xff1"                           # anything but '1' is 0
+    for src in (da, bytes(junk), da[: len(da) * 2 // 3 - 1] + b"1", da[: len(da) // 2 + 17] + b"0", da[:1], b"1", b"", da + b"1111"):
+        lim = min(len(src), len(m))
+        want = np.zeros(len(m), dtype=np.uint8)
+        want[:lim] = np.frombuffer(src[:lim], dtype=np.uint8) == ord("1")
+        if 0 < lim < len(m):
+            want[lim:] = src[lim - 1] == ord("1")
+        got = []
+        fl.set_da(src)
+        got.append(fl.export()[3].copy())
+        pth = tmp_path / "x.da"
+        pth.write_bytes(src)
+        fl.set_da(b"0" * len(m))                                    # (each form starts from another array)
+        fl.set_da_file(str(pth))
+        got.append(fl.export()[3].copy())
+        fl.set_da(b"1" * len(m))
+        t = torch.frombuffer(bytearray(src) if src else bytearray(b"-"), dtype=torch.uint8).cuda()
+        fl.set_da_device(t.data_ptr(), len(src))
+        got.append(fl.export()[3].copy())
+        for words in got:
+            assert np.array_equal(np.unpackbits(words.view(np.uint8), bitorder="little")[: len(m)], want)
+            assert not np.unpackbits(words.view(np.uint8), bitorder="little")[len(m):].any()
+    with pytest.raises(api.EbError, match="could not read file"):
+        fl.set_da_file(str(tmp_path / "absent.da"))
+    # and the call set that comes out of the file form is the reference's
+    fl.set_da_file(str(tmp_path / "x.da"))                          # (da + b"1111": longer than the BWT, the excess is ignored)
+    p = api.make_params()
+    assert api.scan_clusters(g, fl, p).format_snp(p, True)[0] == api.run_two_datasets_da(m, da)
+
+
 def test_flags_import_export_round_trip(oracle):
     e = golden_bytes("het_m.ebwt")
     da = golden_bytes("het_m.da")
@@ -536,6 +578,8 @@ def test_cli_binary_byte_identical(tmp_path):
     assert got == golden_bytes("m3_hom_g2.snp")
     got, _ = run(["-1", str(tmp_path / "tiny.ebwt")], tmp_path / "o4.snp")     # the reference dies with SIGFPE here; we exit 0
     assert got == b""
+    r = subprocess.run([_lib.CLI_PATH, "-1", str(tmp_path / "hom_m.ebwt"), "-d", str(tmp_path / "absent.da"), "-o", str(tmp_path / "o6.snp")], capture_output=True, text=True)
+    assert r.returncode == 1 and f"Error: could not read file {tmp_path / 'absent.da'}" in r.stdout
     bad = bytearray(golden_bytes("tiny.ebwt"))
     bad[3] = ord("N")
     (tmp_path / "bad.ebwt").write_bytes(bytes(bad))
