@@ -4,9 +4,12 @@
 // dH (:157-171), has_run (:144-152) and event_type (:1102-1144).  This part stays on the host in
 // the reference's own language (C++): it is sequential by construction (running cluster_nr / id_nr
 // counters, :52,:72) and touches ~1e-4 of the BWT positions.
+#include <fcntl.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <mutex>
@@ -201,9 +204,46 @@ int format_range(const eb_calls* c, const eb_params* p, int two_samples, uint64_
     return EB_OK;
 }
 
-// Event logic + text for the whole call set.  Large sets are cut into pieces formatted by host threads; the running
-// cluster number is filled in when the pieces are joined, so the text is the same whatever the number of threads.
-int format_calls(const eb_calls* c, const eb_params* p, int two_samples, uint64_t* cluster_nr, uint64_t* events, std::string& o) {
+// Event logic + text for the whole call set.  Large sets are cut into pieces formatted by host threads; a piece's text lacks only
+// the running cluster numbers, which depend on the pieces before it: once all pieces exist their numbers and final sizes are known,
+// and every thread puts its piece where it belongs -- into one buffer (eb_format_snp) or straight into the file at its own offset
+// (eb_write_snp: no joined copy of the text at all).  The text is the same whatever the number of threads.
+unsigned decimal_digits(uint64_t v) {
+    unsigned d = 1;
+    while (v >= 10) { v /= 10; ++d; }
+    return d;
+}
+
+struct Formatted {
+    std::vector<Piece> pieces;
+    std::vector<uint64_t> base_nr;   // cluster number of a piece's first cluster
+    std::vector<uint64_t> offset;    // where its final text starts; offset[pieces.size()] = total length
+    unsigned threads = 1;
+    uint64_t total() const { return offset.empty() ? 0 : offset.back(); }
+    // final text of piece t -> dst (offset[t + 1] - offset[t] bytes)
+    void emit(size_t t, char* dst) const {
+        const Piece& q = pieces[t];
+        size_t from = 0;
+        char num[24];
+        for (const auto& mk : q.marks) {
+            memcpy(dst, q.text.data() + from, mk.first - from);
+            dst += mk.first - from;
+            int len = snprintf(num, sizeof num, "%llu", (unsigned long long)(base_nr[t] + mk.second));
+            memcpy(dst, num, (size_t)len);
+            dst += len;
+            from = mk.first;
+        }
+        memcpy(dst, q.text.data() + from, q.text.size() - from);
+    }
+    template <typename F> void for_each_piece(F f) const {
+        if (threads <= 1) { for (size_t t = 0; t < pieces.size(); ++t) f(t); return; }
+        std::vector<std::thread> pool;
+        for (size_t t = 0; t < pieces.size(); ++t) pool.emplace_back(f, t);
+        for (std::thread& th : pool) th.join();
+    }
+};
+
+int format_calls(const eb_calls* c, const eb_params* p, int two_samples, uint64_t* cluster_nr, uint64_t* events, Formatted& F) {
     if (!c || !p || !cluster_nr) { eb_set_error("null argument"); return EB_ERR_ARG; }
     if (c->k_left != p->k_left || c->k_right != p->k_right) { eb_set_error("call set was produced with other -L/-R values"); return EB_ERR_ARG; }
     unsigned threads = 1;
@@ -211,42 +251,35 @@ int format_calls(const eb_calls* c, const eb_params* p, int two_samples, uint64_
     else if (c->count >= 50000) threads = std::min(std::thread::hardware_concurrency(), 32u);     // ~1 us per cluster: worth it from here
     if (threads < 1) threads = 1;
     if ((uint64_t)threads > c->count) threads = c->count ? (unsigned)c->count : 1u;
-    std::vector<Piece> pieces(threads);
+    F.threads = threads;
+    F.pieces.assign(threads, Piece());
     std::vector<int> rcs(threads, EB_OK);
-    auto work = [&](unsigned t) {
+    F.for_each_piece([&](size_t t) {
         uint64_t i0 = c->count * t / threads, i1 = c->count * (t + 1) / threads;
-        rcs[t] = format_range(c, p, two_samples, i0, i1, pieces[t]);
-    };
-    if (threads == 1) {
-        work(0);
-    } else {
-        std::vector<std::thread> pool;
-        for (unsigned t = 0; t < threads; ++t) pool.emplace_back(work, t);
-        for (std::thread& th : pool) th.join();
-    }
+        rcs[t] = format_range(c, p, two_samples, i0, i1, F.pieces[t]);
+    });
     for (int rc : rcs)
         if (rc != EB_OK) {
             eb_set_error(rc == EB_ERR_STATE ? "corrupt call set: a cluster marked EB_RIGHT_SKIPPED would print" : "corrupt call set: chain index out of range");
             return rc;
         }
-    size_t total = 0;
-    for (const Piece& q : pieces) total += q.text.size() + 20 * q.marks.size();
-    o.reserve(o.size() + total);
+    F.base_nr.assign(threads, 0);
     uint64_t ev = events ? *events : 0;
-    char num[24];
-    for (const Piece& q : pieces) {
-        size_t from = 0;
-        for (const auto& mk : q.marks) {
-            o.append(q.text, from, mk.first - from);
-            int len = snprintf(num, sizeof num, "%llu", (unsigned long long)(*cluster_nr + mk.second));
-            o.append(num, (size_t)len);
-            from = mk.first;
-        }
-        o.append(q.text, from, std::string::npos);
-        *cluster_nr += q.clusters;
-        ev += q.events;
+    for (unsigned t = 0; t < threads; ++t) {
+        F.base_nr[t] = *cluster_nr;
+        *cluster_nr += F.pieces[t].clusters;
+        ev += F.pieces[t].events;
     }
     if (events) *events = ev;
+    std::vector<uint64_t> size(threads, 0);
+    F.for_each_piece([&](size_t t) {
+        const Piece& q = F.pieces[t];
+        uint64_t z = q.text.size();
+        for (const auto& mk : q.marks) z += decimal_digits(F.base_nr[t] + mk.second);
+        size[t] = z;
+    });
+    F.offset.assign(threads + 1, 0);
+    for (unsigned t = 0; t < threads; ++t) F.offset[t + 1] = F.offset[t] + size[t];
     return EB_OK;
 }
 
@@ -515,29 +548,48 @@ extern "C" int eb_calls_unpack(const uint8_t* buf, uint64_t len, eb_calls** out)
 extern "C" int eb_format_snp(const eb_calls* c, const eb_params* p, int two_samples, uint64_t* cluster_nr, uint64_t* events,
                              char** text, uint64_t* len) {
     if (!text || !len) { eb_set_error("null argument"); return EB_ERR_ARG; }
-    std::string o;
-    int rc = format_calls(c, p, two_samples, cluster_nr, events, o);
+    Formatted F;
+    int rc = format_calls(c, p, two_samples, cluster_nr, events, F);
     if (rc != EB_OK) return rc;
-    char* b = static_cast<char*>(malloc(o.size() + 1));
+    char* b = static_cast<char*>(malloc(F.total() + 1));
     if (!b) { eb_set_error("out of memory"); return EB_ERR_NOMEM; }
-    memcpy(b, o.data(), o.size());
-    b[o.size()] = 0;
+    F.for_each_piece([&](size_t t) { F.emit(t, b + F.offset[t]); });
+    b[F.total()] = 0;
     *text = b;
-    *len = o.size();
+    *len = F.total();
     return EB_OK;
 }
 
 extern "C" int eb_write_snp(const eb_calls* c, const eb_params* p, int two_samples, const char* path, int append,
                             uint64_t* cluster_nr, uint64_t* events) {
     if (!path) { eb_set_error("null argument"); return EB_ERR_ARG; }
-    std::string o;
-    int rc = format_calls(c, p, two_samples, cluster_nr, events, o);
+    Formatted F;
+    int rc = format_calls(c, p, two_samples, cluster_nr, events, F);
     if (rc != EB_OK) return rc;
-    FILE* f = fopen(path, append ? "ab" : "wb");
-    if (!f) { eb_set_error("cannot open %s for writing", path); return EB_ERR_IO; }
-    size_t w = o.empty() ? 0 : fwrite(o.data(), 1, o.size(), f);
-    int bad = fclose(f);
-    if (w != o.size() || bad) { eb_set_error("short write to %s", path); return EB_ERR_IO; }
+    int fd = open(path, O_WRONLY | O_CREAT | (append ? 0 : O_TRUNC), 0666);
+    if (fd < 0) { eb_set_error("cannot open %s for writing", path); return EB_ERR_IO; }
+    struct stat st;
+    uint64_t base = 0;
+    if (append) {
+        if (fstat(fd, &st) != 0) { close(fd); eb_set_error("cannot stat %s", path); return EB_ERR_IO; }
+        base = (uint64_t)st.st_size;
+    }
+    // every thread finishes its piece (cluster numbers filled in) and writes it at its own offset of the file
+    std::vector<int> bad(F.pieces.size(), 0);
+    F.for_each_piece([&](size_t t) {
+        const uint64_t z = F.offset[t + 1] - F.offset[t];
+        if (!z) return;
+        std::string out((size_t)z, '\0');
+        F.emit(t, &out[0]);
+        for (uint64_t done = 0; done < z;) {
+            ssize_t w = pwrite(fd, out.data() + done, (size_t)(z - done), (off_t)(base + F.offset[t] + done));
+            if (w <= 0) { bad[t] = 1; return; }
+            done += (uint64_t)w;
+        }
+    });
+    int failed = close(fd);
+    for (int b : bad) failed |= b;
+    if (failed) { eb_set_error("short write to %s", path); return EB_ERR_IO; }
     return EB_OK;
 }
 

@@ -802,6 +802,118 @@ oflags* orc_navigate_one_mt(const oindex* x, int K, int k_right, int threads) {
     return f;
 }
 
+/* ---- a SAMPLE of the two traversals against given bit vectors, for sizes where even the threaded traversal above takes the better
+ * part of an hour (BASELINE configs[4]: 151 G positions): the top of each tree is expanded breadth-first to a frontier of at least
+ * `frontier` records (visited and checked in full), then every `every`-th subtree of the frontier (those with index % every == which)
+ * is walked depth-first with the serial code's rules, and every LCP / minimum slot the reference WOULD WRITE there is compared with
+ * the vectors at hand instead of being written: a leaf interval's interior must read  thrK = (depth >= K), thrR = (depth >= k_right),
+ * minima = 0  throughout; a child border of a node  thrK / thrR likewise and minima = the reference's condition (ebwt2InDel.cpp:357-391).
+ * Sound because every slot has exactly one writer (lcp_values reaches n, :617,670).  out6 = {leaves, nodes, LCP slots, minima expected,
+ * mismatching slots, first mismatching position + 1}. */
+static inline int bits_range_is(const uint64_t* b, uint64_t lo, uint64_t hi, int value) { /* [lo,hi) all == value */
+    if (hi <= lo) return 1;
+    uint64_t w0 = lo >> 6, w1 = (hi - 1) >> 6;
+    for (uint64_t w = w0; w <= w1; ++w) {
+        uint64_t m = ~0ull;
+        if (w == w0) m &= ~0ull << (lo & 63);
+        if (w == w1) m &= ~0ull >> (63 - ((hi - 1) & 63));
+        if (((value ? ~b[w] : b[w]) & m) != 0) return 0;
+    }
+    return 1;
+}
+typedef struct { uint64_t leaves, nodes, lcp, n_min, bad, first_bad; } chk_tally;
+typedef struct { const uint64_t *thrK, *thrR, *minima; } chk_vec;
+static void chk_note(chk_tally* t, uint64_t pos) { if (!t->bad++) t->first_bad = pos + 1; }
+
+static void leaf_check(const oindex* x, const chk_vec* v, int K, int k_right, const oleaf* L, chk_tally* t, leaf_stack* S) {
+    t->leaves++;
+    if (L->rn.r > L->rn.l + 1) { /* update_LCP_leaf :344-355 */
+        const uint64_t lo = L->rn.l + 1, hi = L->rn.r;
+        if (!bits_range_is(v->thrK, lo, hi, (int64_t)L->depth >= K) || !bits_range_is(v->thrR, lo, hi, (int64_t)L->depth >= k_right) ||
+            !bits_range_is(v->minima, lo, hi, 0))
+            chk_note(t, lo);
+        t->lcp += hi - lo;
+    }
+    prange_t e = LF_range(x, L->rn); /* next_leaves dna_bwt.hpp:358-379 */
+    for (int c = 0; c < 4; ++c)
+        if (e.c[c].r - e.c[c].l >= 2) { oleaf ch = {e.c[c], L->depth + 1}; leaf_stack_push(S, ch); }
+}
+static void node_check(const oindex* x, const chk_vec* v, int K, int k_right, const onode* N, chk_tally* t, node_stack* S) {
+    t->nodes++;
+    for (int j = 0; j < 4; ++j) /* update_lcp_threshold include.hpp:826-860; update_lcp_minima ebwt2InDel.cpp:357-391 */
+        if (N->b[j + 1] > N->b[j] && N->b[j + 1] != N->b[5]) {
+            const uint64_t p = N->b[j + 1];
+            const int is_min = j >= 1 && N->b[j + 1] - N->b[j] >= 2 && N->b[j + 1] < N->b[5] - 1;
+            if (bit_get(v->thrK, p) != ((int64_t)N->depth >= K) || bit_get(v->thrR, p) != ((int64_t)N->depth >= k_right) || bit_get(v->minima, p) != is_min)
+                chk_note(t, p);
+            t->lcp++;
+            t->n_min += (uint64_t)is_min;
+        }
+    onode ch[4];
+    LF_node(x, N, ch); /* next_nodes dna_bwt.hpp:381-404 */
+    for (int c = 0; c < 4; ++c)
+        if (node_children(&ch[c]) >= 2) node_stack_push(S, ch[c]);
+}
+
+void orc_navigate_one_sample_check(const oindex* x, int K, int k_right, int threads, uint64_t frontier, uint64_t every, uint64_t which,
+                                   const uint64_t* thrK, const uint64_t* thrR, const uint64_t* minima, uint64_t* out6) {
+    if (threads < 1) threads = 1;
+    if (every < 1) every = 1;
+    const chk_vec v = {thrK, thrR, minima};
+    chk_tally tot = {0, 0, 0, 0, 0, 0};
+    { /* leaves */
+        leaf_stack cur = {0}, nxt = {0};
+        oleaf first = {{0, x->F[0]}, 0};
+        leaf_stack_push(&cur, first);
+        while (cur.n && cur.n < frontier) {
+            nxt.n = 0;
+            for (size_t i = 0; i < cur.n; ++i) leaf_check(x, &v, K, k_right, &cur.a[i], &tot, &nxt);
+            leaf_stack sw = cur; cur = nxt; nxt = sw;
+        }
+        uint64_t a_leaves = 0, a_lcp = 0, a_bad = 0, a_first = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(+ : a_leaves, a_lcp, a_bad) reduction(max : a_first)
+        for (long long i = 0; i < (long long)cur.n; ++i) {
+            if ((uint64_t)i % every != which % every) continue;
+            leaf_stack S = {0};
+            chk_tally t = {0, 0, 0, 0, 0, 0};
+            leaf_stack_push(&S, cur.a[i]);
+            while (S.n) { oleaf L = S.a[--S.n]; leaf_check(x, &v, K, k_right, &L, &t, &S); }
+            free(S.a);
+            a_leaves += t.leaves; a_lcp += t.lcp; a_bad += t.bad;
+            if (t.first_bad > a_first) a_first = t.first_bad;
+        }
+        tot.leaves += a_leaves; tot.lcp += a_lcp; tot.bad += a_bad;
+        if (!tot.first_bad) tot.first_bad = a_first;
+        free(cur.a); free(nxt.a);
+    }
+    { /* nodes */
+        node_stack cur = {0}, nxt = {0};
+        onode root = {{0, x->F[0], x->F[1], x->F[2], x->F[3], x->n}, 0};
+        node_stack_push(&cur, root);
+        while (cur.n && cur.n < frontier) {
+            nxt.n = 0;
+            for (size_t i = 0; i < cur.n; ++i) node_check(x, &v, K, k_right, &cur.a[i], &tot, &nxt);
+            node_stack sw = cur; cur = nxt; nxt = sw;
+        }
+        uint64_t a_nodes = 0, a_lcp = 0, a_min = 0, a_bad = 0, a_first = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(+ : a_nodes, a_lcp, a_min, a_bad) reduction(max : a_first)
+        for (long long i = 0; i < (long long)cur.n; ++i) {
+            if ((uint64_t)i % every != which % every) continue;
+            node_stack S = {0};
+            chk_tally t = {0, 0, 0, 0, 0, 0};
+            node_stack_push(&S, cur.a[i]);
+            while (S.n) { onode N = S.a[--S.n]; node_check(x, &v, K, k_right, &N, &t, &S); }
+            free(S.a);
+            a_nodes += t.nodes; a_lcp += t.lcp; a_min += t.n_min; a_bad += t.bad;
+            if (t.first_bad > a_first) a_first = t.first_bad;
+        }
+        tot.nodes += a_nodes; tot.lcp += a_lcp; tot.n_min += a_min; tot.bad += a_bad;
+        if (!tot.first_bad) tot.first_bad = a_first;
+        free(cur.a); free(nxt.a);
+    }
+    out6[0] = tot.leaves; out6[1] = tot.nodes; out6[2] = tot.lcp; out6[3] = tot.n_min; out6[4] = tot.bad; out6[5] = tot.first_bad;
+}
+
 /* update_DA: ebwt2InDel.cpp:394-425 (with LCP) and :429-449 (DA only) */
 static void leaf_pair_da(oflags* f, const oleaf* L1, const oleaf* L2, int with_lcp, int K, int k_right) {
     uint64_t s1 = L1->rn.l + L2->rn.l, s2 = L2->rn.l + L1->rn.r, e = L1->rn.r + L2->rn.r;

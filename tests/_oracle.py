@@ -89,6 +89,7 @@ class Oracle:
         L.orc_navigate_one.argtypes = [vp, C.c_int, C.c_int]
         L.orc_navigate_one_mt.restype = vp
         L.orc_navigate_one_mt.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+        L.orc_navigate_one_sample_check.argtypes = [vp, C.c_int, C.c_int, C.c_int, u64, u64, u64, vp, vp, vp, vp]
         L.orc_index_from_buffer_mt.restype = vp
         L.orc_index_from_buffer_mt.argtypes = [vp, u64, u8, C.c_int]
         L.orc_index_equal.argtypes = [vp, vp]
@@ -230,6 +231,17 @@ class OracleIndex:
         out = np.zeros((len(nodes7), 28), dtype=np.uint64)
         self.o.lib.orc_lf_node_batch(self.h, nodes7.ctypes.data, len(nodes7), out.ctypes.data)
         return out
+
+
+def traversal_sample_check(orc, idx, K, k_right, vectors, every, which=0, frontier=1 << 16, threads=1):
+    """A sample of the reference's two traversals (every `every`-th subtree below a breadth-first frontier, and the whole top above
+    it) held against given thrK / thrR / minima words slot by slot (oracle/ebwt_oracle.c, orc_navigate_one_sample_check): for sizes
+    where the whole traversal on the host would take the better part of an hour."""
+    v = [np.ascontiguousarray(a, dtype=np.uint64) for a in vectors[:3]]
+    assert all(len(a) >= (idx.n + 63) // 64 for a in v)
+    out = np.zeros(6, dtype=np.uint64)
+    orc.lib.orc_navigate_one_sample_check(idx.h, K, k_right, threads, frontier, every, which, v[0].ctypes.data, v[1].ctypes.data, v[2].ctypes.data, out.ctypes.data)
+    return dict(zip(("leaves", "nodes", "lcp_slots", "minima_expected", "mismatches", "first_mismatch_plus_1"), (int(x) for x in out)))
 
 
 class OracleFlags:

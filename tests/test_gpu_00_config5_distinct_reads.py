@@ -7,7 +7,8 @@ generator, then index -> traversal -> phase 4, every stage against a checker --
               prefix counts of the ASCII symbols around all 35 superblock boundaries; 200 k reads spelled back through access + LF;
   traversal   every LCP slot written once; thrK / thrR = LCP >= K / k_right BY DEFINITION over all 151 G positions, minima = the
               LCP's local minima (the generator's own statement of the vectors, held to the oracle on small inputs in
-              test_gpu_generator.py);
+              test_gpu_generator.py); AND the CPU oracle's own traversal -- the top of both trees in full, then one subtree in 256 below
+              a frontier of 2^16 -- finds every LCP / minimum slot it would write as the GPU wrote it (round 5);
   phase 4     the whole-range .snp BYTE-IDENTICAL to the CPU oracle's whole-range pass (512 shards on the host threads, ~95 s) and, record
               by record with contexts, on 49 windows of 2 M positions (every superblock boundary, both ends, random places); the
               whole-range .snp = 8 shards' (the N = 8 ownership rule).
@@ -43,3 +44,5 @@ def test_config5_one_billion_distinct_reads_whole_pipeline(tmp_path):
         assert got[k] == want[k], (k, got[k], want[k])
     assert got["n"] == 151_000_000_000 and got["every_lcp_slot_written_once"] and got["thrK_thrR_equal_definition"] and got["shards8_equal_whole"] and got["snp_equals_oracle_whole_range"]
     assert got["snp_sha256"] == got["oracle_snp_sha256"]
+    smp = got["oracle_traversal_sample"]          # the reference's traversal itself (a sample of its subtrees + the whole top) against the GPU's vectors
+    assert smp["mismatches"] == 0 and smp["nodes"] > got["nodes"] // (4 * smp["every"]) and smp["lcp_slots"] > got["n"] // (4 * smp["every"])

@@ -111,3 +111,36 @@ def test_streamed_index_equals_the_one_built_from_a_buffer(oracle, n, piece):
             y.append(pos, e[pos:pos + piece], threads=2)
         y.finish(threads=2)
         assert not y.ok and y.bad() == (ord("N"), 4321)
+
+
+@pytest.mark.parametrize("name", ["dip.ebwt", "edge.ebwt", "het_m.ebwt"])
+def test_sampled_traversal_check_is_the_traversal(oracle, name):
+    """orc_navigate_one_sample_check (the traversal check of BASELINE configs[4], where the whole traversal on the host is out of
+    reach): with every subtree sampled it visits exactly the serial traversal's leaves, nodes, LCP slots and minima and finds the serial
+    traversal's own vectors right; the subtrees of a partition of the frontier add up to the whole; and a flipped bit of any vector, in
+    a leaf interval or on a node border, top of the tree or below the frontier, is found by the sample that owns it."""
+    e = golden_bytes(name)
+    x = oracle.index(e)
+    f = _oracle.OracleFlags(oracle, x, None, 16, 30)
+    vec = [v.copy() for v in f.export()[:3]]
+    want = f.counters()
+    whole = _oracle.traversal_sample_check(oracle, x, 16, 30, vec, every=1, frontier=64, threads=3)
+    assert whole["mismatches"] == 0 and whole["first_mismatch_plus_1"] == 0
+    assert (whole["leaves"], whole["nodes"], whole["lcp_slots"] + 1, whole["minima_expected"]) == (want["leaves"], want["nodes"], want["lcp_values"], want["minima"])
+    top = _oracle.traversal_sample_check(oracle, x, 16, 30, vec, every=1 << 40, which=(1 << 40) - 1, frontier=64)        # no subtree at all: the top alone
+    parts = [_oracle.traversal_sample_check(oracle, x, 16, 30, vec, every=5, which=w, frontier=64, threads=2) for w in range(5)]
+    assert all(p_["mismatches"] == 0 for p_ in parts)
+    for k in ("leaves", "nodes", "lcp_slots", "minima_expected"):
+        assert sum(p_[k] - top[k] for p_ in parts) + top[k] == whole[k], k
+    assert 0 < top["nodes"] < min(p_["nodes"] for p_ in parts)
+    # flipped bits: every LCP slot 1 .. n-1 is some sample's, so the five samples together see each flip exactly once
+    rng = np.random.Generator(np.random.PCG64(5))
+    for which_vec in range(3):
+        for pos in rng.integers(1, len(e), size=6):
+            bad = [v.copy() for v in vec]
+            bad[which_vec][pos >> 6] ^= np.uint64(1) << np.uint64(pos & 63)
+            found = [_oracle.traversal_sample_check(oracle, x, 16, 30, bad, every=5, which=w, frontier=64) for w in range(5)]
+            in_top = _oracle.traversal_sample_check(oracle, x, 16, 30, bad, every=1 << 40, which=(1 << 40) - 1, frontier=64)["mismatches"]
+            hits = sum(r["mismatches"] for r in found)
+            assert hits == (5 if in_top else 1), (which_vec, int(pos), hits, in_top)
+            assert all(r["first_mismatch_plus_1"] in (0, ) or r["mismatches"] for r in found)

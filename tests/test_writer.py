@@ -54,6 +54,36 @@ def test_writer_threads_do_not_change_the_text(oracle, monkeypatch, case, thread
     assert calls.format_snp(pp, case["mode"] != 1)[0] == golden_bytes(case["snp"])
 
 
+@pytest.mark.parametrize("threads", ["1", "3", "16"])
+@pytest.mark.parametrize("case", [c for c in CASES if c["name"] in ("m1_default", "m2_het_default", "m3_het_default")], ids=lambda c: c["name"])
+def test_write_snp_puts_every_piece_at_its_offset_of_the_file(oracle, monkeypatch, tmp_path, case, threads):
+    """eb_write_snp: every host thread finishes its piece and writes it at its own offset (no joined text): the file is the
+    reference's; a second call that appends continues the file and the cluster numbers (the multi-GPU executable writes rank by rank)."""
+    p, fl, n = _setup(oracle, case)
+    pp = api.make_params(case["args"])
+    two = case["mode"] != 1
+    monkeypatch.setenv("EB_WRITER_THREADS", threads)
+    out = tmp_path / "o.snp"
+    out.write_bytes(b"stale bytes that a fresh write must not keep " * 4000)
+    rec = fl.scan(p, 0, n, capture=True)
+    calls = api.Calls.unpack(_oracle.pack_calls(rec, p.k_left, p.k_right))
+    cn, ev = calls.write_snp(pp, two, str(out))
+    assert out.read_bytes() == golden_bytes(case["snp"]) and cn == rec["cluster_nr"]
+    # two shards, the second appended
+    cut = n // 2
+    cn, ev = 1, 0
+    for i, (b, e) in enumerate(((0, cut), (cut, n))):
+        r = fl.scan(p, b, e, capture=True)
+        cn, ev = api.Calls.unpack(_oracle.pack_calls(r, p.k_left, p.k_right)).write_snp(pp, two, str(out), append=i > 0, cluster_nr=cn, events=ev)
+    assert out.read_bytes() == golden_bytes(case["snp"]) and cn == rec["cluster_nr"]
+    # appending to a file that does not exist yet creates it
+    fresh = tmp_path / "fresh.snp"
+    calls.write_snp(pp, two, str(fresh), append=True)
+    assert fresh.read_bytes() == golden_bytes(case["snp"])
+    with pytest.raises(api.EbError, match="cannot open"):
+        calls.write_snp(pp, two, str(tmp_path / "no_such_dir" / "o.snp"))
+
+
 @pytest.mark.parametrize("case", [c for c in CASES if c["name"] in ("m1_default", "m1_edge_default", "m2_het_default", "m3_hom_default")],
                          ids=lambda c: c["name"])
 @pytest.mark.parametrize("shards", [2, 5])
