@@ -71,36 +71,58 @@ def launch_ranks(n_gpus: int) -> int:
     return 0
 
 
+def _child_line(extra, args, timeout=600):
+    """One run of this very script in a child process (after the parent's own line was measured): its JSON line, or {"error": ...}."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__)] + extra + ["--read-len", str(args.read_len), "--coverage", str(args.coverage), "--steps", str(min(args.steps, 10)),
+                                                                "--warmup", str(min(args.warmup, 3)), "--cpu-sample-reads", "0", "--rank-queries", str(min(args.rank_queries, 1 << 20)), "--no-other-modes"]
+    t0 = time.time()
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if os.environ.get("EB_BENCH_TRACE") == "1":
+            log(f"[bench] child {' '.join(extra)}, stderr:\n" + "\n".join("    " + ln[:300] for ln in r.stderr.splitlines() if ln.startswith("[")))
+        if r.returncode != 0 or not lines:
+            return {"error": (r.stderr or r.stdout)[-400:], "returncode": r.returncode}
+        d = json.loads(lines[-1])
+        d["process_seconds"] = round(time.time() - t0, 1)
+        return d
+    except Exception as e:      # noqa: BLE001 -- the headline line must not depend on these
+        return {"error": repr(e)[-400:]}
+
+
+def _digest(d):
+    if "error" in d:
+        return d
+    return {"workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+            "step_roofline_frac": d["step_roofline"]["frac"], "algorithmic_bytes_per_position": d["roofline"]["algorithmic_bytes_per_position"],
+            "scan_ms": d["phase4_device_ms"]["scan"], "extend_ms": d["phase4_device_ms"]["extend"], "right_ms": d["phase4_device_ms"]["right"],
+            "scan_reruns": d["phase4_device_ms"]["scan_reruns"], "batch_tiles": d["phase4_device_ms"]["batch_tiles"],
+            "alone": d["phase4_device_ms"]["alone"], "one_shot_ms": d["one_shot"]["ms"] if d.get("one_shot") else None,
+            "ms_per_step_without_fl_table": d["fl_table"]["ms_per_step_without_it"] if d.get("fl_table") else None,
+            "traversal_seconds": d["phases23_gpu"]["seconds"], "nodes": d["phases23_gpu"]["nodes"], "leaves": d["phases23_gpu"]["leaves"],
+            **({"document_array_packed_from_hbm_seconds": d["phases23_gpu"]["document_array_packed_from_hbm_seconds"]} if "document_array_packed_from_hbm_seconds" in d["phases23_gpu"] else {}),
+            "snp_records": d.get("snp_records"), "snp_sha256": d.get("snp_sha256"), "snp_verified": d.get("snp_verified"), "process_seconds": d.get("process_seconds")}
+
+
 def other_modes(args) -> dict:
     """Modes 2 and 3 (BASELINE configs[2], and configs[3] on this one GPU) through this very script, one child process each, so that
     the driver's default run records them too: the same pipelined steps, fewer of them, no CPU leg; a digest of each child's line."""
-    import subprocess
     out = {"what": "short runs of this script with --mode 2 (two BWTs, --reads as two collections) and --mode 3 (merged BWT + document array, twice "
                    "--reads: BASELINE configs[3] on ONE GPU), child processes started after the line above was measured; digest of their lines"}
     for mode, reads in ((2, args.reads), (3, 2 * args.reads)):
-        cmd = [sys.executable, os.path.abspath(__file__), "--mode", str(mode), "--reads", str(reads), "--read-len", str(args.read_len), "--coverage", str(args.coverage),
-               "--steps", str(min(args.steps, 10)), "--warmup", str(min(args.warmup, 3)), "--cpu-sample-reads", "0", "--rank-queries", str(min(args.rank_queries, 1 << 20))]
-        t0 = time.time()
-        try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-            if os.environ.get("EB_BENCH_TRACE") == "1":
-                log(f"[bench] --mode {mode} child, stderr:\n" + "\n".join("    " + ln[:300] for ln in r.stderr.splitlines() if ln.startswith("[")))
-            if r.returncode != 0 or not lines:
-                out[f"mode{mode}"] = {"error": (r.stderr or r.stdout)[-400:], "returncode": r.returncode}
-                continue
-            d = json.loads(lines[-1])
-            out[f"mode{mode}"] = {"workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
-                                  "step_roofline_frac": d["step_roofline"]["frac"], "algorithmic_bytes_per_position": d["roofline"]["algorithmic_bytes_per_position"],
-                                  "scan_ms": d["phase4_device_ms"]["scan"], "extend_ms": d["phase4_device_ms"]["extend"], "right_ms": d["phase4_device_ms"]["right"],
-                                  "alone": d["phase4_device_ms"]["alone"], "one_shot_ms": d["one_shot"]["ms"] if d.get("one_shot") else None,
-                                  "traversal_seconds": d["phases23_gpu"]["seconds"], "nodes": d["phases23_gpu"]["nodes"], "leaves": d["phases23_gpu"]["leaves"],
-                                  "document_array_packed_from_hbm_seconds": d["phases23_gpu"].get("document_array_packed_from_hbm_seconds"),
-                                  "snp_records": d.get("snp_records"), "snp_sha256": d.get("snp_sha256"), "snp_verified": d.get("snp_verified"),
-                                  "process_seconds": round(time.time() - t0, 1)}
-        except Exception as e:      # noqa: BLE001 -- the headline line must not depend on these
-            out[f"mode{mode}"] = {"error": repr(e)[-400:]}
+        out[f"mode{mode}"] = _digest(_child_line(["--mode", str(mode), "--reads", str(reads)], args))
     return out
+
+
+def realistic_reads(args) -> dict:
+    """The metric's workload with the reference's documented kind of input (README.md:88-100): reads with 1 % substitution errors, and
+    half as many such reads plus their reverse complements -- child processes as in other_modes, each held to the full-size oracle record
+    of its input (profiles/r05_fullsize_config2err.json / config2rc.json) when --reads is the default."""
+    return {"what": "short runs of this script with --error-rate-ppm 10000, and with --reads / 2 --error-rate-ppm 10000 --reverse-complements (the same number of reads in the "
+                    "collection); child processes started after the line above was measured; digest of their lines",
+            "errors_1pct": _digest(_child_line(["--reads", str(args.reads), "--error-rate-ppm", "10000"], args)),
+            "errors_1pct_with_reverse_complements": _digest(_child_line(["--reads", str(args.reads // 2), "--error-rate-ppm", "10000", "--reverse-complements"], args))}
 
 
 def main():
@@ -126,7 +148,8 @@ def main():
                     help="one-GPU rehearsal of ONE rank's share of a W-GPU run: scan range W//2 of W, collectives with a single rank "
                          "(needs EB_BENCH_FORCE_DIST=1); the JSON line is labelled and its value counts the share only")
     ap.add_argument("--no-other-modes", action="store_true", help="default run (mode 1, one GPU): do not append the short runs of modes 2 and 3 "
-                    "(child processes of this script: configs[2], and configs[3] on this one GPU) to the line as `other_modes`")
+                    "(child processes of this script: configs[2], and configs[3] on this one GPU) and of reads with errors / reverse complements to the line "
+                    "as `other_modes` / `realistic_reads`")
     ap.add_argument("--no-pipeline", action="store_true", help="finish every step before the next begins (profiling: under rocprofv3 the "
                     "overlapped record download runs as a blit kernel and slows the scan it overlaps)")
     args = ap.parse_args()
@@ -933,6 +956,7 @@ def main():
         line.update(out)
         if args.mode == 1 and world == 1 and not use_dist and not args.no_other_modes and not realistic and args.rehearse_rank_of <= 1:
             line["other_modes"] = other_modes(args)
+            line["realistic_reads"] = realistic_reads(args)
         print(json.dumps(line), flush=True)
     if arena is not None:
         arena.close()

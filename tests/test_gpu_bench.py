@@ -29,6 +29,10 @@ def test_bench_contract_single_gpu():
         o = d["other_modes"][m]
         assert "error" not in o, o
         assert o["snp_records"] > 500 and o["ms_per_step"] > 0 and o["algorithmic_bytes_per_position"] == 0.875 and f"mode {m[-1]}" in o["workload"]
+    for m in ("errors_1pct", "errors_1pct_with_reverse_complements"):
+        o = d["realistic_reads"][m]
+        assert "error" not in o, o
+        assert o["snp_records"] > 500 and o["ms_per_step"] > 0 and "substitution errors" in o["workload"]
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d
