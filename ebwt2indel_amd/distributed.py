@@ -203,8 +203,14 @@ class NodeArena:
         if pin:
             from . import api
             mine = self._base + 4096 + self.rank * depth * self.slot
-            api._check(api.lib().eb_host_register(mine, depth * self.slot))
-            self._pinned = mine
+            if api.lib().eb_host_register(mine, depth * self.slot) == 0:
+                self._pinned = mine
+            else:
+                # the download then goes through the runtime's own staging (slower, same bytes): a node whose limits on locked
+                # memory refuse the registration still runs
+                import sys
+                print(f"[ebwt2indel] rank {self.rank}: the arena's slots could not be page-locked ({api.lib().eb_last_error().decode()}); downloads into it are staged",
+                      file=sys.stderr, flush=True)
         if self.rank == 0:
             self._u64[0] = 0
         self.step = 0                                 # next step this rank publishes
