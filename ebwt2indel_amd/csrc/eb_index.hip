@@ -440,7 +440,14 @@ static int index_alloc(uint64_t n, uint8_t term, int device, eb_index** out) {
     // the scan never shares a queue with the context kernels it runs beside.  (Rounds 2-4 asked for 16 queues instead: more than 4
     // slows every dispatch -- k_scan alone 171 against 143 us for an eighth of config 2, the ordering kernels 45 + 52 against
     // 12 + 15 us -- and which streams end up on one pipe is then left to chance: profiles/r05_hw_queues.txt.)
-    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    // The index's stream carries the phase-4 scans: the chain every pass of a pipelining caller waits for (scan -> ordering -> next
+    // scan), so its workgroups get their wave slots ahead of the context kernels' (streams of the lowest priority, eb_scan_ctx_create)
+    // when both arrive at once: a rank's eighth 0.345 -> 0.326 ms per pass over 200 passes (the passes right behind a pipeline fill
+    // otherwise fall into a phase where the contexts take the slots first and the scan lasts 0.35 instead of 0.25 ms); the whole range
+    // is indifferent (profiles/r05_rank_share.txt).
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi); // (hi: numerically smallest = highest priority)
+    hipError_t e = hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_hi);
     if (e == hipSuccess && eb_scan_ctx_create(h) != EB_OK) e = hipErrorOutOfMemory;
     if (e == hipSuccess) e = hipMalloc(&h->d_chunks, h->n_blocks * 64);
     if (e == hipSuccess) e = hipMalloc(&h->d_super, h->n_super * 4 * sizeof(uint64_t));

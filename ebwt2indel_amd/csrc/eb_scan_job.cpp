@@ -129,8 +129,10 @@ int eb_scan_ctx_create(eb_index* b1) {
     if (b1->scan_ctx) return EB_OK;
     eb_scan_ctx* ctx = new eb_scan_ctx();
     b1->scan_ctx = ctx;
-    EB_HIP(hipStreamCreateWithFlags(&ctx->ctx, hipStreamNonBlocking));
-    EB_HIP(hipStreamCreateWithFlags(&ctx->right, hipStreamNonBlocking));
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi); // lo: numerically greatest = lowest priority (the scan's stream has the highest: index_alloc)
+    EB_HIP(hipStreamCreateWithPriority(&ctx->ctx, hipStreamNonBlocking, prio_lo));
+    EB_HIP(hipStreamCreateWithPriority(&ctx->right, hipStreamNonBlocking, prio_lo));
     EB_HIP(hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking));
     EB_HIP(hipEventCreateWithFlags(&ctx->last_ctx, hipEventDisableTiming));
     EB_HIP(hipEventRecord(ctx->last_ctx, ctx->ctx));
@@ -262,6 +264,8 @@ int enqueue_ordered(eb_scan_job* job, bool* fits) {
     // The ordering step follows the scan on ITS stream, ahead of the previous job's context kernels still queued on the context
     // stream.  (Round 5, a rank's eighth: on the context stream -- the scan stream free for the next scan 45 us earlier -- the pass
     // takes 0.40 ms instead of 0.33: the ordering then queues behind the previous job's extension.)
+    // (A stream of its own for the ordering step -- the next scan then no longer queues behind it -- or the copy stream: no gain,
+    // 0.345 / 0.401 against 0.344 ms, profiles/r05_rank_share.txt.)
     const hipStream_t so = st;
     eb_launch_order(so, job->x1, job->x2, job->df, q, job->slots.as<Survivor>(), bcount, job->n_batches, job->kept.as<uint32_t>(), cnt, job->lw, job->rw,
                     job->blob.as<uint8_t>(), job->report, job->sorted.as<Survivor>(), job->choff.as<uint32_t>(), job->chains.as<uint64_t>());
