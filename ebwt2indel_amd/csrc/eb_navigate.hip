@@ -9,12 +9,9 @@
 // the top keeps the footprint of a depth-first walk; a batch of millions keeps HBM busy with
 // independent 64-byte block reads.  Bit writes are atomicOr on 64-bit words and are skipped when
 // the value is 0 (vectors start zeroed), i.e. for records shallower than K / k_right.
-#include <fcntl.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include <sys/stat.h>
-#include <unistd.h>
 
 #include <chrono>
 #include <string>
@@ -23,1199 +20,12 @@
 
 #include "eb_config.h"
 #include "eb_internal.h"
-#include "eb_pieces.h"
+
+#include "eb_nav_common.h"
+#include "eb_nav_one.h"
+#include "eb_nav_two.h"
 
 namespace {
-
-// Records are padded to a multiple of 16 bytes so that lanes move them as uint4.
-struct alignas(16) Leaf1 { uint64_t l, r, depth, pad; };                              // sa_leaf (include.hpp:513-527)
-struct alignas(16) Node1 { uint64_t b[6]; uint64_t depth, pad; };                     // sa_node (include.hpp:394-413)
-struct alignas(16) Leaf2 { uint64_t l1, r1, l2, r2, depth, pad[3]; };                 // pair<sa_leaf,sa_leaf>
-struct alignas(16) Node2 { uint64_t a[6]; uint64_t b[6]; uint64_t depth, pad[3]; };   // pair<sa_node,sa_node>
-
-// Records travel through the stacks packed: NF 40-bit positions (n < 2^40, checked by the host) and a 16-bit depth that
-// saturates -- the depth is only ever compared with K and k_right (< 65535, checked by the host).  A one-BWT node is
-// 32 bytes instead of 64, a two-BWT node 64 instead of 128, a two-BWT leaf 32 instead of 64: half the record traffic of
-// the traversal and twice the records per arena.
-template <int NF>
-struct alignas(16) Packed { uint64_t w[((NF * 40 + 16 + 127) / 128) * 2]; };
-template <int NF>
-__host__ __device__ __forceinline__ Packed<NF> pack_fields(const uint64_t* f, uint64_t depth) {
-    static_assert(((NF * 40) & 63) <= 48, "the depth must not straddle two words");
-    Packed<NF> p;
-    for (uint64_t& x : p.w) x = 0;
-#pragma unroll
-    for (int k = 0; k < NF; ++k) {
-        const int off = 40 * k, wd = off >> 6, sh = off & 63;
-        const uint64_t v = f[k] & ((1ull << 40) - 1ull);
-        p.w[wd] |= v << sh;
-        if (sh > 24) p.w[wd + 1] |= v >> (64 - sh);
-    }
-    p.w[(NF * 40) >> 6] |= (depth > 0xFFFFull ? 0xFFFFull : depth) << ((NF * 40) & 63);
-    return p;
-}
-template <int NF>
-__host__ __device__ __forceinline__ uint64_t unpack_fields(const Packed<NF>& p, uint64_t* f) {
-#pragma unroll
-    for (int k = 0; k < NF; ++k) {
-        const int off = 40 * k, wd = off >> 6, sh = off & 63;
-        uint64_t v = p.w[wd] >> sh;
-        if (sh > 24) v |= p.w[wd + 1] << (64 - sh);
-        f[k] = v & ((1ull << 40) - 1ull);
-    }
-    return (p.w[(NF * 40) >> 6] >> ((NF * 40) & 63)) & 0xFFFFull;
-}
-using Node1P = Packed<6>;
-using Node2P = Packed<12>;
-using Leaf2P = Packed<4>;
-static_assert(sizeof(Node1P) == 32 && sizeof(Node2P) == 64 && sizeof(Leaf2P) == 32, "packed record sizes");
-__host__ __device__ __forceinline__ Node1P pack_rec(const Node1& n) { return pack_fields<6>(n.b, n.depth); }
-__host__ __device__ __forceinline__ Node2P pack_rec(const Node2& n) { return pack_fields<12>(n.a, n.depth); }   // a[6] and b[6] are contiguous
-__host__ __device__ __forceinline__ Leaf2P pack_rec(const Leaf2& l) { return pack_fields<4>(&l.l1, l.depth); }
-__host__ __device__ __forceinline__ const Leaf1& pack_rec(const Leaf1& l) { return l; }                            // 32 bytes as it is
-__host__ __device__ __forceinline__ void unpack_rec(const Node1P& p, Node1& n) { n.depth = unpack_fields<6>(p, n.b); n.pad = 0; }
-__host__ __device__ __forceinline__ void unpack_rec(const Node2P& p, Node2& n) { n.depth = unpack_fields<12>(p, n.a); n.pad[0] = n.pad[1] = n.pad[2] = 0; }
-__host__ __device__ __forceinline__ void unpack_rec(const Leaf2P& p, Leaf2& l) { l.depth = unpack_fields<4>(p, &l.l1); l.pad[0] = l.pad[1] = l.pad[2] = 0; }
-__host__ __device__ __forceinline__ void unpack_rec(const Leaf1& p, Leaf1& l) { l = p; }
-
-struct NavCounters {
-    unsigned long long pushed;     // children appended by the current launch
-    unsigned long long pad0[7];    // keep the hot word on its own 64-byte line
-    unsigned long long taken;      // k_nodes1c: input records handed out so far by the current launch (reset with `pushed`)
-    unsigned long long pad1[7];
-    unsigned long long leaves, nodes, lcp_values, da_values, minima, ranks, pos_sum, pos_sq_sum;
-};
-
-struct NavParams {
-    int K, k_right;
-    int write;     // 0: expand only (the shared top of the tree on shards other than 0): no bit writes, no statistics
-    uint8_t* lcpb; // one byte per position (bit 0: LCP >= K, bit 1: LCP >= k_right) or null -> interleaved bit words `kr`
-    // below != 0: the COMPLEMENT is collected -- a writer marks its positions iff its depth is BELOW the threshold, and the
-    // vectors are inverted once at the end.  Every position 1..n-1 has exactly one writer (a node border or a leaf
-    // interior; lcp_values reaches n, ebwt2InDel.cpp:617,670) and with reads of 100+ bases nearly all writers lie deeper
-    // than K and k_right: marking the few shallow ones instead of the many deep ones removes ~95 % of the scattered
-    // stores of the traversal (phases 2-3 at 7.55 G positions: 0.58 -> 0.47 s).
-    int below;
-#ifdef EB_SCAN_EXPERIMENTS
-    uint32_t dbg;  // EB_NAV_DEBUG (profiling build only; results are wrong): 1 no LCP stores, 2 no minima, 4 children not appended below depth 40, 8 no DA bits of singleton rows (two BWTs; phase 4 then refuses the flags)
-#endif
-};
-#ifdef EB_SCAN_EXPERIMENTS
-#define EB_NDBG(p) ((p).dbg)
-#else
-#define EB_NDBG(p) 0u
-#endif
-
-// What one expansion launch works on.  It lives in DEVICE memory and is written by k_plan (below), so that the host can enqueue
-// several launches back to back without knowing how many children the previous one pushed.
-struct NavLaunch {
-    const void* in;    // `count` records, popped from the top of the source stack (expanded where they lie)
-    uint64_t count;
-    void* out;         // children are appended here through NavCounters::pushed ...
-    uint64_t out_cap;  // ... up to this many
-    int32_t write;     // 0: expand only (the shared top of the tree on shards other than 0): no bit writes, no statistics
-    int32_t follow;    // k_nodes1c: 1 = a node's first kept child is expanded by the same quad instead of being pushed (0 while a
-                       // sharded traversal still walks level by level towards its cut)
-};
-
-// Power sums of the LCP positions written, modulo 2^64 (eb_nav_stats.lcp_pos_sum / lcp_pos_sq_sum).  The count alone
-// (lcp_values == n) cannot tell "every position 1..n-1 once" from "one twice, one never" -- which the complement form of the
-// thresholds would turn into a wrong bit, and atomicOr hides duplicates -- while sum and sum of squares do (round-2 advisor
-// finding).  Ranges (leaf interiors) use the closed forms: tri(x) = sum of i < x, sq(x) = sum of i^2 < x.
-__host__ __device__ __forceinline__ uint64_t eb_tri(uint64_t x) { return (x & 1ull) ? x * ((x - 1) >> 1) : (x >> 1) * (x - 1); }
-__host__ __device__ __forceinline__ uint64_t eb_sq(uint64_t x) {
-    // (x-1) x (2x-1) / 6: the halving is exact on one factor; the product is a multiple of 3, and 3 is invertible modulo 2^64
-    return eb_tri(x) * (2 * x - 1) * 0xAAAAAAAAAAAAAAABull;
-}
-
-__device__ __forceinline__ uint64_t wave_sum(uint64_t v) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor((unsigned long long)v, o);
-    return v;
-}
-
-// Statistics: every workgroup owns one row of counters in HBM and adds its totals with plain read-modify-writes
-// (launches are sequential; rows are summed on the host at the end) -- no per-wave atomics on shared words.
-#define EB_NAV_STATS 8 /* leaves, nodes, lcp_values, da_values, minima, ranks, sum of the LCP positions written, sum of their squares */
-__device__ __forceinline__ void flush_stats(unsigned long long* rows, const uint64_t* v /* EB_NAV_STATS values of this lane */) {
-    __shared__ unsigned long long sh[EB_NAV_STATS][4];
-    for (int k = 0; k < EB_NAV_STATS; ++k) {
-        uint64_t s = wave_sum(v[k]);
-        if ((threadIdx.x & 63u) == 0) sh[k][threadIdx.x >> 6] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x < EB_NAV_STATS) {
-        unsigned long long* p = rows + (uint64_t)blockIdx.x * EB_NAV_STATS + threadIdx.x;
-        *p += sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
-    }
-}
-
-__device__ __forceinline__ uint64_t pick4(const uint64_t* F, uint32_t c) { return c == 0 ? F[0] : c == 1 ? F[1] : c == 2 ? F[2] : F[3]; }
-
-// ---- phase 2: leaves.  update_LCP_leaf (ebwt2InDel.cpp:344-355) / update_DA (:394-425) and next_leaves
-// (dna_bwt.hpp:358-379; two BWTs: ebwt2InDel.cpp:452-472).  Four lanes per leaf: lane j owns letter j --
-// it loads the j-th chunk of each rank query and builds the child leaf obtained by prepending "ACGT"[j].
-template <int NB>
-__global__ void __launch_bounds__(256) k_leaves(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, uint64_t* __restrict__ kr, NavParams p,
-                                               const NavLaunch* __restrict__ la, NavCounters* cnt, unsigned long long* __restrict__ stat_rows) {
-    using Leaf = typename std::conditional<NB == 1, Leaf1, Leaf2>::type;
-    using Rec = typename std::conditional<NB == 1, Leaf1, Leaf2P>::type; // the record as it lies in the stacks
-    constexpr int STAGE = 1024;
-    const void* in_ = la->in;
-    void* out_ = la->out;
-    const uint64_t count = la->count, out_cap = la->out_cap;
-    p.write = la->write;
-    if ((uint64_t)blockIdx.x * 64 >= count) return; // the grid is sized for a full batch: nothing for this workgroup (uniform)
-    __shared__ uint4 s_buf[STAGE * (sizeof(Rec) / 16)];
-    __shared__ uint32_t s_count;
-    __shared__ unsigned long long s_base;
-    Stager<Rec, STAGE> stage{s_buf, &s_count, &s_base};
-    if (threadIdx.x == 0) s_count = 0;
-    __syncthreads();
-    const Rec* in = static_cast<const Rec*>(in_);
-    Rec* out = static_cast<Rec*>(out_);
-    const uint32_t j = threadIdx.x & 3u, q = threadIdx.x >> 2;
-    uint64_t n_leaf = 0, n_lcp = 0, n_da = 0, n_rank = 0, n_s1 = 0, n_s2 = 0;
-    const uint64_t tiles = (count + 63) / 64;
-    uint32_t trips = 0;
-    for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        uint64_t i = tile * 64 + q;
-        bool active = i < count;
-        Leaf L;
-        memset(&L, 0, sizeof L);
-        if (active) unpack_rec(eb_load_global(in + i), L);
-        Leaf child;
-        memset(&child, 0, sizeof child);
-        bool keep = false;
-        if constexpr (NB == 1) {
-            uint64_t a = eb_rank4_quad(x1, L.l, j);
-            uint64_t b = eb_rank4_quad(x1, L.r > L.l ? L.r : L.l, j);
-            uint64_t Fj = pick4(x1.F, j);
-            child.l = Fj + a; child.r = Fj + b; child.depth = L.depth + 1;
-            keep = active && (b - a >= 2);
-            if (active && p.write && L.r > L.l + 1) {
-                // LCP slots l+1 .. r-1 of the leaf: the quad splits the touched words
-                uint64_t lo = L.l + 1, hi = L.r;
-                bool setK = ((int64_t)L.depth >= p.K) != (p.below != 0), setR = ((int64_t)L.depth >= p.k_right) != (p.below != 0);
-                if ((setK || setR) && p.lcpb) {
-                    uint8_t v = (uint8_t)((setK ? 1 : 0) | (setR ? 2 : 0));
-                    for (uint64_t i2 = lo + j; i2 < hi; i2 += 4) p.lcpb[i2] = v; // every position has one writer: plain byte stores
-                } else if (setK || setR) {
-                    uint64_t w0 = lo >> 6, w1 = (hi - 1) >> 6;
-                    for (uint64_t w = w0 + j; w <= w1; w += 4) {
-                        uint64_t m = ~0ull;
-                        if (w == w0) m &= ~0ull << (lo & 63u);
-                        if (w == w1) m &= ~0ull >> (63u - ((hi - 1) & 63u));
-                        if (setK) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * w), m);
-                        if (setR) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * w + 1), m);
-                    }
-                }
-                if (j == 0) { n_lcp += hi - lo; n_s1 += eb_tri(hi) - eb_tri(lo); n_s2 += eb_sq(hi) - eb_sq(lo); }
-            }
-            if (active && p.write && j == 0) { ++n_leaf; n_rank += L.r > L.l ? 2 : 1; }
-        } else {
-            uint64_t a1 = eb_rank4_quad(x1, L.l1, j), b1 = eb_rank4_quad(x1, L.r1 > L.l1 ? L.r1 : L.l1, j);
-            uint64_t a2 = eb_rank4_quad(x2, L.l2, j), b2 = eb_rank4_quad(x2, L.r2 > L.l2 ? L.r2 : L.l2, j);
-            uint64_t F1 = pick4(x1.F, j), F2 = pick4(x2.F, j);
-            child.l1 = F1 + a1; child.r1 = F1 + b1; child.l2 = F2 + a2; child.r2 = F2 + b2; child.depth = L.depth + 1;
-            keep = active && ((b1 - a1) + (b2 - a2) >= 2);
-            if (active && p.write) {
-                uint64_t s1 = L.l1 + L.l2, s2 = L.l2 + L.r1, e = L.r1 + L.r2;
-                bool setK = ((int64_t)L.depth >= p.K) != (p.below != 0), setR = ((int64_t)L.depth >= p.k_right) != (p.below != 0);
-                // words of [s1, e): DA = 1 on [s2,e) (second collection), LCP bits on [s1+1, e)
-                uint64_t w0 = s1 >> 6, w1 = e > s1 ? (e - 1) >> 6 : w0;
-                for (uint64_t w = w0 + j; w <= w1 && e > s1; w += 4) {
-                    uint64_t base = w << 6;
-                    auto span = [&](uint64_t lo, uint64_t hi) -> uint64_t { // bits of word w inside [lo,hi)
-                        if (hi <= lo || hi <= base || lo >= base + 64) return 0ull;
-                        uint64_t m = ~0ull;
-                        if (lo > base) m &= ~0ull << (lo - base);
-                        if (hi < base + 64) m &= ~0ull >> (base + 64 - hi);
-                        return m;
-                    };
-                    uint64_t md = span(s2, e), ml = span(s1 + 1, e);
-                    if (md) atomicOr(reinterpret_cast<unsigned long long*>(f.da + w), md);
-                    if (!p.lcpb) {
-                        if (ml && setK) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * w), ml);
-                        if (ml && setR) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * w + 1), ml);
-                    }
-                }
-                if (p.lcpb && (setK || setR)) {
-                    uint8_t v = (uint8_t)((setK ? 1 : 0) | (setR ? 2 : 0));
-                    for (uint64_t i2 = s1 + 1 + j; i2 < e; i2 += 4) p.lcpb[i2] = v;
-                }
-                if (j == 0) {
-                    ++n_leaf;
-                    n_da += e - s1;
-                    if (e > s1 + 1) { n_lcp += e - s1 - 1; n_s1 += eb_tri(e) - eb_tri(s1 + 1); n_s2 += eb_sq(e) - eb_sq(s1 + 1); }
-                    n_rank += (L.r1 > L.l1 ? 2 : 1) + (L.r2 > L.l2 ? 2 : 1);
-                }
-            }
-        }
-        stage.push(keep, pack_rec(child));
-        // every tile adds at most 256 records: flushing every STAGE/256 tiles never overflows the buffer, and the
-        // decision is the same in every thread without looking at shared state
-        if (++trips % (STAGE / 256) == 0) stage.flush(out, out_cap, &cnt->pushed);
-    }
-    stage.flush(out, out_cap, &cnt->pushed);
-    const uint64_t st[EB_NAV_STATS] = {n_leaf, 0, n_lcp, n_da, 0, n_rank, n_s1, n_s2};
-    flush_stats(stat_rows, st);
-}
-
-// ---- phase 3, one BWT, software-pipelined (round 3).  One node per quad and trip (four lanes per node: lane j loads the j-th chunk
-// of the six boundary blocks, owns letter j -- the Weiner-link child "ACGT"[j] + W -- and writes border j's LCP / minimum bits), and the
-// memory operations of the NEXT trips are under way while a trip is worked on:
-//   stage A  the record of trip t+1 (loaded during trip t-1) is unpacked; its LCP / minimum bits are set at once -- they
-//            depend on the record alone (borders and depth), not on any rank -- and its six block loads are issued;
-//   stage C  the record of trip t+2 is requested;
-//   stage D  trip t: its six blocks have landed meanwhile (vector-memory operations complete in issue order, so the wait for
-//            record t+1 in stage A covered them); ranks, the four Weiner-link children, staging.
-// k_nodes issued the record load, waited, issued the block loads, waited, computed: two exposed memory latencies per trip with
-// three waves per SIMD to cover them (49 KB of staging per workgroup), ~6.8 us per trip for ~1 us of arithmetic.  Here the only
-// vector-memory operations inside stage D are the staging flush's, so nothing in D waits for the loads issued in A / C.  The
-// superblock table (a global load per rank in eb_rank4_quad_finish) is read from LDS for that reason.
-#define EB_NAV_SUPER_LDS 40 /* superblocks held in LDS (n <= 171 G symbols); beyond that the table is read from memory */
-template <bool SUPER_LDS> // the superblock table fits EB_NAV_SUPER_LDS entries of LDS (a select between an LDS and a global address would become flat loads)
-__global__ void __launch_bounds__(256) k_nodes1p(eb_dev_index x1, eb_dev_flags f, uint64_t* __restrict__ kr, NavParams p, const NavLaunch* __restrict__ la,
-                                                NavCounters* cnt, unsigned long long* __restrict__ stat_rows) {
-    using Rec = Node1P;
-    constexpr int STAGE = 1536;
-    __shared__ uint4 s_buf[STAGE * (sizeof(Rec) / 16)];
-    __shared__ uint32_t s_count;
-    __shared__ unsigned long long s_base;
-    __shared__ unsigned long long s_super[EB_NAV_SUPER_LDS * 4];
-    const Rec* __restrict__ in = static_cast<const Rec*>(la->in);
-    Rec* out = static_cast<Rec*>(la->out);
-    const uint64_t count = la->count, out_cap = la->out_cap;
-    p.write = la->write;
-    const uint64_t tiles = (count + 63) / 64;
-    if ((uint64_t)blockIdx.x >= tiles) return; // the grid is sized for a full batch: nothing for this workgroup (uniform)
-    Stager<Rec, STAGE> stage{s_buf, &s_count, &s_base};
-    if (SUPER_LDS) {
-        const uint64_t n_super = (x1.n >> EB_SUPER_SHIFT) + 1;
-        for (uint32_t k = threadIdx.x; k < n_super * 4; k += blockDim.x) s_super[k] = x1.super[k];
-    }
-    if (threadIdx.x == 0) s_count = 0;
-    __syncthreads();
-    const uint32_t j = threadIdx.x & 3u, q = threadIdx.x >> 2;
-    const uint64_t G = gridDim.x;
-    uint64_t n_node = 0, n_lcp = 0, n_rank = 0, n_min = 0, n_s1 = 0, n_s2 = 0;
-    const uint64_t Fj = pick4(x1.F, j);
-
-    auto load_rec = [&](uint64_t tile) -> Rec {
-        Rec r;
-        r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0;
-        const uint64_t i = tile * 64 + q;
-        if (tile < tiles && i < count) r = eb_load_global(in + i);
-        return r;
-    };
-    // stage A for one record: border bits (update_lcp_threshold include.hpp:826-860, update_lcp_minima ebwt2InDel.cpp:357-391)
-    auto mark = [&](const Node1& N) {
-        uint64_t lo = 0, hi = 0;
-        for (int k = 0; k < 4; ++k) if (j == (uint32_t)k) { lo = N.b[k]; hi = N.b[k + 1]; }
-        if (hi > lo && hi != N.b[5]) {
-            const bool setK = ((int64_t)N.depth >= p.K) != (p.below != 0), setR = ((int64_t)N.depth >= p.k_right) != (p.below != 0);
-            if (p.lcpb) {
-                uint8_t v = (uint8_t)((setK ? 1 : 0) | (setR ? 2 : 0));
-                if (v && !(EB_NDBG(p) & 1u)) p.lcpb[hi] = v;
-            } else {
-                if (setK) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * (hi >> 6)), 1ull << (hi & 63u));
-                if (setR) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * (hi >> 6) + 1), 1ull << (hi & 63u));
-            }
-            ++n_lcp;
-            n_s1 += hi;
-            n_s2 += hi * hi;
-        }
-        if (j >= 1 && hi - lo >= 2 && hi < N.b[5] - 1) {
-            if (!(EB_NDBG(p) & 2u)) eb_bit_set_atomic(f.minima, hi);
-            ++n_min;
-        }
-    };
-
-    uint64_t tile = blockIdx.x;
-    Node1 Nn;          // the node of the next trip (stage A done)
-    uint4 cn[6];       // its six blocks, in flight
-    bool act_n;
-    {
-        Rec r0 = load_rec(tile);
-        unpack_rec(r0, Nn);
-        act_n = tile * 64 + q < count;
-        if (act_n && p.write) mark(Nn);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) cn[k] = eb_rank4_quad_load(x1, Nn.b[k], j);
-    }
-    Rec rr = load_rec(tile + G); // stage C of the prologue
-    uint32_t trips = 0;
-    for (; tile < tiles; tile += G) {
-        const Node1 Nc = Nn;
-        const bool act_c = act_n;
-        uint4 cc[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) cc[k] = cn[k];
-        // stage A: the next trip's record -> node, border bits, block loads
-        unpack_rec(rr, Nn);
-        act_n = tile + G < tiles && (tile + G) * 64 + q < count;
-        if (act_n && p.write) mark(Nn);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) cn[k] = eb_rank4_quad_load(x1, Nn.b[k], j);
-        // stage C: the record after that
-        rr = load_rec(tile + 2 * G);
-        // stage D: this trip's ranks and children (LF(sa_node) dna_bwt.hpp:323-356, next_nodes :381-404)
-        Node1 child;
-        child.pad = 0;
-        int kids = 0;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const uint64_t i = Nc.b[k];
-            uint32_t pc = eb_chunk_counts(cc[k], eb_prefix_mask32((uint32_t)(i & 127u), j));
-            pc = eb_quad_sum(pc);
-            uint64_t sup;
-            if constexpr (SUPER_LDS) sup = s_super[((i >> EB_SUPER_SHIFT) << 2) + j];
-            else sup = x1.super[((i >> EB_SUPER_SHIFT) << 2) + j];
-            child.b[k] = Fj + sup + cc[k].w + ((pc >> (8u * j)) & 0xFFu);
-        }
-        for (int k = 0; k < 5; ++k) kids += child.b[k + 1] > child.b[k];
-        child.depth = Nc.depth + 1;
-        const bool keep = act_c && kids >= 2; // number_of_children (include.hpp:760-768)
-        if (act_c && p.write && j == 0) {
-            ++n_node;
-            n_rank += 1;
-            for (int k = 1; k < 6; ++k) n_rank += Nc.b[k] != Nc.b[k - 1]; // the reference shares the query of equal neighbours
-        }
-        stage.push(keep, pack_rec(child));
-        // every trip adds at most 256 records: flushing every STAGE / 256 trips never overflows the buffer, and the decision is
-        // the same in every thread without looking at shared state
-        if (++trips % (STAGE / 256) == 0) stage.flush(out, out_cap, &cnt->pushed);
-    }
-    stage.flush(out, out_cap, &cnt->pushed);
-    const uint64_t st[EB_NAV_STATS] = {0, n_node, n_lcp, 0, n_min, n_rank, n_s1, n_s2};
-    flush_stats(stat_rows, st);
-}
-
-// ---- pieces shared by the chain-following kernels (k_nodes1c, k_leaves1c, k_nodes2c, k_leaves2c)
-// The launch's input records are handed out through a cursor (NavCounters::taken): a wave takes a chunk with ONE returning atomic,
-// its quads take records from the chunk as their chains end.  Everything here is wave-uniform except `want` / `idx`.
-struct NavCursor {
-    uint64_t next = 0, end = 0; // this wave's chunk
-    uint64_t chunk, count;
-    bool dry = false;           // the input is used up
-    // records per chunk: 16 (one per quad) for small launches, up to 256
-    __device__ __forceinline__ NavCursor(uint64_t count_, uint32_t grid) : count(count_) {
-        const uint64_t waves = (count + 15) / 16 < (uint64_t)grid * 4 ? (count + 15) / 16 : (uint64_t)grid * 4;
-        chunk = count / (waves * 4);
-        chunk = chunk < 16 ? 16 : (chunk > 256 ? 256 : chunk);
-    }
-    // hands input records to the quads that ask for one (`want`, the same in the four lanes of a quad): idx = the record's index,
-    // want stays set where the input ran out
-    __device__ __forceinline__ void take(NavCounters* cnt, bool& want, uint64_t& idx, uint32_t j, uint32_t lane) {
-        for (;;) {
-            const unsigned long long m = __ballot(want && j == 0);
-            if (!m || dry) break;
-            if (next == end) {
-                unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(&cnt->taken, (unsigned long long)chunk);
-                base = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
-                next = base < count ? base : count;
-                end = base + chunk < count ? base + chunk : count;
-                if (next == end) { dry = true; break; }
-            }
-            const uint64_t avail = end - next;
-            const uint32_t rank = (uint32_t)__popcll(m & ((1ull << (lane & ~3u)) - 1ull)); // askers in the quads below this one
-            if (want && rank < avail) { idx = next + rank; want = false; }
-            const uint64_t asked = (uint64_t)__popcll(m);
-            next += asked < avail ? asked : avail;
-        }
-    }
-};
-// A kept child that does not continue in registers: into the small staging buffer, or -- buffer full: the bushy top of the tree --
-// straight to the stack with an atomic of its own.  `make()` packs the record; it is called only when some lane of the wave pushes.
-template <typename Rec, int STAGE, typename Make>
-__device__ __forceinline__ void nav_push_or_spill(bool px, Make make, uint4* s_buf, uint32_t* s_count, Rec* out, uint64_t out_cap, NavCounters* cnt, uint32_t lane) {
-    const unsigned long long pm = __ballot(px);
-    if (!pm) return; // (uniform; most turns nobody pushes)
-    const Rec rec = make();
-    uint32_t wbase = 0;
-    if (lane == 0) wbase = atomicAdd(s_count, (uint32_t)__popcll(pm));
-    wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
-    if (px) {
-        constexpr int W = sizeof(Rec) / 16;
-        const uint32_t slot = wbase + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
-        const uint4* src = reinterpret_cast<const uint4*>(&rec);
-        if (slot < (uint32_t)STAGE) {
-            for (int q = 0; q < W; ++q) s_buf[slot * W + q] = src[q];
-        } else {
-            const unsigned long long g = atomicAdd(&cnt->pushed, 1ull);
-            if (g < out_cap)
-                for (int q = 0; q < W; ++q) eb_store_global(reinterpret_cast<uint4*>(out) + g * W + q, src[q]);
-        }
-    }
-}
-// End of a round of turns: the staging buffer is emptied, and the workgroup goes on while any of its waves has work.
-template <typename Rec, int STAGE>
-__device__ __forceinline__ bool nav_round_end(Stager<Rec, STAGE>& stage, uint32_t* s_count, int* s_alive, Rec* out, uint64_t out_cap, NavCounters* cnt, bool wave_has_work, uint32_t lane) {
-    __syncthreads();
-    if (threadIdx.x == 0 && *s_count > (uint32_t)STAGE) *s_count = STAGE; // (the excess went straight to the stack)
-    stage.flush(out, out_cap, &cnt->pushed);
-    if (threadIdx.x == 0) *s_alive = 0;
-    __syncthreads();
-    if (lane == 0 && wave_has_work) *s_alive = 1;
-    __syncthreads();
-    const int go_on = *s_alive;
-    __syncthreads(); // (nobody resets the flag before everybody has read it)
-    return go_on != 0;
-}
-
-// ---- phase 3, one BWT, CHAINS FOLLOWED IN REGISTERS (round 4).  The suffix tree of a read collection is mostly unary under Weiner
-// links: W is right-maximal because some read ends behind it ('#') while the others go on with one letter, and the same holds for
-// cW, c'cW, ... until the reads run out -- ~135 nodes in a row whose only kept child is the next one (6.1 G nodes, ~50 M such
-// chains at 7.55 G positions).  k_nodes1p sends every one of them through the stack: 32 bytes written, 32 read, packed, staged,
-// unpacked.  Here a quad KEEPS the first kept child of its node -- lane jc's six boundaries are spread over the quad by DPP -- and
-// expands it in its next turn; only the other kept children (one node in a hundred has any) go to the stack, and a quad takes a
-// new record from the launch's input only when its chain ends.  A quad runs TWO chains alternately, so that the block loads of
-// one are in flight while the other computes (the distance k_nodes1p keeps between its stages A and D), plus one input record
-// fetched ahead.  Input records are handed out through a cursor (NavCounters::taken): a wave takes a chunk with one atomic, its
-// quads take records from the chunk as their chains end.  Same bits, same counters: every node is still expanded exactly once.
-// A launch may now push more than four records per input record; the planner's room rule no longer bounds that, so an overflow
-// (never seen: the whole traversal pushes fewer records than ONE stack holds) ends the traversal with an error and the caller
-// walks again with k_nodes1p (flags_build_chains).
-template <bool SUPER_LDS>
-__global__ void __launch_bounds__(256) k_nodes1c(eb_dev_index x1, eb_dev_flags f, uint64_t* __restrict__ kr, NavParams p, const NavLaunch* __restrict__ la,
-                                                NavCounters* cnt, unsigned long long* __restrict__ stat_rows) {
-    using Rec = Node1P;
-    // Pushes are rare here (one node in a hundred has a second kept child), so the staging buffer is small -- the 48 KB of k_nodes1p
-    // would keep the leaf traversal, which runs side by side, off the CUs for the whole of these long launches -- and a record that
-    // finds it full (the bushy top of the tree) goes straight to the stack with an atomic of its own.
-    constexpr int STAGE = 256;
-    __shared__ uint4 s_buf[STAGE * (sizeof(Rec) / 16)];
-    __shared__ uint32_t s_count;
-    __shared__ unsigned long long s_base;
-    __shared__ unsigned long long s_super[EB_NAV_SUPER_LDS * 4];
-    __shared__ int s_alive;
-    const Rec* __restrict__ in = static_cast<const Rec*>(la->in);
-    Rec* out = static_cast<Rec*>(la->out);
-    const uint64_t count = la->count, out_cap = la->out_cap;
-    p.write = la->write;
-    const bool follow = la->follow != 0;
-    if ((uint64_t)blockIdx.x * 64 >= count) return; // the grid is sized for a full batch: nothing for this workgroup (uniform)
-    Stager<Rec, STAGE> stage{s_buf, &s_count, &s_base};
-    if (SUPER_LDS) {
-        const uint64_t n_super = (x1.n >> EB_SUPER_SHIFT) + 1;
-        for (uint32_t k = threadIdx.x; k < n_super * 4; k += blockDim.x) s_super[k] = x1.super[k];
-    }
-    if (threadIdx.x == 0) { s_count = 0; s_alive = 0; }
-    __syncthreads();
-    const uint32_t j = threadIdx.x & 3u, lane = threadIdx.x & 63u;
-    uint64_t n_node = 0, n_lcp = 0, n_rank = 0, n_min = 0, n_s1 = 0, n_s2 = 0;
-    const uint64_t Fj = pick4(x1.F, j);
-    NavCursor cursor(count, gridDim.x);
-
-    // border bits of a node (update_lcp_threshold include.hpp:826-860, update_lcp_minima ebwt2InDel.cpp:357-391), as in k_nodes1p
-    auto mark = [&](const Node1& N) {
-        uint64_t lo = 0, hi = 0;
-        for (int k = 0; k < 4; ++k) if (j == (uint32_t)k) { lo = N.b[k]; hi = N.b[k + 1]; }
-        if (hi > lo && hi != N.b[5]) {
-            const bool setK = ((int64_t)N.depth >= p.K) != (p.below != 0), setR = ((int64_t)N.depth >= p.k_right) != (p.below != 0);
-            if (p.lcpb) {
-                uint8_t v = (uint8_t)((setK ? 1 : 0) | (setR ? 2 : 0));
-                if (v && !(EB_NDBG(p) & 1u)) p.lcpb[hi] = v;
-            } else {
-                if (setK) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * (hi >> 6)), 1ull << (hi & 63u));
-                if (setR) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * (hi >> 6) + 1), 1ull << (hi & 63u));
-            }
-            ++n_lcp;
-            n_s1 += hi;
-            n_s2 += hi * hi;
-        }
-        if (j >= 1 && hi - lo >= 2 && hi < N.b[5] - 1) {
-            if (!(EB_NDBG(p) & 2u)) eb_bit_set_atomic(f.minima, hi);
-            ++n_min;
-        }
-    };
-
-    // ---- two chains per quad + one record fetched ahead
-    Node1 N0, N1;
-    uint4 c0[6], c1[6];
-    bool act0 = false, act1 = false, have_spare = false;
-    Rec spare;
-    spare.w[0] = spare.w[1] = spare.w[2] = spare.w[3] = 0;
-    // the block loads of a node's six boundaries (consumed in its chain's next turn)
-    auto load6 = [&](const Node1& N, uint4 (&c)[6], bool act) {
-        // (Round 5: letting a boundary in the block of its left neighbour take that neighbour's chunk -- most of a unary node's six
-        // boundaries coincide -- is SLOWER, 0.35 against 0.27 s per traversal at 7.55 G positions: the duplicate loads hit the CU's
-        // L1, the five divergent branches per turn do not come free.  profiles/r05_nav_share_blocks_ab.txt)
-#pragma unroll
-        for (int k = 0; k < 6; ++k) c[k] = eb_rank4_quad_load(x1, act ? N.b[k] : 0ull, j);
-    };
-    auto start = [&](Node1& N, uint4 (&c)[6], bool& act) {
-        bool want = true;
-        uint64_t idx = 0;
-        cursor.take(cnt, want, idx, j, lane);
-        act = !want;
-        Rec r;
-        r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0;
-        if (act) r = eb_load_global(in + idx);
-        unpack_rec(r, N);
-        if (act && p.write) mark(N);
-        load6(N, c, true);
-    };
-    start(N0, c0, act0);
-    start(N1, c1, act1);
-    {
-        bool want = true;
-        uint64_t idx = 0;
-        cursor.take(cnt, want, idx, j, lane);
-        have_spare = !want;
-        if (have_spare) spare = eb_load_global(in + idx);
-    }
-    // one turn of a chain = ranks and children of its node (LF(sa_node) dna_bwt.hpp:323-356, next_nodes :381-404), then its next
-    // node: the kept child, or the record fetched ahead.  Six turns (three per chain) between two flushes of the staging buffer.
-    for (;;) {
-        const bool wave_alive = __ballot(act0 || act1 || have_spare) != 0ull;
-        if (wave_alive) {
-#pragma unroll
-            for (int rep = 0; rep < 3; ++rep) {
-#pragma unroll
-                for (int sl = 0; sl < 2; ++sl) {
-                    Node1& N = sl ? N1 : N0;
-                    uint4 (&c)[6] = sl ? c1 : c0;
-                    bool& act = sl ? act1 : act0;
-                    Node1 child;
-                    child.pad = 0;
-                    int kids = 0;
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) {
-                        const uint64_t i = N.b[k];
-                        uint32_t pc = eb_chunk_counts(c[k], eb_prefix_mask32((uint32_t)(i & 127u), j));
-                        pc = eb_quad_sum(pc);
-                        uint64_t sup;
-                        if constexpr (SUPER_LDS) sup = s_super[((i >> EB_SUPER_SHIFT) << 2) + j];
-                        else sup = x1.super[((i >> EB_SUPER_SHIFT) << 2) + j];
-                        child.b[k] = Fj + sup + c[k].w + ((pc >> (8u * j)) & 0xFFu);
-                    }
-                    for (int k = 0; k < 5; ++k) kids += child.b[k + 1] > child.b[k];
-                    child.depth = N.depth + 1;
-                    const bool keep = act && kids >= 2; // number_of_children (include.hpp:760-768)
-                    if (act && p.write && j == 0) {
-                        ++n_node;
-                        n_rank += 1;
-                        for (int k = 1; k < 6; ++k) n_rank += N.b[k] != N.b[k - 1]; // the reference shares the query of equal neighbours
-                    }
-                    // the quad goes on with its first kept child; the others travel through the stack
-                    const uint32_t km = eb_quad_or(keep ? (1u << j) : 0u);
-                    const uint32_t jc = follow && km ? (uint32_t)__ffs((int)km) - 1u : 4u;
-                    nav_push_or_spill<Rec, STAGE>(keep && j != jc, [&] { return pack_rec(child); }, s_buf, &s_count, out, out_cap, cnt, lane);
-                    bool want = false;
-                    if (jc < 4u) {
-#pragma unroll
-                        for (int k = 0; k < 6; ++k) N.b[k] = eb_quad_pick64(child.b[k], j == jc);
-                        N.depth = child.depth;
-                    } else {
-                        // the chain ended (or the slot was idle): on with the record fetched ahead, and another one is asked for
-                        act = have_spare;
-                        if (have_spare) { unpack_rec(spare, N); want = true; }
-                        have_spare = false;
-                    }
-                    uint64_t idx = 0;
-                    bool asked = want;
-                    cursor.take(cnt, want, idx, j, lane);
-                    if (asked && !want) { spare = eb_load_global(in + idx); have_spare = true; }
-                    // the new node of this chain: its border bits, its block loads (consumed in this chain's next turn)
-                    if (act && p.write) mark(N);
-                    load6(N, c, act);
-                }
-            }
-        }
-        // six turns add at most 6 x 256 records: the staging buffer is emptied here, and the workgroup goes on while any of its waves does
-        if (!nav_round_end<Rec, STAGE>(stage, &s_count, &s_alive, out, out_cap, cnt, __ballot(act0 || act1 || have_spare) != 0ull, lane)) break;
-    }
-    const uint64_t st[EB_NAV_STATS] = {0, n_node, n_lcp, 0, n_min, n_rank, n_s1, n_s2};
-    flush_stats(stat_rows, st);
-}
-
-// ---- phase 2, one BWT, chains followed in registers like k_nodes1c.  Two reads that end at the same place share every suffix, so
-// the leaves W#, cW#, c'cW#, ... form a chain as long as the reads (0.58 G leaves in ~4 M chains at 7.55 G positions, which
-// k_leaves walks in lock-step: a hundred launches of 4 M records at the end of the traversal).  A quad keeps the first kept child
-// leaf and expands it in its next turn; two chains per quad alternate, so that the two block loads of one are in flight while the
-// other computes (k_leaves waits for its record, then for its blocks: nothing overlaps), one input record is fetched ahead.
-__global__ void __launch_bounds__(256) k_leaves1c(eb_dev_index x1, eb_dev_flags f, uint64_t* __restrict__ kr, NavParams p, const NavLaunch* __restrict__ la,
-                                                 NavCounters* cnt, unsigned long long* __restrict__ stat_rows) {
-    using Rec = Leaf1;
-    constexpr int STAGE = 256;
-    __shared__ uint4 s_buf[STAGE * (sizeof(Rec) / 16)];
-    __shared__ uint32_t s_count;
-    __shared__ unsigned long long s_base;
-    __shared__ int s_alive;
-    const Rec* __restrict__ in = static_cast<const Rec*>(la->in);
-    Rec* out = static_cast<Rec*>(la->out);
-    const uint64_t count = la->count, out_cap = la->out_cap;
-    p.write = la->write;
-    const bool follow = la->follow != 0;
-    if ((uint64_t)blockIdx.x * 64 >= count) return; // the grid is sized for a full batch: nothing for this workgroup (uniform)
-    Stager<Rec, STAGE> stage{s_buf, &s_count, &s_base};
-    if (threadIdx.x == 0) { s_count = 0; s_alive = 0; }
-    __syncthreads();
-    const uint32_t j = threadIdx.x & 3u, lane = threadIdx.x & 63u;
-    uint64_t n_leaf = 0, n_lcp = 0, n_rank = 0, n_s1 = 0, n_s2 = 0;
-    const uint64_t Fj = pick4(x1.F, j);
-    NavCursor cursor(count, gridDim.x);
-    // LCP slots l+1 .. r-1 of a leaf (update_LCP_leaf, ebwt2InDel.cpp:344-355): the quad splits the touched words
-    auto mark = [&](uint64_t l, uint64_t r, uint64_t depth) {
-        if (r <= l + 1) return;
-        const uint64_t lo = l + 1, hi = r;
-        const bool setK = ((int64_t)depth >= p.K) != (p.below != 0), setR = ((int64_t)depth >= p.k_right) != (p.below != 0);
-        if ((setK || setR) && p.lcpb) {
-            const uint8_t v = (uint8_t)((setK ? 1 : 0) | (setR ? 2 : 0));
-            for (uint64_t i2 = lo + j; i2 < hi; i2 += 4) p.lcpb[i2] = v;
-        } else if (setK || setR) {
-            const uint64_t w0 = lo >> 6, w1 = (hi - 1) >> 6;
-            for (uint64_t w = w0 + j; w <= w1; w += 4) {
-                uint64_t m = ~0ull;
-                if (w == w0) m &= ~0ull << (lo & 63u);
-                if (w == w1) m &= ~0ull >> (63u - ((hi - 1) & 63u));
-                if (setK) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * w), m);
-                if (setR) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * w + 1), m);
-            }
-        }
-        if (j == 0) { n_lcp += hi - lo; n_s1 += eb_tri(hi) - eb_tri(lo); n_s2 += eb_sq(hi) - eb_sq(lo); }
-    };
-    struct Chain { uint64_t l, r, depth; uint4 cl, cr; bool act; };
-    Chain C0, C1;
-    bool have_spare = false;
-    Rec spare;
-    spare.l = spare.r = spare.depth = spare.pad = 0;
-    // a chain's new leaf: its LCP bits, its statistics, its two block loads (consumed in the chain's next turn)
-    auto arm = [&](Chain& C) {
-        if (C.act && p.write) {
-            mark(C.l, C.r, C.depth);
-            if (j == 0) { ++n_leaf; n_rank += C.r > C.l ? 2 : 1; }
-        }
-        C.cl = eb_rank4_quad_load(x1, C.act ? C.l : 0ull, j);
-        C.cr = eb_rank4_quad_load(x1, C.act ? (C.r > C.l ? C.r : C.l) : 0ull, j);
-    };
-    auto start = [&](Chain& C) {
-        bool want = true;
-        uint64_t idx = 0;
-        cursor.take(cnt, want, idx, j, lane);
-        C.act = !want;
-        Rec r;
-        r.l = r.r = r.depth = r.pad = 0;
-        if (C.act) r = eb_load_global(in + idx);
-        C.l = r.l; C.r = r.r; C.depth = r.depth;
-        arm(C);
-    };
-    start(C0);
-    start(C1);
-    {
-        bool want = true;
-        uint64_t idx = 0;
-        cursor.take(cnt, want, idx, j, lane);
-        have_spare = !want;
-        if (have_spare) spare = eb_load_global(in + idx);
-    }
-    for (;;) {
-        const bool wave_alive = __ballot(C0.act || C1.act || have_spare) != 0ull;
-        if (wave_alive) {
-#pragma unroll
-            for (int rep = 0; rep < 3; ++rep) {
-#pragma unroll
-                for (int sl = 0; sl < 2; ++sl) {
-                    Chain& C = sl ? C1 : C0;
-                    // next_leaves (dna_bwt.hpp:358-379): the child obtained by prepending letter j
-                    const uint64_t a = eb_rank4_quad_finish(x1, C.cl, C.l, j), b = eb_rank4_quad_finish(x1, C.cr, C.r > C.l ? C.r : C.l, j);
-                    Rec child;
-                    child.l = Fj + a; child.r = Fj + b; child.depth = C.depth + 1; child.pad = 0;
-                    const bool keep = C.act && (b - a >= 2);
-                    const uint32_t km = eb_quad_or(keep ? (1u << j) : 0u);
-                    const uint32_t jc = follow && km ? (uint32_t)__ffs((int)km) - 1u : 4u;
-                    nav_push_or_spill<Rec, STAGE>(keep && j != jc, [&] { return child; }, s_buf, &s_count, out, out_cap, cnt, lane);
-                    bool want = false;
-                    if (jc < 4u) {
-                        C.l = eb_quad_pick64(child.l, j == jc);
-                        C.r = eb_quad_pick64(child.r, j == jc);
-                        C.depth = child.depth;
-                    } else {
-                        C.act = have_spare;
-                        if (have_spare) { C.l = spare.l; C.r = spare.r; C.depth = spare.depth; want = true; }
-                        have_spare = false;
-                    }
-                    uint64_t idx = 0;
-                    const bool asked = want;
-                    cursor.take(cnt, want, idx, j, lane);
-                    if (asked && !want) { spare = eb_load_global(in + idx); have_spare = true; }
-                    arm(C);
-                }
-            }
-        }
-        if (!nav_round_end<Rec, STAGE>(stage, &s_count, &s_alive, out, out_cap, cnt, __ballot(C0.act || C1.act || have_spare) != 0ull, lane)) break;
-    }
-    const uint64_t st[EB_NAV_STATS] = {n_leaf, 0, n_lcp, 0, 0, n_rank, n_s1, n_s2};
-    flush_stats(stat_rows, st);
-}
-
-// ---- phase 2, two BWTs, chains followed in registers: k_leaves1c for merged leaves (two sa_leaves: four block loads per turn; the DA
-// slots of the leaf's rows are written with its LCP bits).
-__global__ void __launch_bounds__(256) k_leaves2c(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, uint64_t* __restrict__ kr, NavParams p, const NavLaunch* __restrict__ la,
-                                                 NavCounters* cnt, unsigned long long* __restrict__ stat_rows) {
-    using Rec = Leaf2P;
-    constexpr int STAGE = 256;
-    __shared__ uint4 s_buf[STAGE * (sizeof(Rec) / 16)];
-    __shared__ uint32_t s_count;
-    __shared__ unsigned long long s_base;
-    __shared__ int s_alive;
-    const Rec* __restrict__ in = static_cast<const Rec*>(la->in);
-    Rec* out = static_cast<Rec*>(la->out);
-    const uint64_t count = la->count, out_cap = la->out_cap;
-    p.write = la->write;
-    const bool follow = la->follow != 0;
-    if ((uint64_t)blockIdx.x * 64 >= count) return; // the grid is sized for a full batch: nothing for this workgroup (uniform)
-    Stager<Rec, STAGE> stage{s_buf, &s_count, &s_base};
-    if (threadIdx.x == 0) { s_count = 0; s_alive = 0; }
-    __syncthreads();
-    const uint32_t j = threadIdx.x & 3u, lane = threadIdx.x & 63u;
-    uint64_t n_leaf = 0, n_lcp = 0, n_da = 0, n_rank = 0, n_s1 = 0, n_s2 = 0;
-    const uint64_t F1 = pick4(x1.F, j), F2 = pick4(x2.F, j);
-    NavCursor cursor(count, gridDim.x);
-    // DA and LCP slots of a merged leaf (update_DA ebwt2InDel.cpp:394-425, update_LCP_leaf :344-355), as in k_leaves<2>: DA = 1 on the
-    // second collection's rows [s2, e), LCP bits on [s1 + 1, e); the quad splits the touched words
-    auto mark = [&](const Leaf2& L) {
-        const uint64_t s1 = L.l1 + L.l2, s2 = L.l2 + L.r1, e = L.r1 + L.r2;
-        const bool setK = ((int64_t)L.depth >= p.K) != (p.below != 0), setR = ((int64_t)L.depth >= p.k_right) != (p.below != 0);
-        const uint64_t w0 = s1 >> 6, w1 = e > s1 ? (e - 1) >> 6 : w0;
-        for (uint64_t w = w0 + j; w <= w1 && e > s1; w += 4) {
-            const uint64_t base = w << 6;
-            auto span = [&](uint64_t lo, uint64_t hi) -> uint64_t { // bits of word w inside [lo,hi)
-                if (hi <= lo || hi <= base || lo >= base + 64) return 0ull;
-                uint64_t m = ~0ull;
-                if (lo > base) m &= ~0ull << (lo - base);
-                if (hi < base + 64) m &= ~0ull >> (base + 64 - hi);
-                return m;
-            };
-            const uint64_t md = span(s2, e), ml = span(s1 + 1, e);
-            if (md) atomicOr(reinterpret_cast<unsigned long long*>(f.da + w), md);
-            if (!p.lcpb) {
-                if (ml && setK) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * w), ml);
-                if (ml && setR) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * w + 1), ml);
-            }
-        }
-        if (p.lcpb && (setK || setR)) {
-            const uint8_t v = (uint8_t)((setK ? 1 : 0) | (setR ? 2 : 0));
-            for (uint64_t i2 = s1 + 1 + j; i2 < e; i2 += 4) p.lcpb[i2] = v;
-        }
-        if (j == 0) {
-            ++n_leaf;
-            n_da += e - s1;
-            if (e > s1 + 1) { n_lcp += e - s1 - 1; n_s1 += eb_tri(e) - eb_tri(s1 + 1); n_s2 += eb_sq(e) - eb_sq(s1 + 1); }
-            n_rank += (L.r1 > L.l1 ? 2 : 1) + (L.r2 > L.l2 ? 2 : 1);
-        }
-    };
-    struct Chain { Leaf2 L; uint4 cl1, cr1, cl2, cr2; bool act; };
-    Chain C0, C1;
-    bool have_spare = false;
-    uint64_t spare = 0; // index of the input record reserved for this quad's next chain
-    // a chain's new leaf: its DA / LCP bits, its statistics, its four block loads (consumed in the chain's next turn)
-    auto arm = [&](Chain& C) {
-        if (C.act && p.write) mark(C.L);
-        C.cl1 = eb_rank4_quad_load(x1, C.act ? C.L.l1 : 0ull, j);
-        C.cr1 = eb_rank4_quad_load(x1, C.act ? (C.L.r1 > C.L.l1 ? C.L.r1 : C.L.l1) : 0ull, j);
-        C.cl2 = eb_rank4_quad_load(x2, C.act ? C.L.l2 : 0ull, j);
-        C.cr2 = eb_rank4_quad_load(x2, C.act ? (C.L.r2 > C.L.l2 ? C.L.r2 : C.L.l2) : 0ull, j);
-    };
-    auto start = [&](Chain& C) {
-        bool want = true;
-        uint64_t idx = 0;
-        cursor.take(cnt, want, idx, j, lane);
-        C.act = !want;
-        Rec r;
-        for (uint64_t& w : r.w) w = 0;
-        if (C.act) r = eb_load_global(in + idx);
-        unpack_rec(r, C.L);
-        arm(C);
-    };
-    start(C0);
-    start(C1);
-    {
-        bool want = true;
-        uint64_t idx = 0;
-        cursor.take(cnt, want, idx, j, lane);
-        have_spare = !want;
-        spare = idx;
-    }
-    for (;;) {
-        const bool wave_alive = __ballot(C0.act || C1.act || have_spare) != 0ull;
-        if (wave_alive) {
-#pragma unroll
-            for (int rep = 0; rep < 3; ++rep) {
-#pragma unroll
-                for (int sl = 0; sl < 2; ++sl) {
-                    Chain& C = sl ? C1 : C0;
-                    // next_leaves on both BWTs (ebwt2InDel.cpp:452-472): the child obtained by prepending letter j
-                    const uint64_t a1 = eb_rank4_quad_finish(x1, C.cl1, C.L.l1, j), b1 = eb_rank4_quad_finish(x1, C.cr1, C.L.r1 > C.L.l1 ? C.L.r1 : C.L.l1, j);
-                    const uint64_t a2 = eb_rank4_quad_finish(x2, C.cl2, C.L.l2, j), b2 = eb_rank4_quad_finish(x2, C.cr2, C.L.r2 > C.L.l2 ? C.L.r2 : C.L.l2, j);
-                    Leaf2 child;
-                    child.l1 = F1 + a1; child.r1 = F1 + b1; child.l2 = F2 + a2; child.r2 = F2 + b2; child.depth = C.L.depth + 1;
-                    child.pad[0] = child.pad[1] = child.pad[2] = 0;
-                    const bool keep = C.act && ((b1 - a1) + (b2 - a2) >= 2);
-                    const uint32_t km = eb_quad_or(keep ? (1u << j) : 0u);
-                    const uint32_t jc = follow && km ? (uint32_t)__ffs((int)km) - 1u : 4u;
-                    nav_push_or_spill<Rec, STAGE>(keep && j != jc, [&] { return pack_rec(child); }, s_buf, &s_count, out, out_cap, cnt, lane);
-                    bool want = false;
-                    if (jc < 4u) {
-                        C.L.l1 = eb_quad_pick64(child.l1, j == jc);
-                        C.L.r1 = eb_quad_pick64(child.r1, j == jc);
-                        C.L.l2 = eb_quad_pick64(child.l2, j == jc);
-                        C.L.r2 = eb_quad_pick64(child.r2, j == jc);
-                        C.L.depth = child.depth;
-                    } else {
-                        C.act = have_spare;
-                        if (have_spare) { unpack_rec(eb_load_global(in + spare), C.L); want = true; }
-                        have_spare = false;
-                    }
-                    uint64_t idx = 0;
-                    const bool asked = want;
-                    cursor.take(cnt, want, idx, j, lane);
-                    if (asked && !want) { spare = idx; have_spare = true; }
-                    arm(C);
-                }
-            }
-        }
-        if (!nav_round_end<Rec, STAGE>(stage, &s_count, &s_alive, out, out_cap, cnt, __ballot(C0.act || C1.act || have_spare) != 0ull, lane)) break;
-    }
-    const uint64_t st[EB_NAV_STATS] = {n_leaf, 0, n_lcp, n_da, 0, n_rank, n_s1, n_s2};
-    flush_stats(stat_rows, st);
-}
-
-// ---- phase 3, two BWTs, software-pipelined the same way (k_nodes1p).  A merged node is two sa_nodes (12 boundaries); as in
-// the round-2 kernel a block is loaded ONCE for the boundaries of a node that share it (they are sorted and a few dozen rows apart):
-// which boundaries issue a load is decided in stage A and kept as a 12-bit mask for stage D.
-template <bool SUPER_LDS>
-__global__ void __launch_bounds__(256) k_nodes2p(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, uint64_t* __restrict__ kr, NavParams p,
-                                                const NavLaunch* __restrict__ la, NavCounters* cnt, unsigned long long* __restrict__ stat_rows) {
-    using Rec = Node2P;
-    constexpr int STAGE = 768;
-    __shared__ uint4 s_buf[STAGE * (sizeof(Rec) / 16)];
-    __shared__ uint32_t s_count;
-    __shared__ unsigned long long s_base;
-    __shared__ unsigned long long s_super[2][EB_NAV_SUPER_LDS * 4];
-    const Rec* __restrict__ in = static_cast<const Rec*>(la->in);
-    Rec* out = static_cast<Rec*>(la->out);
-    const uint64_t count = la->count, out_cap = la->out_cap;
-    p.write = la->write;
-    const uint64_t tiles = (count + 63) / 64;
-    if ((uint64_t)blockIdx.x >= tiles) return; // the grid is sized for a full batch: nothing for this workgroup (uniform)
-    Stager<Rec, STAGE> stage{s_buf, &s_count, &s_base};
-    if (SUPER_LDS) {
-        const uint64_t ns1 = (x1.n >> EB_SUPER_SHIFT) + 1, ns2 = (x2.n >> EB_SUPER_SHIFT) + 1;
-        for (uint32_t k = threadIdx.x; k < ns1 * 4; k += blockDim.x) s_super[0][k] = x1.super[k];
-        for (uint32_t k = threadIdx.x; k < ns2 * 4; k += blockDim.x) s_super[1][k] = x2.super[k];
-    }
-    if (threadIdx.x == 0) s_count = 0;
-    __syncthreads();
-    const uint32_t j = threadIdx.x & 3u, q = threadIdx.x >> 2;
-    const uint64_t G = gridDim.x;
-    uint64_t n_node = 0, n_lcp = 0, n_da = 0, n_rank = 0, n_min = 0, n_s1 = 0, n_s2 = 0;
-    const uint64_t F1 = pick4(x1.F, j), F2 = pick4(x2.F, j);
-
-    auto load_rec = [&](uint64_t tile) -> Rec {
-        Rec r;
-        for (uint64_t& w : r.w) w = 0;
-        const uint64_t i = tile * 64 + q;
-        if (tile < tiles && i < count) r = eb_load_global(in + i);
-        return r;
-    };
-    // stage A for one record: border bits in merged coordinates (merge_nodes, include.hpp:476-490), DA slots of singleton leaves
-    auto mark = [&](const Node2& N) {
-        uint64_t lo = 0, hi = 0;
-        const uint64_t last = N.a[5] + N.b[5];
-        for (int k = 0; k < 4; ++k) if (j == (uint32_t)k) { lo = N.a[k] + N.b[k]; hi = N.a[k + 1] + N.b[k + 1]; }
-        if (hi > lo && hi != last) {
-            const bool setK = ((int64_t)N.depth >= p.K) != (p.below != 0), setR = ((int64_t)N.depth >= p.k_right) != (p.below != 0);
-            if (p.lcpb) {
-                uint8_t v = (uint8_t)((setK ? 1 : 0) | (setR ? 2 : 0));
-                if (v && !(EB_NDBG(p) & 1u)) p.lcpb[hi] = v;
-            } else {
-                if (setK) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * (hi >> 6)), 1ull << (hi & 63u));
-                if (setR) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * (hi >> 6) + 1), 1ull << (hi & 63u));
-            }
-            ++n_lcp;
-            n_s1 += hi;
-            n_s2 += hi * hi;
-        }
-        if (j >= 1 && hi - lo >= 2 && hi < last - 1) {
-            if (!(EB_NDBG(p) & 2u)) eb_bit_set_atomic(f.minima, hi);
-            ++n_min;
-        }
-        // leaves of merged size 1 were not visited in phase 2: write their DA slot now (find_leaves, ebwt2InDel.cpp:474-527)
-        for (int k = 0; k < 5; ++k) {
-            if ((uint32_t)(k & 3) != j || (k == 4 && j != 0)) continue;
-            uint64_t s1 = N.a[k + 1] - N.a[k], s2 = N.b[k + 1] - N.b[k];
-            if (s1 + s2 == 1) {
-                if (s2 && !(EB_NDBG(p) & 8u)) eb_bit_set_atomic(f.da, N.b[k] + N.a[k + 1]);
-                ++n_da;
-            }
-        }
-    };
-    // which boundaries start a new block (bit k: a[k], bit 6 + k: b[k]); the others reuse their left neighbour's
-    auto load_mask = [&](const Node2& N) -> uint32_t {
-        uint32_t m = 1u | (1u << 6);
-#pragma unroll
-        for (int k = 1; k < 6; ++k) {
-            m |= ((N.a[k] >> 7) != (N.a[k - 1] >> 7) ? 1u : 0u) << k;
-            m |= ((N.b[k] >> 7) != (N.b[k - 1] >> 7) ? 1u : 0u) << (6 + k);
-        }
-        return m;
-    };
-
-    uint64_t tile = blockIdx.x;
-    Node2 Nn;
-    uint4 cna[6], cnb[6];
-    uint32_t mn = 0;
-    bool act_n;
-    {
-        Rec r0 = load_rec(tile);
-        unpack_rec(r0, Nn);
-        act_n = tile * 64 + q < count;
-        if (act_n && p.write) mark(Nn);
-        mn = load_mask(Nn);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            if ((mn >> k) & 1u) cna[k] = eb_rank4_quad_load(x1, Nn.a[k], j);
-            if ((mn >> (6 + k)) & 1u) cnb[k] = eb_rank4_quad_load(x2, Nn.b[k], j);
-        }
-    }
-    Rec rr = load_rec(tile + G);
-    uint32_t trips = 0;
-    for (; tile < tiles; tile += G) {
-        const Node2 Nc = Nn;
-        const bool act_c = act_n;
-        const uint32_t mc = mn;
-        uint4 cca[6], ccb[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) { cca[k] = cna[k]; ccb[k] = cnb[k]; }
-        // stage A: the next trip's record -> node, bits, block loads
-        unpack_rec(rr, Nn);
-        act_n = tile + G < tiles && (tile + G) * 64 + q < count;
-        if (act_n && p.write) mark(Nn);
-        mn = load_mask(Nn);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            if ((mn >> k) & 1u) cna[k] = eb_rank4_quad_load(x1, Nn.a[k], j);
-            if ((mn >> (6 + k)) & 1u) cnb[k] = eb_rank4_quad_load(x2, Nn.b[k], j);
-        }
-        // stage C: the record after that
-        rr = load_rec(tile + 2 * G);
-        // stage D: this trip's ranks and children (LF on both BWTs, next_nodes ebwt2InDel.cpp:529-553)
-        Node2 child;
-        child.pad[0] = child.pad[1] = child.pad[2] = 0;
-        int kids = 0;
-        uint4 cur_a = cca[0], cur_b = ccb[0];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            if ((mc >> k) & 1u) cur_a = cca[k]; // else: the block of the boundary to the left
-            if ((mc >> (6 + k)) & 1u) cur_b = ccb[k];
-            const uint64_t ia = Nc.a[k], ib = Nc.b[k];
-            uint32_t pa = eb_chunk_counts(cur_a, eb_prefix_mask32((uint32_t)(ia & 127u), j));
-            uint32_t pb = eb_chunk_counts(cur_b, eb_prefix_mask32((uint32_t)(ib & 127u), j));
-            pa = eb_quad_sum(pa);
-            pb = eb_quad_sum(pb);
-            uint64_t sa, sb;
-            if constexpr (SUPER_LDS) { sa = s_super[0][((ia >> EB_SUPER_SHIFT) << 2) + j]; sb = s_super[1][((ib >> EB_SUPER_SHIFT) << 2) + j]; }
-            else { sa = x1.super[((ia >> EB_SUPER_SHIFT) << 2) + j]; sb = x2.super[((ib >> EB_SUPER_SHIFT) << 2) + j]; }
-            child.a[k] = F1 + sa + cur_a.w + ((pa >> (8u * j)) & 0xFFu);
-            child.b[k] = F2 + sb + cur_b.w + ((pb >> (8u * j)) & 0xFFu);
-        }
-        for (int k = 0; k < 5; ++k) kids += (child.a[k + 1] > child.a[k]) || (child.b[k + 1] > child.b[k]); // include.hpp:784-792
-        child.depth = Nc.depth + 1;
-        const bool keep = act_c && kids >= 2;
-        if (act_c && p.write && j == 0) {
-            ++n_node;
-            n_rank += 2;
-            for (int k = 1; k < 6; ++k) n_rank += (Nc.a[k] != Nc.a[k - 1]) + (Nc.b[k] != Nc.b[k - 1]);
-        }
-        stage.push(keep, pack_rec(child));
-        if (++trips % (STAGE / 256) == 0) stage.flush(out, out_cap, &cnt->pushed);
-    }
-    stage.flush(out, out_cap, &cnt->pushed);
-    const uint64_t st[EB_NAV_STATS] = {0, n_node, n_lcp, n_da, n_min, n_rank, n_s1, n_s2};
-    flush_stats(stat_rows, st);
-}
-
-// ---- phase 3, two BWTs, chains followed in registers (k_nodes1c for merged nodes).  ONE chain per quad (two, like k_nodes1c, need
-// 256 registers: one wave per SIMD) and one input record fetched ahead; the loads of a turn are covered by the other waves of the
-// SIMD.  The first kept child's twelve boundaries are spread over the quad by DPP, the other kept children go to the stack (small
-// staging buffer, excess straight to the stack).
-template <bool SUPER_LDS>
-__global__ void __launch_bounds__(256) k_nodes2c(eb_dev_index x1, eb_dev_index x2, eb_dev_flags f, uint64_t* __restrict__ kr, NavParams p,
-                                                const NavLaunch* __restrict__ la, NavCounters* cnt, unsigned long long* __restrict__ stat_rows) {
-    using Rec = Node2P;
-    constexpr int STAGE = 256;
-    __shared__ uint4 s_buf[STAGE * (sizeof(Rec) / 16)];
-    __shared__ uint32_t s_count;
-    __shared__ unsigned long long s_base;
-    __shared__ unsigned long long s_super[2][EB_NAV_SUPER_LDS * 4];
-    __shared__ int s_alive;
-    const Rec* __restrict__ in = static_cast<const Rec*>(la->in);
-    Rec* out = static_cast<Rec*>(la->out);
-    const uint64_t count = la->count, out_cap = la->out_cap;
-    p.write = la->write;
-    const bool follow = la->follow != 0;
-    if ((uint64_t)blockIdx.x * 64 >= count) return; // the grid is sized for a full batch: nothing for this workgroup (uniform)
-    Stager<Rec, STAGE> stage{s_buf, &s_count, &s_base};
-    if (SUPER_LDS) {
-        const uint64_t ns1 = (x1.n >> EB_SUPER_SHIFT) + 1, ns2 = (x2.n >> EB_SUPER_SHIFT) + 1;
-        for (uint32_t k = threadIdx.x; k < ns1 * 4; k += blockDim.x) s_super[0][k] = x1.super[k];
-        for (uint32_t k = threadIdx.x; k < ns2 * 4; k += blockDim.x) s_super[1][k] = x2.super[k];
-    }
-    if (threadIdx.x == 0) { s_count = 0; s_alive = 0; }
-    __syncthreads();
-    const uint32_t j = threadIdx.x & 3u, lane = threadIdx.x & 63u;
-    uint32_t n_node = 0, n_lcp = 0, n_da = 0, n_rank = 0, n_min = 0; // per lane and launch: far below 2^32
-    uint64_t n_s1 = 0, n_s2 = 0;
-    const uint64_t F1 = pick4(x1.F, j), F2 = pick4(x2.F, j);
-    NavCursor cursor(count, gridDim.x);
-
-    // border bits in merged coordinates (merge_nodes, include.hpp:476-490), DA slots of singleton leaves: as in k_nodes2p
-    auto mark = [&](const Node2& N) {
-        uint64_t lo = 0, hi = 0;
-        const uint64_t last = N.a[5] + N.b[5];
-        for (int k = 0; k < 4; ++k) if (j == (uint32_t)k) { lo = N.a[k] + N.b[k]; hi = N.a[k + 1] + N.b[k + 1]; }
-        if (hi > lo && hi != last) {
-            const bool setK = ((int64_t)N.depth >= p.K) != (p.below != 0), setR = ((int64_t)N.depth >= p.k_right) != (p.below != 0);
-            if (p.lcpb) {
-                uint8_t v = (uint8_t)((setK ? 1 : 0) | (setR ? 2 : 0));
-                if (v && !(EB_NDBG(p) & 1u)) p.lcpb[hi] = v;
-            } else {
-                if (setK) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * (hi >> 6)), 1ull << (hi & 63u));
-                if (setR) atomicOr(reinterpret_cast<unsigned long long*>(kr + 2 * (hi >> 6) + 1), 1ull << (hi & 63u));
-            }
-            ++n_lcp;
-            n_s1 += hi;
-            n_s2 += hi * hi;
-        }
-        if (j >= 1 && hi - lo >= 2 && hi < last - 1) {
-            if (!(EB_NDBG(p) & 2u)) eb_bit_set_atomic(f.minima, hi);
-            ++n_min;
-        }
-        // leaves of merged size 1 were not visited in phase 2: write their DA slot now (find_leaves, ebwt2InDel.cpp:474-527)
-        for (int k = 0; k < 5; ++k) {
-            if ((uint32_t)(k & 3) != j || (k == 4 && j != 0)) continue;
-            uint64_t s1 = N.a[k + 1] - N.a[k], s2 = N.b[k + 1] - N.b[k];
-            if (s1 + s2 == 1) {
-                if (s2 && !(EB_NDBG(p) & 8u)) eb_bit_set_atomic(f.da, N.b[k] + N.a[k + 1]);
-                ++n_da;
-            }
-        }
-    };
-    // which boundaries start a new block (bit k: a[k], bit 6 + k: b[k]); the others reuse their left neighbour's
-    auto load_mask = [&](const Node2& N) -> uint32_t {
-        // (all twelve loaded unconditionally, measured in round 5: 0.645 s against 0.62 s, profiles/r05_nav2_loads_ab.txt)
-        uint32_t m = 1u | (1u << 6);
-#pragma unroll
-        for (int k = 1; k < 6; ++k) {
-            m |= ((N.a[k] >> 7) != (N.a[k - 1] >> 7) ? 1u : 0u) << k;
-            m |= ((N.b[k] >> 7) != (N.b[k - 1] >> 7) ? 1u : 0u) << (6 + k);
-        }
-        return m;
-    };
-    Node2 N0;
-    uint4 a0[6], b0[6];
-    uint32_t m0 = 0;
-    bool act0 = false, have_spare = false;
-    uint64_t spare = 0; // index of the input record reserved for this quad's next chain (loaded when the chain at hand ends: once in ~135 turns)
-    // a chain's new node: its bits, its block loads (consumed in the chain's next turn)
-    auto arm = [&](Node2& N, uint4 (&ca)[6], uint4 (&cb)[6], uint32_t& m, bool act) {
-        if (act && p.write) mark(N);
-        m = load_mask(N);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            if ((m >> k) & 1u) ca[k] = eb_rank4_quad_load(x1, act ? N.a[k] : 0ull, j);
-            if ((m >> (6 + k)) & 1u) cb[k] = eb_rank4_quad_load(x2, act ? N.b[k] : 0ull, j);
-        }
-    };
-    auto start = [&](Node2& N, uint4 (&ca)[6], uint4 (&cb)[6], uint32_t& m, bool& act) {
-        bool want = true;
-        uint64_t idx = 0;
-        cursor.take(cnt, want, idx, j, lane);
-        act = !want;
-        Rec r;
-        for (uint64_t& w : r.w) w = 0;
-        if (act) r = eb_load_global(in + idx);
-        unpack_rec(r, N);
-        arm(N, ca, cb, m, act);
-    };
-    start(N0, a0, b0, m0, act0);
-    {
-        bool want = true;
-        uint64_t idx = 0;
-        cursor.take(cnt, want, idx, j, lane);
-        have_spare = !want;
-        spare = idx;
-    }
-    for (;;) {
-        const bool wave_alive = __ballot(act0 || have_spare) != 0ull;
-        if (wave_alive) {
-            for (int rep = 0; rep < 6; ++rep) {
-                {
-                    Node2& N = N0;
-                    uint4 (&ca)[6] = a0;
-                    uint4 (&cb)[6] = b0;
-                    uint32_t& mc = m0;
-                    bool& act = act0;
-                    // ranks and children (LF on both BWTs, next_nodes ebwt2InDel.cpp:529-553)
-                    Node2 child;
-                    child.pad[0] = child.pad[1] = child.pad[2] = 0;
-                    int kids = 0;
-                    uint4 cur_a = ca[0], cur_b = cb[0];
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) {
-                        if ((mc >> k) & 1u) cur_a = ca[k]; // else: the block of the boundary to the left
-                        if ((mc >> (6 + k)) & 1u) cur_b = cb[k];
-                        const uint64_t ia = N.a[k], ib = N.b[k];
-                        uint32_t pa = eb_chunk_counts(cur_a, eb_prefix_mask32((uint32_t)(ia & 127u), j));
-                        uint32_t pb = eb_chunk_counts(cur_b, eb_prefix_mask32((uint32_t)(ib & 127u), j));
-                        pa = eb_quad_sum(pa);
-                        pb = eb_quad_sum(pb);
-                        uint64_t sa, sb;
-                        if constexpr (SUPER_LDS) { sa = s_super[0][((ia >> EB_SUPER_SHIFT) << 2) + j]; sb = s_super[1][((ib >> EB_SUPER_SHIFT) << 2) + j]; }
-                        else { sa = x1.super[((ia >> EB_SUPER_SHIFT) << 2) + j]; sb = x2.super[((ib >> EB_SUPER_SHIFT) << 2) + j]; }
-                        child.a[k] = F1 + sa + cur_a.w + ((pa >> (8u * j)) & 0xFFu);
-                        child.b[k] = F2 + sb + cur_b.w + ((pb >> (8u * j)) & 0xFFu);
-                    }
-                    for (int k = 0; k < 5; ++k) kids += (child.a[k + 1] > child.a[k]) || (child.b[k + 1] > child.b[k]); // include.hpp:784-792
-                    child.depth = N.depth + 1;
-                    const bool keep = act && kids >= 2;
-                    if (act && p.write && j == 0) {
-                        ++n_node;
-                        n_rank += 2;
-                        for (int k = 1; k < 6; ++k) n_rank += (N.a[k] != N.a[k - 1]) + (N.b[k] != N.b[k - 1]);
-                    }
-                    const uint32_t km = eb_quad_or(keep ? (1u << j) : 0u);
-                    const uint32_t jc = follow && km ? (uint32_t)__ffs((int)km) - 1u : 4u;
-                    nav_push_or_spill<Rec, STAGE>(keep && j != jc, [&] { return pack_rec(child); }, s_buf, &s_count, out, out_cap, cnt, lane);
-                    bool want = false;
-                    if (jc < 4u) {
-#pragma unroll
-                        for (int k = 0; k < 6; ++k) {
-                            N.a[k] = eb_quad_pick64(child.a[k], j == jc);
-                            N.b[k] = eb_quad_pick64(child.b[k], j == jc);
-                        }
-                        N.depth = child.depth;
-                    } else {
-                        act = have_spare;
-                        if (have_spare) { unpack_rec(eb_load_global(in + spare), N); want = true; }
-                        have_spare = false;
-                    }
-                    uint64_t idx = 0;
-                    const bool asked = want;
-                    cursor.take(cnt, want, idx, j, lane);
-                    if (asked && !want) { spare = idx; have_spare = true; }
-                    arm(N, ca, cb, mc, act);
-                }
-            }
-        }
-        if (!nav_round_end<Rec, STAGE>(stage, &s_count, &s_alive, out, out_cap, cnt, __ballot(act0 || have_spare) != 0ull, lane)) break;
-    }
-    const uint64_t st[EB_NAV_STATS] = {0, n_node, n_lcp, n_da, n_min, n_rank, n_s1, n_s2};
-    flush_stats(stat_rows, st);
-}
 
 // Sharded traversal: at the first level wide enough, every shard keeps the records whose interval start
 // hashes to it -- content-addressed, so all shards agree whatever order their own launches left the level in.
@@ -1279,40 +89,6 @@ __global__ void __launch_bounds__(256) k_pack_lcp(const uint4* __restrict__ lcpb
         thrK[w] = k;
         thrR[w] = r;
     }
-}
-
-// complement form -> final form: thr = ~collected on positions 1 .. n-1, zero elsewhere (position 0 is never written by
-// the reference and stays 0; so do the spare bits behind n)
-__global__ void __launch_bounds__(256) k_invert_thr(uint64_t* __restrict__ thrK, uint64_t* __restrict__ thrR, uint64_t n, uint64_t alloc_words) {
-    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < alloc_words; w += (uint64_t)gridDim.x * blockDim.x) {
-        uint64_t m = 0;
-        const uint64_t base = w << 6;
-        if (base < n) {
-            m = ~0ull;
-            if (n - base < 64) m &= ~0ull >> (64 - (n - base));
-            if (w == 0) m &= ~1ull;
-        }
-        thrK[w] = ~thrK[w] & m;
-        thrR[w] = ~thrR[w] & m;
-    }
-}
-
-// ones in each group of 8 DA words -> exclusive prefix = ones before the group
-__global__ void __launch_bounds__(256) k_da_group_counts(const uint64_t* __restrict__ da, uint64_t words, uint64_t groups,
-                                                         uint64_t* __restrict__ vec4) {
-    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= groups) return;
-    uint64_t s = 0;
-    for (int k = 0; k < 8; ++k) {
-        uint64_t w = g * 8 + k;
-        if (w < words) s += (uint64_t)__popcll(da[w]);
-    }
-    vec4[g * 4] = s;
-    vec4[g * 4 + 1] = vec4[g * 4 + 2] = vec4[g * 4 + 3] = 0;
-}
-__global__ void __launch_bounds__(256) k_take_first(const uint64_t* __restrict__ vec4, uint64_t groups, uint64_t* __restrict__ out) {
-    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < groups) out[g] = vec4[g * 4];
 }
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -1525,70 +301,6 @@ struct Drain {
 };
 
 }  // namespace
-
-int eb_flags_alloc(uint64_t n, int device, bool with_da, eb_flags** out) {
-    int ndev = eb_device_count();
-    if (ndev <= 0) { eb_set_error("no HIP device available: the ebwt2InDel hot path runs on the GPU only (no CPU fallback)"); return EB_ERR_DEVICE; }
-    if (device < 0 || device >= ndev) { eb_set_error("device %d out of range (have %d)", device, ndev); return EB_ERR_ARG; }
-    EB_HIP(hipSetDevice(device));
-    eb_flags* f = new eb_flags();
-    f->device = device;
-    f->n = n;
-    f->words = eb_bit_words(n);
-    size_t bytes = eb_bit_alloc_words(n) * 8;
-    hipError_t e = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking);
-    uint64_t** vecs[5] = {&f->d_thrK, &f->d_thrR, &f->d_min, with_da ? &f->d_da : nullptr, &f->d_flag};
-    for (int i = 0; i < 5 && e == hipSuccess; ++i) {
-        if (!vecs[i]) continue;
-        e = hipMalloc(vecs[i], bytes);
-        if (e == hipSuccess) e = hipMemsetAsync(*vecs[i], 0, bytes, f->stream);
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(f->stream);
-    if (e != hipSuccess) { eb_set_error("flag vector allocation failed: %s", hipGetErrorString(e)); eb_flags_destroy(f); return EB_ERR_NOMEM; }
-    *out = f;
-    return EB_OK;
-}
-
-int eb_flags_build_da_rank(eb_flags* f) {
-    if (!f->d_da) return EB_OK;
-    EB_HIP(hipSetDevice(f->device));
-    uint64_t groups = (f->words + 7) / 8 + 1;
-    uint64_t* d_vec = nullptr;
-    EB_HIP(hipMalloc(&d_vec, groups * 4 * sizeof(uint64_t)));
-    if (f->d_da_rank) { (void)hipFree(f->d_da_rank); f->d_da_rank = nullptr; }
-    EB_HIP(hipMalloc(&f->d_da_rank, groups * sizeof(uint64_t)));
-    unsigned grid = (unsigned)((groups + 255) / 256);
-    hipLaunchKernelGGL(k_da_group_counts, dim3(grid), dim3(256), 0, f->stream, f->d_da, f->words, groups, d_vec);
-    int rc = eb_scan4_exclusive(d_vec, groups, f->stream);
-    if (rc != EB_OK) return rc;
-    hipLaunchKernelGGL(k_take_first, dim3(grid), dim3(256), 0, f->stream, d_vec, groups, f->d_da_rank);
-    EB_HIP(hipMemcpyAsync(&f->da_ones, f->d_da_rank + (groups - 1), sizeof(uint64_t), hipMemcpyDeviceToHost, f->stream)); // the extra last group: ones before the end
-    EB_HIP(hipStreamSynchronize(f->stream));
-    EB_HIP(hipGetLastError());
-    EB_HIP(hipFree(d_vec));
-    return EB_OK;
-}
-
-__global__ void __launch_bounds__(256) k_fuse_flags(const uint64_t* __restrict__ thrK, const uint64_t* __restrict__ minima, uint64_t words,
-                                                   uint64_t* __restrict__ flag) {
-    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < words; w += (uint64_t)gridDim.x * blockDim.x) flag[w] = thrK[w] & ~minima[w];
-}
-
-int eb_flags_derive(eb_flags* f) {
-    EB_HIP(hipSetDevice(f->device));
-    if (f->complemented) { // a traversal (or the sum of its shards) left thrK / thrR in complement form
-        hipLaunchKernelGGL(k_invert_thr, dim3(2048), dim3(256), 0, f->stream, f->d_thrK, f->d_thrR, f->n, eb_bit_alloc_words(f->n));
-        f->complemented = false;
-    }
-    // phase 4 reads LCP_threshold[2i] only as `LCP_threshold[2i] && !LCP_minima[i]` (ebwt2InDel.cpp:1618,1632): one word instead of two
-    hipLaunchKernelGGL(k_fuse_flags, dim3(2048), dim3(256), 0, f->stream, f->d_thrK, f->d_min, eb_bit_alloc_words(f->n), f->d_flag);
-    EB_HIP(hipStreamSynchronize(f->stream));
-    EB_HIP(hipGetLastError());
-    int rc = eb_flags_build_da_rank(f);
-    if (rc != EB_OK) return rc;
-    f->derived = true;
-    return EB_OK;
-}
 
 // derive: finish the vectors (inversion of the complement form, fused flag word, DA ranks) -- eb_flags_build; false: leave them in
 // the form the traversal collected them in, for a caller that still has to combine shards (eb_flags_build_shard)
@@ -1940,281 +652,4 @@ extern "C" int eb_flags_build_shard(eb_index* b1, eb_index* b2, int32_t K, int32
     // eb_flags_export + eb_flags_import_shard_sum) is the same for any number of shards, and a one-shard build that came
     // back finished would be inverted a second time on the host-exchange paths (round-2 advisor finding).
     return flags_build_chains(b1, b2, K, k_right, shard, n_shards, out, stats, true, false);
-}
-
-extern "C" int eb_flags_device_vectors(eb_flags* f, uint64_t* d_vectors[4], uint64_t* words) {
-    if (!f || !d_vectors || !words) { eb_set_error("null argument"); return EB_ERR_ARG; }
-    d_vectors[0] = f->d_thrK;
-    d_vectors[1] = f->d_thrR;
-    d_vectors[2] = f->d_min;
-    d_vectors[3] = f->d_da;
-    *words = f->words;
-    return EB_OK;
-}
-
-// ones in a bit vector: per-workgroup partial sums, added up by the host
-__global__ void __launch_bounds__(256) k_popcount_words(const uint64_t* __restrict__ v, uint64_t words, unsigned long long* __restrict__ partial) {
-    unsigned long long s = 0;
-    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < words; w += (uint64_t)gridDim.x * blockDim.x) s += (unsigned long long)__popcll(v[w]);
-    s = wave_sum(s);
-    __shared__ unsigned long long sh[4];
-    if ((threadIdx.x & 63u) == 0) sh[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
-}
-
-extern "C" int eb_flags_popcounts(eb_flags* f, uint64_t ones[4]) {
-    if (!f || !ones) { eb_set_error("null argument"); return EB_ERR_ARG; }
-    EB_HIP(hipSetDevice(f->device));
-    const unsigned grid = 1024;
-    unsigned long long* d_part = nullptr;
-    EB_HIP(hipMalloc(&d_part, 4 * grid * sizeof(unsigned long long)));
-    struct G { void* p; ~G() { (void)hipFree(p); } } g{d_part};
-    const uint64_t* vec[4] = {f->d_thrK, f->d_thrR, f->d_min, f->d_da};
-    EB_HIP(hipMemsetAsync(d_part, 0, 4 * grid * sizeof(unsigned long long), f->stream));
-    for (int k = 0; k < 4; ++k)
-        if (vec[k]) hipLaunchKernelGGL(k_popcount_words, dim3(grid), dim3(256), 0, f->stream, vec[k], f->words, d_part + (size_t)k * grid);
-    std::vector<unsigned long long> h(4 * grid);
-    EB_HIP(hipMemcpyAsync(h.data(), d_part, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, f->stream));
-    EB_HIP(hipStreamSynchronize(f->stream));
-    EB_HIP(hipGetLastError());
-    for (int k = 0; k < 4; ++k) {
-        ones[k] = 0;
-        for (unsigned b = 0; b < grid; ++b) ones[k] += h[(size_t)k * grid + b];
-    }
-    return EB_OK;
-}
-
-extern "C" int eb_flags_finalize(eb_flags* f) {
-    if (!f) { eb_set_error("null argument"); return EB_ERR_ARG; }
-    return eb_flags_derive(f);
-}
-
-// '1' -> 1, anything else -> 0: 64 ASCII bytes -> one word (ebwt2InDel.cpp:1503-1508)
-__global__ void __launch_bounds__(256) k_pack_da(const uint8_t* __restrict__ ascii, uint64_t len, uint64_t first_word, uint64_t n_words,
-                                                uint64_t* __restrict__ da) {
-    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_words) return;
-    uint64_t off = t * 64, w = 0;
-    if (off + 64 <= len) {
-        const uint4* p4 = reinterpret_cast<const uint4*>(ascii + off);
-        for (int q = 0; q < 4; ++q) {
-            uint4 v = p4[q];
-            uint32_t d[4] = {v.x, v.y, v.z, v.w};
-            for (int k = 0; k < 4; ++k)
-                for (int b = 0; b < 4; ++b)
-                    w |= (uint64_t)(((d[k] >> (8 * b)) & 0xFFu) == '1') << (q * 16 + k * 4 + b);
-        }
-    } else {
-        for (uint64_t k = 0; k < 64 && off + k < len; ++k) w |= (uint64_t)(ascii[off + k] == '1') << k;
-    }
-    da[first_word + t] = w;
-}
-
-// DA[from, n) = 1 (a document-array file that ends early on a '1', see eb_flags_set_da); bits at and beyond n stay 0
-__global__ void __launch_bounds__(256) k_fill_da_tail(uint64_t* __restrict__ da, uint64_t from, uint64_t n) {
-    const uint64_t w0 = from >> 6, w1 = (n - 1) >> 6;
-    for (uint64_t w = w0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w <= w1; w += (uint64_t)gridDim.x * blockDim.x) {
-        uint64_t m = ~0ull;
-        if (w == w0) m &= ~0ull << (from & 63u);
-        if (w == w1) m &= ~0ull >> (63u - ((n - 1) & 63u));
-        da[w] |= m; // one thread per word
-    }
-}
-
-// The document array from one of three places: a host buffer, the bytes of a file (fd), or ASCII bytes already in HBM (d_src).
-// '1' -> 1, anything else -> 0 (ebwt2InDel.cpp:1503-1508).  A source shorter than the BWT: the reference's read() fails and
-// leaves its one-byte buffer untouched, so every remaining slot repeats the LAST byte of the file (k_fill_da_tail); with an empty
-// file that buffer was never written (undefined upstream): zeros here.
-// Large host / file sources go through page-locked pieces filled by the loader's reader threads while earlier pieces are uploaded
-// and packed, on two streams (eb_pieces.h: what the eBWT itself comes in by) -- round 4 copied the whole array from pageable
-// memory in 256 MB pieces, each waited for: ~10 GB/s.
-static int set_da_from(eb_flags* f, const uint8_t* host, int fd, const uint8_t* d_src, uint64_t n) {
-    EB_HIP(hipSetDevice(f->device));
-    const EbConfig& cfg = eb_cfg();
-    const size_t bytes = eb_bit_alloc_words(f->n) * 8;
-    if (!f->d_da) EB_HIP(hipMalloc(&f->d_da, bytes));
-    EB_HIP(hipMemsetAsync(f->d_da, 0, bytes, f->stream));
-    const uint64_t lim = n < f->n ? n : f->n;
-    bool sticky_one = false;
-    if (lim > 0 && lim < f->n) {
-        uint8_t last = 0;
-        if (host) last = host[lim - 1];
-        else if (d_src) EB_HIP(hipMemcpy(&last, d_src + lim - 1, 1, hipMemcpyDeviceToHost));
-        else if (pread(fd, &last, 1, (off_t)(lim - 1)) != 1) { eb_set_error("read error in the document array"); return EB_ERR_IO; }
-        sticky_one = last == '1';
-    }
-    // a document array means phase 4 in two-sample form (twice the chains per cluster): its first job's reservations are made now,
-    // beside the upload (the traversal reserved for one sample: it could not know)
-    std::thread reserve([dev = f->device, n_pos = f->phase4_positions ? f->phase4_positions : f->n] { eb_phase4_reserve(dev, n_pos, true); });
-    struct ReserveGuard { std::thread& t; ~ReserveGuard() { if (t.joinable()) t.join(); } } reserve_guard{reserve};
-    auto pack = [&](const uint8_t* d_piece, uint64_t pos, uint64_t len, hipStream_t st) {
-        const uint64_t n_words = (len + 63) / 64;
-        hipLaunchKernelGGL(k_pack_da, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, d_piece, len, pos / 64, n_words, f->d_da);
-    };
-    int rc = EB_OK;
-    if (d_src) {
-        const uint64_t PIECE = 1ull << 36; // (one launch's grid holds 2^32 workgroups of 256 words)
-        for (uint64_t pos = 0; pos < lim; pos += PIECE) pack(d_src + pos, pos, lim - pos < PIECE ? lim - pos : PIECE, f->stream);
-    } else if (lim) {
-        const bool pinned_path = lim >= cfg.pinned_min || !host;
-        const uint64_t PIECE = pinned_path ? cfg.pinned_piece : (256ull << 20); // multiples of 64 positions
-        const int SLOTS = 4;
-        const uint64_t stage_bytes = lim < PIECE ? lim : PIECE;
-        const size_t n_pieces = (size_t)((lim + PIECE - 1) / PIECE);
-        uint8_t *d_stage[4] = {nullptr, nullptr, nullptr, nullptr}, *h_stage[4] = {nullptr, nullptr, nullptr, nullptr};
-        uint64_t h_cap[4] = {0, 0, 0, 0};
-        size_t d_cap[4] = {0, 0, 0, 0};
-        hipEvent_t done[4] = {nullptr, nullptr, nullptr, nullptr};
-        hipStream_t up[2] = {f->stream, nullptr};
-        hipError_t e = hipSuccess;
-        {
-            PieceReaders readers; // (joined before the pieces it fills go back to the pool)
-            readers.src = host;
-            readers.fd = fd;
-            auto piece_len = [&](size_t k) -> uint64_t { const uint64_t pos = (uint64_t)k * PIECE; return lim - pos < PIECE ? lim - pos : PIECE; };
-            size_t posted = 0;
-            if (pinned_path) readers.start(cfg.copy_threads, n_pieces);
-            for (int i = 0; i < SLOTS && (size_t)i < n_pieces && e == hipSuccess; ++i) {
-                if (pinned_path) {
-                    h_stage[i] = static_cast<uint8_t*>(eb_pinned_get(stage_bytes, &h_cap[i]));
-                    if (!h_stage[i]) { e = hipErrorOutOfMemory; break; }
-                    readers.post((int)posted, h_stage[i], (uint64_t)posted * PIECE, piece_len(posted));
-                    ++posted;
-                }
-                d_stage[i] = static_cast<uint8_t*>(eb_scratch_get(f->device, stage_bytes, &d_cap[i]));
-                if (!d_stage[i]) { e = hipErrorOutOfMemory; break; }
-                e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
-            }
-            if (e == hipSuccess && n_pieces > 1 && hipStreamCreateWithFlags(&up[1], hipStreamNonBlocking) != hipSuccess) up[1] = nullptr;
-            if (!up[1]) up[1] = f->stream;
-            if (e == hipSuccess && up[1] != f->stream) {
-                // the second stream starts behind the memset of the array
-                hipEvent_t zeroed = nullptr;
-                e = hipEventCreateWithFlags(&zeroed, hipEventDisableTiming);
-                if (e == hipSuccess) e = hipEventRecord(zeroed, f->stream);
-                if (e == hipSuccess) e = hipStreamWaitEvent(up[1], zeroed, 0);
-                if (zeroed) (void)hipEventDestroy(zeroed);
-            }
-            for (size_t k = 0; k < n_pieces && e == hipSuccess && rc == EB_OK; ++k) {
-                const hipStream_t st = up[k & 1];
-                const int slot = (int)(k % SLOTS);
-                const uint64_t pos = (uint64_t)k * PIECE, len = piece_len(k);
-                const uint8_t* src = host ? host + pos : nullptr;
-                if (pinned_path) {
-                    if (!readers.wait((int)k)) { eb_set_error("read error in the document array"); rc = EB_ERR_IO; break; }
-                    src = h_stage[slot];
-                } else if (k >= (size_t)SLOTS && (e = hipEventSynchronize(done[slot])) != hipSuccess) break;
-                if ((e = hipMemcpyAsync(d_stage[slot], src, len, hipMemcpyHostToDevice, st)) != hipSuccess) break;
-                pack(d_stage[slot], pos, len, st);
-                if ((e = hipEventRecord(done[slot], st)) != hipSuccess) break;
-                if (pinned_path && k >= 1 && posted < n_pieces) { // the slot of the piece BEFORE this one takes the next piece (as in the index loader)
-                    const int free_slot = (int)((k - 1) % SLOTS);
-                    if ((e = hipEventSynchronize(done[free_slot])) != hipSuccess) break;
-                    readers.post((int)posted, h_stage[free_slot], (uint64_t)posted * PIECE, piece_len(posted));
-                    ++posted;
-                }
-            }
-            if (up[1] != f->stream) {
-                if (hipStreamSynchronize(up[1]) != hipSuccess && e == hipSuccess) e = hipErrorUnknown;
-                (void)hipStreamDestroy(up[1]);
-            }
-            if (hipStreamSynchronize(f->stream) != hipSuccess && e == hipSuccess) e = hipErrorUnknown;
-        }
-        for (int i = 0; i < 4; ++i) {
-            if (d_stage[i]) eb_scratch_put(f->device, d_stage[i], d_cap[i]);
-            if (h_stage[i]) eb_pinned_put(h_stage[i], h_cap[i]);
-            if (done[i]) (void)hipEventDestroy(done[i]);
-        }
-        if (rc == EB_OK && e != hipSuccess) { eb_set_error("document array upload failed: %s", hipGetErrorString(e)); rc = EB_ERR_DEVICE; }
-        if (rc != EB_OK) return rc;
-    }
-    if (sticky_one) hipLaunchKernelGGL(k_fill_da_tail, dim3(2048), dim3(256), 0, f->stream, f->d_da, lim, f->n);
-    EB_HIP(hipStreamSynchronize(f->stream));
-    EB_HIP(hipGetLastError());
-    return eb_flags_build_da_rank(f);
-}
-
-extern "C" int eb_flags_set_da(eb_flags* f, const uint8_t* ascii01, uint64_t n) {
-    if (!f || (!ascii01 && n)) { eb_set_error("null argument"); return EB_ERR_ARG; }
-    static const uint8_t empty = 0;
-    return set_da_from(f, ascii01 ? ascii01 : &empty, -1, nullptr, n);
-}
-
-extern "C" int eb_flags_set_da_device(eb_flags* f, const void* d_ascii01, uint64_t n) {
-    if (!f || (!d_ascii01 && n)) { eb_set_error("null argument"); return EB_ERR_ARG; }
-    static const uint8_t empty = 0;
-    if (!n) return set_da_from(f, &empty, -1, nullptr, 0);
-    return set_da_from(f, nullptr, -1, static_cast<const uint8_t*>(d_ascii01), n);
-}
-
-extern "C" int eb_flags_set_da_file(eb_flags* f, const char* path) {
-    if (!f || !path) { eb_set_error("null argument"); return EB_ERR_ARG; }
-    int fd = open(path, O_RDONLY);
-    if (fd < 0) { eb_set_error("Error: could not read file %s", path); return EB_ERR_IO; }
-    struct stat st;
-    if (fstat(fd, &st) != 0) { close(fd); eb_set_error("cannot stat %s", path); return EB_ERR_IO; }
-    static const uint8_t empty = 0;
-    const uint64_t n = (uint64_t)st.st_size;
-    int rc = n ? set_da_from(f, nullptr, fd, nullptr, n) : set_da_from(f, &empty, -1, nullptr, 0);
-    close(fd);
-    return rc;
-}
-
-extern "C" uint64_t eb_flags_words(const eb_flags* f) { return f ? f->words : 0; }
-extern "C" int eb_flags_has_da(const eb_flags* f) { return f && f->d_da ? 1 : 0; }
-
-extern "C" int eb_flags_export(eb_flags* f, uint64_t* thrK, uint64_t* thrR, uint64_t* minima, uint64_t* da) {
-    if (!f) { eb_set_error("null argument"); return EB_ERR_ARG; }
-    EB_HIP(hipSetDevice(f->device));
-    size_t bytes = f->words * 8;
-    if (thrK) EB_HIP(hipMemcpy(thrK, f->d_thrK, bytes, hipMemcpyDeviceToHost));
-    if (thrR) EB_HIP(hipMemcpy(thrR, f->d_thrR, bytes, hipMemcpyDeviceToHost));
-    if (minima) EB_HIP(hipMemcpy(minima, f->d_min, bytes, hipMemcpyDeviceToHost));
-    if (da) {
-        if (!f->d_da) { eb_set_error("flags carry no document array"); return EB_ERR_STATE; }
-        EB_HIP(hipMemcpy(da, f->d_da, bytes, hipMemcpyDeviceToHost));
-    }
-    return EB_OK;
-}
-
-static int flags_import_impl(uint64_t n, int device, const uint64_t* thrK, const uint64_t* thrR, const uint64_t* minima, const uint64_t* da,
-                             bool complemented, eb_flags** out) {
-    if (!out || !thrK || !thrR || !minima) { eb_set_error("null argument"); return EB_ERR_ARG; }
-    *out = nullptr;
-    eb_flags* f = nullptr;
-    int rc = eb_flags_alloc(n, device, da != nullptr, &f);
-    if (rc != EB_OK) return rc;
-    f->complemented = complemented;
-    size_t bytes = f->words * 8;
-    hipError_t e = hipMemcpy(f->d_thrK, thrK, bytes, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(f->d_thrR, thrR, bytes, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(f->d_min, minima, bytes, hipMemcpyHostToDevice);
-    if (e == hipSuccess && da) e = hipMemcpy(f->d_da, da, bytes, hipMemcpyHostToDevice);
-    if (e != hipSuccess) { eb_set_error("flag upload failed: %s", hipGetErrorString(e)); eb_flags_destroy(f); return EB_ERR_DEVICE; }
-    if ((rc = eb_flags_derive(f)) != EB_OK) { eb_flags_destroy(f); return rc; }
-    *out = f;
-    return EB_OK;
-}
-
-extern "C" int eb_flags_import(uint64_t n, int device, const uint64_t* thrK, const uint64_t* thrR, const uint64_t* minima,
-                               const uint64_t* da, eb_flags** out) {
-    return flags_import_impl(n, device, thrK, thrR, minima, da, false, out);
-}
-
-extern "C" int eb_flags_import_shard_sum(uint64_t n, int device, const uint64_t* thrK_below, const uint64_t* thrR_below, const uint64_t* minima,
-                                         const uint64_t* da, eb_flags** out) {
-    return flags_import_impl(n, device, thrK_below, thrR_below, minima, da, true, out);
-}
-
-extern "C" void eb_flags_destroy(eb_flags* f) {
-    if (!f) return;
-    if (f->device >= 0) (void)hipSetDevice(f->device);
-    uint64_t* v[6] = {f->d_thrK, f->d_thrR, f->d_min, f->d_da, f->d_da_rank, f->d_flag};
-    for (auto p : v)
-        if (p) (void)hipFree(p);
-    if (f->d_mxy) (void)hipFree(f->d_mxy);
-    if (f->d_mxy_spare) (void)hipFree(f->d_mxy_spare);
-    if (f->stream) (void)hipStreamDestroy(f->stream);
-    delete f;
 }

@@ -347,7 +347,7 @@ void eb_free(void* p);
 void eb_config_reload(void);
 
 /* ------------------------------------------------------------------ self-test hooks (host only, no GPU needed)
- * Round trip of the traversal's packed stack records (eb_navigate.hip: 40-bit positions + saturating 16-bit depth;
+ * Round trip of the traversal's packed stack records (eb_nav_common.h: 40-bit positions + saturating 16-bit depth;
  * n_fields = 6 one-BWT node, 12 two-BWT node, 4 two-BWT leaf) through the same code the kernels run.  fields_out gets
  * n_fields values, words_out (may be NULL) the packed words, *n_words their number. */
 int eb_selftest_pack_fields(int32_t n_fields, const uint64_t* fields, uint64_t depth, uint64_t* fields_out, uint64_t* depth_out,

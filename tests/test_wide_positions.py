@@ -1,6 +1,6 @@
 """Host-side checks of everything that carries a BWT position wider than 32 bits (configs[1..4] all live past 2^32;
 the reference is 64-bit throughout with 2^32-symbol superblocks, dna_string.hpp:36-38,140-152):
-  * the traversal's packed stack records (eb_navigate.hip: 40-bit positions, saturating 16-bit depth) round trip through
+  * the traversal's packed stack records (eb_nav_common.h: 40-bit positions, saturating 16-bit depth) round trip through
     the same __host__ __device__ code the kernels run, with every field beyond 2^32;
   * the compact wire images of a call set (EBCALLS4: begin_lo + begin_hi; EBCALLS3: u64 begin) unpack to the friendly
     records with begins >= 2^32, and the writer numbers and prints them.
