@@ -172,6 +172,12 @@ __device__ __forceinline__ uint64_t eb_quad_pick64(uint64_t v, bool mine) {
     return ((uint64_t)hi << 32) | lo;
 }
 __device__ __forceinline__ uint32_t eb_quad_pick32(uint32_t v, bool mine) { return eb_quad_or(mine ? v : 0u); }
+// the value of lane (byte_addr >> 2) of the wave, through the LDS crossbar (no vector-ALU work; the lane read from must be active)
+__device__ __forceinline__ uint64_t eb_bpermute64(int byte_addr, uint64_t v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(byte_addr, (int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(byte_addr, (int)(uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
 
 // Letter j's count before the superblock of position i, with the last answer kept: consecutive queries of a walk nearly always
 // stay in one superblock (2^32 symbols), and the table read is a global load on the path of every step otherwise.

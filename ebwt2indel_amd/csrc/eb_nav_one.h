@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(256) k_nodes1p(eb_dev_index x1, eb_dev_flags f
 // (never seen: the whole traversal pushes fewer records than ONE stack holds) ends the traversal with an error and the caller
 // walks again with k_nodes1p (flags_build_chains).
 template <bool SUPER_LDS>
-__global__ void __launch_bounds__(256) k_nodes1c(eb_dev_index x1, eb_dev_flags f, uint64_t* __restrict__ kr, NavParams p, const NavLaunch* __restrict__ la,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k_nodes1c(eb_dev_index x1, eb_dev_flags f, uint64_t* __restrict__ kr, NavParams p, const NavLaunch* __restrict__ la,
                                                 NavCounters* cnt, unsigned long long* __restrict__ stat_rows) {
     using Rec = Node1P;
     // Pushes are rare here (one node in a hundred has a second kept child), so the staging buffer is small -- the 48 KB of k_nodes1p
@@ -310,6 +310,10 @@ __global__ void __launch_bounds__(256) k_nodes1c(eb_dev_index x1, eb_dev_flags f
             if (!(EB_NDBG(p) & 2u)) eb_bit_set_atomic(f.minima, hi);
             ++n_min;
         }
+        // the node and its rank queries as the reference counts them (it shares the query of equal neighbouring boundaries): one per
+        // DISTINCT boundary = 1 + the non-empty child intervals -- lane j knows about interval j, lane 0 adds the first boundary and T's
+        n_rank += (hi > lo ? 1u : 0u) + (j == 0 ? 1u + (N.b[5] != N.b[4] ? 1u : 0u) : 0u);
+        n_node += j == 0 ? 1u : 0u;
     };
 
     // ---- two chains per quad + one record fetched ahead
@@ -362,32 +366,36 @@ __global__ void __launch_bounds__(256) k_nodes1c(eb_dev_index x1, eb_dev_flags f
                     Node1 child;
                     child.pad = 0;
                     int kids = 0;
+                    // letter j's count before the superblock: read ONCE per node -- its six boundaries lie in one superblock of 2^32
+                    // symbols unless the node straddles a superblock boundary (then per boundary: wave-uniform choice)
+                    auto super_of = [&](uint64_t i) -> uint64_t {
+                        if constexpr (SUPER_LDS) return s_super[((i >> EB_SUPER_SHIFT) << 2) + j];
+                        else return x1.super[((i >> EB_SUPER_SHIFT) << 2) + j];
+                    };
+                    const bool one_super = __ballot((N.b[5] >> EB_SUPER_SHIFT) != (N.b[0] >> EB_SUPER_SHIFT)) == 0ull;
+                    const uint64_t base0 = Fj + super_of(N.b[0]);
 #pragma unroll
                     for (int k = 0; k < 6; ++k) {
-                        const uint64_t i = N.b[k];
-                        uint32_t pc = eb_chunk_counts(c[k], eb_prefix_mask32((uint32_t)(i & 127u), j));
+                        uint32_t pc = eb_chunk_counts(c[k], eb_prefix_mask32((uint32_t)(N.b[k] & 127u), j));
                         pc = eb_quad_sum(pc);
-                        uint64_t sup;
-                        if constexpr (SUPER_LDS) sup = s_super[((i >> EB_SUPER_SHIFT) << 2) + j];
-                        else sup = x1.super[((i >> EB_SUPER_SHIFT) << 2) + j];
-                        child.b[k] = Fj + sup + c[k].w + ((pc >> (8u * j)) & 0xFFu);
+                        const uint64_t base = one_super ? base0 : Fj + super_of(N.b[k]);
+                        child.b[k] = (base + c[k].w) + ((pc >> (8u * j)) & 0xFFu);
                     }
                     for (int k = 0; k < 5; ++k) kids += child.b[k + 1] > child.b[k];
                     child.depth = N.depth + 1;
                     const bool keep = act && kids >= 2; // number_of_children (include.hpp:760-768)
-                    if (act && p.write && j == 0) {
-                        ++n_node;
-                        n_rank += 1;
-                        for (int k = 1; k < 6; ++k) n_rank += N.b[k] != N.b[k - 1]; // the reference shares the query of equal neighbours
-                    }
                     // the quad goes on with its first kept child; the others travel through the stack
                     const uint32_t km = eb_quad_or(keep ? (1u << j) : 0u);
                     const uint32_t jc = follow && km ? (uint32_t)__ffs((int)km) - 1u : 4u;
                     nav_push_or_spill<Rec, STAGE>(keep && j != jc, [&] { return pack_rec(child); }, s_buf, &s_count, out, out_cap, cnt, lane);
                     bool want = false;
-                    if (jc < 4u) {
+                    // lane jc's six boundaries to the whole quad: twelve ds_bpermute (the LDS crossbar, next to idle here) instead of six
+                    // masked quad-ORs of 64 bits -- 36 vector instructions per turn in a kernel whose vector ALUs are busy 92 % of the
+                    // time (profiles/r05_sq_nav.txt).
+                    if (jc < 4u) { // (uniform inside a quad: the lanes a lane reads from are active with it)
+                        const int src = (int)(((lane & ~3u) | jc) << 2);
 #pragma unroll
-                        for (int k = 0; k < 6; ++k) N.b[k] = eb_quad_pick64(child.b[k], j == jc);
+                        for (int k = 0; k < 6; ++k) N.b[k] = eb_bpermute64(src, child.b[k]);
                         N.depth = child.depth;
                     } else {
                         // the chain ended (or the slot was idle): on with the record fetched ahead, and another one is asked for

@@ -356,7 +356,11 @@ __global__ void __launch_bounds__(256) k_nodes2c(eb_dev_index x1, eb_dev_index x
                 if (s2 && !(EB_NDBG(p) & 8u)) eb_bit_set_atomic(f.da, N.b[k] + N.a[k + 1]);
                 ++n_da;
             }
+            // rank queries as the reference counts them (equal neighbouring boundaries share one): one per DISTINCT boundary of each BWT =
+            // 1 + its non-empty child intervals; the lane that looks at interval k counts it, lane 0 adds the two first boundaries
+            n_rank += (s1 ? 1u : 0u) + (s2 ? 1u : 0u);
         }
+        if (j == 0) { ++n_node; n_rank += 2; }
     };
     // which boundaries start a new block (bit k: a[k], bit 6 + k: b[k]); the others reuse their left neighbour's
     auto load_mask = [&](const Node2& N) -> uint32_t {
@@ -418,6 +422,18 @@ __global__ void __launch_bounds__(256) k_nodes2c(eb_dev_index x1, eb_dev_index x
                     child.pad[0] = child.pad[1] = child.pad[2] = 0;
                     int kids = 0;
                     uint4 cur_a = ca[0], cur_b = cb[0];
+                    // letter j's counts before the superblocks: read ONCE per node and BWT -- a node's six boundaries lie in one
+                    // superblock of 2^32 symbols unless it straddles a superblock boundary (then per boundary: wave-uniform choice)
+                    auto super_a = [&](uint64_t i) -> uint64_t {
+                        if constexpr (SUPER_LDS) return s_super[0][((i >> EB_SUPER_SHIFT) << 2) + j];
+                        else return x1.super[((i >> EB_SUPER_SHIFT) << 2) + j];
+                    };
+                    auto super_b = [&](uint64_t i) -> uint64_t {
+                        if constexpr (SUPER_LDS) return s_super[1][((i >> EB_SUPER_SHIFT) << 2) + j];
+                        else return x2.super[((i >> EB_SUPER_SHIFT) << 2) + j];
+                    };
+                    const bool one_super = __ballot((N.a[5] >> EB_SUPER_SHIFT) != (N.a[0] >> EB_SUPER_SHIFT) || (N.b[5] >> EB_SUPER_SHIFT) != (N.b[0] >> EB_SUPER_SHIFT)) == 0ull;
+                    const uint64_t base_a = F1 + super_a(N.a[0]), base_b = F2 + super_b(N.b[0]);
 #pragma unroll
                     for (int k = 0; k < 6; ++k) {
                         if ((mc >> k) & 1u) cur_a = ca[k]; // else: the block of the boundary to the left
@@ -427,29 +443,26 @@ __global__ void __launch_bounds__(256) k_nodes2c(eb_dev_index x1, eb_dev_index x
                         uint32_t pb = eb_chunk_counts(cur_b, eb_prefix_mask32((uint32_t)(ib & 127u), j));
                         pa = eb_quad_sum(pa);
                         pb = eb_quad_sum(pb);
-                        uint64_t sa, sb;
-                        if constexpr (SUPER_LDS) { sa = s_super[0][((ia >> EB_SUPER_SHIFT) << 2) + j]; sb = s_super[1][((ib >> EB_SUPER_SHIFT) << 2) + j]; }
-                        else { sa = x1.super[((ia >> EB_SUPER_SHIFT) << 2) + j]; sb = x2.super[((ib >> EB_SUPER_SHIFT) << 2) + j]; }
-                        child.a[k] = F1 + sa + cur_a.w + ((pa >> (8u * j)) & 0xFFu);
-                        child.b[k] = F2 + sb + cur_b.w + ((pb >> (8u * j)) & 0xFFu);
+                        const uint64_t ba = one_super ? base_a : F1 + super_a(ia), bb = one_super ? base_b : F2 + super_b(ib);
+                        child.a[k] = (ba + cur_a.w) + ((pa >> (8u * j)) & 0xFFu);
+                        child.b[k] = (bb + cur_b.w) + ((pb >> (8u * j)) & 0xFFu);
                     }
                     for (int k = 0; k < 5; ++k) kids += (child.a[k + 1] > child.a[k]) || (child.b[k + 1] > child.b[k]); // include.hpp:784-792
                     child.depth = N.depth + 1;
                     const bool keep = act && kids >= 2;
-                    if (act && p.write && j == 0) {
-                        ++n_node;
-                        n_rank += 2;
-                        for (int k = 1; k < 6; ++k) n_rank += (N.a[k] != N.a[k - 1]) + (N.b[k] != N.b[k - 1]);
-                    }
                     const uint32_t km = eb_quad_or(keep ? (1u << j) : 0u);
                     const uint32_t jc = follow && km ? (uint32_t)__ffs((int)km) - 1u : 4u;
                     nav_push_or_spill<Rec, STAGE>(keep && j != jc, [&] { return pack_rec(child); }, s_buf, &s_count, out, out_cap, cnt, lane);
                     bool want = false;
-                    if (jc < 4u) {
+                    if (jc < 4u) { // (uniform inside a quad: the lanes a lane reads from are active with it)
+                        // lane jc's twelve boundaries to the whole quad through the LDS crossbar (ds_bpermute: no vector-ALU work) instead
+                        // of twelve masked quad-ORs of 64 bits -- 72 vector instructions per turn of a kernel whose vector ALUs are busy 89 %
+                        // of the time (profiles/r05_sq_nav.txt)
+                        const int src = (int)(((lane & ~3u) | jc) << 2);
 #pragma unroll
                         for (int k = 0; k < 6; ++k) {
-                            N.a[k] = eb_quad_pick64(child.a[k], j == jc);
-                            N.b[k] = eb_quad_pick64(child.b[k], j == jc);
+                            N.a[k] = eb_bpermute64(src, child.a[k]);
+                            N.b[k] = eb_bpermute64(src, child.b[k]);
                         }
                         N.depth = child.depth;
                     } else {
