@@ -14,7 +14,7 @@ def run(args, label, want):
     out = os.path.join(tmp, "m23.snp")
     for rep in range(2):
         t = time.time()
-        r = subprocess.run([_lib.CLI_PATH] + args + ["-o", out], capture_output=True, text=True, env=dict(os.environ, EB_TRACE="index"))
+        r = subprocess.run([_lib.CLI_PATH] + args + ["-o", out], capture_output=True, text=True, env=dict(os.environ, EB_TRACE=os.environ.get("EB_TRACE", "index")))
         dt = time.time() - t
         got = open(out, "rb").read() if r.returncode == 0 else b""
         print(f"{label} run {rep}: {dt:.2f}s rc={r.returncode} identical={got == want} records={got.count(b'>')} sha={hashlib.sha256(got).hexdigest()[:16]}")
