@@ -311,7 +311,7 @@ __global__ void __launch_bounds__(256) k_right(eb_dev_index x1, eb_dev_index x2,
 __global__ void k_finish(const ScanCounters* __restrict__ c, JobReport* __restrict__ report) {
     unsigned long long a = c->req_ext[threadIdx.x], b = c->req_right[threadIdx.x], t = c->req_tab[threadIdx.x];
     for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); t += __shfl_xor(t, o); }
-    if (threadIdx.x == 0) { report->req_ext = a; report->req_right = b; report->req_tab = t; report->wire_bad = c->wire_bad; }
+    if (threadIdx.x == 0) { report->req_ext = a; report->req_right = b; report->req_tab = t; report->wire_bad = c->wire_bad; report->n_hot = c->n_hot; report->n_todo = c->n_todo; }
 }
 
 }  // namespace

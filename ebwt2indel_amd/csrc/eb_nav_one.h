@@ -247,8 +247,8 @@ __global__ void __launch_bounds__(256) k_nodes1p(eb_dev_index x1, eb_dev_flags f
 
 // ---- phase 3, one BWT, CHAINS FOLLOWED IN REGISTERS (round 4).  The suffix tree of a read collection is mostly unary under Weiner
 // links: W is right-maximal because some read ends behind it ('#') while the others go on with one letter, and the same holds for
-// cW, c'cW, ... until the reads run out -- ~135 nodes in a row whose only kept child is the next one (6.1 G nodes, ~50 M such
-// chains at 7.55 G positions).  k_nodes1p sends every one of them through the stack: 32 bytes written, 32 read, packed, staged,
+// cW, c'cW, ... until the reads run out -- ~67 nodes in a row whose only kept child is the next one (6.1 G nodes in 92 M records through
+// the stack at 7.55 G positions; 16 in a row on reads with 1 % errors: profiles/r05_input_stats.txt).  k_nodes1p sends every one of them through the stack: 32 bytes written, 32 read, packed, staged,
 // unpacked.  Here a quad KEEPS the first kept child of its node -- lane jc's six boundaries are spread over the quad by DPP -- and
 // expands it in its next turn; only the other kept children (one node in a hundred has any) go to the stack, and a quad takes a
 // new record from the launch's input only when its chain ends.  A quad runs TWO chains alternately, so that the block loads of

@@ -119,6 +119,7 @@ struct DrainState {
     uint32_t last, last_src;              // what the previous step was (DRAIN_*) and which stack it popped
     unsigned long long last_base, last_room;
     uint32_t shard, n_shards, split_done, error;
+    unsigned long long records;           // records popped and expanded so far (= chains started by the chain-following kernels)
     unsigned long long room_hook;         // tests (EB_NAV_CHAINS=3): most room a launch is TOLD it has, so that it really overflows (0: the truth)
     NavLaunch expand;                     // what the next expansion kernel works on (count 0: nothing)
     NavLaunch split;                      // ... and the next k_keep_shard (count 0: nothing)
@@ -183,6 +184,7 @@ __global__ void k_drain_plan(DrainState* st, NavCounters* cnt) {
     st->last_src = src;
     st->last_base = base;
     st->last_room = handed;
+    st->records += B;
     ++st->launches;
 }
 
@@ -278,7 +280,7 @@ struct Drain {
             EB_HIP(hipEventSynchronize(ev[g & 1]));
             const DrainState& s = h_state[g & 1];
             if (trace)
-                fprintf(stderr, "[nav] group %d: launches=%llu pending=%llu max=%llu t=%.3fs\n", g, (unsigned long long)s.launches,
+                fprintf(stderr, "[nav] group %d: launches=%llu records=%llu pending=%llu max=%llu t=%.3fs\n", g, (unsigned long long)s.launches, (unsigned long long)s.records,
                         (unsigned long long)(s.top[0] + s.top[1]), (unsigned long long)s.max_top, now_s() - t_start);
             if (s.split_done) split_pending = false;
             if (s.error || s.top[0] + s.top[1] == 0) {

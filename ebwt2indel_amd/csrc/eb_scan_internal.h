@@ -57,6 +57,7 @@ struct ScanCounters {
     unsigned long long req_ext[EB_REQ_SLOTS], req_right[EB_REQ_SLOTS], req_tab[EB_REQ_SLOTS]; // memory requests counted by k_extend / k_right (count_requests); req_tab: k_right's FL-table chunks
     unsigned long long wire_bad;                                       // records that do not fit the tight wire image
     unsigned int max_batch, pad;                                       // most survivors in one batch of the ordered hand-over
+    unsigned long long n_hot, n_todo;                                  // profiling build only (EB_SCAN_EXPERIMENTS): clusters handed to k_scan's hot / todo queues
     JobLayout lay;
 };
 
@@ -67,6 +68,7 @@ struct JobReport {
     unsigned long long hist[201];
     JobLayout lay;
     unsigned long long req_ext, req_right, req_tab, wire_bad; // part 2
+    unsigned long long n_hot, n_todo;                         // (profiling build: 0 otherwise)
 };
 
 static inline unsigned eb_grid_of(uint64_t threads) { return (unsigned)((threads + 255) / 256); }

@@ -631,6 +631,10 @@ extern "C" int eb_scan_clusters_end(eb_scan_job* job, eb_calls** out, eb_scan_st
             auto at = [&](int k) { float t = 0; (void)hipEventElapsedTime(&t, job->e[E_BEGIN], job->e[k]); return t; };
             fprintf(stderr, "[scan] ms since the scan's start: scan done %.3f  ordered %.3f  extend %.3f-%.3f  right -%.3f  last kernel %.3f  records on host %.3f  (%s, %u reruns)\n",
                     at(E_SCAN1), at(E_ORDER), at(E_EXT0), at(E_EXT1), at(E_RIGHT1), at(E_CTX_DONE), stats->ms_total, job->ordered ? "ordered" : "unordered", job->reruns);
+            if (R.n_hot) // (profiling build)
+                fprintf(stderr, "[scan] of %llu clusters (runs of at least 2 x mcov rows; %llu runs closed): %llu to the hot queue (1 in %.1f), %llu on to the histogram (1 in %.1f), %llu survivors\n",
+                        (unsigned long long)R.clusters, (unsigned long long)R.runs_closed, (unsigned long long)R.n_hot, (double)R.clusters / (double)R.n_hot, (unsigned long long)R.n_todo,
+                        (double)R.clusters / (double)(R.n_todo ? R.n_todo : 1), (unsigned long long)R.nsurv_raw);
         }
     }
     eb_calls* calls = job->calls;

@@ -134,8 +134,9 @@ __device__ __forceinline__ RunGeom run_geometry(const eb_dev_flags& f, uint64_t 
 // (8 B).  What every run needs (CLUST_SIZES, counters) is done by the lane that streams the word, with bit tricks on
 // registers.  What only a few runs need is NOT done there -- a wave would wait for its few busy lanes -- but handed
 // over through two small per-wave queues in LDS and worked off 64 at a time, one run per lane:
-//   hot queue : clusters that contain a change of symbol (found bit-parallel, ~1 in 5)   -> two-popcount necessary test
-//   todo queue: clusters that pass it (~1 in 30)                                         -> histogram, frequent letters, record
+//   hot queue : clusters that can hold two frequent letters at all (found bit-parallel: 1 in 147 on clean reads, 1 in 29 on reads
+//               with 1 % errors, profiles/r05_input_stats.txt)                                -> two-popcount necessary test
+//   todo queue: clusters that pass it (1 in 351 / 1 in 92)                                    -> histogram, frequent letters, record
 // A queued run is a (word, bit) pair; its lane reloads the two flag words and planes (cache hits: just streamed).
 // Runs longer than the two words (and the two-BWT mode, whose symbols live in other coordinates) take the memory path.
 // Persistent grid; statistics leave as one row per workgroup.
@@ -244,6 +245,9 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
         unsigned long long m = __ballot(have);
         if (have) q_todo[wave][todo_n + ones_below(m)] = entry;
         todo_n += (uint32_t)__popcll(m);
+#ifdef EB_SCAN_EXPERIMENTS
+        if (lane == 0 && m) atomicAdd(&cnt->n_todo, (unsigned long long)__popcll(m));
+#endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (todo_n >= 64u) {
@@ -298,6 +302,9 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
         unsigned long long m = __ballot(have);
         if (have) q_hot[wave][hot_n + ones_below(m)] = entry;
         hot_n += (uint32_t)__popcll(m);
+#ifdef EB_SCAN_EXPERIMENTS
+        if (lane == 0 && m) atomicAdd(&cnt->n_hot, (unsigned long long)__popcll(m));
+#endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (hot_n >= 64u) {
@@ -399,7 +406,7 @@ __global__ void __launch_bounds__(256) k_scan(eb_dev_index x1, eb_dev_index x2, 
         //   >= mcov: the lowest differing row of every run is cleared mcov-1 times (a decrement that starts at each
         //            run's first row and is stopped by the closing zero), what is left marks runs with >= mcov;
         //   collect: the run masks plus a non-empty subset of them carry out into exactly their closing positions.
-        // ~19 of 20 clusters (one symbol, or a read start or two) end here.  Rows of a run that lie in the previous word
+        // All but one cluster in 147 (one symbol, or a read start or two; one in 29 on reads with 1 % errors) end here.  Rows of a run that lie in the previous word
         // are counted separately and lower the bar for that one run.
         uint64_t hot = ends;
         {
