@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(256) k_nodes1p(eb_dev_index x1, eb_dev_flags f
 // links: W is right-maximal because some read ends behind it ('#') while the others go on with one letter, and the same holds for
 // cW, c'cW, ... until the reads run out -- ~67 nodes in a row whose only kept child is the next one (6.1 G nodes in 92 M records through
 // the stack at 7.55 G positions; 16 in a row on reads with 1 % errors: profiles/r05_input_stats.txt).  k_nodes1p sends every one of them through the stack: 32 bytes written, 32 read, packed, staged,
-// unpacked.  Here a quad KEEPS the first kept child of its node -- lane jc's six boundaries are spread over the quad by DPP -- and
+// unpacked.  Here a quad KEEPS the first kept child of its node -- lane jc's six boundaries reach the quad through ds_bpermute -- and
 // expands it in its next turn; only the other kept children (one node in a hundred has any) go to the stack, and a quad takes a
 // new record from the launch's input only when its chain ends.  A quad runs TWO chains alternately, so that the block loads of
 // one are in flight while the other computes (the distance k_nodes1p keeps between its stages A and D), plus one input record
@@ -421,7 +421,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
 }
 
 // ---- phase 2, one BWT, chains followed in registers like k_nodes1c.  Two reads that end at the same place share every suffix, so
-// the leaves W#, cW#, c'cW#, ... form a chain as long as the reads (0.58 G leaves in ~4 M chains at 7.55 G positions, which
+// the leaves W#, cW#, c'cW#, ... form a chain as long as the reads (0.58 G leaves in 16 M records through the stack at 7.55 G positions, which
 // k_leaves walks in lock-step: a hundred launches of 4 M records at the end of the traversal).  A quad keeps the first kept child
 // leaf and expands it in its next turn; two chains per quad alternate, so that the two block loads of one are in flight while the
 // other computes (k_leaves waits for its record, then for its blocks: nothing overlaps), one input record is fetched ahead.
