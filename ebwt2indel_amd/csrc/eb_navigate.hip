@@ -203,7 +203,7 @@ struct Drain {
     uint64_t split_min = 4096;
     uint64_t room_hook = 0; // see DrainState
 
-    // The stacks live in one arena shared by both phases (allocating HBM costs ~20 ms per GB, so the arena is sized from
+    // The stacks live in one arena shared by both phases (HBM that was released shortly before -- by this process or the one before it -- is wiped by the driver before it is handed out again, ~20 ms per GB, so the arena is sized from
     // the batch, not from n).  A depth-first drain needs a few batches of room (observed: < 7 batches at 7.55 G
     // positions); if a stack ever fills, the planner shrinks the batch -- in the limit a plain depth-first walk that needs
     // 4 x depth records -- so capacity never affects results.

@@ -1042,6 +1042,37 @@ def test_fresh_inputs_against_the_reference_binary(tmp_path, seed, extra):
     assert want3.count(b">") > 20 and api.run_two_datasets_da(m, da, p) == want3
 
 
+@pytest.mark.skipif(not os.path.exists(_oracle.REF_BIN), reason="reference binary did not travel with the tree")
+@pytest.mark.parametrize("rc", [False, True], ids=["errors", "errors_rc"])
+def test_reads_with_errors_against_the_reference_binary_at_60m_positions(tmp_path, rc):
+    """The reference's documented kind of input (README.md:88-100) straight through the unmodified reference binary on the test box:
+    400 k x 150 bp reads with 1 % substitution errors (and, second case, 200 k such reads plus their reverse complements), 60 M
+    positions built by the GPU generator -- the GPU path must write the reference's bytes (round 4's fresh inputs were error-free;
+    the goldens with errors stop at 0.4 M positions)."""
+    n_reads, L = (200_000, 150) if rc else (400_000, 150)
+    g = sim.random_genome(int(n_reads * (2 if rc else 1) * L / 30), 911)
+    h2 = sim.mutate_haplotype(g, 911)
+    text, offs = sim.haplotype_text([g, h2])
+    starts = sim.sample_read_starts([g, h2], offs, n_reads, L, 911)
+    d_reads, d_starts = sim.error_sample_gpu(text, starts, L, 911, 10_000, rc=rc)
+    dev = sim.build_ebwt_gpu_slabbed(int(d_reads.data_ptr()), int(d_starts.data_ptr()), L, n_reads=int(d_starts.numel()), text_len=int(d_reads.numel()))
+    e, _ = dev.to_host()
+    dev.free()
+    del d_reads, d_starts
+    assert len(e) == 400_000 * 151
+    pth, out = tmp_path / "x.ebwt", tmp_path / "ref.snp"
+    e.tofile(pth)
+    r = subprocess.run([_oracle.REF_BIN, "-1", str(pth), "-o", str(out)], stdout=subprocess.DEVNULL, timeout=600)
+    assert r.returncode == 0
+    want = out.read_bytes()
+    assert want.count(b">") > 2000
+    assert api.run_one_dataset(e, api.make_params()) == want
+    # and the executable on the same file
+    got = tmp_path / "gpu.snp"
+    r = subprocess.run([_lib.CLI_PATH, "-1", str(pth), "-o", str(got)], capture_output=True, text=True)
+    assert r.returncode == 0 and got.read_bytes() == want
+
+
 def test_wire_image_falls_back_to_full_width_records(oracle):
     """A cluster of more than 65535 rows does not fit the tight wire image (16-bit length): the job then packs the
     full-width one, and both unpack to the very records of the host blob."""
