@@ -432,7 +432,7 @@ def main():
         import threading
         sys.setswitchinterval(2e-5)   # the two threads hand the interpreter lock over within microseconds, not CPython's default 5 ms
         begun_q = queue.Queue()
-        in_flight = threading.Semaphore(5)
+        in_flight = threading.Semaphore(int(os.environ.get("EB_BENCH_IN_FLIGHT", "5")))   # passes begun and not yet handed over
         failure = []
 
         def helper():

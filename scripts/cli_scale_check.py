@@ -30,6 +30,7 @@ print(r.stdout.splitlines()[-1] if r.stdout else r.stderr[-500:])
 os.remove("/tmp/scale_g1.snp")
 for rep in range(int(os.environ.get("CLI_REPEATS", "0"))):     # run-to-run spread of both forms (HBM just freed by the previous process)
     for extra in ([], ["-G", "1"]):
+        time.sleep(float(os.environ.get("CLI_SLEEP", "0")))     # (an idle GPU: the driver has wiped what the previous process released)
         t = time.time()
         r = subprocess.run([_lib.CLI_PATH, "-1", path, "-o", "/tmp/scale_rep.snp"] + extra, capture_output=True, text=True)
         print(f"repeat {rep} {' '.join(extra) or 'plain'}: {time.time() - t:.2f}s rc={r.returncode} :: {r.stdout.splitlines()[-1][:160] if r.stdout else r.stderr[-200:]}")
