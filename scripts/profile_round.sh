@@ -8,7 +8,7 @@ ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-B="python3 $ROOT/bench.py --cpu-sample-reads 0 --cpu-dram-reads 0"
+B="python3 $ROOT/bench.py --cpu-sample-reads 0 --cpu-dram-reads 0 --no-other-modes"
 timeout -k 10 280 rocprofv3 --kernel-trace --stats -d "$OUT/np" -o np --output-format csv -- $B --no-pipeline > "$OUT/np.json" 2> "$OUT/np.err"
 timeout -k 10 280 rocprofv3 --kernel-trace --stats -d "$OUT/pl" -o pl --output-format csv -- $B > "$OUT/pl.json" 2> "$OUT/pl.err"
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/fetch" -o fetch --output-format csv -- $B --no-pipeline --steps 5 --warmup 1 > "$OUT/fetch.json" 2> "$OUT/fetch.err"
