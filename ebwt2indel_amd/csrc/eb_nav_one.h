@@ -259,6 +259,8 @@ __global__ void __launch_bounds__(256) k_nodes1p(eb_dev_index x1, eb_dev_flags f
 // (never seen: the whole traversal pushes fewer records than ONE stack holds) ends the traversal with an error and the caller
 // walks again with k_nodes1p (flags_build_chains).
 template <bool SUPER_LDS>
+// (four waves per SIMD = 128 registers: at three -- 130 registers, nothing spilled -- a traversal takes 0.274 instead of 0.260 s, so the
+// kernel is hardly short of waves in flight; at five -- 96 registers -- it spills and takes 0.87 s.  profiles/r05_sq_nav.txt)
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k_nodes1c(eb_dev_index x1, eb_dev_flags f, uint64_t* __restrict__ kr, NavParams p, const NavLaunch* __restrict__ la,
                                                 NavCounters* cnt, unsigned long long* __restrict__ stat_rows) {
     using Rec = Node1P;
