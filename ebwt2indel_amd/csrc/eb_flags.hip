@@ -321,6 +321,7 @@ extern "C" int eb_flags_set_da_device(eb_flags* f, const void* d_ascii01, uint64
     if (!f || (!d_ascii01 && n)) { eb_set_error("null argument"); return EB_ERR_ARG; }
     static const uint8_t empty = 0;
     if (!n) return set_da_from(f, &empty, -1, nullptr, 0);
+    if (reinterpret_cast<uintptr_t>(d_ascii01) & 15u) { eb_set_error("document array in device memory must be 16-byte aligned"); return EB_ERR_ARG; }
     return set_da_from(f, nullptr, -1, static_cast<const uint8_t*>(d_ascii01), n);
 }
 

@@ -436,6 +436,8 @@ def test_document_array_from_buffer_file_and_device_is_the_same_array(monkeypatc
             assert not np.unpackbits(words.view(np.uint8), bitorder="little")[len(m):].any()
     with pytest.raises(api.EbError, match="could not read file"):
         fl.set_da_file(str(tmp_path / "absent.da"))
+    with pytest.raises(api.EbError, match="16-byte aligned"):
+        fl.set_da_device(t.data_ptr() + 1, 100)
     # and the call set that comes out of the file form is the reference's
     fl.set_da_file(str(tmp_path / "x.da"))                          # (da + b"1111": longer than the BWT, the excess is ignored)
     p = api.make_params()
