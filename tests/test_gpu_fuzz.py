@@ -1,0 +1,17 @@
+"""A seeded slice of the randomised differential run (tests/fuzz_vs_oracle.py): random small inputs in all three modes, with and
+without sequencing errors / reverse complements, under random options -- GPU .snp == CPU oracle's, byte for byte."""
+import pytest
+
+from tests import fuzz_vs_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("first", [1000, 2000, 3000])
+def test_random_inputs_and_options_equal_the_oracle(oracle, first):
+    seen = 0
+    for seed in range(first, first + 12):
+        r = fuzz_vs_oracle.one_case(oracle, seed)
+        assert r["same"], r
+        seen += r["records"]
+    assert seen > 50
