@@ -15,3 +15,10 @@ def test_random_inputs_and_options_equal_the_oracle(oracle, first):
         assert r["same"], r
         seen += r["records"]
     assert seen > 50
+
+
+@pytest.mark.parametrize("seed", [501, 502, 503])
+def test_random_medium_size_inputs_equal_the_oracle(oracle, seed):
+    """2-20 M positions from the GPU generator (several tiles per workgroup, many batches, full traversal stacks), random mode and options."""
+    r = fuzz_vs_oracle.medium_case(oracle, seed)
+    assert r["same"] and r["records"] > 100, r
