@@ -128,6 +128,8 @@ def main(first: int, count: int, medium: bool = False) -> int:
         if not r["same"]:
             bad.append(r)
             print("DIFFERS:", r, flush=True)
+        if (seed - first + 1) % 25 == 0:
+            print(f"  ... {seed - first + 1} cases, {recs} records, {len(bad)} differ", flush=True)
     print(f"{count} {'medium-size ' if medium else ''}cases from seed {first} (modes 1/2/3: {by_mode[1]}/{by_mode[2]}/{by_mode[3]}), {recs} records in all: {len(bad)} differ", flush=True)
     return 1 if bad else 0
 
