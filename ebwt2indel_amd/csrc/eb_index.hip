@@ -9,7 +9,10 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <condition_variable>
+#include <mutex>
+#include <thread>
 
 #include "eb_config.h"
 #include "eb_internal.h"
@@ -416,7 +419,9 @@ int eb_index_scan_planes(eb_index* h) {
     return EB_OK;
 }
 
-static int index_alloc(uint64_t n, uint8_t term, int device, eb_index** out) {
+static double idx_now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
+
+static int index_alloc(uint64_t n, uint8_t term, int device, eb_index** out, bool defer_scan_ctx = false) {
     int ndev = eb_device_count();
     if (ndev <= 0) {
         eb_set_error("no HIP device available: the ebwt2InDel hot path runs on the GPU only (no CPU fallback)");
@@ -447,10 +452,16 @@ static int index_alloc(uint64_t n, uint8_t term, int device, eb_index** out) {
     // is indifferent (profiles/r05_rank_share.txt).
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi); // (hi: numerically smallest = highest priority)
+    const double x0 = idx_now();
     hipError_t e = hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_hi);
-    if (e == hipSuccess && eb_scan_ctx_create(h) != EB_OK) e = hipErrorOutOfMemory;
+    const double x1 = idx_now();
+    // (the loader creates them itself a little later, still right behind this one: three streams are ~25 ms in a fresh process,
+    // which its first uploads need not wait for)
+    if (e == hipSuccess && !defer_scan_ctx && eb_scan_ctx_create(h) != EB_OK) e = hipErrorOutOfMemory;
+    const double x2 = idx_now();
     if (e == hipSuccess) e = hipMalloc(&h->d_chunks, h->n_blocks * 64);
     if (e == hipSuccess) e = hipMalloc(&h->d_super, h->n_super * 4 * sizeof(uint64_t));
+    if (eb_cfg().trace_index) fprintf(stderr, "[index] index_alloc: first stream %.3f s, phase-4 streams + events + report block %.3f, index memory %.3f\n", x1 - x0, x2 - x1, idx_now() - x2);
     if (e != hipSuccess) {
         eb_set_error("index allocation failed (%llu bytes): %s", (unsigned long long)(h->n_blocks * 64), hipGetErrorString(e));
         eb_index_destroy(h);
@@ -568,8 +579,6 @@ extern "C" int eb_index_create_from_device(const void* d_ascii, uint64_t n, uint
     return EB_OK;
 }
 
-// ascii: the symbols in host memory, or NULL with fd >= 0: the symbols are the file's bytes (read with pread)
-static double idx_now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
 
 
 // ascii: the symbols in host memory, or NULL with fd >= 0: the symbols are the file's bytes (read with pread)
@@ -614,21 +623,43 @@ static int index_create_from(const uint8_t* ascii, int fd, uint64_t n, uint8_t t
     // The index's own allocation (a few GB of hipMalloc: 40-80 ms in a fresh process) and the device staging buffers are made on a
     // side thread while this one pins the host pieces and starts the readers on them.
     unsigned long long init = ~0ull;
-    int rc_alloc = EB_OK;
+    int rc_alloc = EB_OK, rc_ctx = EB_OK;
     std::string err_alloc;
+    double ta[6] = {0, 0, 0, 0, 0, 0};
+    std::mutex ready_mu;
+    std::condition_variable ready_cv;
+    bool ready = false;
+    std::atomic<hipStream_t> up2{nullptr}; // the second upload stream, once the side thread has created it
     std::thread alloc_thread([&] {
+        ta[0] = idx_now();
         (void)hipSetDevice(device);
-        rc_alloc = index_alloc(n, term, device, &h);
+        ta[1] = idx_now();
+        rc_alloc = index_alloc(n, term, device, &h, true);
+        ta[2] = idx_now();
         hipError_t ea = rc_alloc == EB_OK ? hipMalloc(&d_bad, sizeof init) : hipSuccess;
         for (int i = 0; i < SLOTS && (size_t)i < n_pieces && ea == hipSuccess && rc_alloc == EB_OK; ++i) {
             d_stage[i] = static_cast<uint8_t*>(eb_scratch_get(device, stage_bytes, &d_cap[i]));
             if (!d_stage[i]) ea = hipErrorOutOfMemory;
             if (ea == hipSuccess) ea = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
         }
+        ta[3] = idx_now();
         if (ea == hipSuccess && rc_alloc == EB_OK) ea = hipMemcpy(d_bad, &init, sizeof init, hipMemcpyHostToDevice);
+        ta[4] = idx_now();
         if (rc_alloc != EB_OK) err_alloc = eb_last_error(); // (the message is thread-local)
         else if (ea != hipSuccess) { rc_alloc = EB_ERR_NOMEM; err_alloc = std::string("staging allocation failed: ") + hipGetErrorString(ea); }
+        { std::lock_guard<std::mutex> lk(ready_mu); ready = true; }
+        ready_cv.notify_all();
+        // The uploads run from here on.  What they do not need follows on this thread, in the order the streams' hardware queues
+        // depend on (index_alloc): the index's phase-4 streams right behind its own stream, then the loader's second upload stream
+        // (one copy engine moves ~33 GB/s in a fresh process, the link carries ~50: consecutive pieces alternate between two streams).
+        if (rc_alloc == EB_OK) {
+            rc_ctx = eb_scan_ctx_create(h);
+            hipStream_t s2 = nullptr;
+            if (n_pieces > 1 && hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) == hipSuccess) up2.store(s2, std::memory_order_release);
+        }
+        ta[5] = idx_now();
     });
+    struct JoinGuard { std::thread& t; ~JoinGuard() { if (t.joinable()) t.join(); } } join_guard{alloc_thread};
     size_t posted = 0;
     hipError_t e = hipSuccess;
     if (pinned_path) {
@@ -641,18 +672,24 @@ static int index_create_from(const uint8_t* ascii, int fd, uint64_t n, uint8_t t
         }
     }
     const double tr1 = idx_now();
-    alloc_thread.join();
+    {
+        std::unique_lock<std::mutex> lk(ready_mu);
+        ready_cv.wait(lk, [&] { return ready; });
+    }
     int rc = rc_alloc;
     if (rc == EB_OK && e != hipSuccess) { rc = EB_ERR_NOMEM; err_alloc = std::string("staging allocation failed: ") + hipGetErrorString(e); }
-    if (rc != EB_OK) { eb_set_error("%s", err_alloc.c_str()); release(); if (h) eb_index_destroy(h); return rc; }
-    // consecutive pieces go up on two streams: one copy engine moves ~33 GB/s in a fresh process, the link carries ~50
-    hipStream_t up[2] = {h->stream, nullptr};
-    if (hipStreamCreateWithFlags(&up[1], hipStreamNonBlocking) != hipSuccess) up[1] = h->stream;
-    struct UpGuard { hipStream_t s, own; ~UpGuard() { if (s && s != own) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); } } } up_guard{up[1], h->stream};
+    if (rc != EB_OK) {
+        alloc_thread.join();
+        eb_set_error("%s", err_alloc.c_str());
+        release();
+        if (h) eb_index_destroy(h);
+        return rc;
+    }
     const double tr2 = idx_now();
     double tr_read = 0, tr_slot = 0;
     for (size_t k = 0; k < n_pieces; ++k) {
-        const hipStream_t st = up[k & 1];
+        hipStream_t st = h->stream;
+        if (k & 1) { const hipStream_t s2 = up2.load(std::memory_order_acquire); if (s2) st = s2; }
         const int slot = (int)(k % SLOTS);
         const uint64_t pos = (uint64_t)k * PIECE, len = n ? piece_len(k) : 0;
         const bool last = k + 1 == n_pieces;
@@ -680,14 +717,22 @@ static int index_create_from(const uint8_t* ascii, int fd, uint64_t n, uint8_t t
         }
     }
     if (e != hipSuccess) { eb_set_error("upload failed: %s", hipGetErrorString(e)); rc = EB_ERR_DEVICE; }
-    if (up[1] != h->stream && hipStreamSynchronize(up[1]) != hipSuccess && rc == EB_OK) { eb_set_error("upload failed"); rc = EB_ERR_DEVICE; } // (the counters follow on the index's stream)
+    alloc_thread.join();
+    if (hipStream_t s2 = up2.load()) { // (the counters follow on the index's stream)
+        if (hipStreamSynchronize(s2) != hipSuccess && rc == EB_OK) { eb_set_error("upload failed"); rc = EB_ERR_DEVICE; }
+        (void)hipStreamDestroy(s2);
+    }
+    if (rc == EB_OK && rc_ctx != EB_OK) { eb_set_error("phase-4 streams could not be created"); rc = rc_ctx; }
     if (rc != EB_OK) (void)hipStreamSynchronize(h->stream);
     const double tr3 = idx_now();
     if (rc == EB_OK) rc = finish_index(h, d_bad, nullptr, ascii, fd);
     const double tr4 = idx_now();
     release();
     if (trace)
-        fprintf(stderr, "[index] n=%llu: page-locked pieces + readers started %.3f s, rest of the index allocation on the side thread %.3f, piece loop %.3f (waits for the readers %.3f, "
+        fprintf(stderr, "[index] side thread: device set %.3f s, index_alloc (stream, index memory) %.3f, staging + events %.3f, first host-to-device copy %.3f; then, beside the uploads: phase-4 streams + second upload stream %.3f\n",
+                ta[1] - ta[0], ta[2] - ta[1], ta[3] - ta[2], ta[4] - ta[3], ta[5] - ta[4]);
+    if (trace)
+        fprintf(stderr, "[index] n=%llu: page-locked pieces + readers started %.3f s, then waited for the side thread %.3f, piece loop %.3f (waits for the readers %.3f, "
                         "for an upload %.3f), counters + directory %.3f, release %.3f\n",
                 (unsigned long long)n, tr1 - tr0, tr2 - tr1, tr3 - tr2, tr_read, tr_slot, tr4 - tr3, idx_now() - tr4);
     if (rc != EB_OK) { eb_index_destroy(h); return rc; }

@@ -131,9 +131,11 @@ int eb_scan_ctx_create(eb_index* b1) {
     b1->scan_ctx = ctx;
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi); // lo: numerically greatest = lowest priority (the scan's stream has the highest: index_alloc)
+    const double y0 = BeginTrace::now();
     EB_HIP(hipStreamCreateWithPriority(&ctx->ctx, hipStreamNonBlocking, prio_lo));
     EB_HIP(hipStreamCreateWithPriority(&ctx->right, hipStreamNonBlocking, prio_lo));
     EB_HIP(hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking));
+    if (eb_cfg().trace_index) fprintf(stderr, "[index] three phase-4 streams: %.1f ms\n", BeginTrace::now() - y0);
     EB_HIP(hipEventCreateWithFlags(&ctx->last_ctx, hipEventDisableTiming));
     EB_HIP(hipEventRecord(ctx->last_ctx, ctx->ctx));
     for (int k = 0; k < E_PER_JOB; ++k) {
