@@ -61,7 +61,7 @@ ABI_SYMBOLS = [
     "eb_params_init", "eb_params_resolve", "eb_last_error", "eb_device_count",
     "eb_index_create", "eb_index_create_from_file", "eb_index_create_from_device", "eb_index_destroy", "eb_index_bad_symbol",
     "eb_index_info", "eb_index_build_psi", "eb_index_has_psi", "eb_rank4_batch", "eb_access_batch", "eb_lf_range_batch", "eb_lf_range_sym_batch", "eb_fl_batch",
-    "eb_lf_node_batch", "eb_rank4_batch_device", "eb_flags_build", "eb_nav_covers_every_slot_once", "eb_flags_build_shard", "eb_flags_device_vectors", "eb_flags_popcounts", "eb_flags_finalize", "eb_flags_set_da", "eb_flags_set_da_file", "eb_flags_set_da_device", "eb_flags_words", "eb_flags_has_da",
+    "eb_lf_node_batch", "eb_rank4_batch_device", "eb_flags_build", "eb_nav_covers_every_slot_once", "eb_flags_build_shard", "eb_flags_device_vectors", "eb_flags_popcounts", "eb_flags_finalize", "eb_flags_set_da", "eb_flags_set_da_file", "eb_flags_set_da_device", "eb_da_stage_file", "eb_flags_set_da_staged", "eb_da_staged_free", "eb_flags_words", "eb_flags_has_da",
     "eb_flags_export", "eb_flags_import", "eb_flags_import_shard_sum", "eb_flags_destroy", "eb_scan_clusters", "eb_scan_clusters_begin", "eb_scan_clusters_end",
     "eb_scan_clusters_cancel", "eb_scan_clusters_begin_ex", "eb_scan_job_wait", "eb_scan_job_device_blob", "eb_scan_job_device_wire", "eb_scan_job_wire_to_host", "eb_host_register", "eb_host_unregister", "eb_calls_get", "eb_calls_free",
     "eb_calls_packed_size", "eb_calls_pack", "eb_calls_unpack", "eb_calls_blob", "eb_write_snp", "eb_format_snp", "eb_free",
@@ -122,6 +122,10 @@ def load():
     L.eb_flags_set_da.argtypes = [vp, vp, u64]
     L.eb_flags_set_da_file.argtypes = [vp, C.c_char_p]
     L.eb_flags_set_da_device.argtypes = [vp, vp, u64]
+    L.eb_da_stage_file.argtypes = [C.c_char_p, u64, i32, P(vp)]
+    L.eb_flags_set_da_staged.argtypes = [vp, vp]
+    L.eb_da_staged_free.argtypes = [vp]
+    L.eb_da_staged_free.restype = None
     L.eb_flags_words.argtypes = [vp]
     L.eb_flags_words.restype = u64
     L.eb_flags_has_da.argtypes = [vp]

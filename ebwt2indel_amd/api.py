@@ -227,6 +227,11 @@ class Flags:
     def set_da_file(self, path: str):
         _check(lib().eb_flags_set_da_file(self._h, os.fsencode(path)))
 
+    def set_da_staged(self, staged: "StagedDa"):
+        """Hands a document array loaded ahead (StagedDa) to these flags; the staged object is consumed."""
+        _check(lib().eb_flags_set_da_staged(self._h, staged._h))
+        staged._h = C.c_void_p()            # (consumed on success only)
+
     def set_da_device(self, d_ptr: int, n: int):
         """ASCII '0'/'1' bytes already in HBM on the flags' device (a generator's output)."""
         _check(lib().eb_flags_set_da_device(self._h, C.c_void_p(d_ptr), n))
@@ -255,6 +260,21 @@ class Flags:
     def __del__(self):
         try:
             self.close()
+        except Exception:
+            pass
+
+
+class StagedDa:
+    """A -d file loaded and packed on the GPU ahead of the flags it belongs to (callable on another thread beside the traversal)."""
+
+    def __init__(self, path: str, n_bwt: int, device: int = 0):
+        self._h = C.c_void_p()
+        _check(lib().eb_da_stage_file(os.fsencode(path), n_bwt, device, C.byref(self._h)))
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().eb_da_staged_free(self._h)
         except Exception:
             pass
 

@@ -206,9 +206,25 @@ void rank_main(MultiJob& J, int r) {
 
     // ---- phases 2-3: this rank's Weiner-link subtrees, then the vectors are combined
     t0 = now_s();
+    // (the -d file is loaded and packed on a second host thread beside this rank's traversal)
+    eb_da_staged* staged = nullptr;
+    int rc_da = EB_OK;
+    std::string err_da;
+    std::thread da_loader;
+    if (!J.path_da.empty()) {
+        eb_index_info_t info;
+        (void)eb_index_info(b1, &info);
+        da_loader = std::thread([&, n_bwt = info.n] {
+            rc_da = eb_da_stage_file(J.path_da.c_str(), n_bwt, device, &staged);
+            if (rc_da != EB_OK) err_da = eb_last_error();
+        });
+    }
     rc = eb_flags_build_shard(b1, b2, J.p.K, J.p.k_right, (uint32_t)r, (uint32_t)J.world, &fl, &J.ns[(size_t)r]);
+    if (da_loader.joinable()) da_loader.join();
+    struct StagedGuard { eb_da_staged*& s; ~StagedGuard() { if (s) eb_da_staged_free(s); } } staged_guard{staged};
     if (rc == EB_OK) rc = eb_flags_popcounts(fl, J.ones[(size_t)r].data());
     if (rc != EB_OK) MJ_FAIL(rc, "%s", eb_last_error());
+    else if (rc_da != EB_OK) MJ_FAIL(rc_da, "%s", err_da.c_str());
     if (!sync_ok()) return cleanup();
     const uint64_t n = J.ns[(size_t)r].n;
     uint64_t* v[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -255,7 +271,9 @@ void rank_main(MultiJob& J, int r) {
         else if (!J.host_backend && (rc = eb_flags_finalize(fl)) != EB_OK) MJ_FAIL(rc, "%s", eb_last_error());
     }
     if (J.rc[(size_t)r] == EB_OK && !J.path_da.empty()) {
-        rc = eb_flags_set_da_file(fl, J.path_da.c_str());
+        eb_da_staged* hand = staged;
+        staged = nullptr; // (consumed by the call below)
+        rc = eb_flags_set_da_staged(fl, hand);
         if (rc != EB_OK) MJ_FAIL(rc, "%s", eb_last_error());
     }
     if (!sync_ok()) return cleanup();
@@ -557,8 +575,26 @@ int main(int argc, char** argv) {
     printf(two_bwts ? "\nPhase 2/4: merging eBWTs.\n" : "\nPhase 2/4: navigating suffix tree leaves.\n");
     eb_flags* fl = nullptr;
     eb_nav_stats ns;
+    // the -d file does not depend on the traversal (the reference reads it between phases 3 and 4, :1497-1508): it is loaded and
+    // packed on a second host thread meanwhile
+    eb_da_staged* staged = nullptr;
+    int rc_da = EB_OK;
+    std::string err_da;
+    double t_da = 0;
+    std::thread da_loader;
+    if (with_da) {
+        eb_index_info_t info;
+        (void)eb_index_info(b1, &info);
+        da_loader = std::thread([&, n_bwt = info.n] {
+            const double a = now_s();
+            rc_da = eb_da_stage_file(input_da.c_str(), n_bwt, device, &staged);
+            if (rc_da != EB_OK) err_da = eb_last_error(); // (the message is thread-local)
+            t_da = now_s() - a;
+        });
+    }
     rc = eb_flags_build(b1, b2, p.K, p.k_right, &fl, &ns);
-    if (rc != EB_OK) return fail("Error while navigating the suffix tree");
+    if (da_loader.joinable()) da_loader.join();
+    if (rc != EB_OK) { eb_da_staged_free(staged); return fail("Error while navigating the suffix tree"); }
     if (two_bwts) printf("Computed %llu/%llu DA values.\n", (unsigned long long)ns.da_values, (unsigned long long)ns.n);
     printf("Processed %llu suffix-tree leaves.\n\n", (unsigned long long)ns.leaves);
     printf("Phase 3/4: computing LCP minima.\n");
@@ -568,8 +604,9 @@ int main(int argc, char** argv) {
     double t2 = now_s();
 
     if (with_da) {
-        rc = eb_flags_set_da_file(fl, input_da.c_str());
-        if (rc == EB_ERR_IO) { printf("Error: could not read file %s\n", input_da.c_str()); return 1; }
+        if (rc_da == EB_ERR_IO) { printf("Error: could not read file %s\n", input_da.c_str()); return 1; }
+        if (rc_da != EB_OK) { printf("Error while loading the document array: %s\n", err_da.c_str()); return 1; }
+        rc = eb_flags_set_da_staged(fl, staged);
         if (rc != EB_OK) return fail("Error while loading the document array");
     }
     double t2b = now_s();
@@ -587,7 +624,7 @@ int main(int argc, char** argv) {
     double t4 = now_s();
 
     print_report(ns, ss, two_bwts, with_da, events, cluster_nr);
-    if (with_da) printf("\nDocument array loaded and packed in %.3f s.", t2b - t2);
+    if (with_da) printf("\nDocument array loaded and packed in %.3f s beside the traversal; handed to the flags in %.3f s.", t_da, t2b - t2);
     printf("\nTimings (s): load+index %.3f, phases 2-3 %.3f (leaves %.3f and nodes %.3f side by side, %llu rank queries, %llu launches), "
            "phase 4 device %.3f (scan %.3f ms, extend %.3f ms, right %.3f ms), write %.3f\n",
            t1 - t0, t2 - t1, ns.seconds_leaves, ns.seconds_nodes, (unsigned long long)ns.rank_queries, (unsigned long long)ns.batches,

@@ -41,6 +41,7 @@ extern "C" {
 
 typedef struct eb_index eb_index; /* packed BWT + rank counters, resident on one GPU  (dna_bwt_t) */
 typedef struct eb_flags eb_flags; /* LCP_threshold / LCP_minima / DA bitvectors on the GPU          */
+typedef struct eb_da_staged eb_da_staged; /* a document array loaded ahead of the flags it belongs to (mode 3) */
 typedef struct eb_calls eb_calls; /* phase-4 output: one record per surviving cluster (host memory) */
 
 /* Options of the reference CLI (ebwt2InDel.cpp:20-74, getopt at :1684). */
@@ -181,6 +182,13 @@ int eb_flags_set_da(eb_flags* f, const uint8_t* ascii01, uint64_t n);
  * in HBM on the flags' device (16-byte aligned; a generator's output). */
 int eb_flags_set_da_file(eb_flags* f, const char* path);
 int eb_flags_set_da_device(eb_flags* f, const void* d_ascii01, uint64_t n);
+/* The same in two steps, for a caller that loads the -d file WHILE the traversal runs (the reference reads it between phases 3 and 4,
+ * ebwt2InDel.cpp:1497-1508; the array does not depend on the traversal): eb_da_stage_file loads and packs it into device words of its
+ * own for a BWT of n_bwt positions -- callable on another host thread beside eb_flags_build --, eb_flags_set_da_staged hands those words
+ * to the flags (no copy; the staged object is consumed when the call succeeds).  eb_da_staged_free: a staged array that was never handed over. */
+int eb_da_stage_file(const char* path, uint64_t n_bwt, int device, eb_da_staged** out);
+int eb_flags_set_da_staged(eb_flags* f, eb_da_staged* staged);
+void eb_da_staged_free(eb_da_staged* staged);
 /* Bit i of each vector is bit (i & 63) of word (i >> 6).  Any pointer may be NULL.
  * export: device -> host (tests, broadcast to other ranks); import: host -> device. */
 uint64_t eb_flags_words(const eb_flags* f);

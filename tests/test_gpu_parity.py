@@ -431,13 +431,27 @@ def test_document_array_from_buffer_file_and_device_is_the_same_array(monkeypatc
         t = torch.frombuffer(bytearray(src) if src else bytearray(b"-"), dtype=torch.uint8).cuda()
         fl.set_da_device(t.data_ptr(), len(src))
         got.append(fl.export()[3].copy())
+        # staged ahead (on another thread, as the executable does beside its traversal), then handed over
+        import threading
+        box = []
+        th = threading.Thread(target=lambda: box.append(api.StagedDa(str(pth), len(m))))
+        th.start()
+        th.join()
+        fl.set_da(b"0" * len(m))
+        fl.set_da_staged(box[0])
+        got.append(fl.export()[3].copy())
         for words in got:
             assert np.array_equal(np.unpackbits(words.view(np.uint8), bitorder="little")[: len(m)], want)
             assert not np.unpackbits(words.view(np.uint8), bitorder="little")[len(m):].any()
     with pytest.raises(api.EbError, match="could not read file"):
         fl.set_da_file(str(tmp_path / "absent.da"))
+    with pytest.raises(api.EbError, match="could not read file"):
+        api.StagedDa(str(tmp_path / "absent.da"), len(m))
     with pytest.raises(api.EbError, match="16-byte aligned"):
         fl.set_da_device(t.data_ptr() + 1, 100)
+    wrong = api.StagedDa(str(tmp_path / "x.da"), len(m) + 64)
+    with pytest.raises(api.EbError, match="staged document array was made for"):
+        fl.set_da_staged(wrong)
     # and the call set that comes out of the file form is the reference's
     fl.set_da_file(str(tmp_path / "x.da"))                          # (da + b"1111": longer than the BWT, the excess is ignored)
     p = api.make_params()
