@@ -13,6 +13,7 @@ tmp = os.environ.get("TMPDIR", "/tmp")
 def run(args, label, want):
     out = os.path.join(tmp, "m23.snp")
     for rep in range(2):
+        time.sleep(float(os.environ.get("CLI_SLEEP", "0")))      # (an idle GPU: the driver has wiped what the previous process released)
         t = time.time()
         r = subprocess.run([_lib.CLI_PATH] + args + ["-o", out], capture_output=True, text=True, env=dict(os.environ, EB_TRACE=os.environ.get("EB_TRACE", "index")))
         dt = time.time() - t
